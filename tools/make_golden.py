@@ -1,0 +1,207 @@
+"""Mint the golden fixtures under tests/golden/ from STOCK transformers' UdopForConditionalGeneration
+(transformers 5.15.0 — the importable upstream of the reference's un-vendored fork).
+
+Runs ONLY in the build container.  Nothing of `transformers` travels: the fixtures are data (inputs and
+expected outputs); weights come from the counter-based recipe (markushgrapher_amd/synth.py) or, for G3, from
+tests/golden/g3_weights.npz (tools/train_tiny.py).  While minting, the CPU oracle (oracle/udop_oracle.py) is
+checked against stock on every fixture — that is what pins the oracle.
+
+    python tools/make_golden.py [g0 g1 g2 g3 tables]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+from markushgrapher_amd import synth  # noqa: E402
+from oracle.udop_oracle import Oracle, bucket_table  # noqa: E402
+from tools.stock import stock_model  # noqa: E402
+from tools.train_tiny import copy_task_batch  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def versions():
+    import transformers
+    return np.array([f"transformers={transformers.__version__}", f"torch={torch.__version__}",
+                     "attn_implementation=eager"])
+
+
+def edge_case_inputs(shape, B=2, L=8, seed=5):
+    """Inputs that hit the corner cases of combine_image_text_embeddings (stock:171-251):
+    box mean 0 (question/pad) and mean 1 (sep), two tokens on the same patch, a token centred exactly on a
+    patch boundary, a bbox > 1 before the clip, and a padded row."""
+    n = shape.image_size // shape.patch_size
+    ids = synth.randint("edge.ids", B * L, 3, shape.vocab_size - 1, seed).reshape(B, L)
+    bbox = np.zeros((B, L, 4), np.float32)
+    mask = np.ones((B, L), np.int64)
+    for b in range(B):
+        bbox[b, 2] = 1.0                                   # sep, mean 1 -> last patch dropped, nothing added
+        ids[b, 2] = shape.eos_token_id
+        c = 1.0 / n
+        bbox[b, 3] = [c - 0.1, c - 0.1, c + 0.1, c + 0.1]  # centre exactly on the patch (1,1) corner
+        bbox[b, 4] = [0.30, 0.55, 0.40, 0.60]
+        bbox[b, 5] = [0.31, 0.56, 0.41, 0.61]              # same patch as token 4
+        bbox[b, 6] = [0.90, 0.90, 1.20, 1.10]              # > 1 before the clip
+        bbox[b, 7] = [0.05 + 0.2 * b, 0.7, 0.15 + 0.2 * b, 0.75]
+    ids[1, 6:] = shape.pad_token_id                        # padded row
+    bbox[1, 6:] = 0.0
+    mask[1, 6:] = 0
+    pages = synth.synth_pages_u8(B, shape.image_size, seed)
+    pv = synth.pages_to_pixel_values(pages, shape.image_size)
+    return {"input_ids": ids, "bbox": bbox, "attention_mask": mask, "pixel_values": pv}
+
+
+def run_stock(m, inp, labels, max_length, beams=5):
+    t = {k: torch.from_numpy(v) for k, v in inp.items()}
+    lab = torch.from_numpy(labels)
+    dam = (lab != -100).long()
+    with torch.no_grad():
+        enc = m.encoder(input_ids=t["input_ids"], bbox=t["bbox"].clone(), pixel_values=t["pixel_values"],
+                        attention_mask=t["attention_mask"])
+        enc_nomask = m.encoder(input_ids=t["input_ids"], bbox=t["bbox"].clone(), pixel_values=t["pixel_values"])
+        fw = m(input_ids=t["input_ids"], bbox=t["bbox"].clone(), pixel_values=t["pixel_values"],
+               attention_mask=t["attention_mask"], labels=lab, decoder_attention_mask=dam)
+        g = m.generate(input_ids=t["input_ids"], bbox=t["bbox"].clone(), pixel_values=t["pixel_values"],
+                       attention_mask=t["attention_mask"], labels=lab, num_beams=1, max_length=max_length,
+                       do_sample=False, return_dict_in_generate=True, output_logits=True)
+        gb = m.generate(input_ids=t["input_ids"], bbox=t["bbox"].clone(), pixel_values=t["pixel_values"],
+                        attention_mask=t["attention_mask"], num_beams=beams, max_length=max_length,
+                        do_sample=False, return_dict_in_generate=True, output_scores=True)
+    step_logits = torch.stack(g.logits, dim=1)             # [B, steps, V]
+    top2 = torch.topk(step_logits, 2, dim=-1).values
+    return {
+        "enc_out": enc.last_hidden_state.numpy(), "enc_mask": enc.attention_mask.numpy().astype(np.int64),
+        "enc_out_nomask": enc_nomask.last_hidden_state.numpy(),
+        "logits": fw.logits.numpy(), "loss": np.float32(fw.loss.item()),
+        "greedy_ids": g.sequences.numpy(), "greedy_step_logits": step_logits.numpy(),
+        "greedy_margin": (top2[..., 0] - top2[..., 1]).numpy(),
+        "beam_ids": gb.sequences.numpy(), "beam_scores": gb.sequences_scores.numpy(),
+    }
+
+
+def check_oracle(o, inp, labels, ref, max_length, beams=5, tol=2e-4, ids_strict=True):
+    lab = labels
+    dam = (lab != -100).astype(np.int64)
+    eo, mo = o.encode(inp["input_ids"], inp["bbox"], inp["pixel_values"], inp["attention_mask"])
+    e2, _ = o.encode(inp["input_ids"], inp["bbox"], inp["pixel_values"], None)
+    lo = o.forward(inp["input_ids"], inp["bbox"], inp["pixel_values"], inp["attention_mask"], labels=lab,
+                   decoder_attention_mask=dam)
+    valid = ref["enc_mask"].astype(bool)
+    d_enc = np.abs(eo.numpy() - ref["enc_out"])[valid].max()
+    d_enc2 = np.abs(e2.numpy() - ref["enc_out_nomask"]).max()
+    d_log = np.abs(lo.numpy() - ref["logits"]).max()
+    assert np.array_equal(mo.numpy(), ref["enc_mask"])
+    go = o.greedy(inp["input_ids"], inp["bbox"], inp["pixel_values"], inp["attention_mask"], max_length=max_length)
+    bo, bs = o.beam_search(inp["input_ids"], inp["bbox"], inp["pixel_values"], inp["attention_mask"],
+                           num_beams=beams, max_length=max_length)
+    print(f"   oracle vs stock: enc {d_enc:.2e}  enc(no mask) {d_enc2:.2e}  logits {d_log:.2e}  "
+          f"greedy eq {np.array_equal(go, ref['greedy_ids'])}  beam eq {np.array_equal(bo, ref['beam_ids'])}")
+    assert d_enc < tol and d_enc2 < tol and d_log < tol * 5, (d_enc, d_enc2, d_log)
+    if ids_strict:
+        assert np.array_equal(go, ref["greedy_ids"]) and np.array_equal(bo, ref["beam_ids"])
+        assert np.abs(bs - ref["beam_scores"]).max() < 1e-3
+
+
+def save(name, **arrs):
+    p = os.path.join(OUT, name)
+    np.savez_compressed(p, versions=versions(), **arrs)
+    print("   wrote", p, os.path.getsize(p), "bytes")
+
+
+def g0():
+    print("G0 tiny / recipe weights / edge-case inputs")
+    shape = synth.SHAPES["tiny"]
+    sd = synth.recipe_state_dict(shape, gain=1.0)
+    m = stock_model(shape, sd)
+    inp = edge_case_inputs(shape)
+    labels = synth.randint("g0.lab", 2 * 10, 2, shape.vocab_size - 1, 3).reshape(2, 10)
+    labels[1, 7:] = -100
+    ref = run_stock(m, inp, labels, 16)
+    check_oracle(Oracle(shape, sd), inp, labels, ref, 16)
+    save("g0_tiny.npz", shape=np.array("tiny"), gain=np.float32(1.0), labels=labels, max_length=np.int64(16),
+         **inp, **ref)
+
+
+def g3():
+    print("G3 trained tiny / EOS at different steps / large margins")
+    shape = synth.SHAPES["tiny"]
+    sd = dict(np.load(os.path.join(OUT, "g3_weights.npz")))
+    m = stock_model(shape, sd)
+    b = copy_task_batch(shape, 6, seed=99)
+    labels = b.pop("labels")
+    ref = run_stock(m, b, labels, 16)
+    print("   greedy", ref["greedy_ids"].tolist())
+    print("   beam  ", ref["beam_ids"].tolist())
+    print("   min margin over live steps", float(ref["greedy_margin"].min()))
+    check_oracle(Oracle(shape, sd), b, labels, ref, 16)
+    save("g3_trained_tiny.npz", shape=np.array("tiny"), labels=labels, max_length=np.int64(16), **b, **ref)
+
+
+def g1():
+    print("G1 mid / recipe weights (not stored)")
+    shape = synth.SHAPES["mid"]
+    sd = synth.recipe_state_dict(shape, gain=1.0)
+    m = stock_model(shape, sd)
+    inp = synth.synth_batch(shape, 3, L_min=9, L_max=40, seed=11)
+    labels = synth.randint("g1.lab", 3 * 16, 2, shape.vocab_size - 1, 3).reshape(3, 16)
+    labels[2, 9:] = -100
+    ref = run_stock(m, inp, labels, 24)
+    check_oracle(Oracle(shape, sd), inp, labels, ref, 24, ids_strict=False)
+    save("g1_mid.npz", shape=np.array("mid"), gain=np.float32(1.0), labels=labels, max_length=np.int64(24),
+         synth_args=np.array([3, 9, 40, 11]), **{k: v for k, v in ref.items()})
+
+
+def g2():
+    print("G2 large shape / recipe weights / B=1 L=64 (encoder probes + 8 decode steps)")
+    shape = synth.SHAPES["large"]
+    sd = synth.recipe_state_dict(shape, gain=1.0)
+    m = stock_model(shape, sd)
+    inp = synth.synth_batch(shape, 1, seed=21, fixed_L=64)
+    t = {k: torch.from_numpy(v) for k, v in inp.items()}
+    t0 = time.time()
+    with torch.no_grad():
+        enc = m.encoder(input_ids=t["input_ids"], bbox=t["bbox"].clone(), pixel_values=t["pixel_values"],
+                        attention_mask=t["attention_mask"])
+        g = m.generate(input_ids=t["input_ids"], bbox=t["bbox"].clone(), pixel_values=t["pixel_values"],
+                       attention_mask=t["attention_mask"], num_beams=1, max_length=9, do_sample=False,
+                       return_dict_in_generate=True, output_logits=True)
+    print(f"   stock ran in {time.time() - t0:.1f}s")
+    eo = enc.last_hidden_state[0].numpy()
+    rows = np.array([0, 1, 13, 63, 64, 65, 500, 777, 1000, 1023, 1024, 1040, 1060, 1080, 1086, 1087])
+    rows = rows[rows < eo.shape[0]]
+    step_logits = torch.stack(g.logits, dim=1)[0]
+    top = torch.topk(step_logits, 8, dim=-1)
+    o = Oracle(shape, sd)
+    e_or, m_or = o.encode(inp["input_ids"], inp["bbox"], inp["pixel_values"], inp["attention_mask"])
+    valid = enc.attention_mask[0].numpy().astype(bool)
+    d = np.abs(e_or[0].numpy() - eo)[valid].max()
+    rec = []
+    go = o.greedy(inp["input_ids"], inp["bbox"], inp["pixel_values"], inp["attention_mask"], max_length=9, record=rec)
+    dl = max(float((rec[i][0] - step_logits[i]).abs().max()) for i in range(len(rec)))
+    print(f"   oracle vs stock: enc {d:.2e} step-logits {dl:.2e} ids eq {np.array_equal(go, g.sequences.numpy())}")
+    assert d < 1e-3 and dl < 1e-3
+    save("g2_large.npz", shape=np.array("large"), gain=np.float32(1.0), synth_seed=np.int64(21), fixed_L=np.int64(64),
+         enc_mask=enc.attention_mask.numpy().astype(np.int64), enc_rows=rows, enc_probe=eo[rows],
+         enc_abs_sum=np.float64(np.abs(eo[valid]).astype(np.float64).sum()),
+         enc_sum=np.float64(eo[valid].astype(np.float64).sum()),
+         greedy_ids=g.sequences.numpy(), step_top_vals=top.values.numpy(), step_top_idx=top.indices.numpy())
+
+
+def tables():
+    print("bucket tables (stock:422-468 evaluated by torch on every integer distance)")
+    save("bucket_tables.npz",
+         enc_1d=bucket_table(True, 32, 128, -300, 300), enc_1d_lo=np.int64(-300),
+         enc_hv=bucket_table(True, 32, 100, -150, 150), enc_hv_lo=np.int64(-150),
+         dec_1d=bucket_table(False, 32, 128, -600, 8), dec_1d_lo=np.int64(-600))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["tables", "g0", "g3", "g1", "g2"]
+    os.makedirs(OUT, exist_ok=True)
+    for w in which:
+        globals()[w]()
