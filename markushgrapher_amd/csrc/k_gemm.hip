@@ -1,0 +1,318 @@
+// bf16 MFMA GEMMs of the VTL encoder / CXSMILES decoder (QKV, O, FFN wi/wo, cross-K/V, patch embed, lm_head).
+//   out[m][n] = sum_k X[m][k] * W[n][k]      (nn.Linear: W is [out,in]; stock:412-415, 313-314)
+// Both operands live in HBM in the packed fragment-tile format (mg_device.h), so
+//   * a wave stages one 32x16 fragment with ONE global_load_lds (1 KiB contiguous in HBM, lane-linear in LDS),
+//   * every ds_read_b128 of a fragment is base + 16*lane: conflict-free without swizzling,
+//   * swapping the two MFMA operands transposes the accumulator for free, which lets each epilogue store
+//     16-byte chunks in the layout its consumer wants (packed rows, packed transposed, or row-major fp32).
+#include "mg_kernels.h"
+
+namespace mg {
+
+// ---------------------------------------------------------------------------------------------------------
+// epilogue helpers
+// ---------------------------------------------------------------------------------------------------------
+// One 16-byte chunk of a per-head projection.  `tok0..` semantics depend on the format:
+//  token-major formats (PK_ROWS / NATURAL / STEP_*): chunk = token m, head dims [dim0, dim0+8)
+//  HF_PK_T: chunk = head dim `dim0`, tokens [m, m+8)
+MG_DEV void heads_store(const HeadsOut& ho, int ri, int h, int m, int dim0, const uint4& c) {
+    const int fmt = ho.fmt[ri];
+    uint16_t* base = ho.ptr[ri];
+    if (fmt == HF_PK_ROWS) {
+        const int b = m / ho.S_in, s = m - b * ho.S_in;
+        size_t off = (((size_t)b * ho.H + h) * (size_t)(ho.S_cap >> 5) + (size_t)(s >> 5)) * (4 * TILE_ELEMS) +
+                     (size_t)(dim0 >> 4) * TILE_ELEMS + (size_t)(((dim0 >> 3) & 1) * 256 + (s & 31) * 8);
+        st16(base + off, c);
+    } else if (fmt == HF_PK_T) {
+        const int b = m / ho.S_in, s = m - b * ho.S_in;
+        size_t off = ((((size_t)b * ho.H + h) * 2 + (size_t)(dim0 >> 5)) * (size_t)(ho.S_cap >> 4) + (size_t)(s >> 4)) *
+                         TILE_ELEMS +
+                     (size_t)(((s >> 3) & 1) * 256 + (dim0 & 31) * 8);
+        st16(base + off, c);
+    } else if (fmt == HF_NATURAL) {
+        const int b = m / ho.S_in, s = m - b * ho.S_in;
+        const int row = ho.row_map ? ho.row_map[m] : s;
+        if (row >= 0) st16(base + (((size_t)b * ho.H + h) * (size_t)ho.S_cap + (size_t)row) * 64 + dim0, c);
+    } else if (fmt == HF_STEP_Q) {
+        st16(base + ((size_t)m * ho.H + h) * 64 + dim0, c);
+    } else if (fmt == HF_STEP_KV) {
+        const int row = ho.row_map ? ho.row_map[m] : m;
+        st16(base + (((size_t)row * ho.H + h) * (size_t)ho.S_cap + (size_t)ho.pos) * 64 + dim0, c);
+    }
+}
+
+// Epilogue of one 32x32 accumulator tile.
+//  TOR (operands swapped, D = W·X^T): lane owns token m = m0 + lane%32, rows of D are output features n0 + i.
+//  !TOR (D = X·W^T):                  lane owns feature n = n0 + lane%32, rows of D are tokens m0 + i.
+template <int EPI, bool TOR>
+MG_DEV void tile_epilogue(const GemmArgs& a, const f32x16& acc, int m0, int n0, int lane) {
+    const int half = lane >> 5, l32 = lane & 31;
+    if constexpr (EPI == EPI_F32_STORE || EPI == EPI_F32_RESID) {
+        static_assert(!TOR, "fp32 epilogues use D = X·W^T");
+        const int n = n0 + l32;
+        if (n >= a.N) return;
+        const float bv = (EPI == EPI_F32_STORE && a.bias) ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + acc_row(r, half);
+            if (m < a.M) {
+                float* p = a.out_f32 + (size_t)m * a.ldo + n;
+                if (EPI == EPI_F32_RESID) *p = *p + acc[r];
+                else *p = acc[r] + bv;
+            }
+        }
+    } else if constexpr (EPI == EPI_PK || EPI == EPI_PK_RELU) {
+        f32x16 v = acc;
+        if (EPI == EPI_PK_RELU) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        uint4 ch[2];
+        acc_to_chunks(v, half, ch);
+        const int m = m0 + l32;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int n = n0 + 16 * q + 8 * half;
+            if (m < a.M && n < a.N) st16(a.out_pk + pk_off(m, n, a.N), ch[q]);
+        }
+    } else {  // EPI_HEADS
+        const HeadsOut& ho = a.heads;
+        uint4 ch[2];
+        acc_to_chunks(acc, half, ch);
+        if (TOR) {
+            const int m = m0 + l32;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int n = n0 + 16 * q + 8 * half;
+                if (m < a.M && n < a.N) {
+                    const int ri = n / ho.inner, nn = n - ri * ho.inner;
+                    heads_store(ho, ri, nn >> 6, m, nn & 63, ch[q]);
+                }
+            }
+        } else {
+            const int n = n0 + l32;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int m = m0 + 16 * q + 8 * half;
+                if (m < a.M && n < a.N) {
+                    const int ri = n / ho.inner, nn = n - ri * ho.inner;
+                    heads_store(ho, ri, nn >> 6, m, nn & 63, ch[q]);
+                }
+            }
+        }
+    }
+}
+
+MG_DEV bool heads_region_is_T(const HeadsOut& ho, int n) {
+    const int ri = n / ho.inner;
+    return ho.fmt[ri] == HF_PK_T;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// large-M GEMM: 128x128x64 block tile, 4 waves (2x2), wave tile 64x64 = 2x2 MFMA 32x32x16 accumulators,
+// double-buffered LDS filled by global_load_lds (32 KiB per stage), one barrier per K-step.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int GB_M = 128, GB_N = 128, GB_K = 64;
+constexpr int GB_STAGE_BYTES = (GB_M + GB_N) / 32 * (GB_K / 16) * TILE_BYTES;   // 32 KiB
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs a) {
+    MG_DYN_SMEM(smem);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nbn = (a.N + GB_N - 1) / GB_N;
+    const int nbm = (a.M + GB_M - 1) / GB_M;
+    int bid = blockIdx.x;
+    const int nblk = nbm * nbn;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);   // XCD-contiguous tile ranges (speed only)
+    const int bm = bid / nbn, bn = bid - bm * nbn;
+    const int mt32 = (a.M + 31) >> 5, nt32 = (a.N + 31) >> 5, kt16 = a.K >> 4;
+    const int nks = a.K / GB_K;
+
+    // loader: wave w stages fragments f = 8w .. 8w+7 of the stage; f < 16: X row-tile f/4, k-tile f%4; else W.
+    const char* src[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int f = w * 8 + i, ff = f & 15, rt = ff >> 2, kt = ff & 3;
+        const bool isW = f >= 16;
+        int trow = isW ? (bn * 4 + rt) : (bm * 4 + rt);
+        const int tmax = isW ? nt32 - 1 : mt32 - 1;
+        trow = trow < tmax ? trow : tmax;   // clamp: tiles past the edge re-read the last tile, results are discarded
+        const uint16_t* basep = isW ? a.W : a.X;
+        src[i] = (const char*)(basep + pk_tile_off(trow, kt, a.K)) + lane * 16;
+    }
+    auto stage = [&](int buf, int ks) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            glds16(src[i] + (size_t)ks * (4 * TILE_BYTES), smem + buf * GB_STAGE_BYTES + (w * 8 + i) * TILE_BYTES);
+    };
+
+    const int wr = w >> 1, wc = w & 1;
+    const int m0w = bm * GB_M + wr * 64, n0w = bn * GB_N + wc * 64;
+    bool tor;
+    if (EPI == EPI_F32_STORE || EPI == EPI_F32_RESID) tor = false;
+    else if (EPI == EPI_HEADS) tor = !heads_region_is_T(a.heads, n0w < a.N ? n0w : 0);
+    else tor = true;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = acc_zero();
+
+    stage(0, 0);
+    __syncthreads();
+    for (int ks = 0; ks < nks; ++ks) {
+        const int cur = ks & 1;
+        if (ks + 1 < nks) stage(cur ^ 1, ks + 1);
+        const char* xb = smem + cur * GB_STAGE_BYTES + lane * 16;
+        const char* wb = xb + 16 * TILE_BYTES;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            uint4 xf[2], wf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                xf[i] = ld16(xb + ((wr * 2 + i) * 4 + kt) * TILE_BYTES);
+                wf[i] = ld16(wb + ((wc * 2 + i) * 4 + kt) * TILE_BYTES);
+            }
+            if (tor) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(wf[j], xf[i], acc[i][j]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(xf[i], wf[j], acc[i][j]);
+            }
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m0 = m0w + 32 * i, n0 = n0w + 32 * j;
+            if constexpr (EPI == EPI_F32_STORE || EPI == EPI_F32_RESID) {
+                tile_epilogue<EPI, false>(a, acc[i][j], m0, n0, lane);
+            } else if constexpr (EPI == EPI_HEADS) {
+                if (tor) tile_epilogue<EPI_HEADS, true>(a, acc[i][j], m0, n0, lane);
+                else tile_epilogue<EPI_HEADS, false>(a, acc[i][j], m0, n0, lane);
+            } else {
+                tile_epilogue<EPI, true>(a, acc[i][j], m0, n0, lane);
+            }
+        }
+}
+
+void gemm(const GemmArgs& a, int epi, mgStream_t stream) {
+    const int nblk = ((a.M + GB_M - 1) / GB_M) * ((a.N + GB_N - 1) / GB_N);
+    const dim3 grid(nblk), block(256);
+    const size_t sh = 2 * GB_STAGE_BYTES;
+    switch (epi) {
+        case EPI_F32_STORE: MG_LAUNCH((gemm_big_kernel<EPI_F32_STORE>), grid, block, sh, stream, a); break;
+        case EPI_F32_RESID: MG_LAUNCH((gemm_big_kernel<EPI_F32_RESID>), grid, block, sh, stream, a); break;
+        case EPI_PK_RELU: MG_LAUNCH((gemm_big_kernel<EPI_PK_RELU>), grid, block, sh, stream, a); break;
+        case EPI_PK: MG_LAUNCH((gemm_big_kernel<EPI_PK>), grid, block, sh, stream, a); break;
+        default: MG_LAUNCH((gemm_big_kernel<EPI_HEADS>), grid, block, sh, stream, a); break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// decode-step GEMM (M <= 32*MT live sequences): HBM-bound weight streaming.  One workgroup per 32 output
+// features; its 4 waves split K, each streaming its weight fragments straight to registers (one contiguous
+// 1 KiB wave-load per fragment, no LDS round trip for a stream that is read once), the activation fragments
+// come from L2.  Partial accumulators are combined through LDS in a fixed order (deterministic).
+// ---------------------------------------------------------------------------------------------------------
+template <int EPI, int MT>
+__global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a) {
+    MG_DYN_SMEM(smem);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nt = blockIdx.x;
+    const int kt16 = a.K >> 4;
+    const int per = (kt16 + 3) >> 2;
+    const int k0 = w * per, k1 = (k0 + per) < kt16 ? (k0 + per) : kt16;
+    constexpr bool TOR = !(EPI == EPI_F32_STORE || EPI == EPI_F32_RESID);
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = acc_zero();
+    const char* wp = (const char*)(a.W + pk_tile_off(nt, 0, a.K)) + lane * 16;
+    const char* xp = (const char*)a.X + lane * 16;
+    constexpr int U = 4;
+    int kt = k0;
+    for (; kt + U <= k1; kt += U) {
+        uint4 wf[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) wf[u] = ld16(wp + (size_t)(kt + u) * TILE_BYTES);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const uint4 xf = ld16(xp + ((size_t)i * kt16 + (kt + u)) * TILE_BYTES);
+                acc[i] = TOR ? mfma32(wf[u], xf, acc[i]) : mfma32(xf, wf[u], acc[i]);
+            }
+        }
+    }
+    for (; kt < k1; ++kt) {
+        const uint4 wf = ld16(wp + (size_t)kt * TILE_BYTES);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const uint4 xf = ld16(xp + ((size_t)i * kt16 + kt) * TILE_BYTES);
+            acc[i] = TOR ? mfma32(wf, xf, acc[i]) : mfma32(xf, wf, acc[i]);
+        }
+    }
+    // combine the 4 K-slices: slab[w][i][r][lane]
+    float* slab = (float*)smem;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slab[((w * MT + i) * 16 + r) * 64 + lane] = acc[i][r];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        if ((i & 3) != w) continue;
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = slab[((0 * MT + i) * 16 + r) * 64 + lane];
+            v += slab[((1 * MT + i) * 16 + r) * 64 + lane];
+            v += slab[((2 * MT + i) * 16 + r) * 64 + lane];
+            v += slab[((3 * MT + i) * 16 + r) * 64 + lane];
+            s[r] = v;
+        }
+        tile_epilogue<EPI, TOR>(a, s, 32 * i, 32 * nt, lane);
+    }
+}
+
+template <int EPI>
+static void gemm_rows_mt(const GemmArgs& a, int mt, mgStream_t stream) {
+    const dim3 grid((a.N + 31) / 32), block(256);
+    const size_t sh = (size_t)4 * mt * 16 * 64 * sizeof(float);
+    switch (mt) {
+        case 1: MG_LAUNCH((gemm_rows_kernel<EPI, 1>), grid, block, sh, stream, a); break;
+        case 2: MG_LAUNCH((gemm_rows_kernel<EPI, 2>), grid, block, sh, stream, a); break;
+        case 3: MG_LAUNCH((gemm_rows_kernel<EPI, 3>), grid, block, sh, stream, a); break;
+        case 4: MG_LAUNCH((gemm_rows_kernel<EPI, 4>), grid, block, sh, stream, a); break;
+        case 5: MG_LAUNCH((gemm_rows_kernel<EPI, 5>), grid, block, sh, stream, a); break;
+        case 6: MG_LAUNCH((gemm_rows_kernel<EPI, 6>), grid, block, sh, stream, a); break;
+        default: break;
+    }
+}
+
+void gemm_rows(const GemmArgs& a, int epi, mgStream_t stream) {
+    const int mt = (a.M + 31) / 32;
+    if (mt > 6) {   // many live rows (large beam batches): the tiled kernel is the better shape
+        gemm(a, epi, stream);
+        return;
+    }
+    switch (epi) {
+        case EPI_F32_STORE: gemm_rows_mt<EPI_F32_STORE>(a, mt, stream); break;
+        case EPI_F32_RESID: gemm_rows_mt<EPI_F32_RESID>(a, mt, stream); break;
+        case EPI_PK_RELU: gemm_rows_mt<EPI_PK_RELU>(a, mt, stream); break;
+        case EPI_PK: gemm_rows_mt<EPI_PK>(a, mt, stream); break;
+        default: gemm_rows_mt<EPI_HEADS>(a, mt, stream); break;
+    }
+}
+
+}  // namespace mg

@@ -1,0 +1,157 @@
+// Device-side vocabulary shared by all kernels: bf16 helpers, the MFMA fragment tile format, wave shuffles,
+// direct global->LDS copies.  Target: gfx950 (MI355X, CDNA4) only.  With -DMG_EMU the same sources compile
+// under g++ against tools/simt_emu (test infrastructure; never part of the product build).
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef MG_EMU
+#include "simt_emu.h"
+#define MG_DYN_SMEM(name) char* name = emu::smem()
+#define MG_LAUNCH(kern, grid, block, shmem, stream, ...) \
+    emu::launch(grid, block, shmem, [=]() { kern(__VA_ARGS__); })
+typedef void* mgStream_t;
+struct f32x16 {
+    float v[16];
+    float& operator[](int i) { return v[i]; }
+    const float& operator[](int i) const { return v[i]; }
+};
+#else
+#include <hip/hip_runtime.h>
+#define MG_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#define MG_LAUNCH(kern, grid, block, shmem, stream, ...) \
+    hipLaunchKernelGGL(kern, grid, block, shmem, stream, __VA_ARGS__)
+typedef hipStream_t mgStream_t;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 mg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 mg_bf16x2 __attribute__((ext_vector_type(2)));
+#endif
+
+#define MG_DEV __device__ __forceinline__
+#define MG_HD __host__ __device__ __forceinline__
+
+namespace mg {
+
+constexpr int WAVE = 64;
+// Packed "fragment tile" format used for every MFMA operand kept in HBM (weights and activations):
+// a matrix X[R][K] (bf16) is stored as [R/32][K/16] tiles of 1 KiB; inside a tile the order is
+// [k-half (2)][row (32)][8 consecutive k] so that lane l of a wave reads its v_mfma_f32_32x32x16_bf16
+// operand (row l%32, k = 8*(l/32)..+7) as ONE 16-byte load at tile_base + 16*l: a wave-load is 1 KiB
+// contiguous, and a global_load_lds copy lands in LDS already in fragment order (conflict-free b128 reads).
+constexpr int TILE_ELEMS = 512;
+constexpr int TILE_BYTES = 1024;
+
+MG_HD size_t pk_tile_off(int rt, int kt, int K) { return ((size_t)rt * (size_t)(K >> 4) + (size_t)kt) * TILE_ELEMS; }
+MG_HD size_t pk_off(int r, int k, int K) {
+    return pk_tile_off(r >> 5, k >> 4, K) + (size_t)(((k >> 3) & 1) * 256 + (r & 31) * 8 + (k & 7));
+}
+MG_HD size_t pk_elems(int R, int K) { return (size_t)((R + 31) / 32) * (size_t)(K / 16) * TILE_ELEMS; }
+
+MG_DEV float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+MG_DEV float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
+MG_DEV float bf16hi(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
+// round-to-nearest-even fp32 -> bf16 (finite inputs)
+MG_DEV uint16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+MG_DEV uint32_t pack_bf16(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+MG_DEV f32x16 acc_zero() {
+    f32x16 c;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c[i] = 0.f;
+    return c;
+}
+
+// D = A·B + C for one 32x32x16 bf16 tile.  a: lane holds A[row = l%32][k = 8*(l/32)+0..7];
+// b: lane holds B[k = 8*(l/32)+0..7][col = l%32];  result: lane holds D[row = (r%4)+8*(r/4)+4*(l/32)][col = l%32].
+MG_DEV f32x16 mfma32(const uint4& a, const uint4& b, const f32x16& c) {
+#ifdef MG_EMU
+    f32x16 d = c;
+    emu::mfma_32x32x16_bf16((const uint16_t*)&a, (const uint16_t*)&b, d.v);
+    return d;
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mg_bf16x8, a), __builtin_bit_cast(mg_bf16x8, b),
+                                                   c, 0, 0, 0);
+#endif
+}
+// row of D held in accumulator register r by this lane
+MG_DEV int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// 16-byte direct global->LDS copy: every lane supplies its own source address, the destination is
+// lds_wave_base + 16*lane (wave-uniform base).
+MG_DEV void glds16(const void* gsrc_lane, void* lds_wave_base) {
+#ifdef MG_EMU
+    emu::glds16(gsrc_lane, lds_wave_base);
+#else
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+#endif
+}
+
+MG_DEV uint4 ld16(const void* p) { return *(const uint4*)p; }
+MG_DEV void st16(void* p, const uint4& v) { *(uint4*)p = v; }
+
+// two packed bf16 pairs dotted into an fp32 accumulator
+MG_DEV float dot2_bf16(uint32_t a, uint32_t b, float acc) {
+#ifdef MG_EMU
+    return acc + bf16lo(a) * bf16lo(b) + bf16hi(a) * bf16hi(b);
+#else
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(mg_bf16x2, a), __builtin_bit_cast(mg_bf16x2, b), acc, false);
+#endif
+}
+
+MG_DEV float fast_exp(float x) {
+#ifdef MG_EMU
+    return expf(x);
+#else
+    return __expf(x);
+#endif
+}
+
+MG_DEV float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+MG_DEV float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+
+// Turn one 32x32 accumulator tile into 16-byte bf16 chunks of 8 consecutive ROW indices for this lane's column.
+// In: v[r] = value at D[acc_row(r, half)][lane%32].  Out: chunk[q] (q = 0,1) holds rows 16q + 8*half .. +7 of
+// column lane%32 as 8 packed bf16.  (The halves hold interleaved groups of 4 rows; one exchange with lane^32
+// completes each group of 8.)
+struct PackedAcc { uint32_t p[4][2]; };   // p[g] = rows 8g + 4*half + {0,1},{2,3}
+MG_DEV PackedAcc acc_pack(const f32x16& v) {
+    PackedAcc o;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        o.p[g][0] = pack_bf16(v[4 * g + 0], v[4 * g + 1]);
+        o.p[g][1] = pack_bf16(v[4 * g + 2], v[4 * g + 3]);
+    }
+    return o;
+}
+MG_DEV void packed_to_chunks(const PackedAcc& a, int half, uint4 chunk[2]) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        uint32_t s0 = half ? a.p[2 * q][0] : a.p[2 * q + 1][0];
+        uint32_t s1 = half ? a.p[2 * q][1] : a.p[2 * q + 1][1];
+        uint32_t r0 = __shfl_xor(s0, 32);
+        uint32_t r1 = __shfl_xor(s1, 32);
+        if (half == 0) chunk[q] = make_uint4(a.p[2 * q][0], a.p[2 * q][1], r0, r1);
+        else chunk[q] = make_uint4(r0, r1, a.p[2 * q + 1][0], a.p[2 * q + 1][1]);
+    }
+}
+MG_DEV void acc_to_chunks(const f32x16& v, int half, uint4 chunk[2]) {
+    const PackedAcc a = acc_pack(v);
+    packed_to_chunks(a, half, chunk);
+}
+
+}  // namespace mg

@@ -1,0 +1,161 @@
+// Host-side launchers for the HIP kernels of the MarkushGrapher-2 VTL encoder / CXSMILES decoder path.
+// Every launcher only enqueues work on `stream`; no allocation, no synchronisation.
+#pragma once
+#include "mg_device.h"
+
+namespace mg {
+
+// ---------------------------------------------------------------------------------------------
+// GEMM  out[m][n] = sum_k X[m][k] * W[n][k]   (X, W bf16 in the packed fragment-tile format, fp32 accumulate)
+// ---------------------------------------------------------------------------------------------
+enum GemmEpi : int {
+    EPI_F32_STORE = 0,   // out_f32[m*ldo + n] = acc (+ bias[n])                       (patch embed, logits)
+    EPI_F32_RESID = 1,   // out_f32[m*ldo + n] += acc                                   (attention O, FFN wo)
+    EPI_PK_RELU = 2,     // out_pk packed [M][N] = bf16(relu(acc))                      (FFN wi)
+    EPI_PK = 3,          // out_pk packed [M][N] = bf16(acc)
+    EPI_HEADS = 4,       // per-head Q/K/V targets, see HeadsOut                        (QKV and cross-K/V projections)
+};
+// Destination formats for per-head projections (head dim fixed at 64):
+enum HeadFmt : int {
+    HF_NONE = 0,
+    HF_PK_ROWS = 1,   // [B][H][S_cap/32][4][512]  rows = token, k = head dim   (MFMA operand for Q·K^T)
+    HF_PK_T = 2,      // [B][H][2][S_cap/16][512]  rows = head dim, k = token   (MFMA operand for P·V)
+    HF_NATURAL = 3,   // [B][H][S_cap][64]         row = row_map[token] (or token)  (single-query decode streams)
+    HF_STEP_Q = 4,    // decode step: token m is sequence row m -> [rows][H][64]
+    HF_STEP_KV = 5,   // decode step: -> cache[row][H][S_cap][64] at position `pos`
+};
+struct HeadsOut {
+    uint16_t* ptr[3];      // target of column region n / inner
+    int fmt[3];
+    int inner;             // H * 64
+    int H;
+    int S_in;              // tokens per batch item in the GEMM's row space (m = b*S_in + s)
+    int S_cap;             // token capacity of the destination per (b,h)
+    const int* row_map;    // HF_NATURAL: destination row of token m, or -1 to drop (nullable)
+    int pos;               // HF_STEP: cache position written
+};
+struct GemmArgs {
+    const uint16_t* X;
+    const uint16_t* W;
+    int M, N, K;
+    float* out_f32;
+    int ldo;
+    const float* bias;
+    uint16_t* out_pk;
+    HeadsOut heads;
+};
+void gemm(const GemmArgs& a, int epi, mgStream_t stream);
+
+// small-M (decode step) GEMM: M <= 32*MT rows of live sequences, weights streamed once.
+void gemm_rows(const GemmArgs& a, int epi, mgStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// normalisation / packing
+// ---------------------------------------------------------------------------------------------
+// x_pk[M][d] (packed bf16) = RMSNorm(h[M][d] fp32) * gain * scale ; optionally also out_f32 row-major
+void rmsnorm_pack(const float* h, const float* gain, uint16_t* x_pk, float* out_f32, int M, int d, float eps,
+                  float scale, mgStream_t stream);
+// HF [N][K] weight (fp32 or bf16 bits) -> packed bf16 tiles, rows >= N zero
+void pack_weight(const void* src, int src_is_bf16, int N, int K, uint16_t* dst, int Npad, mgStream_t stream);
+void convert_to_f32(const void* src, int src_is_bf16, float* dst, size_t n, mgStream_t stream);
+void convert_to_bf16(const void* src, int src_is_bf16, uint16_t* dst, size_t n, mgStream_t stream);
+// pixel_values [B][C][I][I] fp32 -> packed bf16 im2col matrix [B*P][C*ps*ps]
+void im2col_pack(const float* pix, uint16_t* x_pk, int B, int C, int I, int ps, mgStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// encoder input assembly (combine_image_text_embeddings + cell embedding)
+// ---------------------------------------------------------------------------------------------
+struct EmbedArgs {
+    const int64_t* input_ids;   // [B][L]
+    const float* bbox;          // [B][L][4]
+    const uint8_t* attn_mask;   // [B][L] or null (null = everything attended, incl. visual padding)
+    const float* patch_emb;     // [B][P][d] fp32
+    const uint16_t* tok_emb;    // [V][d] bf16
+    const uint16_t* x_emb;      // [M2][d] bf16
+    const uint16_t* y_emb;      // [M2][d] bf16
+    int B, L, P, d, n_side, M2, V, S_cap;
+    float* hidden;              // [B][S_cap][d]
+    double* cx;                 // [B][S_cap]  box x-centre (float64 as in the reference)
+    double* cy;
+    uint8_t* mask;              // [B][S_cap]  1 = attended
+    int* xrow;                  // [B][S_cap]  compacted cross-attention row of token s, -1 if masked
+    int* xlen;                  // [B]         number of attended tokens
+    int* err;                   // device error word (bit 0: token id out of range)
+};
+void embed_assemble(const EmbedArgs& a, mgStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// attention over packed Q/K/V^T (encoder self-attention, teacher-forced decoder self- and cross-attention)
+// ---------------------------------------------------------------------------------------------
+enum AttnMode : int { ATT_ENC = 0, ATT_DEC_SELF = 1, ATT_CROSS = 2 };
+struct AttnArgs {
+    const uint16_t* Q;      // HF_PK_ROWS [B][H][Sq_cap/32][4][512]
+    const uint16_t* K;      // HF_PK_ROWS [B][H][Sk_cap/32][4][512]
+    const uint16_t* Vt;     // HF_PK_T    [B][H][2][Sk_cap/16][512]
+    uint16_t* ctx;          // packed [B*Sq_cap][H*64]
+    int B, H, Sq, Sk, Sq_cap, Sk_cap;
+    int mode;
+    const uint8_t* kmask;   // [B][Sk_cap] 1 = attended (nullable = all Sk attended)
+    // ATT_ENC bias: tab1[clamp(j-i)+128][H], tabh/tabv[trunc((c_j-c_i)*100)+100][H]
+    const float* tab1;      // [257][H]  (ENC)  or [Tmax][H] indexed by i-j >= 0 (DEC_SELF)
+    const float* tabh;      // [201][H]
+    const float* tabv;      // [201][H]
+    const double* cx;       // [B][Sk_cap]
+    const double* cy;
+    int tab1_len;
+};
+void attention(const AttnArgs& a, mgStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// decode step (single query per live sequence)
+// ---------------------------------------------------------------------------------------------
+struct AttnStepArgs {
+    const uint16_t* q;        // [rows][H][64] bf16
+    const uint16_t* Kc;       // self: [rows_phys][H][T_cap][64]; cross: [B][H][S_cap][64]
+    const uint16_t* Vc;
+    uint16_t* ctx;            // packed [rows_pad][H*64]
+    int rows, H, group;       // group = beams sharing one cross K/V (1 for self-attention)
+    int cap;                  // T_cap or S_cap
+    const int* len;           // per K/V owner: number of keys (cross: xlen[b]); null = use `n_keys`
+    int n_keys;               // self: t+1
+    const float* bias;        // self: [T_cap][H] indexed by distance t - j (nullable)
+    const int* anc;           // self with beams: [T_cap][rows] physical row holding position j (nullable)
+    int t;                    // current position (self)
+};
+void attention_step(const AttnStepArgs& a, mgStream_t stream);
+
+// h[rows][d] = tok_emb[ids[row]]
+void embed_rows(const int64_t* ids, const uint16_t* tok_emb, float* h, int rows, int d, int V, int* err,
+                mgStream_t stream);
+
+struct ArgmaxArgs {
+    const float* logits;     // [rows][ldl]
+    int rows, V, ldl;
+    int eos, pad, suppress_eos;
+    int64_t* next_ids;       // [rows] token fed to the next step
+    int64_t* out_ids;        // [rows][max_len]
+    int max_len, pos;        // column written
+    int* unfinished;         // [rows]
+    int* n_unfinished;       // [1] recomputed
+    float* top2;             // [rows][2] (nullable) top-1 / top-2 logit of this step
+};
+void greedy_select(const ArgmaxArgs& a, mgStream_t stream);
+
+// beam search step on device: log-softmax + running scores, top-2K over K*V, bookkeeping (gen:3208-3525)
+struct BeamState;   // opaque layout in k_beam.hip
+size_t beam_state_bytes(int B, int K, int max_len);
+void beam_init(void* state, int B, int K, int max_len, int pad, int eos, int start, int64_t* next_ids, mgStream_t stream);
+void beam_step(void* state, const float* logits, int ldl, int V, int B, int K, int max_len, int cur_len, int eos,
+               float length_penalty, int early_stopping, int64_t* next_ids, int* beam_idx, int* cont_flag,
+               mgStream_t stream);
+void beam_finalize(void* state, int B, int K, int max_len, int64_t* out_ids, int* out_len, float* out_scores,
+                   mgStream_t stream);
+// ancestor-table form of the KV-cache reorder (cache_utils.py:100-104): anc[j][row] <- anc[j][beam_idx[row]]
+void beam_reorder_anc(int* anc, int* anc_tmp, const int* beam_idx, int rows, int t_written, int T_cap, mgStream_t stream);
+// physical form: dst[row] = src[beam_idx[row]] for every layer's K and V (micro-benchmark / reference behaviour)
+void beam_reorder_copy(const uint16_t* src, uint16_t* dst, const int* beam_idx, int rows, size_t row_elems,
+                       mgStream_t stream);
+
+int selftest_device(char* msg, int msg_len, mgStream_t stream);
+
+}  // namespace mg
