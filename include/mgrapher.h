@@ -1,5 +1,26 @@
-/* mgrapher.h — C ABI of libmgrapher_hip.so: the MI355X-native MarkushGrapher-2 VTL encoder + CXSMILES decoder
- * forward path.  (Work in progress: engine-level entry points are added below as they land.)
+/* mgrapher.h — C ABI of libmgrapher_hip.so
+ *
+ * MI355X-native (gfx950, hand-written HIP) implementation of ONE path of DS4SD/MarkushGrapher: the
+ * MarkushGrapher-2 VTL (UDOP) encoder + autoregressive CXSMILES decoder forward pass, i.e. what the reference
+ * reaches through its transformers fork (`transformers.models.markushgrapher`, imported at
+ * /root/reference/markushgrapher/core/common/begin.py:7-13):
+ *
+ *   mg_generate         replaces  model.generate(**encoding, num_beams, max_length)
+ *                                 /root/reference/markushgrapher/utils/ocsr/utils_evaluation.py:269-285
+ *   mg_encode + mg_decoder_forward
+ *                       replace   model(**sample).logits (teacher-forced forward)
+ *                                 /root/reference/markushgrapher/core/trainers/curriculumTrainer.py:654-656
+ *   mg_create / mg_load_tensor / mg_finalize
+ *                       replace   MarkushgrapherForConditionalGeneration.from_pretrained(...).to(device)
+ *                                 /root/reference/markushgrapher/core/common/begin.py:128-133
+ *   mg_beam_reorder     the KV-cache reorder of beam search (stock transformers cache_utils.py:100-104),
+ *                       exposed for the beam-reorder micro-benchmark (BASELINE.json configs[2])
+ *
+ * Conventions: plain pointers and sizes, no framework types.  Every `void* stream` is a hipStream_t.  Every data
+ * pointer is a DEVICE pointer unless the name ends in `_host`.  The caller owns all buffers (weights arena,
+ * workspace, inputs, outputs); the library allocates no device memory.  Calls only enqueue work on `stream`
+ * unless documented as synchronising.  Return value: 0 (MG_OK) or a negative MG_E_* code, message via
+ * mg_last_error() (thread-local).  One mg_model may be used from one thread at a time.
  */
 #ifndef MGRAPHER_H
 #define MGRAPHER_H
@@ -10,8 +31,76 @@ extern "C" {
 #endif
 
 enum { MG_OK = 0, MG_E_SHAPE = -1, MG_E_ARG = -2, MG_E_STATE = -3, MG_E_HIP = -4, MG_E_UNSUPPORTED = -5,
-       MG_E_WORKSPACE = -6, MG_E_KEY = -7 };
+       MG_E_WORKSPACE = -6, MG_E_KEY = -7, MG_E_INPUT = -8 };
+enum { MG_KEY_IGNORED = 1 };   /* mg_load_tensor: key recognised as not on this path (e.g. encoder.molscribe_*) */
+enum { MG_F32 = 0, MG_BF16 = 1 };
 
+/* UdopConfig fields the path reads (stock transformers models/udop/configuration_udop.py:43-71). */
+typedef struct mg_config {
+    int vocab_size, d_model, d_kv, d_ff, num_layers, num_decoder_layers, num_heads;
+    int relative_attention_num_buckets, relative_attention_max_distance;
+    int max_2d_position_embeddings, image_size, patch_size, num_channels;
+    int pad_token_id, eos_token_id, decoder_start_token_id;
+    float layer_norm_epsilon;
+    int max_decode_len;          /* capacity of the decoder self-attention cache / bias table (>= max_length) */
+} mg_config;
+
+typedef struct mg_model mg_model;
+
+int mg_create(const mg_config* cfg, mg_model** out);
+void mg_destroy(mg_model* m);
+const char* mg_last_error(void);
+
+/* Weights: caller allocates mg_weights_bytes() of device memory and binds it; mg_load_tensor converts one HF
+ * state-dict tensor (key = HF name, e.g. "encoder.block.0.layer.0.SelfAttention.q.weight"; device pointer;
+ * MG_F32 or MG_BF16) into the library's bf16 fragment-tile layout inside the arena. mg_finalize builds the derived
+ * bias tables, ties lm_head to shared.weight when lm_head.weight was not loaded, and checks completeness. */
+size_t mg_weights_bytes(const mg_model* m);
+int mg_bind_weights(mg_model* m, void* arena);
+int mg_load_tensor(mg_model* m, void* stream, const char* hf_key, const void* src, int dtype, const int64_t* shape,
+                   int ndim);
+int mg_finalize(mg_model* m, void* stream);
+
+/* Workspace for a batch of B images with L text tokens, num_beams beams, decoder length max_length and (for
+ * mg_decoder_forward) T teacher-forced positions (0 if unused). */
+int mg_workspace_bytes(const mg_model* m, int B, int L, int num_beams, int max_length, int T, size_t* out_bytes);
+
+/* Encoder (stock modeling_udop.py:1102-1246 for the encoder stack).  attention_mask may be NULL (= everything
+ * attended, incl. the zero-padded visual slots: stock:1183-1186).  Leaves the encoder state (final hidden states,
+ * mask, compaction map) in the workspace for mg_decoder_forward / mg_generate_from_encoded.
+ * enc_out [B][L+P][d_model] fp32 and enc_mask [B][L+P] u8 are optional outputs. */
+int mg_encode(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* input_ids, const float* bbox,
+              const uint8_t* attention_mask, const float* pixel_values, int B, int L, float* enc_out,
+              uint8_t* enc_mask);
+
+/* Teacher-forced decoder + lm_head over T positions (stock:1448-1574): logits [B][T][vocab] fp32.
+ * decoder_attention_mask may be NULL.  Requires a preceding mg_encode on the same workspace. */
+int mg_decoder_forward(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* decoder_input_ids,
+                       const uint8_t* decoder_attention_mask, int B, int T, float* logits);
+
+/* generate(): encoder once, then KV-cached decode.  num_beams == 1: greedy (stock generation/utils.py:2783-2975);
+ * num_beams > 1: beam search (utils.py:3208-3525, beams_to_keep = 2*num_beams, length_penalty, early_stopping 0/1).
+ * min_length suppresses EOS while the sequence is shorter (MinLengthLogitsProcessor).
+ * out_ids [B][max_length] i64 (row = [start, tok..., eos, pad...]); *out_cols_host = number of valid columns
+ * (the length HF's generate would return).  out_scores [B] (beam: sequences_scores; nullable).
+ * step_top2 [max_length][B*num_beams][2] fp32 top-1/top-2 logits per step (greedy only, nullable; parity tests).
+ * SYNCHRONISES the stream before returning. */
+int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* input_ids, const float* bbox,
+                const uint8_t* attention_mask, const float* pixel_values, int B, int L, int num_beams, int max_length,
+                int min_length, float length_penalty, int early_stopping, int64_t* out_ids, int* out_cols_host,
+                float* out_scores, float* step_top2);
+
+/* Beam-search KV-cache reorder, physical form: for every decoder layer, dst K/V rows [r] = src rows [beam_idx[r]]
+ * (cache_utils.py:100-104 index_select).  kv_src/kv_dst: [layers][2][rows][H][t_cap][64] bf16; only the first
+ * `t_used` positions of every row are copied. */
+int mg_beam_reorder(void* stream, const void* kv_src, void* kv_dst, const int32_t* beam_idx, int layers, int rows,
+                    int H, int t_cap, int t_used);
+
+/* Device self-test of the hardware assumptions the kernels rely on (MFMA fragment layout, global_load_lds
+ * destination rule, cross-half shuffle). Synchronises. msg_host receives a short report. */
+int mg_selftest(void* stream, void* scratch_256k, char* msg_host, int msg_len);
+
+/* ---- kernel-level operator entry points (used by the parity tests) ---- */
 int mgk_pack_weight(void* stream, const void* src, int src_is_bf16, int N, int K, void* dst_pk, int Npad);
 int mgk_rmsnorm_pack(void* stream, const float* h, const float* gain, void* x_pk, float* out_f32, int M, int d,
                      float eps, float scale);
@@ -20,6 +109,19 @@ int mgk_gemm(void* stream, int mode, int epi, const void* X_pk, const void* W_pk
              int ldo, const float* bias, void* out_pk);
 int mgk_gemm_heads(void* stream, int mode, const void* X_pk, const void* W_pk, int M, int N, int K, void* p0, void* p1,
                    void* p2, int f0, int f1, int f2, int H, int S_in, int S_cap, const int* row_map, int pos);
+int mgk_attention(void* stream, int mode, const void* Q, const void* K, const void* Vt, void* ctx_pk, int B, int H,
+                  int Sq, int Sk, int Sq_cap, int Sk_cap, const uint8_t* kmask, const float* tab1, int tab1_len,
+                  const float* tabh, const float* tabv, const double* cx, const double* cy);
+int mgk_attention_step(void* stream, const void* q, const void* Kc, const void* Vc, void* ctx_pk, int rows, int H,
+                       int group, int cap, const int* len, int n_keys, const float* bias, const int* anc, int t);
+int mgk_embed_assemble(void* stream, void* meta_ws, const int64_t* input_ids, const float* bbox,
+                       const uint8_t* attention_mask, const float* patch_emb, const void* tok_emb, const void* x_emb,
+                       const void* y_emb, int B, int L, int P, int d, int n_side, int M2, int V, int S_cap,
+                       float* hidden, double* cx, double* cy, uint8_t* mask, int* xrow, int* xlen, int* err);
+size_t mgk_embed_meta_bytes(int B, int S_cap);
+int mgk_greedy_select(void* stream, const float* logits, int rows, int V, int ldl, int eos, int pad, int min_len,
+                      int64_t* next_ids, int64_t* out_ids, int max_len, int pos, int* unfinished, int* n_unfinished,
+                      float* top2);
 
 #ifdef __cplusplus
 }

@@ -50,4 +50,54 @@ int mgk_gemm_heads(void* stream, int mode, const void* X_pk, const void* W_pk, i
     return MG_OK;
 }
 
+int mgk_attention(void* stream, int mode, const void* Q, const void* K, const void* Vt, void* ctx_pk, int B, int H,
+                  int Sq, int Sk, int Sq_cap, int Sk_cap, const uint8_t* kmask, const float* tab1, int tab1_len,
+                  const float* tabh, const float* tabv, const double* cx, const double* cy) {
+    if ((Sq_cap & 31) || (Sk_cap & 63) || Sk > Sk_cap || Sq > Sq_cap || mode < 0 || mode > 2) return MG_E_SHAPE;
+    AttnArgs a{};
+    a.Q = (const uint16_t*)Q; a.K = (const uint16_t*)K; a.Vt = (const uint16_t*)Vt; a.ctx = (uint16_t*)ctx_pk;
+    a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.Sq_cap = Sq_cap; a.Sk_cap = Sk_cap; a.mode = mode; a.kmask = kmask;
+    a.tab1 = tab1; a.tab1_len = tab1_len; a.tabh = tabh; a.tabv = tabv; a.cx = cx; a.cy = cy;
+    attention(a, (mgStream_t)stream);
+    return MG_OK;
+}
+
+int mgk_attention_step(void* stream, const void* q, const void* Kc, const void* Vc, void* ctx_pk, int rows, int H,
+                       int group, int cap, const int* len, int n_keys, const float* bias, const int* anc, int t) {
+    if (group < 1 || group > 8) return MG_E_SHAPE;
+    AttnStepArgs a{};
+    a.q = (const uint16_t*)q; a.Kc = (const uint16_t*)Kc; a.Vc = (const uint16_t*)Vc; a.ctx = (uint16_t*)ctx_pk;
+    a.rows = rows; a.H = H; a.group = group; a.cap = cap; a.len = len; a.n_keys = n_keys; a.bias = bias; a.anc = anc;
+    a.t = t;
+    attention_step(a, (mgStream_t)stream);
+    return MG_OK;
+}
+
+size_t mgk_embed_meta_bytes(int B, int S_cap) { return embed_meta_bytes(B, S_cap); }
+
+int mgk_embed_assemble(void* stream, void* meta_ws, const int64_t* input_ids, const float* bbox,
+                       const uint8_t* attention_mask, const float* patch_emb, const void* tok_emb, const void* x_emb,
+                       const void* y_emb, int B, int L, int P, int d, int n_side, int M2, int V, int S_cap,
+                       float* hidden, double* cx, double* cy, uint8_t* mask, int* xrow, int* xlen, int* err) {
+    if (S_cap < L + P || (d & 3) || P != n_side * n_side) return MG_E_SHAPE;
+    EmbedArgs a{};
+    a.input_ids = input_ids; a.bbox = bbox; a.attn_mask = attention_mask; a.patch_emb = patch_emb;
+    a.tok_emb = (const uint16_t*)tok_emb; a.x_emb = (const uint16_t*)x_emb; a.y_emb = (const uint16_t*)y_emb;
+    a.B = B; a.L = L; a.P = P; a.d = d; a.n_side = n_side; a.M2 = M2; a.V = V; a.S_cap = S_cap;
+    a.hidden = hidden; a.cx = cx; a.cy = cy; a.mask = mask; a.xrow = xrow; a.xlen = xlen; a.err = err;
+    embed_assemble(a, meta_ws, (mgStream_t)stream);
+    return MG_OK;
+}
+
+int mgk_greedy_select(void* stream, const float* logits, int rows, int V, int ldl, int eos, int pad, int min_len,
+                      int64_t* next_ids, int64_t* out_ids, int max_len, int pos, int* unfinished, int* n_unfinished,
+                      float* top2) {
+    ArgmaxArgs a{};
+    a.logits = logits; a.rows = rows; a.V = V; a.ldl = ldl; a.eos = eos; a.pad = pad; a.min_len = min_len;
+    a.next_ids = next_ids; a.out_ids = out_ids; a.max_len = max_len; a.pos = pos; a.unfinished = unfinished;
+    a.n_unfinished = n_unfinished; a.top2 = top2;
+    greedy_select(a, (mgStream_t)stream);
+    return MG_OK;
+}
+
 }  // extern "C"

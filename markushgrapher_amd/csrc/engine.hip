@@ -1,0 +1,733 @@
+// Engine: the C ABI of include/mgrapher.h on top of the HIP kernels — weight arena layout and loading, workspace
+// carving, the VTL encoder, the teacher-forced decoder, and the KV-cached greedy / beam-search generate loop.
+// Host code only orchestrates launches on the caller's stream; every byte of model arithmetic runs in HIP kernels.
+#include "mg_kernels.h"
+#include "../../include/mgrapher.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace mg;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+int round_up(int x, int a) { return (x + a - 1) / a * a; }
+
+struct EncLayer { size_t wqkv, wo, ln0, wi, wo2, ln1; };
+struct DecLayer { size_t wqkv, wo, ln0, xq, xkv, xo, ln1, wi, wo2, ln2; };
+
+}  // namespace
+
+struct mg_model {
+    mg_config c;
+    int d, H, inner, dff, V, P, n_side, Kpatch, M2, T_cap;
+    char* arena = nullptr;
+    size_t arena_bytes = 0;
+    size_t tok_emb, lm_head, patch_w, patch_b, x_emb, y_emb, rb_raw[3], rb_dec_raw, tab1, tabh, tabv, dec_tab;
+    size_t bk1, bkhv, bkdec, enc_ln, dec_ln;
+    std::vector<EncLayer> enc;
+    std::vector<DecLayer> dec;
+    std::map<std::string, bool> loaded;
+    bool lm_head_loaded = false, finalized = false;
+    std::vector<int> h_bk1, h_bkhv, h_bkdec;
+    // encoder state left in the workspace by the last mg_encode
+    int st_B = 0, st_L = 0, st_S = 0, st_Scap = 0;
+    void* st_ws = nullptr;
+
+    template <typename T> T* at(size_t off) const { return (T*)(arena + off); }
+};
+
+namespace {
+
+// stock:422-468 bucket function on integer distances.  The reference evaluates
+// max_exact + trunc(log(n/max_exact)/log(max_distance/max_exact)*(nb-max_exact)) in fp32; integer n sit exactly
+// on a bucket edge only when n/max_exact is an exact power (e.g. 16, 32, 64 for max_distance 128), where torch
+// yields the clean integer — reproduced here in long double with a tiny upward nudge, and pinned against the
+// torch-evaluated golden table in tests/golden/bucket_tables.npz.
+int bucket_of(long rel, bool bidirectional, int num_buckets, int max_distance) {
+    int ret = 0;
+    long n;
+    if (bidirectional) {
+        num_buckets /= 2;
+        if (rel > 0) ret += num_buckets;
+        n = rel < 0 ? -rel : rel;
+    } else {
+        n = rel < 0 ? -rel : 0;
+    }
+    const int max_exact = num_buckets / 2;
+    if (n < max_exact) return ret + (int)n;
+    long double v = logl((long double)n / max_exact) / logl((long double)max_distance / max_exact) * (num_buckets - max_exact);
+    int large = max_exact + (int)floorl(v + 1e-9L);
+    if (large > num_buckets - 1) large = num_buckets - 1;
+    return ret + large;
+}
+
+__global__ __launch_bounds__(256) void build_table_kernel(const float* raw, const int* bucket, float* out, int n, int H) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n * H; i += gridDim.x * blockDim.x)
+        out[i] = raw[bucket[i / H] * H + (i % H)];
+}
+
+__global__ __launch_bounds__(256) void fill_ids_kernel(int64_t* next_ids, int64_t* out_ids, int* unfinished, int* counters, int rows,
+                                                  int max_len, int64_t start, int64_t pad) {
+    const int r = blockIdx.x;
+    for (int j = threadIdx.x; j < max_len; j += blockDim.x) out_ids[(size_t)r * max_len + j] = (j == 0) ? start : pad;
+    if (threadIdx.x == 0) {
+        next_ids[r] = start;
+        unfinished[r] = 1;
+        if (r == 0) { counters[0] = rows; counters[1] = -1; counters[2] = 0; counters[3] = 0; }
+    }
+}
+// counters: [0] n_unfinished, [1] done_step (first step after which every row had finished), [2] step, [3] input errors
+__global__ void step_end_kernel(int* counters) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (counters[0] == 0 && counters[1] < 0) counters[1] = counters[2];
+        counters[2] += 1;
+    }
+}
+// teacher-forced decoder: pad [B][T] ids to [B][T_cap] rows and build the compact-row map of the valid positions
+__global__ __launch_bounds__(256) void pad_dec_inputs_kernel(const int64_t* ids, const uint8_t* mask, int64_t* ids_pad, uint8_t* mask_pad,
+                                                        int* dst_row, int B, int T, int T_cap) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * T_cap; i += gridDim.x * blockDim.x) {
+        const int b = i / T_cap, t = i - b * T_cap;
+        const bool in = t < T;
+        ids_pad[i] = in ? ids[(size_t)b * T + t] : 0;
+        mask_pad[i] = in ? (mask ? (mask[(size_t)b * T + t] != 0) : 1) : 0;
+        dst_row[i] = in ? b * T + t : -1;
+    }
+}
+__global__ __launch_bounds__(256) void copy_rows_kernel(const float* src, float* dst, int B, int S, int S_cap, int d) {
+    const size_t n = (size_t)B * S * (d / 4);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / (d / 4), c = i - row * (d / 4);
+        const size_t b = row / S, s = row - b * S;
+        ((float4*)dst)[i] = ((const float4*)src)[(b * S_cap + s) * (d / 4) + c];
+    }
+}
+__global__ __launch_bounds__(256) void copy_bytes_rows_kernel(const uint8_t* src, uint8_t* dst, int B, int S, int S_cap) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * S; i += gridDim.x * blockDim.x) {
+        const int b = i / S, s = i - b * S;
+        dst[i] = src[(size_t)b * S_cap + s];
+    }
+}
+
+// ---- workspace -------------------------------------------------------------------------------------------
+struct Ws {
+    // encoder
+    uint16_t *xim, *x_pk, *q_pk, *k_pk, *vt_pk, *ctx_pk, *y_pk, *enc_pk;
+    float *patch_emb, *hidden, *enc_f32;
+    void* meta;
+    double *cx, *cy;
+    uint8_t* mask;
+    int *xrow, *xlen, *counters;
+    // decode (generate)
+    uint16_t *xk, *xv, *sk, *sv, *dq, *dx_pk, *dctx_pk, *dy_pk;
+    float *dh, *logits;
+    int64_t* next_ids;
+    int *unfinished, *anc, *anc_tmp, *beam_idx;
+    void* beam_state;
+    // teacher-forced decoder
+    int64_t* tf_ids;
+    uint8_t* tf_mask;
+    int* tf_rowmap;
+    float* tf_hidden;
+    uint16_t *tf_x, *tf_q, *tf_k, *tf_vt, *tf_ctx, *tf_y, *tf_xk, *tf_xvt, *tf_xc;
+    size_t total;
+};
+
+struct Carver {
+    char* base;
+    size_t off = 0;
+    template <typename T> T* take(size_t n) {
+        off = align_up(off, 256);
+        T* p = base ? (T*)(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+void carve(const mg_model* m, char* base, int B, int L, int K, int max_len, int T, Ws* w) {
+    Carver c{base};
+    const int d = m->d, inner = m->inner, H = m->H;
+    const int S_cap = round_up(L + m->P, 64);
+    const size_t M = (size_t)B * S_cap;
+    const size_t MP = (size_t)round_up(B * m->P, 32);
+    w->xim = c.take<uint16_t>(MP * m->Kpatch);
+    w->patch_emb = c.take<float>(MP * d);
+    w->meta = c.take<char>(embed_meta_bytes(B, S_cap));
+    w->hidden = c.take<float>(M * d);
+    w->x_pk = c.take<uint16_t>(M * d);
+    w->q_pk = c.take<uint16_t>(M * inner);
+    w->k_pk = c.take<uint16_t>(M * inner);
+    w->vt_pk = c.take<uint16_t>(M * inner);
+    w->ctx_pk = c.take<uint16_t>(M * inner);
+    w->y_pk = c.take<uint16_t>(M * m->dff);
+    w->enc_pk = c.take<uint16_t>(M * d);
+    w->enc_f32 = c.take<float>(M * d);
+    w->cx = c.take<double>(M);
+    w->cy = c.take<double>(M);
+    w->mask = c.take<uint8_t>(M);
+    w->xrow = c.take<int>(M);
+    w->xlen = c.take<int>(B);
+    w->counters = c.take<int>(16);
+    if (max_len > 0) {
+        const int R = B * K, Rp = round_up(R, 32);
+        const size_t nl = m->dec.size();
+        w->xk = c.take<uint16_t>(nl * B * H * S_cap * 64);
+        w->xv = c.take<uint16_t>(nl * B * H * S_cap * 64);
+        w->sk = c.take<uint16_t>(nl * R * H * (size_t)m->T_cap * 64);
+        w->sv = c.take<uint16_t>(nl * R * H * (size_t)m->T_cap * 64);
+        w->dq = c.take<uint16_t>((size_t)Rp * inner);
+        w->dx_pk = c.take<uint16_t>((size_t)Rp * d);
+        w->dctx_pk = c.take<uint16_t>((size_t)Rp * inner);
+        w->dy_pk = c.take<uint16_t>((size_t)Rp * m->dff);
+        w->dh = c.take<float>((size_t)Rp * d);
+        w->logits = c.take<float>((size_t)Rp * round_up(m->V, 32));
+        w->next_ids = c.take<int64_t>(Rp);
+        w->unfinished = c.take<int>(Rp);
+        w->anc = c.take<int>((size_t)m->T_cap * R);
+        w->anc_tmp = c.take<int>((size_t)m->T_cap * R);
+        w->beam_idx = c.take<int>(Rp);
+        w->beam_state = c.take<char>(K > 1 ? beam_state_bytes(B, K, max_len) : 16);
+    }
+    if (T > 0) {
+        const int T_cap = round_up(T, 64);
+        const size_t MT = (size_t)B * T_cap;
+        w->tf_ids = c.take<int64_t>(MT);
+        w->tf_mask = c.take<uint8_t>(MT);
+        w->tf_rowmap = c.take<int>(MT);
+        w->tf_hidden = c.take<float>(MT * d);
+        w->tf_x = c.take<uint16_t>(MT * d);
+        w->tf_q = c.take<uint16_t>(MT * inner);
+        w->tf_k = c.take<uint16_t>(MT * inner);
+        w->tf_vt = c.take<uint16_t>(MT * inner);
+        w->tf_ctx = c.take<uint16_t>(MT * inner);
+        w->tf_y = c.take<uint16_t>(MT * m->dff);
+        w->tf_xk = c.take<uint16_t>(M * inner);
+        w->tf_xvt = c.take<uint16_t>(M * inner);
+        w->tf_xc = c.take<uint16_t>((size_t)round_up(B * T, 32) * d);
+    }
+    w->total = align_up(c.off, 256);
+}
+
+int check_launch(const char* what) {
+    const int e = mg_peek_error();
+    if (e != 0) return fail(MG_E_HIP, "%s: HIP error %d (%s)", what, e, mg_error_string(e));
+    return MG_OK;
+}
+
+GemmArgs gemm_args(const uint16_t* X, const uint16_t* W, int M, int N, int K) {
+    GemmArgs a{};
+    a.X = X; a.W = W; a.M = M; a.N = N; a.K = K;
+    return a;
+}
+void set_heads(GemmArgs& a, int H, int S_in, int S_cap, uint16_t* p0, int f0, uint16_t* p1, int f1, uint16_t* p2, int f2) {
+    a.heads.ptr[0] = p0; a.heads.ptr[1] = p1; a.heads.ptr[2] = p2;
+    a.heads.fmt[0] = f0; a.heads.fmt[1] = f1; a.heads.fmt[2] = f2;
+    a.heads.inner = H * 64; a.heads.H = H; a.heads.S_in = S_in; a.heads.S_cap = S_cap;
+}
+
+// one FFN sub-layer on M rows: hidden += wo2 · relu(wi · RMSNorm(hidden))
+void ffn_block(const mg_model* m, bool rows_mode, float* hidden, uint16_t* x_pk, uint16_t* y_pk, int M, size_t ln, size_t wi,
+               size_t wo2, mgStream_t st) {
+    rmsnorm_pack(hidden, m->at<float>(ln), x_pk, nullptr, M, m->d, m->c.layer_norm_epsilon, 1.0f, st);
+    GemmArgs a = gemm_args(x_pk, m->at<uint16_t>(wi), M, m->dff, m->d);
+    a.out_pk = y_pk;
+    rows_mode ? gemm_rows(a, EPI_PK_RELU, st) : gemm(a, EPI_PK_RELU, st);
+    GemmArgs b = gemm_args(y_pk, m->at<uint16_t>(wo2), M, m->d, m->dff);
+    b.out_f32 = hidden; b.ldo = m->d;
+    rows_mode ? gemm_rows(b, EPI_F32_RESID, st) : gemm(b, EPI_F32_RESID, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mg_last_error(void) { return g_err.c_str(); }
+
+int mg_create(const mg_config* cfg, mg_model** out) {
+    if (!cfg || !out) return fail(MG_E_ARG, "mg_create: null argument");
+    const mg_config& c = *cfg;
+    if (c.d_kv != 64) return fail(MG_E_UNSUPPORTED, "d_kv must be 64 (got %d)", c.d_kv);
+    if (c.d_model % 64 || c.d_ff % 64) return fail(MG_E_UNSUPPORTED, "d_model and d_ff must be multiples of 64");
+    if (c.image_size % c.patch_size || c.patch_size % 8) return fail(MG_E_UNSUPPORTED, "bad image/patch size");
+    const int Kpatch = c.num_channels * c.patch_size * c.patch_size;
+    if (Kpatch % 64) return fail(MG_E_UNSUPPORTED, "channels*patch^2 must be a multiple of 64");
+    if (c.num_heads < 1 || c.num_layers < 1 || c.num_decoder_layers < 1 || c.vocab_size < 2)
+        return fail(MG_E_ARG, "bad config");
+    mg_model* m = new mg_model();
+    m->c = c;
+    m->d = c.d_model; m->H = c.num_heads; m->inner = c.num_heads * 64; m->dff = c.d_ff; m->V = c.vocab_size;
+    m->n_side = c.image_size / c.patch_size; m->P = m->n_side * m->n_side; m->Kpatch = Kpatch;
+    m->M2 = c.max_2d_position_embeddings;
+    m->T_cap = round_up(c.max_decode_len > 0 ? c.max_decode_len : 512, 64);
+    // arena layout
+    size_t off = 0;
+    auto take = [&](size_t bytes) { off = align_up(off, 256); size_t o = off; off += bytes; return o; };
+    const int d = m->d, inner = m->inner, dff = m->dff, H = m->H;
+    m->tok_emb = take((size_t)m->V * d * 2);
+    m->lm_head = take(pk_elems(m->V, d) * 2);
+    m->patch_w = take(pk_elems(d, Kpatch) * 2);
+    m->patch_b = take((size_t)d * 4);
+    m->x_emb = take((size_t)m->M2 * d * 2);
+    m->y_emb = take((size_t)m->M2 * d * 2);
+    const int nb = c.relative_attention_num_buckets;
+    for (int i = 0; i < 3; ++i) m->rb_raw[i] = take((size_t)nb * H * 4);
+    m->rb_dec_raw = take((size_t)nb * H * 4);
+    m->tab1 = take((size_t)257 * H * 4);
+    m->tabh = take((size_t)201 * H * 4);
+    m->tabv = take((size_t)201 * H * 4);
+    m->dec_tab = take((size_t)m->T_cap * H * 4);
+    m->bk1 = take(257 * 4); m->bkhv = take(201 * 4); m->bkdec = take((size_t)m->T_cap * 4);
+    m->enc_ln = take((size_t)d * 4); m->dec_ln = take((size_t)d * 4);
+    for (int i = 0; i < c.num_layers; ++i) {
+        EncLayer l;
+        l.wqkv = take(pk_elems(3 * inner, d) * 2); l.wo = take(pk_elems(d, inner) * 2); l.ln0 = take((size_t)d * 4);
+        l.wi = take(pk_elems(dff, d) * 2); l.wo2 = take(pk_elems(d, dff) * 2); l.ln1 = take((size_t)d * 4);
+        m->enc.push_back(l);
+    }
+    for (int i = 0; i < c.num_decoder_layers; ++i) {
+        DecLayer l;
+        l.wqkv = take(pk_elems(3 * inner, d) * 2); l.wo = take(pk_elems(d, inner) * 2); l.ln0 = take((size_t)d * 4);
+        l.xq = take(pk_elems(inner, d) * 2); l.xkv = take(pk_elems(2 * inner, d) * 2); l.xo = take(pk_elems(d, inner) * 2);
+        l.ln1 = take((size_t)d * 4);
+        l.wi = take(pk_elems(dff, d) * 2); l.wo2 = take(pk_elems(d, dff) * 2); l.ln2 = take((size_t)d * 4);
+        m->dec.push_back(l);
+    }
+    m->arena_bytes = align_up(off, 256);
+    // host bucket tables
+    const int md = c.relative_attention_max_distance;
+    for (int i = 0; i < 257; ++i) m->h_bk1.push_back(bucket_of(i - 128, true, nb, 128));
+    for (int i = 0; i < 201; ++i) m->h_bkhv.push_back(bucket_of(i - 100, true, nb, 100));
+    for (int i = 0; i < m->T_cap; ++i) m->h_bkdec.push_back(bucket_of(-(long)i, false, nb, md));
+    *out = m;
+    return MG_OK;
+}
+
+void mg_destroy(mg_model* m) { delete m; }
+
+size_t mg_weights_bytes(const mg_model* m) { return m ? m->arena_bytes : 0; }
+
+int mg_bind_weights(mg_model* m, void* arena) {
+    if (!m || !arena) return fail(MG_E_ARG, "mg_bind_weights: null argument");
+    m->arena = (char*)arena;
+    m->loaded.clear();
+    m->lm_head_loaded = false;
+    m->finalized = false;
+    return MG_OK;
+}
+
+// host copies of the bucket tables the bias tables are built from (parity tests pin them on the golden tables)
+int mg_debug_bucket_table(const mg_model* m, int which, int* out_host, int n) {
+    const std::vector<int>& v = which == 0 ? m->h_bk1 : (which == 1 ? m->h_bkhv : m->h_bkdec);
+    if (n > (int)v.size()) n = (int)v.size();
+    for (int i = 0; i < n; ++i) out_host[i] = v[i];
+    return n;
+}
+
+int mg_load_tensor(mg_model* m, void* stream, const char* hf_key, const void* src, int dtype, const int64_t* shape,
+                   int ndim) {
+    if (!m || !hf_key || !src || !shape) return fail(MG_E_ARG, "mg_load_tensor: null argument");
+    if (!m->arena) return fail(MG_E_STATE, "mg_load_tensor: bind a weights arena first");
+    if (dtype != MG_F32 && dtype != MG_BF16) return fail(MG_E_ARG, "dtype must be MG_F32 or MG_BF16");
+    mgStream_t st = (mgStream_t)stream;
+    const std::string key(hf_key);
+    const int d = m->d, inner = m->inner, dff = m->dff, H = m->H, nb = m->c.relative_attention_num_buckets;
+    auto want = [&](std::initializer_list<int64_t> dims) {
+        if ((int)dims.size() != ndim) return false;
+        int i = 0;
+        for (int64_t v : dims) if (shape[i++] != v) return false;
+        return true;
+    };
+    auto bad_shape = [&]() { return fail(MG_E_SHAPE, "mg_load_tensor: unexpected shape for %s", hf_key); };
+    auto packw = [&](size_t off, int row0, int N, int K) {   // rows [row0, row0+N) of a packed [*,K] matrix
+        pack_weight(src, dtype, N, K, m->at<uint16_t>(off) + pk_elems(row0, K), round_up(N, 32), st);
+    };
+    auto vec32 = [&](size_t off, size_t n) { convert_to_f32(src, dtype, m->at<float>(off), n, st); };
+    auto mark = [&](const std::string& canon) { m->loaded[canon] = true; m->finalized = false; return check_launch(hf_key); };
+
+    if (key == "shared.weight" || key == "encoder.embed_tokens.weight" || key == "decoder.embed_tokens.weight") {
+        if (!want({m->V, d})) return bad_shape();
+        convert_to_bf16(src, dtype, m->at<uint16_t>(m->tok_emb), (size_t)m->V * d, st);
+        if (!m->lm_head_loaded) packw(m->lm_head, 0, m->V, d);    // tied unless lm_head.weight is loaded explicitly
+        return mark("shared.weight");
+    }
+    if (key == "lm_head.weight") {
+        if (!want({m->V, d})) return bad_shape();
+        packw(m->lm_head, 0, m->V, d);
+        m->lm_head_loaded = true;
+        return mark("lm_head.weight");
+    }
+    if (key == "patch_embed.proj.weight" || key == "encoder.embed_patches.proj.weight") {
+        if (!want({d, m->c.num_channels, m->c.patch_size, m->c.patch_size})) return bad_shape();
+        packw(m->patch_w, 0, d, m->Kpatch);
+        return mark("patch_embed.proj.weight");
+    }
+    if (key == "patch_embed.proj.bias" || key == "encoder.embed_patches.proj.bias") {
+        if (!want({d})) return bad_shape();
+        vec32(m->patch_b, d);
+        return mark("patch_embed.proj.bias");
+    }
+    if (key.rfind("decoder.embed_patches.", 0) == 0 || key.rfind("decoder.relative_bias.", 0) == 0)
+        return MG_KEY_IGNORED;   // present in UDOP state dicts, never used by the decoder (stock:1212-1213)
+    if (key.rfind("encoder.molscribe_", 0) == 0) return MG_KEY_IGNORED;   // OCSR e1 branch: SURVEY.md §8 a7 ("next" f-2)
+    if (key == "encoder.cell_2d_embedding.x_position_embeddings.weight" ||
+        key == "encoder.cell_2d_embedding.y_position_embeddings.weight") {
+        if (!want({m->M2, d})) return bad_shape();
+        const bool isx = key.find(".x_position") != std::string::npos;
+        convert_to_bf16(src, dtype, m->at<uint16_t>(isx ? m->x_emb : m->y_emb), (size_t)m->M2 * d, st);
+        return mark(key);
+    }
+    if (key == "encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight" ||
+        key == "encoder.relative_bias.biases.0.relative_attention_bias.weight") {
+        if (!want({nb, H})) return bad_shape();
+        vec32(m->rb_raw[0], (size_t)nb * H);
+        return mark("encoder.relative_bias.biases.0.relative_attention_bias.weight");
+    }
+    if (key == "encoder.relative_bias.biases.1.relative_attention_bias.weight" ||
+        key == "encoder.relative_bias.biases.2.relative_attention_bias.weight") {
+        if (!want({nb, H})) return bad_shape();
+        vec32(m->rb_raw[key[29] - '0'], (size_t)nb * H);
+        return mark(key);
+    }
+    if (key == "decoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight") {
+        if (!want({nb, H})) return bad_shape();
+        vec32(m->rb_dec_raw, (size_t)nb * H);
+        return mark(key);
+    }
+    if (key == "encoder.final_layer_norm.weight" || key == "decoder.final_layer_norm.weight") {
+        if (!want({d})) return bad_shape();
+        vec32(key[0] == 'e' ? m->enc_ln : m->dec_ln, d);
+        return mark(key);
+    }
+    int li = -1, sub = -1;
+    char rest[96] = {0};
+    const bool is_enc = sscanf(hf_key, "encoder.block.%d.layer.%d.%95s", &li, &sub, rest) == 3;
+    const bool is_dec = !is_enc && sscanf(hf_key, "decoder.block.%d.layer.%d.%95s", &li, &sub, rest) == 3;
+    if (is_enc || is_dec) {
+        const std::string r(rest);
+        if (li < 0 || li >= (int)(is_enc ? m->enc.size() : m->dec.size())) return fail(MG_E_KEY, "layer index out of range: %s", hf_key);
+        if (r == "layer_norm.weight") {
+            if (!want({d})) return bad_shape();
+            size_t off;
+            if (is_enc) { if (sub > 1) return fail(MG_E_KEY, "unknown key %s", hf_key); off = sub == 0 ? m->enc[li].ln0 : m->enc[li].ln1; }
+            else { if (sub > 2) return fail(MG_E_KEY, "unknown key %s", hf_key); off = sub == 0 ? m->dec[li].ln0 : (sub == 1 ? m->dec[li].ln1 : m->dec[li].ln2); }
+            vec32(off, d);
+            return mark(key);
+        }
+        const int ffn_sub = is_enc ? 1 : 2;
+        if (sub == ffn_sub && (r == "DenseReluDense.wi.weight" || r == "DenseReluDense.wo.weight")) {
+            const bool wi = r[15] == 'w' && r[16] == 'i';
+            if (wi) { if (!want({dff, d})) return bad_shape(); packw(is_enc ? m->enc[li].wi : m->dec[li].wi, 0, dff, d); }
+            else { if (!want({d, dff})) return bad_shape(); packw(is_enc ? m->enc[li].wo2 : m->dec[li].wo2, 0, d, dff); }
+            return mark(key);
+        }
+        const bool self_att = sub == 0 && r.rfind("SelfAttention.", 0) == 0 && r.size() == 22 && r.substr(15) == ".weight";
+        const bool cross_att = is_dec && sub == 1 && r.rfind("EncDecAttention.", 0) == 0 && r.size() == 24 && r.substr(17) == ".weight";
+        if (self_att || cross_att) {
+            const char p = self_att ? r[14] : r[16];
+            if (p == 'o') {
+                if (!want({d, inner})) return bad_shape();
+                packw(self_att ? (is_enc ? m->enc[li].wo : m->dec[li].wo) : m->dec[li].xo, 0, d, inner);
+                return mark(key);
+            }
+            if (p != 'q' && p != 'k' && p != 'v') return fail(MG_E_KEY, "unknown key %s", hf_key);
+            if (!want({inner, d})) return bad_shape();
+            if (self_att) packw(is_enc ? m->enc[li].wqkv : m->dec[li].wqkv, (p == 'q' ? 0 : (p == 'k' ? 1 : 2)) * inner, inner, d);
+            else if (p == 'q') packw(m->dec[li].xq, 0, inner, d);
+            else packw(m->dec[li].xkv, (p == 'k' ? 0 : 1) * inner, inner, d);
+            return mark(key);
+        }
+    }
+    return fail(MG_E_KEY, "mg_load_tensor: unknown key %s", hf_key);
+}
+
+int mg_finalize(mg_model* m, void* stream) {
+    if (!m || !m->arena) return fail(MG_E_STATE, "mg_finalize: no weights bound");
+    mgStream_t st = (mgStream_t)stream;
+    std::vector<std::string> need = {
+        "shared.weight", "patch_embed.proj.weight", "patch_embed.proj.bias",
+        "encoder.cell_2d_embedding.x_position_embeddings.weight", "encoder.cell_2d_embedding.y_position_embeddings.weight",
+        "encoder.relative_bias.biases.0.relative_attention_bias.weight",
+        "encoder.relative_bias.biases.1.relative_attention_bias.weight",
+        "encoder.relative_bias.biases.2.relative_attention_bias.weight",
+        "decoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight",
+        "encoder.final_layer_norm.weight", "decoder.final_layer_norm.weight"};
+    char buf[160];
+    for (size_t i = 0; i < m->enc.size(); ++i) {
+        for (const char* s : {"0.SelfAttention.q.weight", "0.SelfAttention.k.weight", "0.SelfAttention.v.weight",
+                              "0.SelfAttention.o.weight", "0.layer_norm.weight", "1.DenseReluDense.wi.weight",
+                              "1.DenseReluDense.wo.weight", "1.layer_norm.weight"}) {
+            snprintf(buf, sizeof buf, "encoder.block.%zu.layer.%s", i, s);
+            need.push_back(buf);
+        }
+    }
+    for (size_t i = 0; i < m->dec.size(); ++i) {
+        for (const char* s : {"0.SelfAttention.q.weight", "0.SelfAttention.k.weight", "0.SelfAttention.v.weight",
+                              "0.SelfAttention.o.weight", "0.layer_norm.weight", "1.EncDecAttention.q.weight",
+                              "1.EncDecAttention.k.weight", "1.EncDecAttention.v.weight", "1.EncDecAttention.o.weight",
+                              "1.layer_norm.weight", "2.DenseReluDense.wi.weight", "2.DenseReluDense.wo.weight",
+                              "2.layer_norm.weight"}) {
+            snprintf(buf, sizeof buf, "decoder.block.%zu.layer.%s", i, s);
+            need.push_back(buf);
+        }
+    }
+    for (const std::string& k : need)
+        if (!m->loaded.count(k)) return fail(MG_E_STATE, "mg_finalize: tensor %s was never loaded", k.c_str());
+    const int H = m->H;
+    mg_memcpy_async(m->at<int>(m->bk1), m->h_bk1.data(), 257 * 4, st);
+    mg_memcpy_async(m->at<int>(m->bkhv), m->h_bkhv.data(), 201 * 4, st);
+    mg_memcpy_async(m->at<int>(m->bkdec), m->h_bkdec.data(), (size_t)m->T_cap * 4, st);
+    MG_LAUNCH(build_table_kernel, dim3(8), dim3(256), 0, st, (const float*)m->at<float>(m->rb_raw[0]), (const int*)m->at<int>(m->bk1), m->at<float>(m->tab1), 257, H);
+    MG_LAUNCH(build_table_kernel, dim3(8), dim3(256), 0, st, (const float*)m->at<float>(m->rb_raw[1]), (const int*)m->at<int>(m->bkhv), m->at<float>(m->tabh), 201, H);
+    MG_LAUNCH(build_table_kernel, dim3(8), dim3(256), 0, st, (const float*)m->at<float>(m->rb_raw[2]), (const int*)m->at<int>(m->bkhv), m->at<float>(m->tabv), 201, H);
+    MG_LAUNCH(build_table_kernel, dim3(8), dim3(256), 0, st, (const float*)m->at<float>(m->rb_dec_raw), (const int*)m->at<int>(m->bkdec), m->at<float>(m->dec_tab), m->T_cap, H);
+    mg_stream_sync(st);    // the host tables above must outlive the copies
+    const int rc = check_launch("mg_finalize");
+    if (rc != MG_OK) return rc;
+    m->finalized = true;
+    return MG_OK;
+}
+
+int mg_workspace_bytes(const mg_model* m, int B, int L, int num_beams, int max_length, int T, size_t* out_bytes) {
+    if (!m || !out_bytes || B < 1 || L < 1 || num_beams < 1 || max_length < 0 || T < 0) return fail(MG_E_ARG, "mg_workspace_bytes: bad argument");
+    Ws w;
+    carve(m, nullptr, B, L, num_beams, max_length, T, &w);
+    *out_bytes = w.total;
+    return MG_OK;
+}
+
+int mg_encode(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* input_ids, const float* bbox,
+              const uint8_t* attention_mask, const float* pixel_values, int B, int L, float* enc_out, uint8_t* enc_mask) {
+    if (!m || !ws || !input_ids || !bbox || !pixel_values) return fail(MG_E_ARG, "mg_encode: null argument");
+    if (!m->finalized) return fail(MG_E_STATE, "mg_encode: call mg_finalize first");
+    if (B < 1 || L < 1) return fail(MG_E_SHAPE, "mg_encode: B and L must be >= 1");
+    mgStream_t st = (mgStream_t)stream;
+    Ws w;
+    carve(m, (char*)ws, B, L, 1, 0, 0, &w);
+    if (w.total > ws_bytes) return fail(MG_E_WORKSPACE, "mg_encode: workspace too small (%zu < %zu)", ws_bytes, w.total);
+    const int d = m->d, H = m->H, inner = m->inner, P = m->P;
+    const int S = L + P, S_cap = round_up(S, 64), M = B * S_cap;
+    mg_memset_async(w.counters, 0, 16 * sizeof(int), st);
+    // patch embedding (stock:254-280) = im2col + GEMM + bias
+    im2col_pack(pixel_values, w.xim, B, m->c.num_channels, m->c.image_size, m->c.patch_size, st);
+    {
+        GemmArgs a = gemm_args(w.xim, m->at<uint16_t>(m->patch_w), B * P, d, m->Kpatch);
+        a.out_f32 = w.patch_emb; a.ldo = d; a.bias = m->at<float>(m->patch_b);
+        gemm(a, EPI_F32_STORE, st);
+    }
+    {
+        EmbedArgs e{};
+        e.input_ids = input_ids; e.bbox = bbox; e.attn_mask = attention_mask; e.patch_emb = w.patch_emb;
+        e.tok_emb = m->at<uint16_t>(m->tok_emb); e.x_emb = m->at<uint16_t>(m->x_emb); e.y_emb = m->at<uint16_t>(m->y_emb);
+        e.B = B; e.L = L; e.P = P; e.d = d; e.n_side = m->n_side; e.M2 = m->M2; e.V = m->V; e.S_cap = S_cap;
+        e.hidden = w.hidden; e.cx = w.cx; e.cy = w.cy; e.mask = w.mask; e.xrow = w.xrow; e.xlen = w.xlen;
+        e.err = w.counters + 3;
+        embed_assemble(e, w.meta, st);
+    }
+    for (size_t li = 0; li < m->enc.size(); ++li) {
+        const EncLayer& l = m->enc[li];
+        rmsnorm_pack(w.hidden, m->at<float>(l.ln0), w.x_pk, nullptr, M, d, m->c.layer_norm_epsilon, 1.0f, st);
+        GemmArgs a = gemm_args(w.x_pk, m->at<uint16_t>(l.wqkv), M, 3 * inner, d);
+        set_heads(a, H, S_cap, S_cap, w.q_pk, HF_PK_ROWS, w.k_pk, HF_PK_ROWS, w.vt_pk, HF_PK_T);
+        gemm(a, EPI_HEADS, st);
+        AttnArgs t{};
+        t.Q = w.q_pk; t.K = w.k_pk; t.Vt = w.vt_pk; t.ctx = w.ctx_pk; t.B = B; t.H = H; t.Sq = S; t.Sk = S;
+        t.Sq_cap = S_cap; t.Sk_cap = S_cap; t.mode = ATT_ENC; t.kmask = w.mask;
+        t.tab1 = m->at<float>(m->tab1); t.tab1_len = 257; t.tabh = m->at<float>(m->tabh); t.tabv = m->at<float>(m->tabv);
+        t.cx = w.cx; t.cy = w.cy;
+        attention(t, st);
+        GemmArgs o = gemm_args(w.ctx_pk, m->at<uint16_t>(l.wo), M, d, inner);
+        o.out_f32 = w.hidden; o.ldo = d;
+        gemm(o, EPI_F32_RESID, st);
+        ffn_block(m, false, w.hidden, w.x_pk, w.y_pk, M, l.ln1, l.wi, l.wo2, st);
+    }
+    rmsnorm_pack(w.hidden, m->at<float>(m->enc_ln), w.enc_pk, w.enc_f32, M, d, m->c.layer_norm_epsilon, 1.0f, st);
+    if (enc_out) MG_LAUNCH(copy_rows_kernel, dim3(1024), dim3(256), 0, st, (const float*)w.enc_f32, enc_out, B, S, S_cap, d);
+    if (enc_mask) MG_LAUNCH(copy_bytes_rows_kernel, dim3(64), dim3(256), 0, st, (const uint8_t*)w.mask, enc_mask, B, S, S_cap);
+    m->st_B = B; m->st_L = L; m->st_S = S; m->st_Scap = S_cap; m->st_ws = ws;
+    return check_launch("mg_encode");
+}
+
+int mg_decoder_forward(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* decoder_input_ids,
+                       const uint8_t* decoder_attention_mask, int B, int T, float* logits) {
+    if (!m || !ws || !decoder_input_ids || !logits) return fail(MG_E_ARG, "mg_decoder_forward: null argument");
+    if (m->st_ws != ws || m->st_B != B) return fail(MG_E_STATE, "mg_decoder_forward: run mg_encode on this workspace/batch first");
+    if (T < 1 || T > m->T_cap) return fail(MG_E_SHAPE, "mg_decoder_forward: T must be in [1, %d]", m->T_cap);
+    mgStream_t st = (mgStream_t)stream;
+    Ws w;
+    carve(m, (char*)ws, B, m->st_L, 1, 0, T, &w);
+    if (w.total > ws_bytes) return fail(MG_E_WORKSPACE, "mg_decoder_forward: workspace too small (%zu < %zu)", ws_bytes, w.total);
+    const int d = m->d, H = m->H, inner = m->inner;
+    const int T_cap = round_up(T, 64), MT = B * T_cap, S = m->st_S, S_cap = m->st_Scap, M = B * S_cap;
+    MG_LAUNCH(pad_dec_inputs_kernel, dim3(64), dim3(256), 0, st, decoder_input_ids, decoder_attention_mask, w.tf_ids, w.tf_mask,
+              w.tf_rowmap, B, T, T_cap);
+    embed_rows(w.tf_ids, m->at<uint16_t>(m->tok_emb), w.tf_hidden, MT, d, m->V, w.counters + 3, st);
+    for (size_t li = 0; li < m->dec.size(); ++li) {
+        const DecLayer& l = m->dec[li];
+        rmsnorm_pack(w.tf_hidden, m->at<float>(l.ln0), w.tf_x, nullptr, MT, d, m->c.layer_norm_epsilon, 1.0f, st);
+        GemmArgs a = gemm_args(w.tf_x, m->at<uint16_t>(l.wqkv), MT, 3 * inner, d);
+        set_heads(a, H, T_cap, T_cap, w.tf_q, HF_PK_ROWS, w.tf_k, HF_PK_ROWS, w.tf_vt, HF_PK_T);
+        gemm(a, EPI_HEADS, st);
+        AttnArgs t{};
+        t.Q = w.tf_q; t.K = w.tf_k; t.Vt = w.tf_vt; t.ctx = w.tf_ctx; t.B = B; t.H = H; t.Sq = T; t.Sk = T;
+        t.Sq_cap = T_cap; t.Sk_cap = T_cap; t.mode = ATT_DEC_SELF; t.kmask = w.tf_mask;
+        t.tab1 = m->at<float>(m->dec_tab); t.tab1_len = m->T_cap;
+        attention(t, st);
+        GemmArgs o = gemm_args(w.tf_ctx, m->at<uint16_t>(l.wo), MT, d, inner);
+        o.out_f32 = w.tf_hidden; o.ldo = d;
+        gemm(o, EPI_F32_RESID, st);
+        // cross-attention (stock:611-640): queries from the decoder, keys/values from the encoder output
+        rmsnorm_pack(w.tf_hidden, m->at<float>(l.ln1), w.tf_x, nullptr, MT, d, m->c.layer_norm_epsilon, 1.0f, st);
+        GemmArgs q = gemm_args(w.tf_x, m->at<uint16_t>(l.xq), MT, inner, d);
+        set_heads(q, H, T_cap, T_cap, w.tf_q, HF_PK_ROWS, nullptr, HF_NONE, nullptr, HF_NONE);
+        gemm(q, EPI_HEADS, st);
+        GemmArgs kv = gemm_args(w.enc_pk, m->at<uint16_t>(l.xkv), M, 2 * inner, d);
+        set_heads(kv, H, S_cap, S_cap, w.tf_xk, HF_PK_ROWS, w.tf_xvt, HF_PK_T, nullptr, HF_NONE);
+        gemm(kv, EPI_HEADS, st);
+        AttnArgs x{};
+        x.Q = w.tf_q; x.K = w.tf_xk; x.Vt = w.tf_xvt; x.ctx = w.tf_ctx; x.B = B; x.H = H; x.Sq = T; x.Sk = S;
+        x.Sq_cap = T_cap; x.Sk_cap = S_cap; x.mode = ATT_CROSS; x.kmask = w.mask;
+        attention(x, st);
+        GemmArgs xo = gemm_args(w.tf_ctx, m->at<uint16_t>(l.xo), MT, d, inner);
+        xo.out_f32 = w.tf_hidden; xo.ldo = d;
+        gemm(xo, EPI_F32_RESID, st);
+        ffn_block(m, false, w.tf_hidden, w.tf_x, w.tf_y, MT, l.ln2, l.wi, l.wo2, st);
+    }
+    // final norm, d_model^-0.5 (tied head, stock:1554-1555), lm_head on the B*T real positions only
+    rmsnorm_pack_rows(w.tf_hidden, m->at<float>(m->dec_ln), w.tf_xc, w.tf_rowmap, MT, d, m->c.layer_norm_epsilon,
+                      1.0f / sqrtf((float)d), st);
+    GemmArgs lg = gemm_args(w.tf_xc, m->at<uint16_t>(m->lm_head), B * T, m->V, d);
+    lg.out_f32 = logits; lg.ldo = m->V;
+    gemm(lg, EPI_F32_STORE, st);
+    return check_launch("mg_decoder_forward");
+}
+
+int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* input_ids, const float* bbox,
+                const uint8_t* attention_mask, const float* pixel_values, int B, int L, int num_beams, int max_length,
+                int min_length, float length_penalty, int early_stopping, int64_t* out_ids, int* out_cols_host,
+                float* out_scores, float* step_top2) {
+    if (!m || !out_ids || !out_cols_host) return fail(MG_E_ARG, "mg_generate: null argument");
+    if (max_length < 2 || max_length > m->T_cap) return fail(MG_E_SHAPE, "mg_generate: max_length must be in [2, %d]", m->T_cap);
+    if (num_beams < 1 || num_beams > 8) return fail(MG_E_UNSUPPORTED, "mg_generate: num_beams must be in [1, 8]");
+    mgStream_t st = (mgStream_t)stream;
+    const int K = num_beams;
+    Ws w;
+    carve(m, (char*)ws, B, L, K, max_length, 0, &w);
+    if (w.total > ws_bytes) return fail(MG_E_WORKSPACE, "mg_generate: workspace too small (%zu < %zu)", ws_bytes, w.total);
+    int rc = mg_encode(m, stream, ws, ws_bytes, input_ids, bbox, attention_mask, pixel_values, B, L, nullptr, nullptr);
+    if (rc != MG_OK) return rc;
+    const int d = m->d, H = m->H, inner = m->inner, S_cap = m->st_Scap, M = B * S_cap;
+    const int R = B * K, T_cap = m->T_cap;
+    const size_t nl = m->dec.size();
+    const size_t xkv_stride = (size_t)B * H * S_cap * 64, skv_stride = (size_t)R * H * T_cap * 64;
+    // cross-attention K/V of every decoder layer, once per image (stock:524-538), compacted to attended positions
+    for (size_t li = 0; li < nl; ++li) {
+        GemmArgs kv = gemm_args(w.enc_pk, m->at<uint16_t>(m->dec[li].xkv), M, 2 * inner, d);
+        set_heads(kv, H, S_cap, S_cap, w.xk + li * xkv_stride, HF_NATURAL, w.xv + li * xkv_stride, HF_NATURAL, nullptr, HF_NONE);
+        kv.heads.row_map = w.xrow;
+        gemm(kv, EPI_HEADS, st);
+    }
+    int* counters = w.counters;
+    const int64_t start = m->c.decoder_start_token_id, pad = m->c.pad_token_id;
+    if (K == 1) {
+        MG_LAUNCH(fill_ids_kernel, dim3(R), dim3(64), 0, st, w.next_ids, out_ids, w.unfinished, counters, R, max_length, start, pad);
+    } else {
+        beam_init(w.beam_state, B, K, max_length, (int)pad, m->c.eos_token_id, (int)start, w.next_ids, w.anc, T_cap, counters, st);
+    }
+    int steps_done = 0;
+    int host_flag[4] = {0, 0, 0, 0};
+    for (int t = 0; t + 1 < max_length; ++t) {
+        embed_rows(w.next_ids, m->at<uint16_t>(m->tok_emb), w.dh, R, d, m->V, counters + 3, st);
+        for (size_t li = 0; li < nl; ++li) {
+            const DecLayer& l = m->dec[li];
+            uint16_t* sk = w.sk + li * skv_stride;
+            uint16_t* sv = w.sv + li * skv_stride;
+            rmsnorm_pack(w.dh, m->at<float>(l.ln0), w.dx_pk, nullptr, R, d, m->c.layer_norm_epsilon, 1.0f, st);
+            GemmArgs a = gemm_args(w.dx_pk, m->at<uint16_t>(l.wqkv), R, 3 * inner, d);
+            set_heads(a, H, R, T_cap, w.dq, HF_STEP_Q, sk, HF_STEP_KV, sv, HF_STEP_KV);
+            a.heads.pos = t;
+            gemm_rows(a, EPI_HEADS, st);
+            AttnStepArgs s{};
+            s.q = w.dq; s.Kc = sk; s.Vc = sv; s.ctx = w.dctx_pk; s.rows = R; s.H = H; s.group = 1; s.cap = T_cap;
+            s.n_keys = t + 1; s.bias = m->at<float>(m->dec_tab); s.anc = K > 1 ? w.anc : nullptr; s.t = t;
+            attention_step(s, st);
+            GemmArgs o = gemm_args(w.dctx_pk, m->at<uint16_t>(l.wo), R, d, inner);
+            o.out_f32 = w.dh; o.ldo = d;
+            gemm_rows(o, EPI_F32_RESID, st);
+            rmsnorm_pack(w.dh, m->at<float>(l.ln1), w.dx_pk, nullptr, R, d, m->c.layer_norm_epsilon, 1.0f, st);
+            GemmArgs q = gemm_args(w.dx_pk, m->at<uint16_t>(l.xq), R, inner, d);
+            set_heads(q, H, R, T_cap, w.dq, HF_STEP_Q, nullptr, HF_NONE, nullptr, HF_NONE);
+            gemm_rows(q, EPI_HEADS, st);
+            AttnStepArgs x{};
+            x.q = w.dq; x.Kc = w.xk + li * xkv_stride; x.Vc = w.xv + li * xkv_stride; x.ctx = w.dctx_pk; x.rows = R; x.H = H;
+            x.group = K; x.cap = S_cap; x.len = w.xlen;
+            attention_step(x, st);
+            GemmArgs xo = gemm_args(w.dctx_pk, m->at<uint16_t>(l.xo), R, d, inner);
+            xo.out_f32 = w.dh; xo.ldo = d;
+            gemm_rows(xo, EPI_F32_RESID, st);
+            ffn_block(m, true, w.dh, w.dx_pk, w.dy_pk, R, l.ln2, l.wi, l.wo2, st);
+        }
+        rmsnorm_pack(w.dh, m->at<float>(m->dec_ln), w.dx_pk, nullptr, R, d, m->c.layer_norm_epsilon, 1.0f / sqrtf((float)d), st);
+        const int ldl = round_up(m->V, 32);
+        GemmArgs lg = gemm_args(w.dx_pk, m->at<uint16_t>(m->lm_head), R, m->V, d);
+        lg.out_f32 = w.logits; lg.ldo = ldl;
+        gemm_rows(lg, EPI_F32_STORE, st);
+        if (K == 1) {
+            ArgmaxArgs g{};
+            g.logits = w.logits; g.rows = R; g.V = m->V; g.ldl = ldl; g.eos = m->c.eos_token_id; g.pad = (int)pad;
+            g.min_len = min_length; g.next_ids = w.next_ids; g.out_ids = out_ids; g.max_len = max_length; g.pos = t + 1;
+            g.unfinished = w.unfinished; g.n_unfinished = counters; g.top2 = step_top2 ? step_top2 + (size_t)(t + 1) * R * 2 : nullptr;
+            greedy_select(g, st);
+        } else {
+            beam_step(w.beam_state, w.logits, ldl, m->V, B, K, max_length, t + 1, m->c.eos_token_id, min_length, length_penalty,
+                      early_stopping, w.next_ids, w.beam_idx, counters, st);
+            beam_reorder_anc(w.anc, w.anc_tmp, w.beam_idx, R, t + 1, T_cap, counters, st);
+        }
+        MG_LAUNCH(step_end_kernel, dim3(1), dim3(64), 0, st, counters);
+        steps_done = t + 1;
+        // termination is checked every 8 steps (and at the end): overrunning only appends pad columns, which are
+        // trimmed with the device-recorded `done_step`
+        if ((t & 7) == 7 || t + 2 >= max_length) {
+            mg_memcpy_async(host_flag, counters, sizeof host_flag, st);
+            mg_stream_sync(st);
+            if (host_flag[0] == 0) break;
+        }
+    }
+    if (K > 1) beam_finalize(w.beam_state, B, K, max_length, out_ids, counters + 4, out_scores, st);
+    mg_memcpy_async(host_flag, counters, sizeof host_flag, st);
+    int beam_cols = 0;
+    if (K > 1) mg_memcpy_async(&beam_cols, counters + 4, sizeof(int), st);
+    mg_stream_sync(st);
+    rc = check_launch("mg_generate");
+    if (rc != MG_OK) return rc;
+    if (host_flag[3] != 0) return fail(MG_E_INPUT, "mg_generate: %d token ids outside [0, vocab)", host_flag[3]);
+    if (K == 1) *out_cols_host = 1 + (host_flag[1] >= 0 ? host_flag[1] + 1 : steps_done);
+    else *out_cols_host = beam_cols;
+    return MG_OK;
+}
+
+int mg_beam_reorder(void* stream, const void* kv_src, void* kv_dst, const int32_t* beam_idx, int layers, int rows, int H,
+                    int t_cap, int t_used) {
+    if (!kv_src || !kv_dst || !beam_idx || t_used > t_cap) return fail(MG_E_ARG, "mg_beam_reorder: bad argument");
+    beam_reorder_copy((const uint16_t*)kv_src, (uint16_t*)kv_dst, beam_idx, layers * 2, rows, H, t_cap, t_used, (mgStream_t)stream);
+    return check_launch("mg_beam_reorder");
+}
+
+}  // extern "C"

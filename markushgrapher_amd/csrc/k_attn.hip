@@ -1,0 +1,217 @@
+// Attention over packed Q / K / V^T with the relative-position bias fused into the score tile
+// (the [B,H,S,S] bias of stock:904-953,1012-1029 is never materialised):
+//   ATT_ENC      joint patch+text+layout self-attention: bias = 1-D(j-i) + horizontal + vertical buckets
+//                (stock:956-1009; box centres in float64, (c_j-c_i) -> fp32, *100, truncation: stock:914-923)
+//   ATT_DEC_SELF teacher-forced decoder self-attention: causal, T5 1-D bias of block 0 (stock:470-485,1234-1237)
+//   ATT_CROSS    teacher-forced cross-attention: no bias (stock:543-550)
+// No 1/sqrt(d_k) scaling (stock:402-403).  Masked keys get a large negative finite score.
+//
+// Structure: workgroup = 4 waves = 128 consecutive queries of one (b,h); each wave owns 32 queries.
+// Scores are computed TRANSPOSED (S^T = K·Q^T, MFMA A = K fragment, B = Q fragment) so a lane owns ONE query:
+// running max / sum / rescale are lane-local, and the bf16 P^T tile is directly the B operand of
+// O^T = V^T · P^T after one exchange with lane^32.  K and V^T tiles of 64 keys are staged with global_load_lds
+// (double-buffered, fragment order, conflict-free b128 reads); per-key metadata (mask, box centres) and the
+// three bias tables of head h live in LDS for the whole workgroup.
+#include "mg_kernels.h"
+
+namespace mg {
+
+constexpr int AT_KEYS = 64;                         // keys per stage
+constexpr int AT_STAGE_BYTES = 16 * TILE_BYTES;     // 8 K fragments + 8 V^T fragments
+constexpr float AT_NEG = -1.0e30f;
+
+template <int MODE>
+__global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
+    MG_DYN_SMEM(smem);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int half = lane >> 5, l32 = lane & 31;
+    const int nqb = (a.Sq_cap + 127) / 128;
+    const int qb = blockIdx.x % nqb;
+    const int bh = blockIdx.x / nqb;
+    const int h = bh % a.H, b = bh / a.H;
+    const int Sk_pad = (a.Sk + AT_KEYS - 1) / AT_KEYS * AT_KEYS;
+
+    // LDS carve: [2 stages][tables: tab1 | tabh | tabv][kmask bytes][cx doubles][cy doubles]
+    char* st_base = smem;
+    float* tab1 = (float*)(smem + 2 * AT_STAGE_BYTES);
+    const int t1n = (MODE == ATT_CROSS) ? 0 : a.tab1_len;
+    float* tabh = tab1 + ((t1n + 3) & ~3);
+    float* tabv = tabh + 204;
+    double* kcx = (double*)(tabv + 204);
+    double* kcy = kcx + ((MODE == ATT_ENC) ? Sk_pad : 0);
+    unsigned char* kmk = (unsigned char*)(kcy + ((MODE == ATT_ENC) ? Sk_pad : 0));
+
+    for (int i = tid; i < t1n; i += 256) tab1[i] = a.tab1[(size_t)i * a.H + h];
+    if (MODE == ATT_ENC) {
+        for (int i = tid; i < 201; i += 256) {
+            tabh[i] = a.tabh[(size_t)i * a.H + h];
+            tabv[i] = a.tabv[(size_t)i * a.H + h];
+        }
+        for (int i = tid; i < Sk_pad; i += 256) {
+            const bool in = i < a.Sk;
+            kcx[i] = in ? a.cx[(size_t)b * a.Sk_cap + i] : 0.0;
+            kcy[i] = in ? a.cy[(size_t)b * a.Sk_cap + i] : 0.0;
+        }
+    }
+    for (int i = tid; i < Sk_pad; i += 256)
+        kmk[i] = (i < a.Sk) ? (a.kmask ? a.kmask[(size_t)b * a.Sk_cap + i] : 1) : 0;
+
+    // this wave's 32 queries
+    const int q0 = qb * 128 + w * 32;
+    int qrt = q0 >> 5;
+    const int qrt_max = (a.Sq_cap >> 5) - 1;
+    if (qrt > qrt_max) qrt = qrt_max;
+    const uint16_t* Qb = a.Q + (((size_t)b * a.H + h) * (size_t)(a.Sq_cap >> 5) + (size_t)qrt) * (4 * TILE_ELEMS);
+    uint4 qf[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) qf[kt] = ld16((const char*)(Qb + kt * TILE_ELEMS) + lane * 16);
+    const int qi = q0 + l32;                 // this lane's query index
+    double qcx = 0.0, qcy = 0.0;
+    if (MODE == ATT_ENC) {
+        const int qc = qi < a.Sk_cap ? qi : a.Sk_cap - 1;
+        qcx = a.cx[(size_t)b * a.Sk_cap + qc];
+        qcy = a.cy[(size_t)b * a.Sk_cap + qc];
+    }
+
+    const uint16_t* Kb = a.K + ((size_t)b * a.H + h) * (size_t)(a.Sk_cap >> 5) * (4 * TILE_ELEMS);
+    const uint16_t* Vb = a.Vt + ((size_t)b * a.H + h) * 2 * (size_t)(a.Sk_cap >> 4) * TILE_ELEMS;
+    const int krt_max = (a.Sk_cap >> 5) - 1, vkt_max = (a.Sk_cap >> 4) - 1;
+    // stage loader: wave w copies fragments 4w..4w+3 (0..7 = K: key-tile f/4, dk-tile f%4; 8..15 = V^T: d-tile, key-k-tile)
+    auto stage = [&](int buf, int st) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = w * 4 + i;
+            const char* src;
+            if (f < 8) {
+                int krt = st * 2 + (f >> 2);
+                krt = krt < krt_max ? krt : krt_max;
+                src = (const char*)(Kb + ((size_t)krt * 4 + (f & 3)) * TILE_ELEMS);
+            } else {
+                const int g = f - 8, dt = g >> 2;
+                int vkt = st * 4 + (g & 3);
+                vkt = vkt < vkt_max ? vkt : vkt_max;
+                src = (const char*)(Vb + ((size_t)dt * (size_t)(a.Sk_cap >> 4) + (size_t)vkt) * TILE_ELEMS);
+            }
+            glds16(src + lane * 16, st_base + buf * AT_STAGE_BYTES + f * TILE_BYTES);
+        }
+    };
+
+    int nst = Sk_pad / AT_KEYS;
+    if (MODE == ATT_DEC_SELF) {   // keys beyond the workgroup's last query are all causally masked
+        const int last_q = qb * 128 + 127;
+        const int lim = last_q / AT_KEYS + 1;
+        nst = nst < lim ? nst : lim;
+    }
+
+    f32x16 o[2] = {acc_zero(), acc_zero()};
+    float m_run = AT_NEG, l_run = 0.f;
+
+    stage(0, 0);
+    __syncthreads();
+    for (int st = 0; st < nst; ++st) {
+        const int cur = st & 1;
+        if (st + 1 < nst) stage(cur ^ 1, st + 1);
+        const char* kb = st_base + cur * AT_STAGE_BYTES + lane * 16;
+        const char* vb = kb + 8 * TILE_BYTES;
+        // S^T tiles: rows = keys, cols = queries
+        f32x16 s[2];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            s[t2] = acc_zero();
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) s[t2] = mfma32(ld16(kb + (t2 * 4 + kt) * TILE_BYTES), qf[kt], s[t2]);
+        }
+        // bias + mask + running max
+        float mloc = AT_NEG;
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = st * AT_KEYS + t2 * 32 + acc_row(r, half);
+                float v = s[t2][r];
+                bool ok = kmk[key] != 0;
+                if (MODE == ATT_ENC) {
+                    int d1 = key - qi;
+                    d1 = d1 < -128 ? -128 : (d1 > 128 ? 128 : d1);
+                    const float fx = (float)(kcx[key] - qcx) * 100.0f;
+                    const float fy = (float)(kcy[key] - qcy) * 100.0f;
+                    int dx = (int)fmaxf(fminf(fx, 100.0f), -100.0f);
+                    int dy = (int)fmaxf(fminf(fy, 100.0f), -100.0f);
+                    v += tab1[d1 + 128] + tabh[dx + 100] + tabv[dy + 100];
+                } else if (MODE == ATT_DEC_SELF) {
+                    const int dist = qi - key;
+                    ok = ok && dist >= 0;
+                    const int di = dist < 0 ? 0 : (dist < t1n ? dist : t1n - 1);
+                    v += tab1[di];
+                }
+                v = ok ? v : AT_NEG;
+                s[t2][r] = v;
+                mloc = fmaxf(mloc, v);
+            }
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = fast_exp(m_run - m_new);
+        m_run = m_new;
+        // P^T = exp(S^T - m), rounded to bf16; the row sum uses the ROUNDED values so that O/l is a convex combination
+        float psum = 0.f;
+        uint4 pch[4];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            f32x16 p;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) p[r] = fast_exp(s[t2][r] - m_new);
+            const PackedAcc pa = acc_pack(p);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) psum += (bf16lo(pa.p[g][0]) + bf16hi(pa.p[g][0])) + (bf16lo(pa.p[g][1]) + bf16hi(pa.p[g][1]));
+            packed_to_chunks(pa, half, &pch[2 * t2]);
+        }
+        psum += __shfl_xor(psum, 32);
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) o[dt] = mfma32(ld16(vb + (dt * 4 + kk) * TILE_BYTES), pch[kk], o[dt]);
+        }
+        __syncthreads();
+    }
+
+    // O^T / l -> packed context rows [b*Sq_cap + q][h*64 + dim]
+    const float inv = 1.0f / l_run;
+    const int HD = a.H * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        f32x16 v;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = o[dt][r] * inv;
+        uint4 ch[2];
+        acc_to_chunks(v, half, ch);
+        if (qi < a.Sq_cap) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                st16(a.ctx + pk_off(b * a.Sq_cap + qi, h * 64 + dt * 32 + q * 16 + half * 8, HD), ch[q]);
+        }
+    }
+}
+
+static size_t attn_smem(const AttnArgs& a) {
+    const int Sk_pad = (a.Sk + AT_KEYS - 1) / AT_KEYS * AT_KEYS;
+    const int t1n = (a.mode == ATT_CROSS) ? 0 : a.tab1_len;
+    size_t sz = 2 * AT_STAGE_BYTES + (size_t)(((t1n + 3) & ~3) + 408) * 4;
+    if (a.mode == ATT_ENC) sz += (size_t)Sk_pad * 16;
+    sz += (size_t)Sk_pad + 16;
+    return (sz + 15) & ~(size_t)15;
+}
+
+void attention(const AttnArgs& a, mgStream_t stream) {
+    const int nqb = (a.Sq_cap + 127) / 128;
+    const dim3 grid(a.B * a.H * nqb), block(256);
+    const size_t sh = attn_smem(a);
+    if (a.mode == ATT_ENC) MG_LAUNCH((attention_kernel<ATT_ENC>), grid, block, sh, stream, a);
+    else if (a.mode == ATT_DEC_SELF) MG_LAUNCH((attention_kernel<ATT_DEC_SELF>), grid, block, sh, stream, a);
+    else MG_LAUNCH((attention_kernel<ATT_CROSS>), grid, block, sh, stream, a);
+}
+
+}  // namespace mg

@@ -1,0 +1,392 @@
+// Beam search on the device, restating stock transformers 5.15 `_beam_search` (generation/utils.py:3208-3525):
+// log_softmax + running scores, top-2K over the K*V continuations (utils.py:3077-3130), running beams for the next
+// step (3131-3152), finished-beam merge (3153-3206), early-stop heuristic (3008-3053), loop condition (3055-3075).
+// The KV-cache reorder (cache_utils.py:100-104) exists in two forms: an ancestor table (the product path: the
+// single-query attention kernel gathers each cached position from the physical row that wrote it, so no K/V bytes
+// move) and a physical index_select copy (the reference's behaviour; exposed for the micro-benchmark).
+// Selection order everywhere: value descending, then index ascending (deterministic).
+#include "mg_kernels.h"
+
+namespace mg {
+
+struct BeamLayout {
+    size_t running_seq, sequences, top_seq, tmp_seq, tmp_idx, running_scores, beam_scores, topv, topi, is_fin, heur, run_idx, beam_idx_out,
+        top_run_idx, flags, total;
+};
+static BeamLayout beam_layout(int B, int K, int max_len) {
+    BeamLayout l;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { off = (off + 255) / 256 * 256; size_t o = off; off += bytes; return o; };
+    const size_t ml = max_len, il = max_len - 1;
+    l.running_seq = take((size_t)B * K * ml * 8);
+    l.sequences = take((size_t)B * K * ml * 8);
+    l.top_seq = take((size_t)B * 2 * K * ml * 8);
+    l.tmp_seq = take((size_t)B * K * ml * 8);
+    l.tmp_idx = take((size_t)B * K * ml * 4);
+    l.running_scores = take((size_t)B * K * 4);
+    l.beam_scores = take((size_t)B * K * 4);
+    l.topv = take((size_t)B * 2 * K * 4);
+    l.topi = take((size_t)B * 2 * K * 4);
+    l.is_fin = take((size_t)B * K);
+    l.heur = take((size_t)B);
+    l.run_idx = take((size_t)B * K * il * 4);
+    l.beam_idx_out = take((size_t)B * K * il * 4);
+    l.top_run_idx = take((size_t)B * 2 * K * il * 4);
+    l.flags = take((size_t)B * 4 * 4);
+    l.total = (off + 255) / 256 * 256;
+    return l;
+}
+size_t beam_state_bytes(int B, int K, int max_len) { return beam_layout(B, K, max_len).total; }
+
+struct BeamPtrs {
+    int64_t *running_seq, *sequences, *top_seq, *tmp_seq;
+    int* tmp_idx;
+    float *running_scores, *beam_scores, *topv;
+    int* topi;
+    uint8_t *is_fin, *heur;
+    int *run_idx, *beam_idx_out, *top_run_idx, *flags;
+};
+static BeamPtrs beam_ptrs(void* state, int B, int K, int max_len) {
+    const BeamLayout l = beam_layout(B, K, max_len);
+    char* s = (char*)state;
+    BeamPtrs p;
+    p.running_seq = (int64_t*)(s + l.running_seq); p.sequences = (int64_t*)(s + l.sequences); p.top_seq = (int64_t*)(s + l.top_seq);
+    p.tmp_seq = (int64_t*)(s + l.tmp_seq); p.tmp_idx = (int*)(s + l.tmp_idx);
+    p.running_scores = (float*)(s + l.running_scores); p.beam_scores = (float*)(s + l.beam_scores); p.topv = (float*)(s + l.topv);
+    p.topi = (int*)(s + l.topi); p.is_fin = (uint8_t*)(s + l.is_fin); p.heur = (uint8_t*)(s + l.heur);
+    p.run_idx = (int*)(s + l.run_idx); p.beam_idx_out = (int*)(s + l.beam_idx_out); p.top_run_idx = (int*)(s + l.top_run_idx);
+    p.flags = (int*)(s + l.flags);
+    return p;
+}
+
+// utils.py:3316-3351 initial values (fill value = pad_token_id or eos: pad id 0 is falsy -> EOS, utils.py:3319)
+__global__ __launch_bounds__(256) void beam_init_kernel(BeamPtrs p, int B, int K, int max_len, int fill, int start, int64_t* next_ids,
+                                                   int* anc, int T_cap, int* counters) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int R = B * K;
+    for (int i = tid; i < K * max_len; i += 256) {
+        const int64_t v = (i % max_len == 0) ? start : fill;
+        p.running_seq[(size_t)b * K * max_len + i] = v;
+        p.sequences[(size_t)b * K * max_len + i] = v;
+    }
+    for (int i = tid; i < K * (max_len - 1); i += 256) {
+        p.run_idx[(size_t)b * K * (max_len - 1) + i] = -1;
+        p.beam_idx_out[(size_t)b * K * (max_len - 1) + i] = -1;
+    }
+    for (int i = tid; i < K; i += 256) {
+        p.running_scores[b * K + i] = i == 0 ? 0.f : -1.0e9f;
+        p.beam_scores[b * K + i] = -1.0e9f;
+        p.is_fin[b * K + i] = 0;
+        next_ids[b * K + i] = start;
+    }
+    for (int i = tid; i < T_cap * K; i += 256) {   // identity ancestor table for this image's rows
+        const int j = i / K, k = i - j * K;
+        anc[(size_t)j * R + b * K + k] = b * K + k;
+    }
+    if (tid == 0) {
+        p.heur[b] = 1;
+        if (b == 0) { counters[0] = 1; counters[1] = -1; counters[2] = 0; counters[3] = 0; counters[4] = 0; }
+    }
+}
+void beam_init(void* state, int B, int K, int max_len, int pad, int eos, int start, int64_t* next_ids, int* anc, int T_cap,
+               int* counters, mgStream_t stream) {
+    const BeamPtrs p = beam_ptrs(state, B, K, max_len);
+    MG_LAUNCH(beam_init_kernel, dim3(B), dim3(256), 0, stream, p, B, K, max_len, pad ? pad : eos, start, next_ids, anc, T_cap, counters);
+}
+
+MG_DEV bool cand_before(float v1, int i1, float v2, int i2) { return v1 > v2 || (v1 == v2 && i1 < i2); }
+
+// block-wide reductions through LDS (256 threads)
+MG_DEV float block_max(float v, float* red, int tid) {
+    v = wave_max(v);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    const float r = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    return r;
+}
+MG_DEV float block_sum(float v, float* red, int tid) {
+    v = wave_sum(v);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    const float r = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    return r;
+}
+
+// a. log-probs + running scores, b. top-2K over K*V by 2K rounds of block-wide selection
+template <int KMAX>
+__global__ __launch_bounds__(256) void beam_topk_kernel(BeamPtrs p, const float* logits, int ldl, int V, int K, int cur_len, int eos,
+                                                   int min_len, const int* counters) {
+    if (counters[0] == 0) return;
+    MG_DYN_SMEM(smem);
+    float* red = (float*)smem;            // [4]
+    float* rmax = red + 4;                // [KMAX]
+    float* rlse = rmax + KMAX;            // [KMAX]
+    float* selv = rlse + KMAX;            // [4]
+    int* seli = (int*)(selv + 4);         // [4]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const bool no_eos = cur_len < min_len;
+    for (int k = 0; k < K; ++k) {
+        const float* lg = logits + (size_t)(b * K + k) * ldl;
+        float mx = -3.0e38f;
+        for (int v = tid; v < V; v += 256) mx = fmaxf(mx, lg[v]);
+        mx = block_max(mx, red, tid);
+        float s = 0.f;
+        for (int v = tid; v < V; v += 256) s += expf(lg[v] - mx);
+        s = block_sum(s, red, tid);
+        if (tid == 0) { rmax[k] = mx; rlse[k] = logf(s); }
+    }
+    __syncthreads();
+    float lastv = 3.0e38f;
+    int lasti = -1;
+    const int keep = 2 * K;
+    for (int round = 0; round < keep; ++round) {
+        float bv = -3.0e38f;
+        int bi = 0x7fffffff;
+        for (int k = 0; k < K; ++k) {
+            const float* lg = logits + (size_t)(b * K + k) * ldl;
+            const float mx = rmax[k], lse = rlse[k], rs = p.running_scores[b * K + k];
+            for (int v = tid; v < V; v += 256) {
+                float lp = (lg[v] - mx) - lse;
+                if (no_eos && v == eos) lp = -INFINITY;
+                const float val = lp + rs;
+                const int idx = k * V + v;
+                if (cand_before(lastv, lasti, val, idx) && cand_before(val, idx, bv, bi)) { bv = val; bi = idx; }
+            }
+        }
+        // wave then block argmax in (value desc, index asc) order
+#pragma unroll
+        for (int step = 1; step < 64; step <<= 1) {
+            const float ov = __shfl_xor(bv, step);
+            const int oi = __shfl_xor(bi, step);
+            if (cand_before(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+        }
+        if ((tid & 63) == 0) { selv[tid >> 6] = bv; seli[tid >> 6] = bi; }
+        __syncthreads();
+        for (int ww = 0; ww < 4; ++ww)
+            if (cand_before(selv[ww], seli[ww], bv, bi)) { bv = selv[ww]; bi = seli[ww]; }
+        __syncthreads();
+        lastv = bv; lasti = bi;
+        if (tid == 0) { p.topv[b * keep + round] = bv; p.topi[b * keep + round] = bi; }
+    }
+}
+
+// c.-g. bookkeeping for one image (K <= 8, 2K <= 16 candidates)
+__global__ __launch_bounds__(256) void beam_update_kernel(BeamPtrs p, int B, int K, int V, int max_len, int cur_len, int eos,
+                                                     float fin_div, float heur_div, int early_stopping, int64_t* next_ids,
+                                                     int* beam_idx, const int* counters) {
+    if (counters[0] == 0) return;
+    MG_DYN_SMEM(smem);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int keep = 2 * K, ml = max_len, il = max_len - 1;
+    int* src = (int*)smem;                  // [16] source beam of candidate c
+    int* hit = src + 16;                    // [16]
+    int* nxt = hit + 16;                    // [8] candidate chosen as running beam k
+    int* sel = nxt + 8;                     // [8] merged index chosen as finished slot k
+    float* fin = (float*)(sel + 8);         // [16]
+    float* runlp = fin + 16;                // [16]
+    float* msc = runlp + 16;                // [24]
+    int* mfin = (int*)(msc + 24);           // [24]
+    int* misc = mfin + 24;                  // [4]
+    int64_t* rs = p.running_seq + (size_t)b * K * ml;
+    int64_t* sq = p.sequences + (size_t)b * K * ml;
+    int64_t* ts = p.top_seq + (size_t)b * keep * ml;
+    int* ri = p.run_idx + (size_t)b * K * il;
+    int* bo = p.beam_idx_out + (size_t)b * K * il;
+    int* tr = p.top_run_idx + (size_t)b * keep * il;
+
+    if (tid < keep) {
+        const int idx = p.topi[b * keep + tid];
+        src[tid] = idx / V;
+        const int tok = idx - src[tid] * V;
+        hit[tid] = (tok == eos) || (cur_len + 1 >= max_len);
+    }
+    __syncthreads();
+    // top-2K sequences / beam-index histories (utils.py:3115-3127)
+    for (int i = tid; i < keep * ml; i += 256) {
+        const int c = i / ml, j = i - c * ml;
+        int64_t v = rs[(size_t)src[c] * ml + j];
+        if (j == cur_len) v = p.topi[b * keep + c] - src[c] * V;
+        ts[i] = v;
+    }
+    for (int i = tid; i < keep * il; i += 256) {
+        const int c = i / il, j = i - c * il;
+        int v = ri[(size_t)src[c] * il + j];
+        if (j == cur_len - 1) v = src[c] + b * K;
+        tr[i] = v;
+    }
+    if (tid < keep) {
+        const float tv = p.topv[b * keep + tid];
+        runlp[tid] = tv + (hit[tid] ? 1.0f : 0.0f) * -1.0e9f;            // utils.py:3145
+        bool allfin = true;
+        for (int k = 0; k < K; ++k) allfin = allfin && p.is_fin[b * K + k];
+        float f = tv / fin_div;                                           // utils.py:3182
+        f += ((allfin && early_stopping) ? 1.0f : 0.0f) * -1.0e9f;        // 3184-3185
+        f += (p.heur[b] ? 0.0f : 1.0f) * -1.0e9f;                         // 3187
+        const bool just = hit[tid] && tid < K;                            // 3178
+        f += (just ? 0.0f : 1.0f) * -1.0e9f;                              // 3190
+        fin[tid] = f;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // e. running beams: top-K of runlp (utils.py:3147)
+        bool used[16];
+        for (int c = 0; c < keep; ++c) used[c] = false;
+        for (int k = 0; k < K; ++k) {
+            int best = -1;
+            for (int c = 0; c < keep; ++c)
+                if (!used[c] && (best < 0 || runlp[c] > runlp[best])) best = c;
+            used[best] = true;
+            nxt[k] = best;
+        }
+        // f. finished beams: top-K of [beam_scores (K) | fin (2K)] (utils.py:3195-3203)
+        for (int k = 0; k < K; ++k) { msc[k] = p.beam_scores[b * K + k]; mfin[k] = p.is_fin[b * K + k]; }
+        for (int c = 0; c < keep; ++c) { msc[K + c] = fin[c]; mfin[K + c] = hit[c] && c < K; }
+        bool used2[24];
+        for (int c = 0; c < K + keep; ++c) used2[c] = false;
+        for (int k = 0; k < K; ++k) {
+            int best = -1;
+            for (int c = 0; c < K + keep; ++c)
+                if (!used2[c] && (best < 0 || msc[c] > msc[best])) best = c;
+            used2[best] = true;
+            sel[k] = best;
+        }
+    }
+    __syncthreads();
+    // new finished set: gathered from the OLD sequences / candidates into temporaries, then copied back
+    int64_t* tq = p.tmp_seq + (size_t)b * K * ml;
+    int* ti = p.tmp_idx + (size_t)b * K * ml;
+    for (int i = tid; i < K * ml; i += 256) {
+        const int k = i / ml, j = i - k * ml, s2 = sel[k];
+        tq[i] = s2 < K ? sq[(size_t)s2 * ml + j] : ts[(size_t)(s2 - K) * ml + j];
+    }
+    for (int i = tid; i < K * il; i += 256) {
+        const int k = i / il, j = i - k * il, s2 = sel[k];
+        ti[i] = s2 < K ? bo[(size_t)s2 * il + j] : tr[(size_t)(s2 - K) * il + j];
+    }
+    __syncthreads();
+    for (int i = tid; i < K * ml; i += 256) sq[i] = tq[i];
+    for (int i = tid; i < K * il; i += 256) bo[i] = ti[i];
+    for (int i = tid; i < K * ml; i += 256) { const int k = i / ml, j = i - k * ml; rs[i] = ts[(size_t)nxt[k] * ml + j]; }
+    for (int i = tid; i < K * il; i += 256) { const int k = i / il, j = i - k * il; ri[i] = tr[(size_t)nxt[k] * il + j]; }
+    __syncthreads();
+    if (tid == 0) {
+        float nbs[8], nrs[8];
+        int nf[8];
+        for (int k = 0; k < K; ++k) { nbs[k] = msc[sel[k]]; nf[k] = mfin[sel[k]]; nrs[k] = runlp[nxt[k]]; }
+        bool allfin = true, allhit = true;
+        for (int k = 0; k < K; ++k) {
+            p.beam_scores[b * K + k] = nbs[k];
+            p.is_fin[b * K + k] = (uint8_t)nf[k];
+            p.running_scores[b * K + k] = nrs[k];
+            allfin = allfin && nf[k];
+        }
+        for (int c = 0; c < keep; ++c) allhit = allhit && hit[c];
+        // g. early-stop heuristic with the incremented cur_len (utils.py:3047-3052)
+        float worst = nbs[0];
+        for (int k = 1; k < K; ++k) worst = fminf(worst, nbs[k]);
+        const float best_possible = nrs[0] / heur_div;
+        bool any = false;
+        for (int k = 0; k < K; ++k) any = any || (best_possible > (nf[k] ? worst : -1.0e9f));
+        const bool h = p.heur[b] && any;
+        p.heur[b] = h;
+        p.flags[b * 4 + 0] = h; p.flags[b * 4 + 1] = allfin; p.flags[b * 4 + 2] = allhit;
+    }
+    __syncthreads();
+    if (tid < K) {
+        next_ids[b * K + tid] = rs[(size_t)tid * ml + cur_len];
+        beam_idx[b * K + tid] = ri[(size_t)tid * il + cur_len - 1];
+    }
+}
+
+// loop condition (utils.py:3055-3075), reduced over the batch; counters[0] = continue?
+__global__ void beam_flags_kernel(BeamPtrs p, int B, int early_stopping, int* counters) {
+    if (threadIdx.x != 0 || blockIdx.x != 0 || counters[0] == 0) return;
+    bool any_h = false, all_fin = true, all_hit = true;
+    for (int b = 0; b < B; ++b) {
+        any_h = any_h || p.flags[b * 4 + 0];
+        all_fin = all_fin && p.flags[b * 4 + 1];
+        all_hit = all_hit && p.flags[b * 4 + 2];
+    }
+    counters[0] = (any_h && !(all_fin && early_stopping) && !all_hit) ? 1 : 0;
+}
+
+void beam_step(void* state, const float* logits, int ldl, int V, int B, int K, int max_len, int cur_len, int eos, int min_len,
+               float length_penalty, int early_stopping, int64_t* next_ids, int* beam_idx, int* counters, mgStream_t stream) {
+    const BeamPtrs p = beam_ptrs(state, B, K, max_len);
+    MG_LAUNCH((beam_topk_kernel<8>), dim3(B), dim3(256), 256, stream, p, logits, ldl, V, K, cur_len, eos, min_len, (const int*)counters);
+    const float fin_div = (float)pow((double)cur_len, (double)length_penalty);    // (cur_len + 1 - prompt_len)^lp, prompt = 1
+    const float heur_div = (float)pow((double)cur_len, (double)length_penalty);   // ((cur_len+1) - prompt_len)^lp after the increment
+    MG_LAUNCH(beam_update_kernel, dim3(B), dim3(256), 1024, stream, p, B, K, V, max_len, cur_len, eos, fin_div, heur_div, early_stopping,
+              next_ids, beam_idx, (const int*)counters);
+    MG_LAUNCH(beam_flags_kernel, dim3(1), dim3(64), 0, stream, p, B, early_stopping, counters);
+}
+
+// utils.py:3510-3523: best beam per image, generated length from its beam-index history
+__global__ __launch_bounds__(256) void beam_finalize_kernel(BeamPtrs p, int B, int K, int max_len, int64_t* out_ids, int* out_cols,
+                                                       float* out_scores) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int ml = max_len, il = max_len - 1;
+    for (int j = tid; j < ml; j += 256) out_ids[(size_t)b * ml + j] = p.sequences[(size_t)b * K * ml + j];
+    int c = 0;
+    for (int j = tid; j < il; j += 256) c += p.beam_idx_out[(size_t)b * K * il + j] != -1;
+    MG_DYN_SMEM(smem);
+    int* tot = (int*)smem;
+    if (tid == 0) *tot = 0;
+    __syncthreads();
+    if (c) atomicAdd(tot, c);
+    __syncthreads();
+    if (tid == 0) {
+        atomicMax(out_cols, 1 + *tot);
+        if (out_scores) out_scores[b] = p.beam_scores[b * K];
+    }
+}
+void beam_finalize(void* state, int B, int K, int max_len, int64_t* out_ids, int* out_cols, float* out_scores, mgStream_t stream) {
+    const BeamPtrs p = beam_ptrs(state, B, K, max_len);
+    mg_memset_async(out_cols, 0, sizeof(int), stream);
+    MG_LAUNCH(beam_finalize_kernel, dim3(B), dim3(256), 16, stream, p, B, K, max_len, out_ids, out_cols, out_scores);
+}
+
+// ancestor-table reorder: one workgroup per cached position j < t_written, in place
+__global__ __launch_bounds__(256) void beam_reorder_anc_kernel(int* anc, const int* beam_idx, int rows, const int* counters) {
+    if (counters[0] == 0) return;
+    const int j = blockIdx.x;
+    int v[4];
+    int n = 0;
+    for (int r = threadIdx.x; r < rows; r += 256) v[n++] = anc[(size_t)j * rows + beam_idx[r]];
+    __syncthreads();
+    n = 0;
+    for (int r = threadIdx.x; r < rows; r += 256) anc[(size_t)j * rows + r] = v[n++];
+}
+void beam_reorder_anc(int* anc, int* anc_tmp, const int* beam_idx, int rows, int t_written, int T_cap, const int* counters,
+                      mgStream_t stream) {
+    (void)anc_tmp; (void)T_cap;
+    MG_LAUNCH(beam_reorder_anc_kernel, dim3(t_written), dim3(256), 0, stream, anc, beam_idx, rows, counters);
+}
+
+// physical reorder (cache_utils.py:100-104): dst[lk][r] = src[lk][beam_idx[r]], 16-byte copies, HBM-bound
+__global__ __launch_bounds__(256) void beam_reorder_copy_kernel(const uint4* src, uint4* dst, const int* beam_idx, int rows, int H,
+                                                           int t_cap, int t_used) {
+    const size_t per_h = (size_t)t_cap * 8, used_h = (size_t)t_used * 8;      // uint4 per (row, head)
+    const size_t per_row = per_h * H;
+    const int lk = blockIdx.y;
+    const size_t n = (size_t)rows * H * used_h;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / (H * used_h), rem = i - r * (H * used_h);
+        const size_t h = rem / used_h, e = rem - h * used_h;
+        const size_t so = ((size_t)lk * rows + beam_idx[r]) * per_row + h * per_h + e;
+        const size_t dof = ((size_t)lk * rows + r) * per_row + h * per_h + e;
+        dst[dof] = src[so];
+    }
+}
+void beam_reorder_copy(const uint16_t* src, uint16_t* dst, const int* beam_idx, int nlk, int rows, int H, int t_cap, int t_used,
+                       mgStream_t stream) {
+    const size_t n = (size_t)rows * H * t_used * 8;
+    int bx = (int)((n + 255) / 256);
+    if (bx > 2048) bx = 2048;
+    if (bx < 1) bx = 1;
+    MG_LAUNCH(beam_reorder_copy_kernel, dim3(bx, nlk), dim3(256), 0, stream, (const uint4*)src, (uint4*)dst, beam_idx, rows, H, t_cap, t_used);
+}
+
+}  // namespace mg

@@ -37,7 +37,8 @@ MG_DEV void heads_store(const HeadsOut& ho, int ri, int h, int m, int dim0, cons
         st16(base + ((size_t)m * ho.H + h) * 64 + dim0, c);
     } else if (fmt == HF_STEP_KV) {
         const int row = ho.row_map ? ho.row_map[m] : m;
-        st16(base + (((size_t)row * ho.H + h) * (size_t)ho.S_cap + (size_t)ho.pos) * 64 + dim0, c);
+        const int pos = ho.pos_dev ? *ho.pos_dev : ho.pos;
+        st16(base + (((size_t)row * ho.H + h) * (size_t)ho.S_cap + (size_t)pos) * 64 + dim0, c);
     }
 }
 

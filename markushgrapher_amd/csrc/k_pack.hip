@@ -84,7 +84,7 @@ void im2col_pack(const float* pix, uint16_t* x_pk, int B, int C, int I, int ps, 
 // per step -> one 16-byte chunk of the packed operand.  Rows >= M of the last 32-row tile are zero-filled by
 // the caller's buffer initialisation (their GEMM results are discarded anyway).
 __global__ __launch_bounds__(256) void rmsnorm_pack_kernel(const float* h, const float* gain, uint16_t* x_pk, float* out_f32,
-                                                      int M, int d, float eps, float scale) {
+                                                      const int* dst_row, int M, int d, float eps, float scale) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nch = d >> 3;
     for (int m = blockIdx.x * 4 + w; m < M; m += gridDim.x * 4) {
@@ -109,8 +109,9 @@ __global__ __launch_bounds__(256) void rmsnorm_pack_kernel(const float* h, const
                 *(float4*)(out_f32 + (size_t)m * d + c * 8) = make_float4(v[0], v[1], v[2], v[3]);
                 *(float4*)(out_f32 + (size_t)m * d + c * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
             }
-            if (x_pk)
-                st16(x_pk + pk_off(m, c * 8, d),
+            const int mo = dst_row ? dst_row[m] : m;
+            if (x_pk && mo >= 0)
+                st16(x_pk + pk_off(mo, c * 8, d),
                      make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])));
         }
     }
@@ -120,7 +121,14 @@ void rmsnorm_pack(const float* h, const float* gain, uint16_t* x_pk, float* out_
     int blocks = (M + 3) / 4;
     if (blocks > 8192) blocks = 8192;
     if (blocks < 1) blocks = 1;
-    MG_LAUNCH(rmsnorm_pack_kernel, dim3(blocks), dim3(256), 0, stream, h, gain, x_pk, out_f32, M, d, eps, scale);
+    MG_LAUNCH(rmsnorm_pack_kernel, dim3(blocks), dim3(256), 0, stream, h, gain, x_pk, out_f32, (const int*)nullptr, M, d, eps, scale);
+}
+void rmsnorm_pack_rows(const float* h, const float* gain, uint16_t* x_pk, const int* dst_row, int M, int d, float eps,
+                       float scale, mgStream_t stream) {
+    int blocks = (M + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    MG_LAUNCH(rmsnorm_pack_kernel, dim3(blocks), dim3(256), 0, stream, h, gain, x_pk, (float*)nullptr, dst_row, M, d, eps, scale);
 }
 
 }  // namespace mg

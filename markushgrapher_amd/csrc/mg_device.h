@@ -27,6 +27,24 @@ typedef __bf16 mg_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 mg_bf16x2 __attribute__((ext_vector_type(2)));
 #endif
 
+// host-side runtime shims (the emulator "device" is host memory)
+#ifdef MG_EMU
+#include <string.h>
+static inline int mg_memset_async(void* p, int v, size_t n, mgStream_t) { memset(p, v, n); return 0; }
+static inline int mg_memcpy_async(void* d, const void* s, size_t n, mgStream_t) { memmove(d, s, n); return 0; }
+static inline int mg_stream_sync(mgStream_t) { return 0; }
+static inline int mg_peek_error() { return 0; }
+static inline const char* mg_error_string(int) { return "emu"; }
+#else
+static inline int mg_memset_async(void* p, int v, size_t n, mgStream_t st) { return (int)hipMemsetAsync(p, v, n, st); }
+static inline int mg_memcpy_async(void* d, const void* s, size_t n, mgStream_t st) {
+    return (int)hipMemcpyAsync(d, s, n, hipMemcpyDefault, st);
+}
+static inline int mg_stream_sync(mgStream_t st) { return (int)hipStreamSynchronize(st); }
+static inline int mg_peek_error() { return (int)hipGetLastError(); }
+static inline const char* mg_error_string(int e) { return hipGetErrorString((hipError_t)e); }
+#endif
+
 #define MG_DEV __device__ __forceinline__
 #define MG_HD __host__ __device__ __forceinline__
 

@@ -33,6 +33,7 @@ struct HeadsOut {
     int S_cap;             // token capacity of the destination per (b,h)
     const int* row_map;    // HF_NATURAL: destination row of token m, or -1 to drop (nullable)
     int pos;               // HF_STEP: cache position written
+    const int* pos_dev;    // if non-null the position is read from device memory (graph replay)
 };
 struct GemmArgs {
     const uint16_t* X;
@@ -55,6 +56,9 @@ void gemm_rows(const GemmArgs& a, int epi, mgStream_t stream);
 // x_pk[M][d] (packed bf16) = RMSNorm(h[M][d] fp32) * gain * scale ; optionally also out_f32 row-major
 void rmsnorm_pack(const float* h, const float* gain, uint16_t* x_pk, float* out_f32, int M, int d, float eps,
                   float scale, mgStream_t stream);
+// same, but source row m is written to packed row dst_row[m] (skipped when negative)
+void rmsnorm_pack_rows(const float* h, const float* gain, uint16_t* x_pk, const int* dst_row, int M, int d, float eps,
+                       float scale, mgStream_t stream);
 // HF [N][K] weight (fp32 or bf16 bits) -> packed bf16 tiles, rows >= N zero
 void pack_weight(const void* src, int src_is_bf16, int N, int K, uint16_t* dst, int Npad, mgStream_t stream);
 void convert_to_f32(const void* src, int src_is_bf16, float* dst, size_t n, mgStream_t stream);
@@ -82,7 +86,8 @@ struct EmbedArgs {
     int* xlen;                  // [B]         number of attended tokens
     int* err;                   // device error word (bit 0: token id out of range)
 };
-void embed_assemble(const EmbedArgs& a, mgStream_t stream);
+size_t embed_meta_bytes(int B, int S_cap);
+void embed_assemble(const EmbedArgs& a, void* meta_ws, mgStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
 // attention over packed Q/K/V^T (encoder self-attention, teacher-forced decoder self- and cross-attention)
@@ -121,6 +126,7 @@ struct AttnStepArgs {
     const float* bias;        // self: [T_cap][H] indexed by distance t - j (nullable)
     const int* anc;           // self with beams: [T_cap][rows] physical row holding position j (nullable)
     int t;                    // current position (self)
+    const int* t_dev;         // if non-null: t (and n_keys = t+1 for self-attention) are read from device memory
 };
 void attention_step(const AttnStepArgs& a, mgStream_t stream);
 
@@ -135,25 +141,26 @@ struct ArgmaxArgs {
     int64_t* next_ids;       // [rows] token fed to the next step
     int64_t* out_ids;        // [rows][max_len]
     int max_len, pos;        // column written
+    const int* pos_dev;      // if non-null the column is *pos_dev
+    int min_len;             // EOS is suppressed while pos < min_len (MinLengthLogitsProcessor)
     int* unfinished;         // [rows]
     int* n_unfinished;       // [1] recomputed
     float* top2;             // [rows][2] (nullable) top-1 / top-2 logit of this step
 };
 void greedy_select(const ArgmaxArgs& a, mgStream_t stream);
 
-// beam search step on device: log-softmax + running scores, top-2K over K*V, bookkeeping (gen:3208-3525)
-struct BeamState;   // opaque layout in k_beam.hip
+// beam search on the device (k_beam.hip; restates stock generation/utils.py:3208-3525)
 size_t beam_state_bytes(int B, int K, int max_len);
-void beam_init(void* state, int B, int K, int max_len, int pad, int eos, int start, int64_t* next_ids, mgStream_t stream);
-void beam_step(void* state, const float* logits, int ldl, int V, int B, int K, int max_len, int cur_len, int eos,
-               float length_penalty, int early_stopping, int64_t* next_ids, int* beam_idx, int* cont_flag,
-               mgStream_t stream);
-void beam_finalize(void* state, int B, int K, int max_len, int64_t* out_ids, int* out_len, float* out_scores,
-                   mgStream_t stream);
-// ancestor-table form of the KV-cache reorder (cache_utils.py:100-104): anc[j][row] <- anc[j][beam_idx[row]]
-void beam_reorder_anc(int* anc, int* anc_tmp, const int* beam_idx, int rows, int t_written, int T_cap, mgStream_t stream);
-// physical form: dst[row] = src[beam_idx[row]] for every layer's K and V (micro-benchmark / reference behaviour)
-void beam_reorder_copy(const uint16_t* src, uint16_t* dst, const int* beam_idx, int rows, size_t row_elems,
+void beam_init(void* state, int B, int K, int max_len, int pad, int eos, int start, int64_t* next_ids, int* anc, int T_cap,
+               int* counters, mgStream_t stream);
+void beam_step(void* state, const float* logits, int ldl, int V, int B, int K, int max_len, int cur_len, int eos, int min_len,
+               float length_penalty, int early_stopping, int64_t* next_ids, int* beam_idx, int* counters, mgStream_t stream);
+void beam_finalize(void* state, int B, int K, int max_len, int64_t* out_ids, int* out_cols, float* out_scores, mgStream_t stream);
+// ancestor-table form of the KV-cache reorder (cache_utils.py:100-104): anc[j][row] <- anc[j][beam_idx[row]], j < t_written
+void beam_reorder_anc(int* anc, int* anc_tmp, const int* beam_idx, int rows, int t_written, int T_cap, const int* counters,
+                      mgStream_t stream);
+// physical form: dst[lk][row] = src[lk][beam_idx[row]] for nlk = layers*2 K/V planes of [rows][H][t_cap][64] bf16
+void beam_reorder_copy(const uint16_t* src, uint16_t* dst, const int* beam_idx, int nlk, int rows, int H, int t_cap, int t_used,
                        mgStream_t stream);
 
 int selftest_device(char* msg, int msg_len, mgStream_t stream);

@@ -1,0 +1,219 @@
+"""Thin ctypes binding of libmgrapher_hip.so (include/mgrapher.h).  PyTorch-ROCm is only the memory carrier:
+device buffers are torch tensors, every computation is a HIP kernel behind the C ABI.
+
+`Engine` is written against a tiny memory-provider interface so the parity tests can also drive the SAME C ABI
+compiled for the CPU SIMT emulator with numpy buffers (tests/backends.py) — the product default, `TorchMem`, is
+the only provider in this package and requires a GPU; there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import _lib
+from .synth import ModelShape
+
+
+class MgConfig(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "vocab_size", "d_model", "d_kv", "d_ff", "num_layers", "num_decoder_layers", "num_heads",
+        "relative_attention_num_buckets", "relative_attention_max_distance", "max_2d_position_embeddings",
+        "image_size", "patch_size", "num_channels", "pad_token_id", "eos_token_id", "decoder_start_token_id")] + [
+        ("layer_norm_epsilon", C.c_float), ("max_decode_len", C.c_int)]
+
+
+class MgError(RuntimeError):
+    pass
+
+
+class TorchMem:
+    """Device memory carried by torch tensors on one GPU."""
+
+    def __init__(self, device=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("markushgrapher_amd needs an MI355X GPU (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        self.torch = torch
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+
+    _NP2T = None
+
+    def _dt(self, dtype):
+        t = self.torch
+        return {np.dtype(np.float32): t.float32, np.dtype(np.float64): t.float64, np.dtype(np.int64): t.int64,
+                np.dtype(np.int32): t.int32, np.dtype(np.uint8): t.uint8, np.dtype(np.uint16): t.int16}[np.dtype(dtype)]
+
+    def empty(self, shape, dtype):
+        return self.torch.empty(shape, dtype=self._dt(dtype), device=self.device)
+
+    def zeros(self, shape, dtype):
+        return self.torch.zeros(shape, dtype=self._dt(dtype), device=self.device)
+
+    def asarray(self, x, dtype):
+        """numpy array or torch tensor -> contiguous device tensor of `dtype` (no copy when already right)."""
+        t = self.torch
+        if isinstance(x, np.ndarray):
+            if x.dtype == np.uint16:
+                x = x.view(np.int16)
+            x = t.from_numpy(np.ascontiguousarray(x))
+        want = self._dt(dtype)
+        if x.dtype == t.bfloat16 and np.dtype(dtype) == np.uint16:
+            x = x.view(t.int16)
+        return x.to(device=self.device, dtype=want, non_blocking=True).contiguous()
+
+    def ptr(self, h):
+        return C.c_void_p(h.data_ptr())
+
+    def stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def sync(self):
+        self.torch.cuda.synchronize(self.device)
+
+    def numpy(self, h):
+        self.sync()
+        return h.detach().cpu().numpy()
+
+
+class Engine:
+    def __init__(self, shape: ModelShape, lib=None, mem=None, max_decode_len: int = 512):
+        self.lib = lib if lib is not None else _lib.load()
+        self.mem = mem if mem is not None else TorchMem()
+        self.shape = shape
+        self._declare()
+        cfg = MgConfig(shape.vocab_size, shape.d_model, shape.d_kv, shape.d_ff, shape.num_layers,
+                       shape.num_decoder_layers, shape.num_heads, shape.relative_attention_num_buckets,
+                       shape.relative_attention_max_distance, shape.max_2d_position_embeddings, shape.image_size,
+                       shape.patch_size, shape.num_channels, shape.pad_token_id, shape.eos_token_id,
+                       shape.decoder_start_token_id, shape.layer_norm_epsilon, max_decode_len)
+        self.model = C.c_void_p()
+        self._chk(self.lib.mg_create(C.byref(cfg), C.byref(self.model)))
+        self.max_decode_len = (max_decode_len + 63) // 64 * 64
+        self.arena = self.mem.zeros((int(self.lib.mg_weights_bytes(self.model)),), np.uint8)
+        self._chk(self.lib.mg_bind_weights(self.model, self.mem.ptr(self.arena)))
+        self._ws = None
+        self._ws_bytes = 0
+        self.ignored_keys = []
+
+    def _declare(self):
+        L = self.lib
+        L.mg_last_error.restype = C.c_char_p
+        L.mg_weights_bytes.restype = C.c_size_t
+        L.mg_weights_bytes.argtypes = [C.c_void_p]
+        L.mg_destroy.argtypes = [C.c_void_p]
+        L.mg_bind_weights.argtypes = [C.c_void_p, C.c_void_p]
+        L.mg_finalize.argtypes = [C.c_void_p, C.c_void_p]
+        L.mg_load_tensor.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]
+        L.mg_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
+        L.mg_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.mg_decoder_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                         C.c_int, C.c_int, C.c_void_p]
+        L.mg_generate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
+                                  C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
+        L.mg_debug_bucket_table.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int]
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise MgError(f"libmgrapher error {rc}: {self.lib.mg_last_error().decode()}")
+        return rc
+
+    def close(self):
+        if self.model:
+            self.lib.mg_destroy(self.model)
+            self.model = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------------------------------
+    def load_state_dict(self, sd: Dict[str, object], finalize: bool = True):
+        """sd: HF state-dict names -> numpy (fp32 / uint16 bf16 bits) or torch tensors (fp32 / bf16)."""
+        st = self.mem.stream()
+        keep = []
+        for key, val in sd.items():
+            is_bf16 = (isinstance(val, np.ndarray) and val.dtype == np.uint16) or \
+                      (not isinstance(val, np.ndarray) and str(val.dtype) == "torch.bfloat16")
+            h = self.mem.asarray(val, np.uint16 if is_bf16 else np.float32)
+            keep.append(h)
+            shp = (C.c_int64 * len(val.shape))(*[int(s) for s in val.shape])
+            rc = self._chk(self.lib.mg_load_tensor(self.model, st, key.encode(), self.mem.ptr(h), 1 if is_bf16 else 0,
+                                                   shp, len(val.shape)))
+            if rc == 1:
+                self.ignored_keys.append(key)
+        if finalize:
+            self._chk(self.lib.mg_finalize(self.model, st))
+        self.mem.sync()
+        del keep
+
+    def bucket_table(self, which: int, n: int) -> np.ndarray:
+        out = (C.c_int * n)()
+        k = self.lib.mg_debug_bucket_table(self.model, which, out, n)
+        return np.array(out[:k], dtype=np.int32)
+
+    def workspace(self, B, L, num_beams, max_length, T):
+        need = C.c_size_t()
+        self._chk(self.lib.mg_workspace_bytes(self.model, B, L, num_beams, max_length, T, C.byref(need)))
+        if need.value > self._ws_bytes:
+            self._ws = None
+            self._ws = self.mem.empty((need.value,), np.uint8)
+            self._ws_bytes = need.value
+        return self._ws, self._ws_bytes
+
+    def _inputs(self, input_ids, bbox, attention_mask, pixel_values):
+        ids = self.mem.asarray(input_ids, np.int64)
+        bb = self.mem.asarray(bbox, np.float32)
+        pv = self.mem.asarray(pixel_values, np.float32)
+        am = None if attention_mask is None else self.mem.asarray(attention_mask, np.uint8)
+        B, L = int(ids.shape[0]), int(ids.shape[1])
+        s = self.shape
+        if tuple(bb.shape) != (B, L, 4):
+            raise ValueError(f"bbox must be [B,L,4], got {tuple(bb.shape)}")
+        if tuple(pv.shape) != (B, s.num_channels, s.image_size, s.image_size):
+            raise ValueError(f"pixel_values must be [B,{s.num_channels},{s.image_size},{s.image_size}], got {tuple(pv.shape)}")
+        return ids, bb, am, pv, B, L
+
+    def encode(self, input_ids, bbox, attention_mask, pixel_values, max_length=0, num_beams=1, T=0, want_out=True):
+        ids, bb, am, pv, B, L = self._inputs(input_ids, bbox, attention_mask, pixel_values)
+        ws, nb = self.workspace(B, L, num_beams, max_length, T)
+        S = L + self.shape.num_patches
+        out = self.mem.empty((B, S, self.shape.d_model), np.float32) if want_out else None
+        msk = self.mem.empty((B, S), np.uint8) if want_out else None
+        self._chk(self.lib.mg_encode(self.model, self.mem.stream(), self.mem.ptr(ws), nb, self.mem.ptr(ids), self.mem.ptr(bb),
+                                     self.mem.ptr(am) if am is not None else None, self.mem.ptr(pv), B, L,
+                                     self.mem.ptr(out) if want_out else None, self.mem.ptr(msk) if want_out else None))
+        self._keep = (ids, bb, am, pv)
+        return out, msk
+
+    def forward_logits(self, input_ids, bbox, attention_mask, pixel_values, decoder_input_ids, decoder_attention_mask=None):
+        dec = self.mem.asarray(decoder_input_ids, np.int64)
+        B, T = int(dec.shape[0]), int(dec.shape[1])
+        dm = None if decoder_attention_mask is None else self.mem.asarray(decoder_attention_mask, np.uint8)
+        enc_out, enc_mask = self.encode(input_ids, bbox, attention_mask, pixel_values, T=T)
+        ws, nb = self.workspace(B, int(enc_out.shape[1]) - self.shape.num_patches, 1, 0, T)
+        logits = self.mem.empty((B, T, self.shape.vocab_size), np.float32)
+        self._chk(self.lib.mg_decoder_forward(self.model, self.mem.stream(), self.mem.ptr(ws), nb, self.mem.ptr(dec),
+                                              self.mem.ptr(dm) if dm is not None else None, B, T, self.mem.ptr(logits)))
+        return logits, enc_out, enc_mask
+
+    def generate(self, input_ids, bbox, attention_mask, pixel_values, num_beams=1, max_length=512, min_length=0,
+                 length_penalty=1.0, early_stopping=False, return_top2=False):
+        ids, bb, am, pv, B, L = self._inputs(input_ids, bbox, attention_mask, pixel_values)
+        ws, nb = self.workspace(B, L, num_beams, max_length, 0)
+        out = self.mem.empty((B, max_length), np.int64)
+        scores = self.mem.zeros((B,), np.float32)
+        top2 = self.mem.zeros((max_length, B * num_beams, 2), np.float32) if (return_top2 and num_beams == 1) else None
+        cols = C.c_int(0)
+        self._chk(self.lib.mg_generate(self.model, self.mem.stream(), self.mem.ptr(ws), nb, self.mem.ptr(ids), self.mem.ptr(bb),
+                                       self.mem.ptr(am) if am is not None else None, self.mem.ptr(pv), B, L, num_beams,
+                                       max_length, min_length, C.c_float(length_penalty), 1 if early_stopping is True else 0,
+                                       self.mem.ptr(out), C.byref(cols), self.mem.ptr(scores),
+                                       self.mem.ptr(top2) if top2 is not None else None))
+        return out[:, :cols.value], scores, top2

@@ -41,6 +41,7 @@ class Buf:
 class Backend:
     def __init__(self, name):
         self.name = name
+        self._keep = []
         if name == "emu":
             import importlib.util
             spec = importlib.util.spec_from_file_location(
@@ -58,10 +59,12 @@ class Backend:
             self.stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def buf(self, arr):
-        return Buf(self, np.asarray(arr))
+        b = Buf(self, np.asarray(arr))
+        self._keep.append(b)      # buffers passed inline as be.p(be.buf(..)) must outlive the call
+        return b
 
     def zeros(self, shape, dtype):
-        return Buf(self, np.zeros(shape, dtype))
+        return self.buf(np.zeros(shape, dtype))
 
     def sync(self):
         if self.name != "emu":
@@ -79,4 +82,44 @@ _cache = {}
 def get_backend(name):
     if name not in _cache:
         _cache[name] = Backend(name)
+    _cache[name].sync()
+    _cache[name]._keep.clear()    # a test calls get_backend() first: drop the previous test's buffers
     return _cache[name]
+
+
+class NumpyMem:
+    """Memory provider for markushgrapher_amd.engine.Engine on the emulator backend (host memory)."""
+
+    def empty(self, shape, dtype):
+        return np.zeros(shape, dtype)
+
+    zeros = empty
+
+    def asarray(self, x, dtype):
+        if not isinstance(x, np.ndarray):
+            x = x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
+        return np.ascontiguousarray(x).astype(dtype, copy=True)
+
+    def ptr(self, h):
+        return ctypes.c_void_p(h.ctypes.data)
+
+    def stream(self):
+        return ctypes.c_void_p(0)
+
+    def sync(self):
+        pass
+
+    def numpy(self, h):
+        return h
+
+
+def make_engine(be_name, shape, sd, max_decode_len=64):
+    """Engine over the chosen backend with the given fp32 (bf16-exact) state dict loaded."""
+    from markushgrapher_amd.engine import Engine
+    be = get_backend(be_name)
+    if be_name == "emu":
+        eng = Engine(shape, lib=be.lib, mem=NumpyMem(), max_decode_len=max_decode_len)
+    else:
+        eng = Engine(shape, max_decode_len=max_decode_len)
+    eng.load_state_dict(sd)
+    return eng

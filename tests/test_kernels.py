@@ -172,3 +172,225 @@ def test_im2col_pack(be_name):
     out = be.zeros((B * n * n * Cc * ps * ps,), np.uint16)
     assert be.lib.mgk_im2col_pack(be.stream, be.p(pb), be.p(out), B, Cc, I, ps) == 0
     np.testing.assert_array_equal(pk.unpack_tiles(out.numpy(), B * n * n, Cc * ps * ps), pk.bf16_round(ref))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# attention
+# ---------------------------------------------------------------------------------------------------------
+def pack_heads_rows(x):
+    """fp32 [B][H][S][64] -> HF_PK_ROWS bits"""
+    B, H, S, D = x.shape
+    t = pk.bf16_bits(x).reshape(B, H, S // 32, 32, 4, 2, 8).transpose(0, 1, 2, 4, 5, 3, 6)
+    return np.ascontiguousarray(t).reshape(-1)
+
+
+def pack_heads_t(x):
+    """fp32 [B][H][S][64] -> HF_PK_T bits  [b][h][dt][kt][half][dim32][8 tok]"""
+    B, H, S, D = x.shape
+    t = pk.bf16_bits(x).reshape(B, H, S // 16, 2, 8, 2, 32).transpose(0, 1, 5, 2, 3, 6, 4)
+    return np.ascontiguousarray(t).reshape(-1)
+
+
+def enc_tables(w1, wh, wv):
+    import torch
+    from oracle.udop_oracle import relative_position_bucket as rpb
+    b1 = rpb(torch.arange(-128, 129), True, 32, 128).numpy()
+    bhv = rpb(torch.arange(-100, 101), True, 32, 100).numpy()
+    return w1[b1].astype(np.float32), wh[bhv].astype(np.float32), wv[bhv].astype(np.float32)
+
+
+def softmax_ref(scores):
+    m = scores.max(-1, keepdims=True)
+    e = np.exp(scores - m)
+    return e / e.sum(-1, keepdims=True)
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+@pytest.mark.parametrize("S,S_cap", [(23, 64), (150, 192)])
+def test_attention_encoder_bias(be_name, S, S_cap):
+    import torch
+    from oracle.udop_oracle import relative_position_bucket as rpb
+    be = get_backend(be_name)
+    B, H = 2, 2
+    q, k, v = [pk.bf16_round(rnd((B, H, S_cap, 64), 20 + i, 0.5)) for i in range(3)]
+    rs = np.random.RandomState(5)
+    cx, cy = rs.rand(B, S_cap), rs.rand(B, S_cap)
+    cx[:, 3] = cx[:, 4]   # zero horizontal distance
+    cx = (np.round(cx * 64) / 64.0)   # exact multiples: distances land exactly on integer *100 boundaries sometimes
+    mask = np.ones((B, S_cap), np.uint8)
+    mask[1, 5:9] = 0
+    mask[:, S:] = 0
+    w1, wh, wv = [rnd((32, H), 30 + i) for i in range(3)]
+    t1, th, tv = enc_tables(w1, wh, wv)
+    # reference (stock:904-953 semantics)
+    pos = np.arange(S)
+    b1 = rpb(torch.from_numpy(pos[None, :] - pos[:, None]), True, 32, 128).numpy()
+    ref = np.zeros((B, H, S, 64), np.float32)
+    for b in range(B):
+        dx = ((torch.from_numpy(cx[b, None, :S] - cx[b, :S, None]).float() * 100).to(torch.long))
+        dy = ((torch.from_numpy(cy[b, None, :S] - cy[b, :S, None]).float() * 100).to(torch.long))
+        bh, bv = rpb(dx, True, 32, 100).numpy(), rpb(dy, True, 32, 100).numpy()
+        for h in range(H):
+            sc = q[b, h, :S] @ k[b, h, :S].T + w1[b1, h] + wh[bh, h] + wv[bv, h]
+            sc = np.where(mask[b, None, :S] != 0, sc, -1e30)
+            ref[b, h] = softmax_ref(sc) @ v[b, h, :S]
+    Q, K, V = be.buf(pack_heads_rows(q)), be.buf(pack_heads_rows(k)), be.buf(pack_heads_t(v))
+    ctx = be.zeros((B * S_cap * H * 64,), np.uint16)
+    rc = be.lib.mgk_attention(be.stream, 0, be.p(Q), be.p(K), be.p(V), be.p(ctx), B, H, S, S, S_cap, S_cap,
+                              be.p(be.buf(mask)), be.p(be.buf(t1)), 257, be.p(be.buf(th)), be.p(be.buf(tv)),
+                              be.p(be.buf(cx)), be.p(be.buf(cy)))
+    assert rc == 0
+    got = pk.unpack_tiles(ctx.numpy(), B * S_cap, H * 64).reshape(B, S_cap, H, 64).transpose(0, 2, 1, 3)[:, :, :S]
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-2)
+    assert np.abs(got - ref).mean() < 2e-3
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+def test_attention_decoder_self_and_cross(be_name):
+    import torch
+    from oracle.udop_oracle import relative_position_bucket as rpb
+    be = get_backend(be_name)
+    B, H, T, T_cap, Sk, Sk_cap = 2, 2, 40, 64, 100, 128
+    q, k, v = [pk.bf16_round(rnd((B, H, T_cap, 64), 40 + i, 0.5)) for i in range(3)]
+    wd = rnd((32, H), 45)
+    dist = torch.arange(0, 64)
+    tab = wd[rpb(-dist, False, 32, 128).numpy()].astype(np.float32)       # [64][H] indexed by i-j
+    dmask = np.ones((B, T_cap), np.uint8)
+    dmask[1, 30:] = 0
+    ref = np.zeros((B, H, T, 64), np.float32)
+    ii, jj = np.arange(T)[:, None], np.arange(T)[None, :]
+    for b in range(B):
+        for h in range(H):
+            sc = q[b, h, :T] @ k[b, h, :T].T + tab[np.clip(ii - jj, 0, 63), h]
+            sc = np.where((jj <= ii) & (dmask[b, None, :T] != 0), sc, -1e30)
+            ref[b, h] = softmax_ref(sc) @ v[b, h, :T]
+    Q, K, V = be.buf(pack_heads_rows(q)), be.buf(pack_heads_rows(k)), be.buf(pack_heads_t(v))
+    ctx = be.zeros((B * T_cap * H * 64,), np.uint16)
+    assert be.lib.mgk_attention(be.stream, 1, be.p(Q), be.p(K), be.p(V), be.p(ctx), B, H, T, T, T_cap, T_cap,
+                                be.p(be.buf(dmask)), be.p(be.buf(tab)), 64, None, None, None, None) == 0
+    got = pk.unpack_tiles(ctx.numpy(), B * T_cap, H * 64).reshape(B, T_cap, H, 64).transpose(0, 2, 1, 3)[:, :, :T]
+    valid = np.ones((B, T), bool)
+    valid[1, 30:] = True   # rows whose every key is masked still see key 0..i with dmask -> compare all defined rows
+    np.testing.assert_allclose(got[0], ref[0], rtol=0, atol=2e-2)
+    np.testing.assert_allclose(got[1, :, :30], ref[1, :, :30], rtol=0, atol=2e-2)
+    # cross
+    kx, vx = [pk.bf16_round(rnd((B, H, Sk_cap, 64), 50 + i, 0.5)) for i in range(2)]
+    xm = np.ones((B, Sk_cap), np.uint8)
+    xm[0, 7:20] = 0
+    xm[:, Sk:] = 0
+    refx = np.zeros((B, H, T, 64), np.float32)
+    for b in range(B):
+        for h in range(H):
+            sc = q[b, h, :T] @ kx[b, h, :Sk].T
+            sc = np.where(xm[b, None, :Sk] != 0, sc, -1e30)
+            refx[b, h] = softmax_ref(sc) @ vx[b, h, :Sk]
+    KX, VX = be.buf(pack_heads_rows(kx)), be.buf(pack_heads_t(vx))
+    ctx2 = be.zeros((B * T_cap * H * 64,), np.uint16)
+    assert be.lib.mgk_attention(be.stream, 2, be.p(Q), be.p(KX), be.p(VX), be.p(ctx2), B, H, T, Sk, T_cap, Sk_cap,
+                                be.p(be.buf(xm)), None, 0, None, None, None, None) == 0
+    got2 = pk.unpack_tiles(ctx2.numpy(), B * T_cap, H * 64).reshape(B, T_cap, H, 64).transpose(0, 2, 1, 3)[:, :, :T]
+    np.testing.assert_allclose(got2, refx, rtol=0, atol=2e-2)
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+@pytest.mark.parametrize("group", [1, 5])
+def test_attention_step(be_name, group):
+    be = get_backend(be_name)
+    owners, H, cap = 3, 2, 96
+    rows = owners * group
+    q = pk.bf16_round(rnd((rows, H, 64), 60, 0.5))
+    kc, vc = [pk.bf16_round(rnd((owners, H, cap, 64), 61 + i, 0.5)) for i in range(2)]
+    lens = np.array([96, 37, 1], np.int32)
+    bias = rnd((cap, H), 63) if group == 1 else None
+    t = 40
+    ref = np.zeros((rows, H, 64), np.float32)
+    for r in range(rows):
+        o = r // group
+        n = (t + 1) if group == 1 else lens[o]
+        for h in range(H):
+            sc = kc[o, h, :n] @ q[r, h]
+            if bias is not None:
+                sc = sc + bias[t - np.arange(n), h]
+            p = softmax_ref(sc[None])[0]
+            ref[r, h] = p @ vc[o, h, :n]
+    ctx = be.zeros((((rows + 31) // 32 * 32) * H * 64,), np.uint16)
+    rc = be.lib.mgk_attention_step(be.stream, be.p(be.buf(pk.bf16_bits(q))), be.p(be.buf(pk.bf16_bits(kc))),
+                                   be.p(be.buf(pk.bf16_bits(vc))), be.p(ctx), rows, H, group, cap,
+                                   None if group == 1 else be.p(be.buf(lens)), t + 1,
+                                   be.p(be.buf(bias)) if bias is not None else None, None, t)
+    assert rc == 0
+    got = pk.unpack_tiles(ctx.numpy(), rows, H * 64).reshape(rows, H, 64)
+    np.testing.assert_allclose(got, ref, rtol=1 / 128, atol=2e-3)
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+def test_greedy_select(be_name):
+    be = get_backend(be_name)
+    rows, V, ldl, max_len = 5, 1000, 1024, 8
+    lg = rnd((rows, ldl), 70)
+    lg[0, 17] = lg[0, 900] = 9.0          # tie -> lowest index
+    lg[1, 1] = 12.0                        # EOS wins
+    lg[2, 1] = 12.0                        # EOS wins but row already finished -> pad
+    lg[3, 1] = 12.0                        # EOS suppressed by min_length in the second call
+    unf = np.array([1, 1, 0, 1, 1], np.int32)
+    nxt, out = be.zeros((rows,), np.int64), be.zeros((rows, max_len), np.int64)
+    ub, nu, t2 = be.buf(unf), be.zeros((1,), np.int32), be.zeros((rows, 2), np.float32)
+    L = be.buf(lg)
+    assert be.lib.mgk_greedy_select(be.stream, be.p(L), rows, V, ldl, 1, 0, 0, be.p(nxt), be.p(out), max_len, 3, be.p(ub),
+                                    be.p(nu), be.p(t2)) == 0
+    exp = np.array([17, 1, 0, 1, int(np.argmax(lg[4, :V]))])
+    assert np.array_equal(nxt.numpy(), exp) and np.array_equal(out.numpy()[:, 3], exp)
+    assert np.array_equal(ub.numpy(), [1, 0, 0, 0, 1]) and nu.numpy()[0] == 2
+    srt = np.sort(lg[4, :V])
+    np.testing.assert_allclose(t2.numpy()[4], [srt[-1], srt[-2]])
+    ub2 = be.buf(unf)
+    assert be.lib.mgk_greedy_select(be.stream, be.p(L), rows, V, ldl, 1, 0, 6, be.p(nxt), be.p(out), max_len, 3, be.p(ub2),
+                                    be.p(nu), None) == 0
+    l3 = lg[3, :V].copy(); l3[1] = -np.inf
+    assert nxt.numpy()[3] == int(np.argmax(l3)) and ub2.numpy()[3] == 1
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+@pytest.mark.parametrize("with_mask", [True, False])
+def test_embed_assemble_matches_oracle(be_name, with_mask):
+    import torch
+    from markushgrapher_amd import synth
+    from oracle.udop_oracle import Oracle
+    from tests.conftest import load_golden
+    be = get_backend(be_name)
+    g = load_golden("g0_tiny.npz")
+    shape = synth.SHAPES["tiny"]
+    sd = synth.recipe_state_dict(shape, gain=1.0)
+    o = Oracle(shape, sd)
+    ids, bbox, am = g["input_ids"], g["bbox"], g["attention_mask"]
+    B, L = ids.shape
+    P, d, n = shape.num_patches, shape.d_model, shape.image_size // shape.patch_size
+    S, S_cap = L + P, 64
+    img = pk.bf16_round(rnd((B, P, d), 80))     # stand-in patch embeddings
+    tok = o.w["shared.weight"][torch.from_numpy(ids)]
+    emb, bbox64, mask = o.combine(torch.from_numpy(img), tok, torch.from_numpy(bbox), torch.from_numpy(am) if with_mask else None)
+    cell, _ = o.cell_embed(bbox64)
+    ref = (emb + cell).numpy()
+    ref_mask = mask.numpy() if with_mask else np.ones((B, S), np.int64)
+    hid, cx, cy = be.zeros((B, S_cap, d), np.float32), be.zeros((B, S_cap), np.float64), be.zeros((B, S_cap), np.float64)
+    mk, xrow, xlen, err = be.zeros((B, S_cap), np.uint8), be.zeros((B, S_cap), np.int32), be.zeros((B,), np.int32), be.zeros((1,), np.int32)
+    be.lib.mgk_embed_meta_bytes.restype = C.c_size_t
+    meta = be.zeros((be.lib.mgk_embed_meta_bytes(B, S_cap),), np.uint8)
+    rc = be.lib.mgk_embed_assemble(
+        be.stream, be.p(meta), be.p(be.buf(ids)), be.p(be.buf(bbox)), be.p(be.buf(am.astype(np.uint8))) if with_mask else None,
+        be.p(be.buf(img)), be.p(be.buf(pk.bf16_bits(sd["shared.weight"]))),
+        be.p(be.buf(pk.bf16_bits(sd["encoder.cell_2d_embedding.x_position_embeddings.weight"]))),
+        be.p(be.buf(pk.bf16_bits(sd["encoder.cell_2d_embedding.y_position_embeddings.weight"]))),
+        B, L, P, d, n, shape.max_2d_position_embeddings, shape.vocab_size, S_cap,
+        be.p(hid), be.p(cx), be.p(cy), be.p(mk), be.p(xrow), be.p(xlen), be.p(err))
+    assert rc == 0 and err.numpy()[0] == 0
+    np.testing.assert_allclose(hid.numpy()[:, :S], ref, rtol=0, atol=1e-6)
+    assert np.all(hid.numpy()[:, S:] == 0)
+    assert np.array_equal(mk.numpy()[:, :S], ref_mask.astype(np.uint8)) and np.all(mk.numpy()[:, S:] == 0)
+    np.testing.assert_array_equal(cx.numpy()[:, :S], bbox64[:, :, [0, 2]].mean(-1).numpy())
+    np.testing.assert_array_equal(cy.numpy()[:, :S], bbox64[:, :, [1, 3]].mean(-1).numpy())
+    for b in range(B):
+        att = np.flatnonzero(mk.numpy()[b])
+        assert xlen.numpy()[b] == len(att)
+        assert np.array_equal(xrow.numpy()[b, att], np.arange(len(att)))
+        assert np.all(xrow.numpy()[b, mk.numpy()[b] == 0] == -1)
