@@ -1,0 +1,169 @@
+#!/usr/bin/env python
+"""Headline benchmark (BASELINE.json): images/s, greedy CXSMILES decode, 1024 px crops, batch 32 per GPU.
+
+One "step" = one pass of the hot path over one batch of 32 synthetic pages per GPU: VTL encoder + cross-K/V
+projection + 256 greedy decode steps (EOS suppressed: min_length = max_length = 257) on the
+UDOP-large-shaped MarkushGrapher-2 model with recipe (random-init, bf16-exact) weights.  Inputs (pixel_values at the
+model's 512 px input resolution, produced from the 1024 px synthetic crops; token ids; boxes; masks) are resident in
+HBM when the timed region starts.  With --gpus N, every rank runs its own 32-image shard (weak scaling) and the
+decoded token ids are all-gathered over RCCL inside the timed region.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel (single-query cross-attention over the
+per-image K/V stream: ~80 % of the decode step's HBM bytes), timed live with HIP events on the launch stream.
+`cpu_baseline` times the fp32 CPU oracle (oracle/udop_oracle.py) on a bounded sample on this box's host cores.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "images/sec whole-node (greedy CXSMILES decode, 1024px crops, bs=32/GPU)"
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def cpu_baseline(shape, sd, new_tokens=16, B=2, L=128):
+    """fp32 CPU oracle (oracle/udop_oracle.py, kind "port") on a bounded sample, extrapolated to 256 new tokens."""
+    import torch
+    from markushgrapher_amd import synth
+    from oracle.udop_oracle import Oracle
+    o = Oracle(shape, sd)
+    inp = synth.synth_batch(shape, B, seed=7, fixed_L=L)
+    with torch.no_grad():
+        t0 = time.time()
+        enc, mask = o.encode(inp["input_ids"], inp["bbox"], inp["pixel_values"], inp["attention_mask"])
+        xkv = o.cross_kv(enc)
+        t_enc = time.time() - t0
+        seq = torch.zeros((B, 1), dtype=torch.long)
+        kv, cur = None, seq
+        t0 = time.time()
+        for t in range(new_tokens):
+            hid, kv = o.decoder_stack(cur, mask, xkv, kv, t)
+            cur = torch.argmax(o.lm_logits(hid[:, -1:, :])[:, 0, :], dim=-1)[:, None]
+        t_step = (time.time() - t0) / new_tokens
+    ips = B / (t_enc + 256 * t_step)
+    return {"value": round(ips, 5), "unit": "images/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": f"oracle fp32 torch-CPU, UDOP-large shape, B={B}, L={L}: encoder+cross-KV {t_enc:.2f}s, "
+                      f"{new_tokens} decode steps at {t_step * 1e3:.1f} ms/step, extrapolated to 256 new tokens"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--shape", default="large")
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--new-tokens", type=int, default=256)
+    ap.add_argument("--beams", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-every", type=int, default=16)
+    args = ap.parse_args()
+
+    import torch
+    from markushgrapher_amd import synth
+    from markushgrapher_amd.engine import Engine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+
+    shape = synth.SHAPES[args.shape]
+    B, new_tokens = args.batch, args.new_tokens
+    max_length = new_tokens + 1
+    t0 = time.time()
+    sd = synth.recipe_state_dict(shape, gain=1.0)
+    t_weights = time.time() - t0
+    eng = Engine(shape, max_decode_len=max(512, max_length))
+    eng.load_state_dict(sd)
+    # each rank gets its own shard of the global batch (independent images, no data-path exchange)
+    inp = synth.synth_batch(shape, B, seed=20260928 + rank)
+    dev = {k: eng.mem.asarray(v, {"input_ids": np.int64, "bbox": np.float32, "attention_mask": np.uint8,
+                                  "pixel_values": np.float32}[k]) for k, v in inp.items()}
+    L = inp["input_ids"].shape[1]
+    gathered = torch.empty((world * B, max_length), dtype=torch.int64, device="cuda") if world > 1 else None
+
+    def step():
+        ids, _, _ = eng.generate(dev["input_ids"], dev["bbox"], dev["attention_mask"], dev["pixel_values"],
+                                 num_beams=args.beams, max_length=max_length, min_length=max_length)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, ids.contiguous())
+        return ids
+
+    for _ in range(args.warmup):
+        step()
+    # live timing of the dominant kernel on the launch stream (HIP events), sampled every N-th decode step
+    eng.lib.mg_profile_cross_attention.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    eng.lib.mg_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    nl = shape.num_decoder_layers
+    eng.lib.mg_profile_cross_attention(eng.model, args.profile_every, (new_tokens // max(args.profile_every, 1) + 1) * nl)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(args.steps):
+        ids = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.time() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    n_l, ms, keys = C.c_long(0), C.c_double(0), C.c_double(0)
+    eng.lib.mg_profile_read(eng.model, C.byref(n_l), C.byref(ms), C.byref(keys))
+    assert ids.shape == (B, max_length), ids.shape
+
+    if rank == 0:
+        H = shape.num_heads
+        roof = None
+        if n_l.value > 0:
+            bytes_per_launch = keys.value / n_l.value * H * 64 * 2 * 2     # K and V rows of 64 bf16, all heads
+            dur_s = ms.value / n_l.value * 1e-3
+            ach = bytes_per_launch / dur_s / 1e9
+            roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "kernel": "attn_step_kernel<1> (decoder cross-attention, single query per image/head)",
+                    "bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(dur_s * 1e6, 2),
+                    "launches_timed": int(n_l.value)}
+        out = {
+            "metric": METRIC, "value": round(world * B * args.steps / dt, 3), "unit": "images/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "configs[1]: batch 32/GPU synthetic 1024x1024 crops -> 512px model input, greedy "
+                                   f"decode, {new_tokens} forced new tokens (EOS suppressed), UDOP-large-shaped "
+                                   "MarkushGrapher-2 VTL encoder + CXSMILES decoder, recipe weights",
+                       "shape": args.shape, "batch_per_gpu": B, "text_len_padded": int(L), "new_tokens": new_tokens,
+                       "num_beams": args.beams, "parallelism": f"dp{world} (independent image shards, one RCCL all-gather of token ids)"},
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(shape, sd)
+        else:
+            out["cpu_baseline"] = None
+        out["setup_s"] = {"recipe_weights": round(t_weights, 1)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

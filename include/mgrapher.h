@@ -96,6 +96,14 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
 int mg_beam_reorder(void* stream, const void* kv_src, void* kv_dst, const int32_t* beam_idx, int layers, int rows,
                     int H, int t_cap, int t_used);
 
+/* Live timing of the dominant decode kernel (single-query cross-attention over the per-image K/V stream): when
+ * every > 0, each `every`-th decode step of mg_generate brackets every decoder layer's launch with HIP events on the
+ * caller's stream (at most max_samples launches per call). mg_profile_read returns the number of launches timed, their
+ * summed duration and the summed number of (image, key) rows each of them streamed (bytes = rows * H * 64 * 2 * 2). */
+int mg_profile_cross_attention(mg_model* m, int every, int max_samples);
+int mg_profile_read(mg_model* m, long* launches_host, double* total_ms_host, double* total_keys_host);
+int mg_debug_bucket_table(const mg_model* m, int which, int* out_host, int n);
+
 /* Device self-test of the hardware assumptions the kernels rely on (MFMA fragment layout, global_load_lds
  * destination rule, cross-half shuffle). Synchronises. msg_host receives a short report. */
 int mg_selftest(void* stream, void* scratch_256k, char* msg_host, int msg_len);

@@ -50,6 +50,13 @@ struct mg_model {
     // encoder state left in the workspace by the last mg_encode
     int st_B = 0, st_L = 0, st_S = 0, st_Scap = 0;
     void* st_ws = nullptr;
+    // optional live timing of the dominant decode kernel (cross-attention K/V stream), HIP events on the caller's stream
+    int prof_every = 0;
+    std::vector<mgEvent_t> prof_ev;
+    size_t prof_used = 0;
+    double prof_ms = 0.0;
+    long prof_n = 0;
+    double prof_keys = 0.0;   // sum over timed launches of the number of (image, key) pairs streamed
 
     template <typename T> T* at(size_t off) const { return (T*)(arena + off); }
 };
@@ -678,7 +685,10 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
             AttnStepArgs x{};
             x.q = w.dq; x.Kc = w.xk + li * xkv_stride; x.Vc = w.xv + li * xkv_stride; x.ctx = w.dctx_pk; x.rows = R; x.H = H;
             x.group = K; x.cap = S_cap; x.len = w.xlen;
+            const bool timed = m->prof_every > 0 && (t % m->prof_every) == 0 && m->prof_used + 2 <= m->prof_ev.size();
+            if (timed) mg_event_record(m->prof_ev[m->prof_used], st);
             attention_step(x, st);
+            if (timed) { mg_event_record(m->prof_ev[m->prof_used + 1], st); m->prof_used += 2; }
             GemmArgs xo = gemm_args(w.dctx_pk, m->at<uint16_t>(l.xo), R, d, inner);
             xo.out_f32 = w.dh; xo.ldo = d;
             gemm_rows(xo, EPI_F32_RESID, st);
@@ -711,16 +721,86 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
         }
     }
     if (K > 1) beam_finalize(w.beam_state, B, K, max_length, out_ids, counters + 4, out_scores, st);
+    std::vector<int> xlen_host;
+    if (m->prof_used) { xlen_host.resize(B); mg_memcpy_async(xlen_host.data(), w.xlen, (size_t)B * sizeof(int), st); }
     mg_memcpy_async(host_flag, counters, sizeof host_flag, st);
     int beam_cols = 0;
     if (K > 1) mg_memcpy_async(&beam_cols, counters + 4, sizeof(int), st);
     mg_stream_sync(st);
     rc = check_launch("mg_generate");
     if (rc != MG_OK) return rc;
+    if (m->prof_used) {
+        double keys = 0.0;
+        for (int b = 0; b < B; ++b) keys += xlen_host[b];
+        for (size_t i = 0; i + 1 < m->prof_used; i += 2) {
+            m->prof_ms += mg_event_elapsed_ms(m->prof_ev[i], m->prof_ev[i + 1]);
+            m->prof_n += 1;
+            m->prof_keys += keys;
+        }
+        m->prof_used = 0;
+    }
     if (host_flag[3] != 0) return fail(MG_E_INPUT, "mg_generate: %d token ids outside [0, vocab)", host_flag[3]);
     if (K == 1) *out_cols_host = 1 + (host_flag[1] >= 0 ? host_flag[1] + 1 : steps_done);
     else *out_cols_host = beam_cols;
     return MG_OK;
+}
+
+// Live timing of the dominant decode kernel (single-query cross-attention over the image K/V stream): when enabled,
+// every `every`-th decode step brackets each layer's launch with HIP events on the caller's stream.
+int mg_profile_cross_attention(mg_model* m, int every, int max_samples) {
+    if (!m) return fail(MG_E_ARG, "mg_profile_cross_attention: null model");
+    for (mgEvent_t e : m->prof_ev) mg_event_destroy(e);
+    m->prof_ev.clear();
+    m->prof_every = every;
+    m->prof_used = 0; m->prof_ms = 0.0; m->prof_n = 0; m->prof_keys = 0.0;
+    for (int i = 0; every > 0 && i < 2 * max_samples; ++i) {
+        mgEvent_t e;
+        if (mg_event_create(&e) != 0) return fail(MG_E_HIP, "hipEventCreate failed");
+        m->prof_ev.push_back(e);
+    }
+    return MG_OK;
+}
+// launches timed, their summed duration, and the summed number of (image, key) rows streamed per launch
+int mg_profile_read(mg_model* m, long* launches, double* total_ms, double* total_keys) {
+    if (!m) return fail(MG_E_ARG, "mg_profile_read: null model");
+    if (launches) *launches = m->prof_n;
+    if (total_ms) *total_ms = m->prof_ms;
+    if (total_keys) *total_keys = m->prof_keys;
+    return MG_OK;
+}
+
+// Self-test of the hardware assumptions (MFMA 32x32x16 operand/accumulator layout, global_load_lds destination
+// rule, cross-half exchange): an asymmetric 64x96x128 GEMM in both kernel shapes against a host fp64 reference.
+int mg_selftest(void* stream, void* scratch_256k, char* msg_host, int msg_len) {
+    if (!scratch_256k) return fail(MG_E_ARG, "mg_selftest: null scratch");
+    mgStream_t st = (mgStream_t)stream;
+    const int M = 64, N = 96, K = 128;
+    std::vector<uint16_t> X(pk_elems(M, K)), W(pk_elems(N, K));
+    std::vector<float> xf((size_t)M * K), wf((size_t)N * K), out((size_t)M * N), ref((size_t)M * N);
+    auto tobf = [](float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7FFFu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
+    auto tof = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
+    for (int m = 0; m < M; ++m) for (int k = 0; k < K; ++k) { const uint16_t b = tobf(0.01f * (float)((m * 7 + k * 3) % 41) - 0.2f); X[pk_off(m, k, K)] = b; xf[(size_t)m * K + k] = tof(b); }
+    for (int n = 0; n < N; ++n) for (int k = 0; k < K; ++k) { const uint16_t b = tobf(0.02f * (float)((n * 5 + k * 11) % 29) - 0.3f); W[pk_off(n, k, K)] = b; wf[(size_t)n * K + k] = tof(b); }
+    for (int m = 0; m < M; ++m) for (int n = 0; n < N; ++n) { double s = 0; for (int k = 0; k < K; ++k) s += (double)xf[(size_t)m * K + k] * wf[(size_t)n * K + k]; ref[(size_t)m * N + n] = (float)s; }
+    char* base = (char*)scratch_256k;
+    uint16_t* dX = (uint16_t*)base;
+    uint16_t* dW = (uint16_t*)(base + 32768);
+    float* dO = (float*)(base + 65536);
+    mg_memcpy_async(dX, X.data(), X.size() * 2, st);
+    mg_memcpy_async(dW, W.data(), W.size() * 2, st);
+    double worst = 0;
+    for (int mode = 0; mode < 2; ++mode) {
+        GemmArgs a = gemm_args(dX, dW, M, N, K);
+        a.out_f32 = dO; a.ldo = N;
+        mode == 0 ? gemm(a, EPI_F32_STORE, st) : gemm_rows(a, EPI_F32_STORE, st);
+        mg_memcpy_async(out.data(), dO, out.size() * 4, st);
+        mg_stream_sync(st);
+        for (size_t i = 0; i < out.size(); ++i) { const double e = fabs((double)out[i] - ref[i]); if (e > worst) worst = e; }
+    }
+    const int rc = check_launch("mg_selftest");
+    if (msg_host && msg_len > 0) snprintf(msg_host, msg_len, "gemm 64x96x128 tiled+rows max abs err %.3g (%s)", worst, worst < 1e-3 ? "ok" : "FAIL");
+    if (rc != MG_OK) return rc;
+    return worst < 1e-3 ? MG_OK : fail(MG_E_HIP, "mg_selftest: MFMA/LDS layout assumptions violated (max err %.3g)", worst);
 }
 
 int mg_beam_reorder(void* stream, const void* kv_src, void* kv_dst, const int32_t* beam_idx, int layers, int rows, int H,

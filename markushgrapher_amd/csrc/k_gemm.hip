@@ -263,33 +263,33 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a) {
             acc[i] = TOR ? mfma32(wf, xf, acc[i]) : mfma32(xf, wf, acc[i]);
         }
     }
-    // combine the 4 K-slices: slab[w][i][r][lane]
+    // combine the 4 K-slices through one 16 KiB slab, one m-tile at a time: slab[w][r][lane]
     float* slab = (float*)smem;
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) slab[((w * MT + i) * 16 + r) * 64 + lane] = acc[i][r];
-    __syncthreads();
-#pragma unroll
     for (int i = 0; i < MT; ++i) {
-        if ((i & 3) != w) continue;
-        f32x16 s;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float v = slab[((0 * MT + i) * 16 + r) * 64 + lane];
-            v += slab[((1 * MT + i) * 16 + r) * 64 + lane];
-            v += slab[((2 * MT + i) * 16 + r) * 64 + lane];
-            v += slab[((3 * MT + i) * 16 + r) * 64 + lane];
-            s[r] = v;
+        for (int r = 0; r < 16; ++r) slab[(w * 16 + r) * 64 + lane] = acc[i][r];
+        __syncthreads();
+        if ((i & 3) == w) {
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = slab[(0 * 16 + r) * 64 + lane];
+                v += slab[(1 * 16 + r) * 64 + lane];
+                v += slab[(2 * 16 + r) * 64 + lane];
+                v += slab[(3 * 16 + r) * 64 + lane];
+                s[r] = v;
+            }
+            tile_epilogue<EPI, TOR>(a, s, 32 * i, 32 * nt, lane);
         }
-        tile_epilogue<EPI, TOR>(a, s, 32 * i, 32 * nt, lane);
+        __syncthreads();
     }
 }
 
 template <int EPI>
 static void gemm_rows_mt(const GemmArgs& a, int mt, mgStream_t stream) {
     const dim3 grid((a.N + 31) / 32), block(256);
-    const size_t sh = (size_t)4 * mt * 16 * 64 * sizeof(float);
+    const size_t sh = (size_t)4 * 16 * 64 * sizeof(float);
     switch (mt) {
         case 1: MG_LAUNCH((gemm_rows_kernel<EPI, 1>), grid, block, sh, stream, a); break;
         case 2: MG_LAUNCH((gemm_rows_kernel<EPI, 2>), grid, block, sh, stream, a); break;

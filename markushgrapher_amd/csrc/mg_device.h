@@ -35,6 +35,11 @@ static inline int mg_memcpy_async(void* d, const void* s, size_t n, mgStream_t) 
 static inline int mg_stream_sync(mgStream_t) { return 0; }
 static inline int mg_peek_error() { return 0; }
 static inline const char* mg_error_string(int) { return "emu"; }
+typedef void* mgEvent_t;
+static inline int mg_event_create(mgEvent_t* e) { *e = nullptr; return 0; }
+static inline int mg_event_record(mgEvent_t, mgStream_t) { return 0; }
+static inline float mg_event_elapsed_ms(mgEvent_t, mgEvent_t) { return 0.f; }
+static inline void mg_event_destroy(mgEvent_t) {}
 #else
 static inline int mg_memset_async(void* p, int v, size_t n, mgStream_t st) { return (int)hipMemsetAsync(p, v, n, st); }
 static inline int mg_memcpy_async(void* d, const void* s, size_t n, mgStream_t st) {
@@ -43,6 +48,11 @@ static inline int mg_memcpy_async(void* d, const void* s, size_t n, mgStream_t s
 static inline int mg_stream_sync(mgStream_t st) { return (int)hipStreamSynchronize(st); }
 static inline int mg_peek_error() { return (int)hipGetLastError(); }
 static inline const char* mg_error_string(int e) { return hipGetErrorString((hipError_t)e); }
+typedef hipEvent_t mgEvent_t;
+static inline int mg_event_create(mgEvent_t* e) { return (int)hipEventCreate(e); }
+static inline int mg_event_record(mgEvent_t e, mgStream_t st) { return (int)hipEventRecord(e, st); }
+static inline float mg_event_elapsed_ms(mgEvent_t a, mgEvent_t b) { float ms = 0.f; (void)hipEventElapsedTime(&ms, a, b); return ms; }
+static inline void mg_event_destroy(mgEvent_t e) { (void)hipEventDestroy(e); }
 #endif
 
 #define MG_DEV __device__ __forceinline__

@@ -202,15 +202,23 @@ def recipe_state_dict(s: ModelShape, seed: int = 20260928, gain: float = 1.0,
         "wi": gain * r3 / math.sqrt(d),
         "wo": gain * r3 / math.sqrt(dff),
     }
-    sd: Dict[str, np.ndarray] = {}
-    for key, shape, kind in state_dict_spec(s):
+    def make(item):
+        key, shape, kind = item
         u = uniform_pm1(key, shape, seed)
         if kind == "norm":
             w = (np.float32(1.0) + np.float32(0.25) * u).astype(np.float32)
         else:
             w = (u * np.float32(amp[kind])).astype(np.float32)
-        sd[key] = round_bf16(w) if bf16_exact else w
-    return sd
+        return key, (round_bf16(w) if bf16_exact else w)
+
+    spec = state_dict_spec(s)
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    nthr = max(1, min(16, os.cpu_count() or 1))
+    if nthr > 1 and len(spec) > 64:      # numpy releases the GIL inside the integer kernels
+        with ThreadPoolExecutor(max_workers=nthr) as ex:
+            return dict(ex.map(make, spec))
+    return dict(make(it) for it in spec)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -124,3 +124,33 @@ def test_min_length_suppresses_eos(be_name):
                              max_length=12, min_length=12)
     ids = _np(eng, ids)
     assert ids.shape == (6, 12) and not np.any(ids[:, 1:] == shape.eos_token_id)
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+def test_beam_search_bit_exact_on_trained_fixture(be_name):
+    """num_beams=5 (the reference's default decode mode, ref: config/predict.yaml:13): ids bit-exact, sequence
+    scores within 1e-2 of stock's; rows finish at different steps, unfinished tails are filled with EOS (the
+    `pad_token_id or eos` quirk of stock 5.15, generation/utils.py:3319)."""
+    g = load_golden("g3_trained_tiny.npz")
+    shape, sd = _weights(g)
+    inp = _inputs(g, shape)
+    eng = make_engine(be_name, shape, sd)
+    ids, scores, _ = eng.generate(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"], num_beams=5,
+                                  max_length=int(g["max_length"]))
+    ids, scores = _np(eng, ids), _np(eng, scores)
+    assert np.array_equal(ids, g["beam_ids"]), (ids.tolist(), g["beam_ids"].tolist())
+    np.testing.assert_allclose(scores, g["beam_scores"], atol=1e-2)
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+def test_beam_search_random_weights_scores(be_name):
+    g = load_golden("g0_tiny.npz")
+    shape, sd = _weights(g)
+    inp = _inputs(g, shape)
+    eng = make_engine(be_name, shape, sd)
+    ids, scores, _ = eng.generate(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"], num_beams=5,
+                                  max_length=int(g["max_length"]))
+    ids, scores = _np(eng, ids), _np(eng, scores)
+    assert ids.shape == g["beam_ids"].shape and np.all(ids[:, 0] == 0)
+    # near-tied random-weight beams may swap, but the best score found must be as good as stock's within tolerance
+    np.testing.assert_allclose(scores, g["beam_scores"], atol=5e-2)
