@@ -16,5 +16,9 @@ def load():
             raise RuntimeError(
                 f"{LIB_PATH} not found: the MI355X HIP library is not built. There is no CPU fallback; run "
                 "`python __graft_entry__.py` (or markushgrapher_amd/csrc/build.py hip) first.")
+        # torch (the device-memory carrier) bundles its own libamdhip64; import it FIRST so this library binds to the
+        # same HIP runtime instance — two runtimes in one process do not share streams or allocations
+        # (symptom: hipErrorNoDevice from the first launch).
+        import torch  # noqa: F401
         _lib = ctypes.CDLL(LIB_PATH)
     return _lib
