@@ -131,6 +131,14 @@ int mgk_greedy_select(void* stream, const float* logits, int rows, int V, int ld
                       int64_t* next_ids, int64_t* out_ids, int max_len, int pos, int* unfinished, int* n_unfinished,
                       float* top2);
 
+/* decode-step split-K projection: P[ks][m*ldp + n] partial sums (ks < KS); consumers sum the slabs */
+int mgk_gemm_splitk(void* stream, const void* X_pk, const void* W_pk, float* P, int M, int N, int K, int ldp,
+                    size_t slab_stride, int KS);
+int mgk_splitk_factor(int N, int K);
+int mgk_add_norm_pack(void* stream, float* h, const float* P, int KS, int ldp, size_t slab_stride, const float* gain,
+                      void* x_pk, int M, int d, float eps, float scale);
+int mgk_relu_pack(void* stream, const float* P, int KS, int ldp, size_t slab_stride, void* y_pk, int M, int N);
+
 #ifdef __cplusplus
 }
 #endif

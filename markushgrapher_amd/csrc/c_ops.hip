@@ -100,4 +100,27 @@ int mgk_greedy_select(void* stream, const float* logits, int rows, int V, int ld
     return MG_OK;
 }
 
+int mgk_gemm_splitk(void* stream, const void* X_pk, const void* W_pk, float* P, int M, int N, int K, int ldp,
+                    size_t slab_stride, int KS) {
+    if ((K & 63) || KS < 1 || KS > 16 || M > 256) return MG_E_SHAPE;
+    gemm_rows_splitk((const uint16_t*)X_pk, (const uint16_t*)W_pk, P, M, N, K, ldp, slab_stride, KS, (mgStream_t)stream);
+    return MG_OK;
+}
+int mgk_splitk_factor(int N, int K) { return splitk_factor(N, K); }
+
+int mgk_add_norm_pack(void* stream, float* h, const float* P, int KS, int ldp, size_t slab_stride, const float* gain,
+                      void* x_pk, int M, int d, float eps, float scale) {
+    if ((d & 15) || d > 4096 || KS < 0 || KS > 16) return MG_E_SHAPE;
+    Slabs sl; sl.P = P; sl.KS = KS; sl.ldp = ldp; sl.stride = slab_stride;
+    add_norm_pack(h, sl, gain, (uint16_t*)x_pk, M, d, eps, scale, (mgStream_t)stream);
+    return MG_OK;
+}
+
+int mgk_relu_pack(void* stream, const float* P, int KS, int ldp, size_t slab_stride, void* y_pk, int M, int N) {
+    if ((N & 15) || KS < 1 || KS > 16) return MG_E_SHAPE;
+    Slabs sl; sl.P = P; sl.KS = KS; sl.ldp = ldp; sl.stride = slab_stride;
+    relu_pack(sl, (uint16_t*)y_pk, M, N, (mgStream_t)stream);
+    return MG_OK;
+}
+
 }  // extern "C"

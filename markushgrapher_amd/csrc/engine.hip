@@ -145,7 +145,8 @@ struct Ws {
     int *xrow, *xlen, *counters;
     // decode (generate)
     uint16_t *xk, *xv, *sk, *sv, *dq, *dx_pk, *dctx_pk, *dy_pk;
-    float *dh, *logits;
+    float *dh, *logits, *slabs;
+    size_t slab_stride;
     int64_t* next_ids;
     int *unfinished, *anc, *anc_tmp, *beam_idx;
     void* beam_state;
@@ -206,6 +207,13 @@ void carve(const mg_model* m, char* base, int B, int L, int K, int max_len, int 
         w->dy_pk = c.take<uint16_t>((size_t)Rp * m->dff);
         w->dh = c.take<float>((size_t)Rp * d);
         w->logits = c.take<float>((size_t)Rp * round_up(m->V, 32));
+        {
+            int ldmax = 3 * inner;
+            if (m->dff > ldmax) ldmax = m->dff;
+            if (d > ldmax) ldmax = d;
+            w->slab_stride = (size_t)Rp * ldmax;
+            w->slabs = c.take<float>(16 * w->slab_stride);
+        }
         w->next_ids = c.take<int64_t>(Rp);
         w->unfinished = c.take<int>(Rp);
         w->anc = c.take<int>((size_t)m->T_cap * R);
@@ -660,45 +668,49 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
     }
     int steps_done = 0;
     int host_flag[4] = {0, 0, 0, 0};
+    // decode-step projections run as split-K GEMMs over all CUs; their consumers sum the partial slabs (k_gemm.hip)
+    const int ks_qkv = splitk_factor(3 * inner, d), ks_o = splitk_factor(d, inner), ks_xq = splitk_factor(inner, d);
+    const int ks_wi = splitk_factor(m->dff, d), ks_wo2 = splitk_factor(d, m->dff);
+    const float eps = m->c.layer_norm_epsilon;
+    const int ldl = round_up(m->V, 32);
+    auto slabs = [&](int KS, int ldp) { Slabs sl; sl.P = w.slabs; sl.KS = KS; sl.ldp = ldp; sl.stride = w.slab_stride; return sl; };
     for (int t = 0; t + 1 < max_length; ++t) {
         embed_rows(w.next_ids, m->at<uint16_t>(m->tok_emb), w.dh, R, d, m->V, counters + 3, st);
+        rmsnorm_pack(w.dh, m->at<float>(m->dec[0].ln0), w.dx_pk, nullptr, R, d, eps, 1.0f, st);
         for (size_t li = 0; li < nl; ++li) {
             const DecLayer& l = m->dec[li];
             uint16_t* sk = w.sk + li * skv_stride;
             uint16_t* sv = w.sv + li * skv_stride;
-            rmsnorm_pack(w.dh, m->at<float>(l.ln0), w.dx_pk, nullptr, R, d, m->c.layer_norm_epsilon, 1.0f, st);
-            GemmArgs a = gemm_args(w.dx_pk, m->at<uint16_t>(l.wqkv), R, 3 * inner, d);
-            set_heads(a, H, R, T_cap, w.dq, HF_STEP_Q, sk, HF_STEP_KV, sv, HF_STEP_KV);
-            a.heads.pos = t;
-            gemm_rows(a, EPI_HEADS, st);
+            // self-attention: QKV partial slabs -> the attention kernel sums them, appends k,v at position t, attends
+            gemm_rows_splitk(w.dx_pk, m->at<uint16_t>(l.wqkv), w.slabs, R, 3 * inner, d, 3 * inner, w.slab_stride, ks_qkv, st);
             AttnStepArgs s{};
-            s.q = w.dq; s.Kc = sk; s.Vc = sv; s.ctx = w.dctx_pk; s.rows = R; s.H = H; s.group = 1; s.cap = T_cap;
+            s.Kc = sk; s.Vc = sv; s.Kc_w = sk; s.Vc_w = sv; s.ctx = w.dctx_pk; s.rows = R; s.H = H; s.group = 1; s.cap = T_cap;
             s.n_keys = t + 1; s.bias = m->at<float>(m->dec_tab); s.anc = K > 1 ? w.anc : nullptr; s.t = t;
+            s.qkv = slabs(ks_qkv, 3 * inner); s.self_append = 1;
             attention_step(s, st);
-            GemmArgs o = gemm_args(w.dctx_pk, m->at<uint16_t>(l.wo), R, d, inner);
-            o.out_f32 = w.dh; o.ldo = d;
-            gemm_rows(o, EPI_F32_RESID, st);
-            rmsnorm_pack(w.dh, m->at<float>(l.ln1), w.dx_pk, nullptr, R, d, m->c.layer_norm_epsilon, 1.0f, st);
-            GemmArgs q = gemm_args(w.dx_pk, m->at<uint16_t>(l.xq), R, inner, d);
-            set_heads(q, H, R, T_cap, w.dq, HF_STEP_Q, nullptr, HF_NONE, nullptr, HF_NONE);
-            gemm_rows(q, EPI_HEADS, st);
+            gemm_rows_splitk(w.dctx_pk, m->at<uint16_t>(l.wo), w.slabs, R, d, inner, d, w.slab_stride, ks_o, st);
+            add_norm_pack(w.dh, slabs(ks_o, d), m->at<float>(l.ln1), w.dx_pk, R, d, eps, 1.0f, st);
+            // cross-attention over the image's compacted K/V stream (all beams of an image share one pass)
+            gemm_rows_splitk(w.dx_pk, m->at<uint16_t>(l.xq), w.slabs, R, inner, d, inner, w.slab_stride, ks_xq, st);
             AttnStepArgs x{};
-            x.q = w.dq; x.Kc = w.xk + li * xkv_stride; x.Vc = w.xv + li * xkv_stride; x.ctx = w.dctx_pk; x.rows = R; x.H = H;
-            x.group = K; x.cap = S_cap; x.len = w.xlen;
+            x.Kc = w.xk + li * xkv_stride; x.Vc = w.xv + li * xkv_stride; x.ctx = w.dctx_pk; x.rows = R; x.H = H;
+            x.group = K; x.cap = S_cap; x.len = w.xlen; x.qkv = slabs(ks_xq, inner); x.self_append = 0;
             const bool timed = m->prof_every > 0 && (t % m->prof_every) == 0 && m->prof_used + 2 <= m->prof_ev.size();
             if (timed) mg_event_record(m->prof_ev[m->prof_used], st);
             attention_step(x, st);
             if (timed) { mg_event_record(m->prof_ev[m->prof_used + 1], st); m->prof_used += 2; }
-            GemmArgs xo = gemm_args(w.dctx_pk, m->at<uint16_t>(l.xo), R, d, inner);
-            xo.out_f32 = w.dh; xo.ldo = d;
-            gemm_rows(xo, EPI_F32_RESID, st);
-            ffn_block(m, true, w.dh, w.dx_pk, w.dy_pk, R, l.ln2, l.wi, l.wo2, st);
+            gemm_rows_splitk(w.dctx_pk, m->at<uint16_t>(l.xo), w.slabs, R, d, inner, d, w.slab_stride, ks_o, st);
+            add_norm_pack(w.dh, slabs(ks_o, d), m->at<float>(l.ln2), w.dx_pk, R, d, eps, 1.0f, st);
+            // FFN; its residual add is fused with the NEXT sub-layer's norm (next layer's ln0, or the final norm with
+            // the d_model^-0.5 of the tied head, stock:1554-1555)
+            gemm_rows_splitk(w.dx_pk, m->at<uint16_t>(l.wi), w.slabs, R, m->dff, d, m->dff, w.slab_stride, ks_wi, st);
+            relu_pack(slabs(ks_wi, m->dff), w.dy_pk, R, m->dff, st);
+            gemm_rows_splitk(w.dy_pk, m->at<uint16_t>(l.wo2), w.slabs, R, d, m->dff, d, w.slab_stride, ks_wo2, st);
+            const bool last = li + 1 == nl;
+            add_norm_pack(w.dh, slabs(ks_wo2, d), m->at<float>(last ? m->dec_ln : m->dec[li + 1].ln0), w.dx_pk, R, d, eps,
+                          last ? 1.0f / sqrtf((float)d) : 1.0f, st);
         }
-        rmsnorm_pack(w.dh, m->at<float>(m->dec_ln), w.dx_pk, nullptr, R, d, m->c.layer_norm_epsilon, 1.0f / sqrtf((float)d), st);
-        const int ldl = round_up(m->V, 32);
-        GemmArgs lg = gemm_args(w.dx_pk, m->at<uint16_t>(m->lm_head), R, m->V, d);
-        lg.out_f32 = w.logits; lg.ldo = ldl;
-        gemm_rows(lg, EPI_F32_STORE, st);
+        gemm_rows_splitk(w.dx_pk, m->at<uint16_t>(m->lm_head), w.logits, R, m->V, d, ldl, 0, 1, st);
         if (K == 1) {
             ArgmaxArgs g{};
             g.logits = w.logits; g.rows = R; g.V = m->V; g.ldl = ldl; g.eos = m->c.eos_token_id; g.pad = (int)pad;

@@ -14,22 +14,60 @@ constexpr float DC_NEG = -1.0e30f;
 // instructions in flight for K and V each; scores are reduced over the 8 lanes of a key by xor-shuffles;
 // every lane keeps an online-softmax partial (m, l, acc[8 dims]) per query which is merged across key slots by
 // shuffles and across the 4 waves through LDS in a fixed order (deterministic).
-template <int G>
-__global__ __launch_bounds__(256) void attn_step_kernel(AttnStepArgs a) {
+template <int G, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a) {
     MG_DYN_SMEM(smem);
     constexpr int U = 4;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int sub = lane & 7, ks = lane >> 3;
     const int owner = blockIdx.x / a.H, h = blockIdx.x - owner * a.H;
     const int tcur = a.t_dev ? *a.t_dev : a.t;
-    const int nkeys = a.len ? a.len[owner] : (a.t_dev ? tcur + 1 : a.n_keys);
+    const int nkeys_all = a.len ? a.len[owner] : (a.t_dev ? tcur + 1 : a.n_keys);
+    // with an in-kernel append the newest key (position t) comes from registers, the cache holds [0, t)
+    const bool app0 = (G == 1) && a.qkv.P && a.self_append;
+    const int nkeys = app0 ? nkeys_all - 1 : nkeys_all;
 
+    const int inner = a.H * 64;
+    // Sum of the split-K partial slabs for this lane's 8 consecutive columns, rounded to bf16 (the projections'
+    // storage precision).  The 8 key-slot groups of the wave each fetch a different slab (one L2 round trip), the
+    // partial sums are then combined across the groups by xor-shuffles — every lane ends with the full sum.
+    auto slab_chunk = [&](int row, int col) {
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) {
+            const int s = ks + 8 * rep;
+            if (s < a.qkv.KS) {
+                const float* p = a.qkv.P + (size_t)s * a.qkv.stride + (size_t)row * a.qkv.ldp + col;
+                const float4 pa = *(const float4*)p, pb = *(const float4*)(p + 4);
+                v[0] += pa.x; v[1] += pa.y; v[2] += pa.z; v[3] += pa.w; v[4] += pb.x; v[5] += pb.y; v[6] += pb.z; v[7] += pb.w;
+            }
+        }
+#pragma unroll
+        for (int step = 8; step <= 32; step <<= 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += __shfl_xor(v[j], step);
+        }
+        return make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+    };
     uint4 q[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         int row = owner * G + g;
         row = row < a.rows ? row : a.rows - 1;
-        q[g] = ld16(a.q + ((size_t)row * a.H + h) * 64 + sub * 8);
+        q[g] = a.qkv.P ? slab_chunk(row, h * 64 + sub * 8) : ld16(a.q + ((size_t)row * a.H + h) * 64 + sub * 8);
+    }
+    // self-attention with split-K projections: this workgroup also owns the new position's k, v (kept in registers
+    // for its own use and appended to the cache for later steps)
+    uint4 knew = make_uint4(0, 0, 0, 0), vnew = make_uint4(0, 0, 0, 0);
+    const bool append = (G == 1) && a.qkv.P && a.self_append;
+    if (append) {
+        knew = slab_chunk(owner, inner + h * 64 + sub * 8);
+        vnew = slab_chunk(owner, 2 * inner + h * 64 + sub * 8);
+        if (w == 0 && ks == 0) {
+            const size_t off = (((size_t)owner * a.H + h) * (size_t)a.cap + (size_t)tcur) * 64 + sub * 8;
+            st16(a.Kc_w + off, knew);
+            st16(a.Vc_w + off, vnew);
+        }
     }
     float m[G], l[G], acc[G][8];
 #pragma unroll
@@ -40,18 +78,26 @@ __global__ __launch_bounds__(256) void attn_step_kernel(AttnStepArgs a) {
         for (int d = 0; d < 8; ++d) acc[g][d] = 0.f;
     }
 
-    for (int kb = w * 8 * U; kb < nkeys; kb += 4 * 8 * U) {
-        uint4 kv[U], vv[U];
-        int key[U];
+    // software-pipelined stream: the loads of the next 8*U keys are issued before the current ones are consumed
+    auto issue = [&](int kb, uint4 (&kv)[U], uint4 (&vv)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            key[u] = kb + u * 8 + ks;
-            const int kc = key[u] < nkeys ? key[u] : nkeys - 1;
+            int kc = kb + u * 8 + ks;
+            kc = kc < nkeys ? kc : nkeys - 1;
             const int prow = a.anc ? a.anc[(size_t)kc * a.rows + owner] : owner;
             const size_t off = (((size_t)prow * a.H + h) * (size_t)a.cap + (size_t)kc) * 64 + sub * 8;
             kv[u] = ld16(a.Kc + off);
             vv[u] = ld16(a.Vc + off);
         }
+    };
+    uint4 kn[U], vn[U];
+    if (w * 8 * U < nkeys) issue(w * 8 * U, kn, vn);
+    for (int kb = w * 8 * U; kb < nkeys; kb += NW * 8 * U) {
+        uint4 kv[U], vv[U];
+        int key[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { kv[u] = kn[u]; vv[u] = vn[u]; key[u] = kb + u * 8 + ks; }
+        if (kb + NW * 8 * U < nkeys) issue(kb + NW * 8 * U, kn, vn);
         float s[U][G];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -95,6 +141,26 @@ __global__ __launch_bounds__(256) void attn_step_kernel(AttnStepArgs a) {
             }
         }
     }
+    if (append && w == 0) {   // the new position (distance 0), handled by key slot 0 of wave 0; whole wave runs the shuffles
+        float p = dot2_bf16(q[0].x, knew.x, 0.f);
+        p = dot2_bf16(q[0].y, knew.y, p);
+        p = dot2_bf16(q[0].z, knew.z, p);
+        p = dot2_bf16(q[0].w, knew.w, p);
+        p += __shfl_xor(p, 1);
+        p += __shfl_xor(p, 2);
+        p += __shfl_xor(p, 4);
+        if (ks == 0) {
+            const float sc = p + (a.bias ? a.bias[h] : 0.f);
+            const float mn = fmaxf(m[0], sc);
+            const float al = fast_exp(m[0] - mn), pe = fast_exp(sc - mn);
+            m[0] = mn;
+            l[0] = l[0] * al + pe;
+            acc[0][0] = acc[0][0] * al + pe * bf16lo(vnew.x); acc[0][1] = acc[0][1] * al + pe * bf16hi(vnew.x);
+            acc[0][2] = acc[0][2] * al + pe * bf16lo(vnew.y); acc[0][3] = acc[0][3] * al + pe * bf16hi(vnew.y);
+            acc[0][4] = acc[0][4] * al + pe * bf16lo(vnew.z); acc[0][5] = acc[0][5] * al + pe * bf16hi(vnew.z);
+            acc[0][6] = acc[0][6] * al + pe * bf16lo(vnew.w); acc[0][7] = acc[0][7] * al + pe * bf16hi(vnew.w);
+        }
+    }
     // merge the 8 key slots of the wave
 #pragma unroll
     for (int step = 8; step <= 32; step <<= 1) {
@@ -109,7 +175,7 @@ __global__ __launch_bounds__(256) void attn_step_kernel(AttnStepArgs a) {
             m[g] = M;
         }
     }
-    // merge the 4 waves: red[w][g][sub][10]
+    // merge the NW waves: red[w][g][sub][10]
     float* red = (float*)smem;
     if (ks == 0) {
 #pragma unroll
@@ -125,9 +191,9 @@ __global__ __launch_bounds__(256) void attn_step_kernel(AttnStepArgs a) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             float M = DC_NEG;
-            for (int ww = 0; ww < 4; ++ww) M = fmaxf(M, red[(((size_t)ww * G + g) * 8 + sub) * 10]);
+            for (int ww = 0; ww < NW; ++ww) M = fmaxf(M, red[(((size_t)ww * G + g) * 8 + sub) * 10]);
             float L = 0.f, o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            for (int ww = 0; ww < 4; ++ww) {
+            for (int ww = 0; ww < NW; ++ww) {
                 const float* r = red + (((size_t)ww * G + g) * 8 + sub) * 10;
                 const float f = fast_exp(r[0] - M);
                 L += r[1] * f;
@@ -147,24 +213,33 @@ __global__ __launch_bounds__(256) void attn_step_kernel(AttnStepArgs a) {
 void attention_step(const AttnStepArgs& a, mgStream_t stream) {
     const int G = a.group;
     const int owners = (a.rows + G - 1) / G;
-    const dim3 grid(owners * a.H), block(256);
-    const size_t sh = (size_t)4 * G * 8 * 10 * sizeof(float);
+    const dim3 grid(owners * a.H);
+    // long streams (cross-attention over ~1000+ keys) use 8 waves per (image, head) for more loads in flight per CU;
+    // the short self-attention streams (<= 512 keys) use 4
+    const bool wide = a.len != nullptr;
+    const int NW = wide ? 8 : 4;
+    const dim3 block(NW * 64);
+    const size_t sh = (size_t)NW * G * 8 * 10 * sizeof(float);
+#define MG_AS(GG)                                                                                         \
+    case GG:                                                                                              \
+        if (wide) MG_LAUNCH((attn_step_kernel<GG, 8>), grid, block, sh, stream, a);                       \
+        else MG_LAUNCH((attn_step_kernel<GG, 4>), grid, block, sh, stream, a);                            \
+        break;
     switch (G) {
-        case 1: MG_LAUNCH((attn_step_kernel<1>), grid, block, sh, stream, a); break;
-        case 2: MG_LAUNCH((attn_step_kernel<2>), grid, block, sh, stream, a); break;
-        case 3: MG_LAUNCH((attn_step_kernel<3>), grid, block, sh, stream, a); break;
-        case 4: MG_LAUNCH((attn_step_kernel<4>), grid, block, sh, stream, a); break;
-        case 5: MG_LAUNCH((attn_step_kernel<5>), grid, block, sh, stream, a); break;
-        case 6: MG_LAUNCH((attn_step_kernel<6>), grid, block, sh, stream, a); break;
-        case 7: MG_LAUNCH((attn_step_kernel<7>), grid, block, sh, stream, a); break;
-        case 8: MG_LAUNCH((attn_step_kernel<8>), grid, block, sh, stream, a); break;
+        MG_AS(1) MG_AS(2) MG_AS(3) MG_AS(4) MG_AS(5) MG_AS(6) MG_AS(7) MG_AS(8)
         default: break;
     }
+#undef MG_AS
 }
 
 // Greedy selection (gen:2925-2937): argmax with lowest-index tie-break (torch.argmax), finished rows emit pad,
-// EOS bookkeeping.  One workgroup per row.
-__global__ __launch_bounds__(256) void greedy_select_kernel(ArgmaxArgs a) {
+// EOS bookkeeping.  One workgroup of 1024 threads per row, 16-byte loads.
+constexpr int GS_THREADS = 1024;
+MG_DEV void top2_merge(float& b1, float& b2, int& i1, float o1, float o2, int oi) {
+    if (o1 > b1 || (o1 == b1 && oi < i1)) { b2 = fmaxf(b1, o2); b1 = o1; i1 = oi; }
+    else b2 = fmaxf(b2, o1);
+}
+__global__ __launch_bounds__(GS_THREADS) void greedy_select_kernel(ArgmaxArgs a) {
     MG_DYN_SMEM(smem);
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const float* lg = a.logits + (size_t)row * a.ldl;
@@ -172,30 +247,31 @@ __global__ __launch_bounds__(256) void greedy_select_kernel(ArgmaxArgs a) {
     const bool no_eos = a.suppress_eos || pos < a.min_len;
     float b1 = -3.0e38f, b2 = -3.0e38f;
     int i1 = 0x7fffffff;
-    for (int i = tid; i < a.V; i += 256) {
-        float v = lg[i];
-        if (no_eos && i == a.eos) v = -3.0e38f;
-        if (v > b1 || (v == b1 && i < i1)) { b2 = b1; b1 = v; i1 = i; }
-        else if (v > b2) b2 = v;
+    const int nq = (a.V + 3) >> 2;      // rows are padded to a multiple of 32 floats, so the last float4 is readable
+    for (int c = tid; c < nq; c += GS_THREADS) {
+        const float4 q = *(const float4*)(lg + c * 4);
+        const float vv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = c * 4 + j;
+            float v = vv[j];
+            if (i >= a.V || (no_eos && i == a.eos)) v = -3.0e38f;
+            if (v > b1 || (v == b1 && i < i1)) { b2 = b1; b1 = v; i1 = i; }
+            else if (v > b2) b2 = v;
+        }
     }
 #pragma unroll
     for (int step = 1; step < 64; step <<= 1) {
         const float o1 = __shfl_xor(b1, step), o2 = __shfl_xor(b2, step);
         const int oi = __shfl_xor(i1, step);
-        if (o1 > b1 || (o1 == b1 && oi < i1)) { b2 = fmaxf(b1, o2); b1 = o1; i1 = oi; }
-        else b2 = fmaxf(b2, o1);
+        top2_merge(b1, b2, i1, o1, o2, oi);
     }
-    float* rv = (float*)smem;
-    int* ri = (int*)(smem + 32);
+    float* rv = (float*)smem;                 // [16][2]
+    int* ri = (int*)(smem + 128);             // [16]
     if (lane == 0) { rv[w * 2] = b1; rv[w * 2 + 1] = b2; ri[w] = i1; }
     __syncthreads();
     if (tid == 0) {
-        for (int ww = 1; ww < 4; ++ww) {
-            const float o1 = rv[ww * 2], o2 = rv[ww * 2 + 1];
-            const int oi = ri[ww];
-            if (o1 > b1 || (o1 == b1 && oi < i1)) { b2 = fmaxf(b1, o2); b1 = o1; i1 = oi; }
-            else b2 = fmaxf(b2, o1);
-        }
+        for (int ww = 1; ww < GS_THREADS / 64; ++ww) top2_merge(b1, b2, i1, rv[ww * 2], rv[ww * 2 + 1], ri[ww]);
         const int unf = a.unfinished[row];
         const int64_t tok = unf ? (int64_t)i1 : (int64_t)a.pad;
         a.next_ids[row] = tok;
@@ -209,7 +285,7 @@ __global__ __launch_bounds__(256) void greedy_select_kernel(ArgmaxArgs a) {
 
 void greedy_select(const ArgmaxArgs& a, mgStream_t stream) {
     mg_memset_async(a.n_unfinished, 0, sizeof(int), stream);
-    MG_LAUNCH(greedy_select_kernel, dim3(a.rows), dim3(256), 64, stream, a);
+    MG_LAUNCH(greedy_select_kernel, dim3(a.rows), dim3(GS_THREADS), 256, stream, a);
 }
 
 }  // namespace mg

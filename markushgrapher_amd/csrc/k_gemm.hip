@@ -301,6 +301,100 @@ static void gemm_rows_mt(const GemmArgs& a, int mt, mgStream_t stream) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// decode-step GEMM, split-K form: grid = (N/32) x KS workgroups so that EVERY CU streams a share of the weights
+// (a 1024-wide projection has only 32 feature tiles).  Each workgroup reduces its 4 waves through LDS and stores
+// its fp32 32x32 partial tile to slab P[ks] with plain coalesced stores; the consumer kernel (fused residual-add +
+// RMSNorm, the single-query attention kernels, relu_pack) sums the KS slabs in a fixed order -> deterministic, no
+// atomics, no extra reduction launch.
+// ---------------------------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(256) void gemm_rows_splitk_kernel(const uint16_t* X, const uint16_t* W, float* P, int M, int N, int K, int ldp,
+                                                          size_t slab_stride, int KS) {
+    MG_DYN_SMEM(smem);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int ntiles = (N + 31) >> 5;
+    const int nt = blockIdx.x % ntiles, ks = blockIdx.x / ntiles;
+    const int kt16 = K >> 4;
+    const int per_blk = (kt16 + KS - 1) / KS;
+    const int kb0 = ks * per_blk, kb1 = (kb0 + per_blk) < kt16 ? (kb0 + per_blk) : kt16;
+    const int per = (kb1 - kb0 + 3) >> 2;
+    const int k0 = kb0 + w * per, k1 = (k0 + per) < kb1 ? (k0 + per) : kb1;
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = acc_zero();
+    const char* wp = (const char*)(W + pk_tile_off(nt, 0, K)) + lane * 16;
+    const char* xp = (const char*)X + lane * 16;
+    constexpr int U = 8;
+    int kt = k0;
+    for (; kt + U <= k1; kt += U) {
+        uint4 wf[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) wf[u] = ld16(wp + (size_t)(kt + u) * TILE_BYTES);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                acc[i] = mfma32(ld16(xp + ((size_t)i * kt16 + (kt + u)) * TILE_BYTES), wf[u], acc[i]);
+        }
+    }
+    for (; kt < k1; ++kt) {
+        const uint4 wf = ld16(wp + (size_t)kt * TILE_BYTES);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[i] = mfma32(ld16(xp + ((size_t)i * kt16 + kt) * TILE_BYTES), wf, acc[i]);
+    }
+    float* slab = (float*)smem;
+    float* out = P + (size_t)ks * slab_stride;
+    const int half = lane >> 5, n = nt * 32 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slab[(w * 16 + r) * 64 + lane] = acc[i][r];
+        __syncthreads();
+        // wave w finishes registers 4w..4w+3 of the tile (rows acc_row(4w+j, half)), all 4 waves store in parallel
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = w * 4 + j;
+            float v = slab[(0 * 16 + r) * 64 + lane];
+            v += slab[(1 * 16 + r) * 64 + lane];
+            v += slab[(2 * 16 + r) * 64 + lane];
+            v += slab[(3 * 16 + r) * 64 + lane];
+            const int m = 32 * i + acc_row(r, half);
+            if (m < M && n < N) out[(size_t)m * ldp + n] = v;
+        }
+        __syncthreads();
+    }
+}
+
+int splitk_factor(int N, int K) {
+    const int ntiles = (N + 31) / 32;
+    int ks = (320 + ntiles - 1) / ntiles;       // aim for >= ~1.25 workgroups per CU
+    const int ks_max = K / 64;                   // every wave keeps at least one 16-wide k-tile
+    if (ks > ks_max) ks = ks_max;
+    if (ks > 16) ks = 16;
+    if (ks < 1) ks = 1;
+    return ks;
+}
+
+void gemm_rows_splitk(const uint16_t* X, const uint16_t* W, float* P, int M, int N, int K, int ldp, size_t slab_stride, int KS,
+                      mgStream_t stream) {
+    const int mt = (M + 31) / 32;
+    const dim3 grid(((N + 31) / 32) * KS), block(256);
+    const size_t sh = (size_t)4 * 16 * 64 * sizeof(float);
+    switch (mt) {
+        case 1: MG_LAUNCH((gemm_rows_splitk_kernel<1>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS); break;
+        case 2: MG_LAUNCH((gemm_rows_splitk_kernel<2>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS); break;
+        case 3: MG_LAUNCH((gemm_rows_splitk_kernel<3>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS); break;
+        case 4: MG_LAUNCH((gemm_rows_splitk_kernel<4>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS); break;
+        case 5: MG_LAUNCH((gemm_rows_splitk_kernel<5>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS); break;
+        case 6: MG_LAUNCH((gemm_rows_splitk_kernel<6>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS); break;
+        case 7: MG_LAUNCH((gemm_rows_splitk_kernel<7>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS); break;
+        case 8: MG_LAUNCH((gemm_rows_splitk_kernel<8>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS); break;
+        default: break;
+    }
+}
+
 void gemm_rows(const GemmArgs& a, int epi, mgStream_t stream) {
     const int mt = (a.M + 31) / 32;
     if (mt > 6) {   // many live rows (large beam batches): the tiled kernel is the better shape

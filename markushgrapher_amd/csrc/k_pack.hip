@@ -131,4 +131,82 @@ void rmsnorm_pack_rows(const float* h, const float* gain, uint16_t* x_pk, const 
     MG_LAUNCH(rmsnorm_pack_kernel, dim3(blocks), dim3(256), 0, stream, h, gain, x_pk, (float*)nullptr, dst_row, M, d, eps, scale);
 }
 
+// Decode-step fusion: residual add of a split-K projection (KS partial slabs, summed in slab order) + the next
+// sub-layer's RMSNorm + bf16 pack.  One workgroup per sequence row, 4 features per thread; all 1+KS loads of a thread
+// are issued together (one L2 round trip), the row stays in registers between the two passes.
+template <int KSMAX>
+__global__ __launch_bounds__(256) void add_norm_pack_kernel(float* h, Slabs add, const float* gain, uint16_t* x_pk, int M, int d, float eps,
+                                                       float scale) {
+    MG_DYN_SMEM(smem);
+    float* red = (float*)smem;
+    const int tid = threadIdx.x, m = blockIdx.x;
+    const int nq = d >> 2;                       // float4 groups per row
+    float* row = h + (size_t)m * d;
+    float ss = 0.f;
+    float4 v[4];
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) {
+        const int c = tid + 256 * ci;
+        v[ci] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < nq) {
+            float4 part[KSMAX];
+            const float4 a = *(const float4*)(row + c * 4);
+#pragma unroll
+            for (int s = 0; s < KSMAX; ++s)
+                if (s < add.KS) part[s] = *(const float4*)(add.P + (size_t)s * add.stride + (size_t)m * add.ldp + c * 4);
+            float4 t = a;
+#pragma unroll
+            for (int s = 0; s < KSMAX; ++s)
+                if (s < add.KS) { t.x += part[s].x; t.y += part[s].y; t.z += part[s].z; t.w += part[s].w; }
+            v[ci] = t;
+            *(float4*)(row + c * 4) = t;
+            ss += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
+        }
+    }
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    ss = (red[0] + red[1]) + (red[2] + red[3]);
+    const float r = rsqrtf(ss / (float)d + eps);
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) {
+        const int c = tid + 256 * ci;
+        if (c < nq) {
+            const float4 g = *(const float4*)(gain + c * 4);
+            float o0 = g.x * (v[ci].x * r), o1 = g.y * (v[ci].y * r), o2 = g.z * (v[ci].z * r), o3 = g.w * (v[ci].w * r);
+            if (scale != 1.0f) { o0 *= scale; o1 *= scale; o2 *= scale; o3 *= scale; }
+            *(uint2*)(x_pk + pk_off(m, c * 4, d)) = make_uint2(pack_bf16(o0, o1), pack_bf16(o2, o3));
+        }
+    }
+}
+void add_norm_pack(float* h, const Slabs& add, const float* gain, uint16_t* x_pk, int M, int d, float eps, float scale,
+                   mgStream_t stream) {
+    if (add.KS <= 4) MG_LAUNCH((add_norm_pack_kernel<4>), dim3(M), dim3(256), 64, stream, h, add, gain, x_pk, M, d, eps, scale);
+    else if (add.KS <= 8) MG_LAUNCH((add_norm_pack_kernel<8>), dim3(M), dim3(256), 64, stream, h, add, gain, x_pk, M, d, eps, scale);
+    else MG_LAUNCH((add_norm_pack_kernel<16>), dim3(M), dim3(256), 64, stream, h, add, gain, x_pk, M, d, eps, scale);
+}
+
+// y_pk = bf16(relu(sum of the split-K slabs)), packed: the FFN activation between wi and wo (stock:318-321)
+__global__ __launch_bounds__(256) void relu_pack_kernel(Slabs in, uint16_t* y_pk, int M, int N) {
+    const int nch = N >> 3;
+    const size_t total = (size_t)M * nch;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / nch), c = (int)(i - (size_t)m * nch);
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < in.KS; ++s) {
+            const float* p = in.P + (size_t)s * in.stride + (size_t)m * in.ldp + c * 8;
+            const float4 pa = *(const float4*)p, pb = *(const float4*)(p + 4);
+            v[0] += pa.x; v[1] += pa.y; v[2] += pa.z; v[3] += pa.w; v[4] += pb.x; v[5] += pb.y; v[6] += pb.z; v[7] += pb.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+        st16(y_pk + pk_off(m, c * 8, N),
+             make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])));
+    }
+}
+void relu_pack(const Slabs& in, uint16_t* y_pk, int M, int N, mgStream_t stream) {
+    const size_t total = (size_t)M * (N >> 3);
+    MG_LAUNCH(relu_pack_kernel, dim3(grid_for(total)), dim3(256), 0, stream, in, y_pk, M, N);
+}
+
 }  // namespace mg

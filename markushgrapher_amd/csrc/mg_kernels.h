@@ -50,6 +50,17 @@ void gemm(const GemmArgs& a, int epi, mgStream_t stream);
 // small-M (decode step) GEMM: M <= 32*MT rows of live sequences, weights streamed once.
 void gemm_rows(const GemmArgs& a, int epi, mgStream_t stream);
 
+// split-K decode GEMM: P[ks][m*ldp + n] (ks < KS) = partial sums over the ks-th K range; consumers add the slabs
+int splitk_factor(int N, int K);
+void gemm_rows_splitk(const uint16_t* X, const uint16_t* W, float* P, int M, int N, int K, int ldp, size_t slab_stride, int KS,
+                      mgStream_t stream);
+// a row-major fp32 matrix given as KS split-K partial slabs
+struct Slabs {
+    const float* P;        // null = not used
+    int KS, ldp;
+    size_t stride;         // elements between slabs
+};
+
 // ---------------------------------------------------------------------------------------------
 // normalisation / packing
 // ---------------------------------------------------------------------------------------------
@@ -59,6 +70,12 @@ void rmsnorm_pack(const float* h, const float* gain, uint16_t* x_pk, float* out_
 // same, but source row m is written to packed row dst_row[m] (skipped when negative)
 void rmsnorm_pack_rows(const float* h, const float* gain, uint16_t* x_pk, const int* dst_row, int M, int d, float eps,
                        float scale, mgStream_t stream);
+// h[m][:] += sum_s add.P[s][m][:] (fixed order), then x_pk = pack(RMSNorm(h) * gain * scale)   (decode-step fusion of
+// the residual add of the previous projection with the next sub-layer's norm)
+void add_norm_pack(float* h, const Slabs& add, const float* gain, uint16_t* x_pk, int M, int d, float eps, float scale,
+                   mgStream_t stream);
+// y_pk[M][N] packed = bf16(relu(sum_s in.P[s]))
+void relu_pack(const Slabs& in, uint16_t* y_pk, int M, int N, mgStream_t stream);
 // HF [N][K] weight (fp32 or bf16 bits) -> packed bf16 tiles, rows >= N zero
 void pack_weight(const void* src, int src_is_bf16, int N, int K, uint16_t* dst, int Npad, mgStream_t stream);
 void convert_to_f32(const void* src, int src_is_bf16, float* dst, size_t n, mgStream_t stream);
@@ -127,6 +144,13 @@ struct AttnStepArgs {
     const int* anc;           // self with beams: [T_cap][rows] physical row holding position j (nullable)
     int t;                    // current position (self)
     const int* t_dev;         // if non-null: t (and n_keys = t+1 for self-attention) are read from device memory
+    // split-K form of the projections feeding this step: q (and for self-attention k, v of the new position) are
+    // given as fp32 partial slabs [rows][ldp] with q | k | v at column offsets 0 | inner | 2*inner; the kernel sums
+    // them, rounds to bf16, appends k, v to the cache at position t and attends over [0, t] (self) or the cross keys.
+    Slabs qkv;
+    int self_append;          // 1: slabs carry q,k,v and the new position is appended; 0: slabs carry q only
+    uint16_t* Kc_w;           // writable cache pointers for the append
+    uint16_t* Vc_w;
 };
 void attention_step(const AttnStepArgs& a, mgStream_t stream);
 

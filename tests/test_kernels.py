@@ -394,3 +394,30 @@ def test_embed_assemble_matches_oracle(be_name, with_mask):
         assert xlen.numpy()[b] == len(att)
         assert np.array_equal(xrow.numpy()[b, att], np.arange(len(att)))
         assert np.all(xrow.numpy()[b, mk.numpy()[b] == 0] == -1)
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+@pytest.mark.parametrize("M,N,K,KS", [(32, 96, 256, 3), (20, 64, 128, 2), (70, 128, 512, 8)])
+def test_gemm_splitk_add_norm_relu(be_name, M, N, K, KS):
+    be = get_backend(be_name)
+    x, w = rnd((M, K), 90), rnd((N, K), 91, 0.3)
+    ref = pk.bf16_round(x) @ pk.bf16_round(w).T
+    X, W = be.buf(pk.pack_tiles(x)), be.buf(pk.pack_tiles(w))
+    Mp = (M + 31) // 32 * 32
+    P = be.zeros((KS, Mp, N), np.float32)
+    assert be.lib.mgk_gemm_splitk(be.stream, be.p(X), be.p(W), be.p(P), M, N, K, N, C.c_size_t(Mp * N), KS) == 0
+    np.testing.assert_allclose(P.numpy()[:, :M].sum(0), ref, rtol=1e-4, atol=1e-4)
+    # relu_pack
+    y = be.zeros((Mp * N,), np.uint16)
+    assert be.lib.mgk_relu_pack(be.stream, be.p(P), KS, N, C.c_size_t(Mp * N), be.p(y), M, N) == 0
+    np.testing.assert_allclose(pk.unpack_tiles(y.numpy(), M, N), np.maximum(ref, 0), rtol=1 / 128, atol=1e-3)
+    # fused residual add + RMSNorm + pack (d = N)
+    h0, g = rnd((M, N), 92), 1 + 0.2 * rnd((N,), 93)
+    h = be.buf(h0)
+    xp = be.zeros((Mp * N,), np.uint16)
+    assert be.lib.mgk_add_norm_pack(be.stream, be.p(h), be.p(P), KS, N, C.c_size_t(Mp * N), be.p(be.buf(g)), be.p(xp), M, N,
+                                    C.c_float(1e-6), C.c_float(1.0)) == 0
+    hn = h0 + ref
+    np.testing.assert_allclose(h.numpy(), hn, rtol=1e-4, atol=1e-4)
+    xr = g * (hn / np.sqrt((hn ** 2).mean(-1, keepdims=True) + 1e-6))
+    np.testing.assert_allclose(pk.unpack_tiles(xp.numpy(), M, N), xr, rtol=1 / 100, atol=2e-3)

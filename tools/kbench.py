@@ -1,0 +1,113 @@
+"""Isolated timing of the decode-step kernels on a real MI355X (HBM-cold: every launch reads a different copy of its
+weights / K-V streams so the 256 MiB Infinity Cache cannot serve them).  Prints one line per case:
+   name  avg_us  GB/s(algorithmic)
+Usage (on the GPU box):  python tools/kbench.py [gemm] [attn] [norm]
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+from markushgrapher_amd import _lib  # noqa: E402
+
+lib = _lib.load()
+dev = torch.device("cuda:0")
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def timeit(fn, iters=200, warm=20):
+    for i in range(warm):
+        fn(i)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(iters):
+        fn(i)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3     # us
+
+
+def bench_gemm():
+    M = 32
+    for name, N, K in [("qkv", 3072, 1024), ("o/xq/xo", 1024, 1024), ("wi", 4096, 1024), ("wo2", 1024, 4096), ("lm_head", 33201, 1024)]:
+        wbytes = ((N + 31) // 32 * 32) * K * 2
+        ncopy = max(2, min(256, int(700e6 // wbytes)))
+        W = torch.randint(-3000, 3000, (ncopy, wbytes // 2), dtype=torch.int16, device=dev)
+        X = torch.randint(-3000, 3000, (M * K,), dtype=torch.int16, device=dev)
+        ks_auto = lib.mgk_splitk_factor(N, K)
+        for KS in sorted(set([1, 2, 4, 8, 16, ks_auto])):
+            if KS > K // 64:
+                continue
+            ldp = (N + 31) // 32 * 32
+            Pb = torch.empty((KS, 32, ldp), dtype=torch.float32, device=dev)
+
+            def f(i):
+                lib.mgk_gemm_splitk(stream(), P(X), P(W[i % ncopy]), P(Pb), M, N, K, ldp, C.c_size_t(32 * ldp), KS)
+            us = timeit(f)
+            print(f"gemm_splitk {name:8s} N={N:5d} K={K:4d} KS={KS:2d}{'*' if KS == ks_auto else ' '} blocks={(N + 31) // 32 * KS:5d} "
+                  f"{us:7.2f} us  {wbytes / us / 1e3:7.1f} GB/s")
+
+
+def bench_attn():
+    B, H, cap = 32, 16, 1280
+    for name, group, lens in [("cross", 1, 1072), ("cross-full", 1, 1280), ("self t=128", 0, 129), ("self t=400", 0, 401)]:
+        is_self = group == 0
+        rows = B
+        ncopy = 5 if not is_self else 24
+        caps = cap if not is_self else 512
+        Kc = torch.randint(-3000, 3000, (ncopy, rows, H, caps, 64), dtype=torch.int16, device=dev)
+        Vc = torch.randint(-3000, 3000, (ncopy, rows, H, caps, 64), dtype=torch.int16, device=dev)
+        q = torch.randint(-3000, 3000, (rows, H, 64), dtype=torch.int16, device=dev)
+        ctx = torch.empty((rows * H * 64,), dtype=torch.int16, device=dev)
+        ln = torch.full((rows,), lens, dtype=torch.int32, device=dev)
+        bias = torch.zeros((512, H), dtype=torch.float32, device=dev)
+
+        def f(i):
+            c = i % ncopy
+            lib.mgk_attention_step(stream(), P(q), P(Kc[c]), P(Vc[c]), P(ctx), rows, H, 1, caps,
+                                   None if is_self else P(ln), lens, P(bias) if is_self else None, None, lens - 1)
+        us = timeit(f)
+        nbytes = rows * H * lens * 64 * 2 * 2
+        print(f"attn_step {name:12s} keys={lens:5d} {us:7.2f} us  {nbytes / us / 1e3:7.1f} GB/s")
+
+
+def bench_norm():
+    M, d = 32, 1024
+    for KS in (4, 8, 10):
+        h = torch.randn((M, d), device=dev)
+        Pb = torch.randn((KS, M, d), device=dev)
+        g = torch.ones((d,), device=dev)
+        xp = torch.empty((M * d,), dtype=torch.int16, device=dev)
+
+        def f(i):
+            lib.mgk_add_norm_pack(stream(), P(h), P(Pb), KS, d, C.c_size_t(M * d), P(g), P(xp), M, d, C.c_float(1e-6), C.c_float(1.0))
+        print(f"add_norm_pack KS={KS:2d} {timeit(f):7.2f} us")
+    Pb = torch.randn((3, M, 4096), device=dev)
+    y = torch.empty((M * 4096,), dtype=torch.int16, device=dev)
+
+    def f2(i):
+        lib.mgk_relu_pack(stream(), P(Pb), 3, 4096, C.c_size_t(M * 4096), P(y), M, 4096)
+    print(f"relu_pack KS=3 {timeit(f2):7.2f} us")
+
+
+if __name__ == "__main__":
+    lib.mgk_gemm_splitk.argtypes = [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_size_t, C.c_int]
+    what = sys.argv[1:] or ["gemm", "attn", "norm"]
+    if "gemm" in what:
+        bench_gemm()
+    if "attn" in what:
+        bench_attn()
+    if "norm" in what:
+        bench_norm()
