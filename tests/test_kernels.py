@@ -421,3 +421,18 @@ def test_gemm_splitk_add_norm_relu(be_name, M, N, K, KS):
     np.testing.assert_allclose(h.numpy(), hn, rtol=1e-4, atol=1e-4)
     xr = g * (hn / np.sqrt((hn ** 2).mean(-1, keepdims=True) + 1e-6))
     np.testing.assert_allclose(pk.unpack_tiles(xp.numpy(), M, N), xr, rtol=1 / 100, atol=2e-3)
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+def test_beam_reorder_physical_copy(be_name):
+    """mg_beam_reorder = index_select(0, beam_idx) on every layer's K and V (stock cache_utils.py:100-104)."""
+    be = get_backend(be_name)
+    layers, rows, H, cap, used = 2, 10, 2, 16, 5
+    src = np.random.RandomState(3).randint(0, 65535, (layers, 2, rows, H, cap, 64)).astype(np.uint16)
+    idx = np.random.RandomState(4).randint(0, rows, (rows,)).astype(np.int32)
+    dst = be.zeros(src.shape, np.uint16)
+    rc = be.lib.mg_beam_reorder(be.stream, be.p(be.buf(src)), be.p(dst), be.p(be.buf(idx)), layers, rows, H, cap, used)
+    assert rc == 0
+    got = dst.numpy()
+    assert np.array_equal(got[:, :, :, :, :used], src[:, :, idx][:, :, :, :, :used])
+    assert np.all(got[:, :, :, :, used:] == 0)
