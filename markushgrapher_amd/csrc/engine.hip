@@ -669,8 +669,7 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
     int steps_done = 0;
     int host_flag[4] = {0, 0, 0, 0};
     // decode-step projections run as split-K GEMMs over all CUs; their consumers sum the partial slabs (k_gemm.hip)
-    const int ks_qkv = splitk_factor(3 * inner, d), ks_o = splitk_factor(d, inner), ks_xq = splitk_factor(inner, d);
-    const int ks_wi = splitk_factor(m->dff, d), ks_wo2 = splitk_factor(d, m->dff);
+    const int ks_o = splitk_factor(d, inner), ks_xq = splitk_factor(inner, d), ks_wo2 = splitk_factor(d, m->dff);
     const float eps = m->c.layer_norm_epsilon;
     const int ldl = round_up(m->V, 32);
     auto slabs = [&](int KS, int ldp) { Slabs sl; sl.P = w.slabs; sl.KS = KS; sl.ldp = ldp; sl.stride = w.slab_stride; return sl; };
@@ -682,11 +681,15 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
             uint16_t* sk = w.sk + li * skv_stride;
             uint16_t* sv = w.sv + li * skv_stride;
             // self-attention: QKV partial slabs -> the attention kernel sums them, appends k,v at position t, attends
-            gemm_rows_splitk(w.dx_pk, m->at<uint16_t>(l.wqkv), w.slabs, R, 3 * inner, d, 3 * inner, w.slab_stride, ks_qkv, st);
+            {
+                GemmArgs a = gemm_args(w.dx_pk, m->at<uint16_t>(l.wqkv), R, 3 * inner, d);
+                set_heads(a, H, R, T_cap, w.dq, HF_STEP_Q, sk, HF_STEP_KV, sv, HF_STEP_KV);
+                a.heads.pos = t;
+                gemm_rows(a, EPI_HEADS, st);      // q -> dq, k/v appended to the cache at position t
+            }
             AttnStepArgs s{};
-            s.Kc = sk; s.Vc = sv; s.Kc_w = sk; s.Vc_w = sv; s.ctx = w.dctx_pk; s.rows = R; s.H = H; s.group = 1; s.cap = T_cap;
+            s.q = w.dq; s.Kc = sk; s.Vc = sv; s.ctx = w.dctx_pk; s.rows = R; s.H = H; s.group = 1; s.cap = T_cap;
             s.n_keys = t + 1; s.bias = m->at<float>(m->dec_tab); s.anc = K > 1 ? w.anc : nullptr; s.t = t;
-            s.qkv = slabs(ks_qkv, 3 * inner); s.self_append = 1;
             attention_step(s, st);
             gemm_rows_splitk(w.dctx_pk, m->at<uint16_t>(l.wo), w.slabs, R, d, inner, d, w.slab_stride, ks_o, st);
             add_norm_pack(w.dh, slabs(ks_o, d), m->at<float>(l.ln1), w.dx_pk, R, d, eps, 1.0f, st);
@@ -703,8 +706,11 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
             add_norm_pack(w.dh, slabs(ks_o, d), m->at<float>(l.ln2), w.dx_pk, R, d, eps, 1.0f, st);
             // FFN; its residual add is fused with the NEXT sub-layer's norm (next layer's ln0, or the final norm with
             // the d_model^-0.5 of the tied head, stock:1554-1555)
-            gemm_rows_splitk(w.dx_pk, m->at<uint16_t>(l.wi), w.slabs, R, m->dff, d, m->dff, w.slab_stride, ks_wi, st);
-            relu_pack(slabs(ks_wi, m->dff), w.dy_pk, R, m->dff, st);
+            {
+                GemmArgs a = gemm_args(w.dx_pk, m->at<uint16_t>(l.wi), R, m->dff, d);
+                a.out_pk = w.dy_pk;
+                gemm_rows(a, EPI_PK_RELU, st);
+            }
             gemm_rows_splitk(w.dy_pk, m->at<uint16_t>(l.wo2), w.slabs, R, d, m->dff, d, w.slab_stride, ks_wo2, st);
             const bool last = li + 1 == nl;
             add_norm_pack(w.dh, slabs(ks_wo2, d), m->at<float>(last ? m->dec_ln : m->dec[li + 1].ln0), w.dx_pk, R, d, eps,

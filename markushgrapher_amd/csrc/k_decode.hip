@@ -17,7 +17,9 @@ constexpr float DC_NEG = -1.0e30f;
 template <int G, int NW>
 __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a) {
     MG_DYN_SMEM(smem);
-    constexpr int U = 4;
+    // keys per wave per round = 8*U: the 8-wave (long-stream) form uses U = 2 so the last, partially filled round of a
+    // ~1000-key stream wastes < 10 % of the wave-rounds instead of ~20 %
+    constexpr int U = (NW >= 8) ? 2 : 4;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int sub = lane & 7, ks = lane >> 3;
     const int owner = blockIdx.x / a.H, h = blockIdx.x - owner * a.H;
@@ -113,9 +115,7 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a) {
                 p = dot2_bf16(q[g].y, kv[u].y, p);
                 p = dot2_bf16(q[g].z, kv[u].z, p);
                 p = dot2_bf16(q[g].w, kv[u].w, p);
-                p += __shfl_xor(p, 1);
-                p += __shfl_xor(p, 2);
-                p += __shfl_xor(p, 4);
+                p = sum8(p);
                 s[u][g] = key[u] < nkeys ? p + bias : DC_NEG;
             }
         }
@@ -146,9 +146,7 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a) {
         p = dot2_bf16(q[0].y, knew.y, p);
         p = dot2_bf16(q[0].z, knew.z, p);
         p = dot2_bf16(q[0].w, knew.w, p);
-        p += __shfl_xor(p, 1);
-        p += __shfl_xor(p, 2);
-        p += __shfl_xor(p, 4);
+        p = sum8(p);
         if (ks == 0) {
             const float sc = p + (a.bias ? a.bias[h] : 0.f);
             const float mn = fmaxf(m[0], sc);

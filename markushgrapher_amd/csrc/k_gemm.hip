@@ -46,7 +46,7 @@ MG_DEV void heads_store(const HeadsOut& ho, int ri, int h, int m, int dim0, cons
 //  TOR (operands swapped, D = W·X^T): lane owns token m = m0 + lane%32, rows of D are output features n0 + i.
 //  !TOR (D = X·W^T):                  lane owns feature n = n0 + lane%32, rows of D are tokens m0 + i.
 template <int EPI, bool TOR>
-MG_DEV void tile_epilogue(const GemmArgs& a, const f32x16& acc, int m0, int n0, int lane) {
+MG_DEV void tile_epilogue(const GemmArgs& a, const f32x16& acc, int m0, int n0, int lane, int qmask = 3) {
     const int half = lane >> 5, l32 = lane & 31;
     if constexpr (EPI == EPI_F32_STORE || EPI == EPI_F32_RESID) {
         static_assert(!TOR, "fp32 epilogues use D = X·W^T");
@@ -74,7 +74,7 @@ MG_DEV void tile_epilogue(const GemmArgs& a, const f32x16& acc, int m0, int n0, 
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int n = n0 + 16 * q + 8 * half;
-            if (m < a.M && n < a.N) st16(a.out_pk + pk_off(m, n, a.N), ch[q]);
+            if (m < a.M && n < a.N && ((qmask >> q) & 1)) st16(a.out_pk + pk_off(m, n, a.N), ch[q]);
         }
     } else {  // EPI_HEADS
         const HeadsOut& ho = a.heads;
@@ -85,7 +85,7 @@ MG_DEV void tile_epilogue(const GemmArgs& a, const f32x16& acc, int m0, int n0, 
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int n = n0 + 16 * q + 8 * half;
-                if (m < a.M && n < a.N) {
+                if (m < a.M && n < a.N && ((qmask >> q) & 1)) {
                     const int ri = n / ho.inner, nn = n - ri * ho.inner;
                     heads_store(ho, ri, nn >> 6, m, nn & 63, ch[q]);
                 }
@@ -225,11 +225,16 @@ void gemm(const GemmArgs& a, int epi, mgStream_t stream) {
 // 1 KiB wave-load per fragment, no LDS round trip for a stream that is read once), the activation fragments
 // come from L2.  Partial accumulators are combined through LDS in a fixed order (deterministic).
 // ---------------------------------------------------------------------------------------------------------
-template <int EPI, int MT>
+// HALF: one workgroup per 16 output features (half a weight tile; the other half's lanes feed zeros to the MFMA) —
+// doubles the number of workgroups for projections whose epilogue must see complete sums (relu, bf16 per-head stores).
+template <int EPI, int MT, bool HALF>
 __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a) {
     MG_DYN_SMEM(smem);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int nt = blockIdx.x;
+    const int nt = HALF ? (blockIdx.x >> 1) : blockIdx.x;
+    const int sub = HALF ? (blockIdx.x & 1) : 0;
+    const bool wvalid = !HALF || (((lane & 31) >> 4) == sub);
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
     const int kt16 = a.K >> 4;
     const int per = (kt16 + 3) >> 2;
     const int k0 = w * per, k1 = (k0 + per) < kt16 ? (k0 + per) : kt16;
@@ -240,12 +245,12 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a) {
     for (int i = 0; i < MT; ++i) acc[i] = acc_zero();
     const char* wp = (const char*)(a.W + pk_tile_off(nt, 0, a.K)) + lane * 16;
     const char* xp = (const char*)a.X + lane * 16;
-    constexpr int U = 4;
+    constexpr int U = 8;
     int kt = k0;
     for (; kt + U <= k1; kt += U) {
         uint4 wf[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) wf[u] = ld16(wp + (size_t)(kt + u) * TILE_BYTES);
+        for (int u = 0; u < U; ++u) wf[u] = wvalid ? ld16(wp + (size_t)(kt + u) * TILE_BYTES) : zero4;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
@@ -256,7 +261,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a) {
         }
     }
     for (; kt < k1; ++kt) {
-        const uint4 wf = ld16(wp + (size_t)kt * TILE_BYTES);
+        const uint4 wf = wvalid ? ld16(wp + (size_t)kt * TILE_BYTES) : zero4;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const uint4 xf = ld16(xp + ((size_t)i * kt16 + kt) * TILE_BYTES);
@@ -280,25 +285,26 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a) {
                 v += slab[(3 * 16 + r) * 64 + lane];
                 s[r] = v;
             }
-            tile_epilogue<EPI, TOR>(a, s, 32 * i, 32 * nt, lane);
+            tile_epilogue<EPI, TOR>(a, s, 32 * i, 32 * nt, lane, HALF ? (1 << sub) : 3);
         }
         __syncthreads();
     }
 }
 
 template <int EPI>
-static void gemm_rows_mt(const GemmArgs& a, int mt, mgStream_t stream) {
-    const dim3 grid((a.N + 31) / 32), block(256);
+static void gemm_rows_mt(const GemmArgs& a, int mt, bool half, mgStream_t stream) {
+    const dim3 grid(((a.N + 31) / 32) * (half ? 2 : 1)), block(256);
     const size_t sh = (size_t)4 * 16 * 64 * sizeof(float);
+#define MG_GR(MTV)                                                                                   \
+    case MTV:                                                                                        \
+        if (half) MG_LAUNCH((gemm_rows_kernel<EPI, MTV, true>), grid, block, sh, stream, a);         \
+        else MG_LAUNCH((gemm_rows_kernel<EPI, MTV, false>), grid, block, sh, stream, a);             \
+        break;
     switch (mt) {
-        case 1: MG_LAUNCH((gemm_rows_kernel<EPI, 1>), grid, block, sh, stream, a); break;
-        case 2: MG_LAUNCH((gemm_rows_kernel<EPI, 2>), grid, block, sh, stream, a); break;
-        case 3: MG_LAUNCH((gemm_rows_kernel<EPI, 3>), grid, block, sh, stream, a); break;
-        case 4: MG_LAUNCH((gemm_rows_kernel<EPI, 4>), grid, block, sh, stream, a); break;
-        case 5: MG_LAUNCH((gemm_rows_kernel<EPI, 5>), grid, block, sh, stream, a); break;
-        case 6: MG_LAUNCH((gemm_rows_kernel<EPI, 6>), grid, block, sh, stream, a); break;
+        MG_GR(1) MG_GR(2) MG_GR(3) MG_GR(4) MG_GR(5) MG_GR(6) MG_GR(7) MG_GR(8)
         default: break;
     }
+#undef MG_GR
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -397,16 +403,18 @@ void gemm_rows_splitk(const uint16_t* X, const uint16_t* W, float* P, int M, int
 
 void gemm_rows(const GemmArgs& a, int epi, mgStream_t stream) {
     const int mt = (a.M + 31) / 32;
-    if (mt > 6) {   // many live rows (large beam batches): the tiled kernel is the better shape
+    if (mt > 8) {   // many live rows: the tiled kernel is the better shape
         gemm(a, epi, stream);
         return;
     }
+    // projections with few feature tiles get one workgroup per 16 features (packed / per-head epilogues only)
+    const bool half = (epi == EPI_PK_RELU || epi == EPI_PK || epi == EPI_HEADS) && ((a.N + 31) / 32) < 256 && (a.N % 16) == 0;
     switch (epi) {
-        case EPI_F32_STORE: gemm_rows_mt<EPI_F32_STORE>(a, mt, stream); break;
-        case EPI_F32_RESID: gemm_rows_mt<EPI_F32_RESID>(a, mt, stream); break;
-        case EPI_PK_RELU: gemm_rows_mt<EPI_PK_RELU>(a, mt, stream); break;
-        case EPI_PK: gemm_rows_mt<EPI_PK>(a, mt, stream); break;
-        default: gemm_rows_mt<EPI_HEADS>(a, mt, stream); break;
+        case EPI_F32_STORE: gemm_rows_mt<EPI_F32_STORE>(a, mt, false, stream); break;
+        case EPI_F32_RESID: gemm_rows_mt<EPI_F32_RESID>(a, mt, false, stream); break;
+        case EPI_PK_RELU: gemm_rows_mt<EPI_PK_RELU>(a, mt, half, stream); break;
+        case EPI_PK: gemm_rows_mt<EPI_PK>(a, mt, half, stream); break;
+        default: gemm_rows_mt<EPI_HEADS>(a, mt, half, stream); break;
     }
 }
 

@@ -141,6 +141,22 @@ MG_DEV float fast_exp(float x) {
 #endif
 }
 
+// sum over each aligned group of 8 lanes, result in all 8 (DPP: quad_perm xor 1, quad_perm xor 2, row_half_mirror —
+// pure VALU, no LDS crossbar traffic unlike ds_bpermute-based shuffles)
+MG_DEV float sum8(float p) {
+#ifdef MG_EMU
+    p += __shfl_xor(p, 1);
+    p += __shfl_xor(p, 2);
+    p += __shfl_xor(p, 4);
+    return p;
+#else
+    p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0xB1, 0xF, 0xF, false));
+    p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x4E, 0xF, 0xF, false));
+    p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x141, 0xF, 0xF, false));
+    return p;
+#endif
+}
+
 MG_DEV float wave_sum(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);

@@ -62,10 +62,10 @@ def bench_gemm():
 
 def bench_attn():
     B, H, cap = 32, 16, 1280
-    for name, group, lens in [("cross", 1, 1072), ("cross-full", 1, 1280), ("self t=128", 0, 129), ("self t=400", 0, 401)]:
+    for name, group, lens in [("cross", 1, 1072), ("cross-warm", 1, 1072), ("cross-full", 1, 1280), ("self t=128", 0, 129), ("self t=400", 0, 401)]:
         is_self = group == 0
         rows = B
-        ncopy = 5 if not is_self else 24
+        ncopy = (1 if "warm" in name else 5) if not is_self else 24
         caps = cap if not is_self else 512
         Kc = torch.randint(-3000, 3000, (ncopy, rows, H, caps, 64), dtype=torch.int16, device=dev)
         Vc = torch.randint(-3000, 3000, (ncopy, rows, H, caps, 64), dtype=torch.int16, device=dev)
