@@ -36,6 +36,8 @@ def cpu_baseline(shape, sd, new_tokens=16, B=2, L=128):
     import torch
     from markushgrapher_amd import synth
     from oracle.udop_oracle import Oracle
+    # a small batch on a 100+-core host is slower with every core than with a few dozen threads (memory-bound GEMV)
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
     o = Oracle(shape, sd)
     inp = synth.synth_batch(shape, B, seed=7, fixed_L=L)
     with torch.no_grad():
@@ -139,8 +141,16 @@ def main():
             bytes_per_launch = keys.value / n_l.value * H * 64 * 2 * 2     # K and V rows of 64 bf16, all heads
             dur_s = ms.value / n_l.value * 1e-3
             ach = bytes_per_launch / dur_s / 1e9
+            traffic, traffic_src = None, None
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_cross_attention.json")
+            if os.path.exists(pmc) and args.shape == "large" and B == 32 and args.beams == 1:
+                with open(pmc) as f:
+                    pj = json.load(f)
+                traffic = int(pj["traffic_bytes_per_launch"])      # HBM bytes per launch from the separate --pmc pass
+                traffic_src = pj["source"]
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
+                    "traffic_source": traffic_src,
                     "kernel": "attn_step_kernel<1> (decoder cross-attention, single query per image/head)",
                     "bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(dur_s * 1e6, 2),
                     "launches_timed": int(n_l.value)}
