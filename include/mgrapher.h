@@ -135,6 +135,10 @@ int mgk_greedy_select(void* stream, const float* logits, int rows, int V, int ld
 int mgk_gemm_splitk(void* stream, const void* X_pk, const void* W_pk, float* P, int M, int N, int K, int ldp,
                     size_t slab_stride, int KS);
 int mgk_splitk_factor(int N, int K);
+/* decode-step residual projection with the next RMSNorm folded in: h += X W^T (optionally scaled per row by the deferred
+ * statistic rs_*), x_pk = bf16(h*gain*gscale) un-normalised, part[m][N/8] = per-block sums of h^2 */
+int mgk_gemm_resid(void* stream, const void* X_pk, const void* W_pk, float* h, const float* gain, float gscale, void* x_pk,
+                   float* part, int M, int N, int K, const float* rs_part, int rs_nparts, float rs_inv_d, float rs_eps);
 int mgk_add_norm_pack(void* stream, float* h, const float* P, int KS, int ldp, size_t slab_stride, const float* gain,
                       void* x_pk, int M, int d, float eps, float scale);
 int mgk_relu_pack(void* stream, const float* P, int KS, int ldp, size_t slab_stride, void* y_pk, int M, int N);

@@ -103,10 +103,19 @@ int mgk_greedy_select(void* stream, const float* logits, int rows, int V, int ld
 int mgk_gemm_splitk(void* stream, const void* X_pk, const void* W_pk, float* P, int M, int N, int K, int ldp,
                     size_t slab_stride, int KS) {
     if ((K & 63) || KS < 1 || KS > 16 || M > 256) return MG_E_SHAPE;
-    gemm_rows_splitk((const uint16_t*)X_pk, (const uint16_t*)W_pk, P, M, N, K, ldp, slab_stride, KS, (mgStream_t)stream);
+    RowScale rs{};
+    gemm_rows_splitk((const uint16_t*)X_pk, (const uint16_t*)W_pk, P, M, N, K, ldp, slab_stride, KS, rs, (mgStream_t)stream);
     return MG_OK;
 }
 int mgk_splitk_factor(int N, int K) { return splitk_factor(N, K); }
+
+int mgk_gemm_resid(void* stream, const void* X_pk, const void* W_pk, float* h, const float* gain, float gscale, void* x_pk,
+                   float* part, int M, int N, int K, const float* rs_part, int rs_nparts, float rs_inv_d, float rs_eps) {
+    if ((K & 63) || (N & 31) || M > 256) return MG_E_SHAPE;
+    RowScale rs{rs_part, rs_nparts, rs_inv_d, rs_eps};
+    gemm_rows_resid((const uint16_t*)X_pk, (const uint16_t*)W_pk, h, gain, gscale, (uint16_t*)x_pk, part, M, N, K, rs, (mgStream_t)stream);
+    return MG_OK;
+}
 
 int mgk_add_norm_pack(void* stream, float* h, const float* P, int KS, int ldp, size_t slab_stride, const float* gain,
                       void* x_pk, int M, int d, float eps, float scale) {

@@ -145,7 +145,7 @@ struct Ws {
     int *xrow, *xlen, *counters;
     // decode (generate)
     uint16_t *xk, *xv, *sk, *sv, *dq, *dx_pk, *dctx_pk, *dy_pk;
-    float *dh, *logits, *slabs;
+    float *dh, *logits, *slabs, *rs_part;
     size_t slab_stride;
     int64_t* next_ids;
     int *unfinished, *anc, *anc_tmp, *beam_idx;
@@ -213,6 +213,7 @@ void carve(const mg_model* m, char* base, int B, int L, int K, int max_len, int 
             if (d > ldmax) ldmax = d;
             w->slab_stride = (size_t)Rp * ldmax;
             w->slabs = c.take<float>(16 * w->slab_stride);
+            w->rs_part = c.take<float>((size_t)Rp * (d / 8));
         }
         w->next_ids = c.take<int64_t>(Rp);
         w->unfinished = c.take<int>(Rp);
@@ -668,11 +669,15 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
     }
     int steps_done = 0;
     int host_flag[4] = {0, 0, 0, 0};
-    // decode-step projections run as split-K GEMMs over all CUs; their consumers sum the partial slabs (k_gemm.hip)
-    const int ks_o = splitk_factor(d, inner), ks_xq = splitk_factor(inner, d), ks_wo2 = splitk_factor(d, m->dff);
+    // Decode step, 8 launches per layer.  Residual projections (O, cross-O, FFN wo) run with complete sums per
+    // workgroup and fold the NEXT sub-layer's RMSNorm in: they leave bf16(h*gain) un-normalised plus per-row partial
+    // sums of squares, and the consuming projection multiplies its outputs by rsqrt(mean(h^2)+eps) (RowScale).
+    const int ks_xq = splitk_factor(inner, d);
     const float eps = m->c.layer_norm_epsilon;
     const int ldl = round_up(m->V, 32);
     auto slabs = [&](int KS, int ldp) { Slabs sl; sl.P = w.slabs; sl.KS = KS; sl.ldp = ldp; sl.stride = w.slab_stride; return sl; };
+    RowScale none{};
+    RowScale rsd{w.rs_part, d / 8, 1.0f / (float)d, eps};
     for (int t = 0; t + 1 < max_length; ++t) {
         embed_rows(w.next_ids, m->at<uint16_t>(m->tok_emb), w.dh, R, d, m->V, counters + 3, st);
         rmsnorm_pack(w.dh, m->at<float>(m->dec[0].ln0), w.dx_pk, nullptr, R, d, eps, 1.0f, st);
@@ -680,21 +685,20 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
             const DecLayer& l = m->dec[li];
             uint16_t* sk = w.sk + li * skv_stride;
             uint16_t* sv = w.sv + li * skv_stride;
-            // self-attention: QKV partial slabs -> the attention kernel sums them, appends k,v at position t, attends
             {
                 GemmArgs a = gemm_args(w.dx_pk, m->at<uint16_t>(l.wqkv), R, 3 * inner, d);
                 set_heads(a, H, R, T_cap, w.dq, HF_STEP_Q, sk, HF_STEP_KV, sv, HF_STEP_KV);
                 a.heads.pos = t;
+                a.rs = li == 0 ? none : rsd;      // layer 0 reads the explicitly normalised embedding
                 gemm_rows(a, EPI_HEADS, st);      // q -> dq, k/v appended to the cache at position t
             }
             AttnStepArgs s{};
             s.q = w.dq; s.Kc = sk; s.Vc = sv; s.ctx = w.dctx_pk; s.rows = R; s.H = H; s.group = 1; s.cap = T_cap;
             s.n_keys = t + 1; s.bias = m->at<float>(m->dec_tab); s.anc = K > 1 ? w.anc : nullptr; s.t = t;
             attention_step(s, st);
-            gemm_rows_splitk(w.dctx_pk, m->at<uint16_t>(l.wo), w.slabs, R, d, inner, d, w.slab_stride, ks_o, st);
-            add_norm_pack(w.dh, slabs(ks_o, d), m->at<float>(l.ln1), w.dx_pk, R, d, eps, 1.0f, st);
+            gemm_rows_resid(w.dctx_pk, m->at<uint16_t>(l.wo), w.dh, m->at<float>(l.ln1), 1.0f, w.dx_pk, w.rs_part, R, d, inner, none, st);
             // cross-attention over the image's compacted K/V stream (all beams of an image share one pass)
-            gemm_rows_splitk(w.dx_pk, m->at<uint16_t>(l.xq), w.slabs, R, inner, d, inner, w.slab_stride, ks_xq, st);
+            gemm_rows_splitk(w.dx_pk, m->at<uint16_t>(l.xq), w.slabs, R, inner, d, inner, w.slab_stride, ks_xq, rsd, st);
             AttnStepArgs x{};
             x.Kc = w.xk + li * xkv_stride; x.Vc = w.xv + li * xkv_stride; x.ctx = w.dctx_pk; x.rows = R; x.H = H;
             x.group = K; x.cap = S_cap; x.len = w.xlen; x.qkv = slabs(ks_xq, inner); x.self_append = 0;
@@ -702,21 +706,19 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
             if (timed) mg_event_record(m->prof_ev[m->prof_used], st);
             attention_step(x, st);
             if (timed) { mg_event_record(m->prof_ev[m->prof_used + 1], st); m->prof_used += 2; }
-            gemm_rows_splitk(w.dctx_pk, m->at<uint16_t>(l.xo), w.slabs, R, d, inner, d, w.slab_stride, ks_o, st);
-            add_norm_pack(w.dh, slabs(ks_o, d), m->at<float>(l.ln2), w.dx_pk, R, d, eps, 1.0f, st);
-            // FFN; its residual add is fused with the NEXT sub-layer's norm (next layer's ln0, or the final norm with
-            // the d_model^-0.5 of the tied head, stock:1554-1555)
+            gemm_rows_resid(w.dctx_pk, m->at<uint16_t>(l.xo), w.dh, m->at<float>(l.ln2), 1.0f, w.dx_pk, w.rs_part, R, d, inner, none, st);
             {
                 GemmArgs a = gemm_args(w.dx_pk, m->at<uint16_t>(l.wi), R, m->dff, d);
                 a.out_pk = w.dy_pk;
+                a.rs = rsd;
                 gemm_rows(a, EPI_PK_RELU, st);
             }
-            gemm_rows_splitk(w.dy_pk, m->at<uint16_t>(l.wo2), w.slabs, R, d, m->dff, d, w.slab_stride, ks_wo2, st);
+            // FFN output; folded norm = next layer's ln0, or the final norm with the d_model^-0.5 of the tied head
             const bool last = li + 1 == nl;
-            add_norm_pack(w.dh, slabs(ks_wo2, d), m->at<float>(last ? m->dec_ln : m->dec[li + 1].ln0), w.dx_pk, R, d, eps,
-                          last ? 1.0f / sqrtf((float)d) : 1.0f, st);
+            gemm_rows_resid(w.dy_pk, m->at<uint16_t>(l.wo2), w.dh, m->at<float>(last ? m->dec_ln : m->dec[li + 1].ln0),
+                            last ? 1.0f / sqrtf((float)d) : 1.0f, w.dx_pk, w.rs_part, R, d, m->dff, none, st);
         }
-        gemm_rows_splitk(w.dx_pk, m->at<uint16_t>(m->lm_head), w.logits, R, m->V, d, ldl, 0, 1, st);
+        gemm_rows_splitk(w.dx_pk, m->at<uint16_t>(m->lm_head), w.logits, R, m->V, d, ldl, 0, 1, rsd, st);
         if (K == 1) {
             ArgmaxArgs g{};
             g.logits = w.logits; g.rows = R; g.V = m->V; g.ldl = ldl; g.eos = m->c.eos_token_id; g.pad = (int)pad;

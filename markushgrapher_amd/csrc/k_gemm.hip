@@ -9,6 +9,28 @@
 
 namespace mg {
 
+// Deferred RMSNorm scales r(m) = rsqrt(sum_i part[m][i] * inv_d + eps) for rows [0, nrows) into LDS, computed by the
+// whole workgroup: 8 threads per row, each summing nparts/8 partials with independent 16-byte loads (one L2 round
+// trip, issued before the weight stream), combined by a fixed DPP tree.  Callers read `out` after their next barrier.
+MG_DEV void block_row_scales(const RowScale& rs, int M, int nrows, float* out, int tid, int nthreads) {
+    for (int base = 0; base < nrows; base += nthreads >> 3) {
+        const int row = base + (tid >> 3), j = tid & 7;
+        float s = 0.f;
+        if (rs.part && row < nrows) {
+            const int mr = row < M ? row : M - 1;
+            const int per = rs.nparts >> 3;                               // floats per thread
+            const float* p = rs.part + (size_t)mr * rs.nparts + j * per;
+            if ((per & 3) == 0) {
+                for (int i = 0; i < per; i += 4) { const float4 a = *(const float4*)(p + i); s += (a.x + a.y) + (a.z + a.w); }
+            } else {
+                for (int i = 0; i < per; ++i) s += p[i];
+            }
+        }
+        s = sum8(s);
+        if (j == 0 && row < nrows) out[row] = rs.part ? rsqrtf(s * rs.inv_d + rs.eps) : 1.0f;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // epilogue helpers
 // ---------------------------------------------------------------------------------------------------------
@@ -239,6 +261,8 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a) {
     const int per = (kt16 + 3) >> 2;
     const int k0 = w * per, k1 = (k0 + per) < kt16 ? (k0 + per) : kt16;
     constexpr bool TOR = !(EPI == EPI_F32_STORE || EPI == EPI_F32_RESID);
+    float* rsl = (float*)(smem + 4 * 16 * 64 * sizeof(float));     // [32*MT] deferred RMSNorm scale per row
+    if (TOR) block_row_scales(a.rs, a.M, 32 * MT, rsl, tid, 256);
 
     f32x16 acc[MT];
 #pragma unroll
@@ -283,7 +307,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a) {
                 v += slab[(1 * 16 + r) * 64 + lane];
                 v += slab[(2 * 16 + r) * 64 + lane];
                 v += slab[(3 * 16 + r) * 64 + lane];
-                s[r] = v;
+                s[r] = TOR ? v * rsl[32 * i + (lane & 31)] : v;
             }
             tile_epilogue<EPI, TOR>(a, s, 32 * i, 32 * nt, lane, HALF ? (1 << sub) : 3);
         }
@@ -294,7 +318,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a) {
 template <int EPI>
 static void gemm_rows_mt(const GemmArgs& a, int mt, bool half, mgStream_t stream) {
     const dim3 grid(((a.N + 31) / 32) * (half ? 2 : 1)), block(256);
-    const size_t sh = (size_t)4 * 16 * 64 * sizeof(float);
+    const size_t sh = (size_t)4 * 16 * 64 * sizeof(float) + (size_t)32 * mt * sizeof(float);
 #define MG_GR(MTV)                                                                                   \
     case MTV:                                                                                        \
         if (half) MG_LAUNCH((gemm_rows_kernel<EPI, MTV, true>), grid, block, sh, stream, a);         \
@@ -316,9 +340,11 @@ static void gemm_rows_mt(const GemmArgs& a, int mt, bool half, mgStream_t stream
 // ---------------------------------------------------------------------------------------------------------
 template <int MT>
 __global__ __launch_bounds__(256) void gemm_rows_splitk_kernel(const uint16_t* X, const uint16_t* W, float* P, int M, int N, int K, int ldp,
-                                                          size_t slab_stride, int KS) {
+                                                          size_t slab_stride, int KS, RowScale rs) {
     MG_DYN_SMEM(smem);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    float* rsl = (float*)(smem + 4 * 16 * 64 * sizeof(float));     // [32*MT] deferred RMSNorm scale per row
+    block_row_scales(rs, M, 32 * MT, rsl, tid, 256);
     const int ntiles = (N + 31) >> 5;
     const int nt = blockIdx.x % ntiles, ks = blockIdx.x / ntiles;
     const int kt16 = K >> 4;
@@ -367,10 +393,111 @@ __global__ __launch_bounds__(256) void gemm_rows_splitk_kernel(const uint16_t* X
             v += slab[(2 * 16 + r) * 64 + lane];
             v += slab[(3 * 16 + r) * 64 + lane];
             const int m = 32 * i + acc_row(r, half);
-            if (m < M && n < N) out[(size_t)m * ldp + n] = v;
+            if (m < M && n < N) out[(size_t)m * ldp + n] = v * rsl[m];
         }
         __syncthreads();
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// residual projection of the decode step + next RMSNorm folded in (see mg_kernels.h gemm_rows_resid)
+// workgroup = NW waves, 8 output features (a quarter weight tile; other lanes feed zeros), all M rows.
+// ---------------------------------------------------------------------------------------------------------
+template <int MT, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_rows_resid_kernel(const uint16_t* X, const uint16_t* W, float* h, const float* gain, float gscale,
+                                                             uint16_t* x_pk, float* part, int M, int N, int K, RowScale rs) {
+    MG_DYN_SMEM(smem);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int half = lane >> 5, l32 = lane & 31;
+    const int nt = blockIdx.x >> 2, sub = blockIdx.x & 3;
+    const bool wvalid = (l32 >> 3) == sub;
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    const int kt16 = K >> 4;
+    const int per = (kt16 + NW - 1) / NW;
+    const int k0 = w * per, k1 = (k0 + per) < kt16 ? (k0 + per) : kt16;
+    float* rsl = (float*)(smem + NW * 4 * 64 * sizeof(float));     // [32*MT]
+    block_row_scales(rs, M, 32 * MT, rsl, tid, NW * 64);
+    f32x16 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = acc_zero();
+    const char* wp = (const char*)(W + pk_tile_off(nt, 0, K)) + lane * 16;
+    const char* xp = (const char*)X + lane * 16;
+    constexpr int U = 8;
+    int kt = k0;
+    for (; kt + U <= k1; kt += U) {
+        uint4 wf[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) wf[u] = wvalid ? ld16(wp + (size_t)(kt + u) * TILE_BYTES) : zero4;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) acc[i] = mfma32(wf[u], ld16(xp + ((size_t)i * kt16 + (kt + u)) * TILE_BYTES), acc[i]);
+        }
+    }
+    for (; kt < k1; ++kt) {
+        const uint4 wf = wvalid ? ld16(wp + (size_t)kt * TILE_BYTES) : zero4;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[i] = mfma32(wf, ld16(xp + ((size_t)i * kt16 + kt) * TILE_BYTES), acc[i]);
+    }
+    // D rows = features of the tile; the valid 8 (8*sub .. +7) sit in registers 4*sub .. 4*sub+3:
+    // lane (row m = l32, half) holds features 8*sub + 4*half + j.  Reduce those 4 registers over the NW waves.
+    float* slab = (float*)smem;                         // [NW][4][64]
+    const int n0 = nt * 32 + sub * 8 + half * 4;
+    const int nparts = N >> 3;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) if (r == 4 * sub + j) v = acc[i][r];     // sub is workgroup-uniform
+            slab[(w * 4 + j) * 64 + lane] = v;
+        }
+        __syncthreads();
+        if ((i % NW) == w) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t = 0.f;
+                for (int ww = 0; ww < NW; ++ww) t += slab[(ww * 4 + j) * 64 + lane];
+                v[j] = t * rsl[32 * i + l32];
+            }
+            const int m = 32 * i + l32;
+            float ss = 0.f;
+            if (m < M) {
+                float4 hv = *(const float4*)(h + (size_t)m * N + n0);
+                hv.x += v[0]; hv.y += v[1]; hv.z += v[2]; hv.w += v[3];
+                *(float4*)(h + (size_t)m * N + n0) = hv;
+                ss = (hv.x * hv.x + hv.y * hv.y) + (hv.z * hv.z + hv.w * hv.w);
+                const float4 g = *(const float4*)(gain + n0);
+                *(uint2*)(x_pk + pk_off(m, n0, N)) =
+                    make_uint2(pack_bf16(hv.x * g.x * gscale, hv.y * g.y * gscale), pack_bf16(hv.z * g.z * gscale, hv.w * g.w * gscale));
+            }
+            ss += __shfl_xor(ss, 32);
+            if (m < M && half == 0) part[(size_t)m * nparts + blockIdx.x] = ss;
+        }
+        __syncthreads();
+    }
+}
+
+void gemm_rows_resid(const uint16_t* X, const uint16_t* W, float* h, const float* gain, float gscale, uint16_t* x_pk, float* part,
+                     int M, int N, int K, const RowScale& rs, mgStream_t stream) {
+    const int mt = (M + 31) / 32;
+    const dim3 grid(N / 8);
+    const bool wide = K > 2048;
+    const int NW = wide ? 16 : 8;
+    const dim3 block(NW * 64);
+    const size_t sh = (size_t)NW * 4 * 64 * sizeof(float) + (size_t)32 * mt * sizeof(float);
+#define MG_RR(MTV)                                                                                                        \
+    case MTV:                                                                                                             \
+        if (wide) MG_LAUNCH((gemm_rows_resid_kernel<MTV, 16>), grid, block, sh, stream, X, W, h, gain, gscale, x_pk, part, M, N, K, rs); \
+        else MG_LAUNCH((gemm_rows_resid_kernel<MTV, 8>), grid, block, sh, stream, X, W, h, gain, gscale, x_pk, part, M, N, K, rs);       \
+        break;
+    switch (mt) {
+        MG_RR(1) MG_RR(2) MG_RR(3) MG_RR(4) MG_RR(5) MG_RR(6) MG_RR(7) MG_RR(8)
+        default: break;
+    }
+#undef MG_RR
 }
 
 int splitk_factor(int N, int K) {
@@ -384,19 +511,19 @@ int splitk_factor(int N, int K) {
 }
 
 void gemm_rows_splitk(const uint16_t* X, const uint16_t* W, float* P, int M, int N, int K, int ldp, size_t slab_stride, int KS,
-                      mgStream_t stream) {
+                      const RowScale& rs, mgStream_t stream) {
     const int mt = (M + 31) / 32;
     const dim3 grid(((N + 31) / 32) * KS), block(256);
-    const size_t sh = (size_t)4 * 16 * 64 * sizeof(float);
+    const size_t sh = (size_t)4 * 16 * 64 * sizeof(float) + (size_t)32 * mt * sizeof(float);
     switch (mt) {
-        case 1: MG_LAUNCH((gemm_rows_splitk_kernel<1>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS); break;
-        case 2: MG_LAUNCH((gemm_rows_splitk_kernel<2>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS); break;
-        case 3: MG_LAUNCH((gemm_rows_splitk_kernel<3>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS); break;
-        case 4: MG_LAUNCH((gemm_rows_splitk_kernel<4>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS); break;
-        case 5: MG_LAUNCH((gemm_rows_splitk_kernel<5>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS); break;
-        case 6: MG_LAUNCH((gemm_rows_splitk_kernel<6>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS); break;
-        case 7: MG_LAUNCH((gemm_rows_splitk_kernel<7>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS); break;
-        case 8: MG_LAUNCH((gemm_rows_splitk_kernel<8>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS); break;
+        case 1: MG_LAUNCH((gemm_rows_splitk_kernel<1>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS, rs); break;
+        case 2: MG_LAUNCH((gemm_rows_splitk_kernel<2>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS, rs); break;
+        case 3: MG_LAUNCH((gemm_rows_splitk_kernel<3>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS, rs); break;
+        case 4: MG_LAUNCH((gemm_rows_splitk_kernel<4>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS, rs); break;
+        case 5: MG_LAUNCH((gemm_rows_splitk_kernel<5>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS, rs); break;
+        case 6: MG_LAUNCH((gemm_rows_splitk_kernel<6>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS, rs); break;
+        case 7: MG_LAUNCH((gemm_rows_splitk_kernel<7>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS, rs); break;
+        case 8: MG_LAUNCH((gemm_rows_splitk_kernel<8>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS, rs); break;
         default: break;
     }
 }

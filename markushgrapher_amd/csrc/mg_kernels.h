@@ -35,6 +35,14 @@ struct HeadsOut {
     int pos;               // HF_STEP: cache position written
     const int* pos_dev;    // if non-null the position is read from device memory (graph replay)
 };
+// Deferred RMSNorm statistic of the decode step: the activations X were stored UN-normalised (bf16(h * gain)) by the
+// previous residual projection, which also left per-row partial sums of squares; since RMSNorm is a per-row scalar,
+// the consumer GEMM multiplies its outputs by r(m) = rsqrt(sum_i part[m*nparts + i] * inv_d + eps) instead.
+struct RowScale {
+    const float* part;     // null = X is already normalised (scale 1)
+    int nparts;            // multiple of 4
+    float inv_d, eps;
+};
 struct GemmArgs {
     const uint16_t* X;
     const uint16_t* W;
@@ -44,6 +52,7 @@ struct GemmArgs {
     const float* bias;
     uint16_t* out_pk;
     HeadsOut heads;
+    RowScale rs;           // decode-step kernels only
 };
 void gemm(const GemmArgs& a, int epi, mgStream_t stream);
 
@@ -53,7 +62,13 @@ void gemm_rows(const GemmArgs& a, int epi, mgStream_t stream);
 // split-K decode GEMM: P[ks][m*ldp + n] (ks < KS) = partial sums over the ks-th K range; consumers add the slabs
 int splitk_factor(int N, int K);
 void gemm_rows_splitk(const uint16_t* X, const uint16_t* W, float* P, int M, int N, int K, int ldp, size_t slab_stride, int KS,
-                      mgStream_t stream);
+                      const RowScale& rs, mgStream_t stream);
+// Residual projection of the decode step with the NEXT sub-layer's RMSNorm folded in (no separate norm launch):
+//   h[m][n] += sum_k X[m][k] W[n][k];   x_pk = pack(bf16(h * gain * gscale))  (un-normalised);
+//   part[m*(N/8) + n/8] = sum over the block's 8 features of h^2  (consumers turn them into r(m), see RowScale).
+// One workgroup per 8 output features (complete sums, deterministic), K split over the workgroup's waves.
+void gemm_rows_resid(const uint16_t* X, const uint16_t* W, float* h, const float* gain, float gscale, uint16_t* x_pk, float* part,
+                     int M, int N, int K, const RowScale& rs, mgStream_t stream);
 // a row-major fp32 matrix given as KS split-K partial slabs
 struct Slabs {
     const float* P;        // null = not used

@@ -436,3 +436,35 @@ def test_beam_reorder_physical_copy(be_name):
     got = dst.numpy()
     assert np.array_equal(got[:, :, :, :, :used], src[:, :, idx][:, :, :, :, :used])
     assert np.all(got[:, :, :, :, used:] == 0)
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+@pytest.mark.parametrize("M,N,K", [(32, 64, 128), (20, 128, 256), (70, 64, 4096)])
+def test_gemm_resid_deferred_norm(be_name, M, N, K):
+    """h += X W^T; x = bf16(h*gain*gscale) un-normalised; per-row partial sums of squares; and a consumer that applies
+    the deferred rsqrt(mean(h^2)+eps) must reproduce RMSNorm(h)*gain followed by the projection."""
+    be = get_backend(be_name)
+    be.lib.mgk_gemm_resid.argtypes = [C.c_void_p] * 5 + [C.c_float] + [C.c_void_p] * 2 + [C.c_int] * 3 + [C.c_void_p, C.c_int, C.c_float, C.c_float]
+    x, w = rnd((M, K), 100), rnd((N, K), 101, 0.1)
+    h0, g = rnd((M, N), 102), 1 + 0.2 * rnd((N,), 103)
+    ref_h = h0 + pk.bf16_round(x) @ pk.bf16_round(w).T
+    Mp = (M + 31) // 32 * 32
+    h = be.buf(h0)
+    xp = be.zeros((Mp * N,), np.uint16)
+    part = be.zeros((Mp, N // 8), np.float32)
+    assert be.lib.mgk_gemm_resid(be.stream, be.p(be.buf(pk.pack_tiles(x))), be.p(be.buf(pk.pack_tiles(w))), be.p(h), be.p(be.buf(g)),
+                                 0.5, be.p(xp), be.p(part), M, N, K, None, 0, 0.0, 0.0) == 0
+    tol = 1e-4 * max(1.0, np.sqrt(K / 128))
+    np.testing.assert_allclose(h.numpy(), ref_h, rtol=1e-4, atol=tol)
+    np.testing.assert_allclose(pk.unpack_tiles(xp.numpy(), M, N), ref_h * g * 0.5, rtol=1 / 100, atol=2e-3)
+    np.testing.assert_allclose(part.numpy()[:M].sum(1), (ref_h ** 2).sum(1), rtol=1e-4)
+    # consumer with the deferred scale: second residual projection W2 on x (gscale folded back out by construction)
+    w2 = rnd((64, N), 104, 0.1)
+    h2 = be.zeros((M, 64), np.float32)
+    xp2 = be.zeros((Mp * 64,), np.uint16)
+    part2 = be.zeros((Mp, 8), np.float32)
+    g2 = np.ones((64,), np.float32)
+    assert be.lib.mgk_gemm_resid(be.stream, be.p(xp), be.p(be.buf(pk.pack_tiles(w2))), be.p(h2), be.p(be.buf(g2)), 1.0, be.p(xp2),
+                                 be.p(part2), M, 64, N, be.p(part), N // 8, 1.0 / N, 1e-6) == 0
+    xn = pk.bf16_round(ref_h * g * 0.5) / np.sqrt((ref_h ** 2).mean(-1, keepdims=True) + 1e-6)
+    np.testing.assert_allclose(h2.numpy(), xn @ pk.bf16_round(w2).T, rtol=2e-3, atol=2e-3)
