@@ -249,8 +249,8 @@ void gemm(const GemmArgs& a, int epi, mgStream_t stream) {
 // ---------------------------------------------------------------------------------------------------------
 // HALF: one workgroup per 16 output features (half a weight tile; the other half's lanes feed zeros to the MFMA) —
 // doubles the number of workgroups for projections whose epilogue must see complete sums (relu, bf16 per-head stores).
-template <int EPI, int MT, bool HALF>
-__global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a) {
+template <int EPI, int MT, bool HALF, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void gemm_rows_kernel(GemmArgs a) {
     MG_DYN_SMEM(smem);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nt = HALF ? (blockIdx.x >> 1) : blockIdx.x;
@@ -258,11 +258,11 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a) {
     const bool wvalid = !HALF || (((lane & 31) >> 4) == sub);
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
     const int kt16 = a.K >> 4;
-    const int per = (kt16 + 3) >> 2;
+    const int per = (kt16 + NW - 1) / NW;
     const int k0 = w * per, k1 = (k0 + per) < kt16 ? (k0 + per) : kt16;
     constexpr bool TOR = !(EPI == EPI_F32_STORE || EPI == EPI_F32_RESID);
-    float* rsl = (float*)(smem + 4 * 16 * 64 * sizeof(float));     // [32*MT] deferred RMSNorm scale per row
-    if (TOR) block_row_scales(a.rs, a.M, 32 * MT, rsl, tid, 256);
+    float* rsl = (float*)(smem + NW * 16 * 64 * sizeof(float));     // [32*MT] deferred RMSNorm scale per row
+    if (TOR) block_row_scales(a.rs, a.M, 32 * MT, rsl, tid, NW * 64);
 
     f32x16 acc[MT];
 #pragma unroll
@@ -292,21 +292,20 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a) {
             acc[i] = TOR ? mfma32(wf, xf, acc[i]) : mfma32(xf, wf, acc[i]);
         }
     }
-    // combine the 4 K-slices through one 16 KiB slab, one m-tile at a time: slab[w][r][lane]
+    // combine the NW K-slices through one LDS slab, one m-tile at a time: slab[w][r][lane]
     float* slab = (float*)smem;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) slab[(w * 16 + r) * 64 + lane] = acc[i][r];
         __syncthreads();
-        if ((i & 3) == w) {
+        if ((i % NW) == w) {
             f32x16 s;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float v = slab[(0 * 16 + r) * 64 + lane];
-                v += slab[(1 * 16 + r) * 64 + lane];
-                v += slab[(2 * 16 + r) * 64 + lane];
-                v += slab[(3 * 16 + r) * 64 + lane];
+                float v = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < NW; ++ww) v += slab[(ww * 16 + r) * 64 + lane];
                 s[r] = TOR ? v * rsl[32 * i + (lane & 31)] : v;
             }
             tile_epilogue<EPI, TOR>(a, s, 32 * i, 32 * nt, lane, HALF ? (1 << sub) : 3);
@@ -317,12 +316,14 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs a) {
 
 template <int EPI>
 static void gemm_rows_mt(const GemmArgs& a, int mt, bool half, mgStream_t stream) {
-    const dim3 grid(((a.N + 31) / 32) * (half ? 2 : 1)), block(256);
-    const size_t sh = (size_t)4 * 16 * 64 * sizeof(float) + (size_t)32 * mt * sizeof(float);
+    // half-tile projections (few workgroups, latency-bound): 8 waves split K so each wave's share is one load round
+    const int NW = half ? 8 : 4;
+    const dim3 grid(((a.N + 31) / 32) * (half ? 2 : 1)), block(NW * 64);
+    const size_t sh = (size_t)NW * 16 * 64 * sizeof(float) + (size_t)32 * mt * sizeof(float);
 #define MG_GR(MTV)                                                                                   \
     case MTV:                                                                                        \
-        if (half) MG_LAUNCH((gemm_rows_kernel<EPI, MTV, true>), grid, block, sh, stream, a);         \
-        else MG_LAUNCH((gemm_rows_kernel<EPI, MTV, false>), grid, block, sh, stream, a);             \
+        if (half) MG_LAUNCH((gemm_rows_kernel<EPI, MTV, true, 8>), grid, block, sh, stream, a);      \
+        else MG_LAUNCH((gemm_rows_kernel<EPI, MTV, false, 4>), grid, block, sh, stream, a);          \
         break;
     switch (mt) {
         MG_GR(1) MG_GR(2) MG_GR(3) MG_GR(4) MG_GR(5) MG_GR(6) MG_GR(7) MG_GR(8)
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_rows_resid_kernel(const uint16_t
     for (int i = 0; i < MT; ++i) acc[i] = acc_zero();
     const char* wp = (const char*)(W + pk_tile_off(nt, 0, K)) + lane * 16;
     const char* xp = (const char*)X + lane * 16;
-    constexpr int U = 8;
+    constexpr int U = (NW >= 16) ? 16 : 8;       // the wide (K = d_ff) form keeps its whole K share in flight at once
     int kt = k0;
     for (; kt + U <= k1; kt += U) {
         uint4 wf[U];
