@@ -117,9 +117,13 @@ int mgk_gemm(void* stream, int mode, int epi, const void* X_pk, const void* W_pk
              int ldo, const float* bias, void* out_pk);
 int mgk_gemm_heads(void* stream, int mode, const void* X_pk, const void* W_pk, int M, int N, int K, void* p0, void* p1,
                    void* p2, int f0, int f1, int f2, int H, int S_in, int S_cap, const int* row_map, int pos);
+/* mode 0 (encoder): tab1/tabh/tabv are the RAW bucket tables [32][H]; bk1[257] / bkhv[201] the bucket ids of integer
+ * distances -128..128 / -100..100; bidx_scratch [B][Sk_cap/32][Sk_cap][32] u16 receives the per-pair bucket indices.
+ * mode 1 (decoder self): tab1 = [tab1_len][H] by distance; mode 2 (cross): no bias. */
 int mgk_attention(void* stream, int mode, const void* Q, const void* K, const void* Vt, void* ctx_pk, int B, int H,
                   int Sq, int Sk, int Sq_cap, int Sk_cap, const uint8_t* kmask, const float* tab1, int tab1_len,
-                  const float* tabh, const float* tabv, const double* cx, const double* cy);
+                  const float* tabh, const float* tabv, const double* cx, const double* cy, const int* bk1, const int* bkhv,
+                  void* bidx_scratch);
 int mgk_attention_step(void* stream, const void* q, const void* Kc, const void* Vc, void* ctx_pk, int rows, int H,
                        int group, int cap, const int* len, int n_keys, const float* bias, const int* anc, int t);
 int mgk_embed_assemble(void* stream, void* meta_ws, const int64_t* input_ids, const float* bbox,

@@ -52,12 +52,18 @@ int mgk_gemm_heads(void* stream, int mode, const void* X_pk, const void* W_pk, i
 
 int mgk_attention(void* stream, int mode, const void* Q, const void* K, const void* Vt, void* ctx_pk, int B, int H,
                   int Sq, int Sk, int Sq_cap, int Sk_cap, const uint8_t* kmask, const float* tab1, int tab1_len,
-                  const float* tabh, const float* tabv, const double* cx, const double* cy) {
+                  const float* tabh, const float* tabv, const double* cx, const double* cy, const int* bk1, const int* bkhv,
+                  void* bidx_scratch) {
     if ((Sq_cap & 31) || (Sk_cap & 63) || Sk > Sk_cap || Sq > Sq_cap || mode < 0 || mode > 2) return MG_E_SHAPE;
     AttnArgs a{};
     a.Q = (const uint16_t*)Q; a.K = (const uint16_t*)K; a.Vt = (const uint16_t*)Vt; a.ctx = (uint16_t*)ctx_pk;
     a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.Sq_cap = Sq_cap; a.Sk_cap = Sk_cap; a.mode = mode; a.kmask = kmask;
-    a.tab1 = tab1; a.tab1_len = tab1_len; a.tabh = tabh; a.tabv = tabv; a.cx = cx; a.cy = cy;
+    a.tab1 = tab1; a.tab1_len = tab1_len; a.tabh = tabh; a.tabv = tabv;
+    if (mode == ATT_ENC) {
+        if (!bidx_scratch || !bk1 || !bkhv || !cx || !cy || Sq_cap != Sk_cap) return MG_E_ARG;
+        bias_index((uint16_t*)bidx_scratch, cx, cy, kmask, bk1, bkhv, B, Sk, Sk_cap, (mgStream_t)stream);
+        a.bidx = (const uint16_t*)bidx_scratch;
+    }
     attention(a, (mgStream_t)stream);
     return MG_OK;
 }

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void copy_bytes_rows_kernel(const uint8_t* src
 // ---- workspace -------------------------------------------------------------------------------------------
 struct Ws {
     // encoder
-    uint16_t *xim, *x_pk, *q_pk, *k_pk, *vt_pk, *ctx_pk, *y_pk, *enc_pk;
+    uint16_t *xim, *x_pk, *q_pk, *k_pk, *vt_pk, *ctx_pk, *y_pk, *enc_pk, *bidx;
     float *patch_emb, *hidden, *enc_f32;
     void* meta;
     double *cx, *cy;
@@ -188,6 +188,7 @@ void carve(const mg_model* m, char* base, int B, int L, int K, int max_len, int 
     w->y_pk = c.take<uint16_t>(M * m->dff);
     w->enc_pk = c.take<uint16_t>(M * d);
     w->enc_f32 = c.take<float>(M * d);
+    w->bidx = c.take<uint16_t>(M * (size_t)S_cap);
     w->cx = c.take<double>(M);
     w->cy = c.take<double>(M);
     w->mask = c.take<uint8_t>(M);
@@ -557,6 +558,8 @@ int mg_encode(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_
         e.err = w.counters + 3;
         embed_assemble(e, w.meta, st);
     }
+    // bucket indices of the three relative biases: shared by all layers and heads, computed once per batch
+    bias_index(w.bidx, w.cx, w.cy, w.mask, m->at<int>(m->bk1), m->at<int>(m->bkhv), B, S, S_cap, st);
     for (size_t li = 0; li < m->enc.size(); ++li) {
         const EncLayer& l = m->enc[li];
         rmsnorm_pack(w.hidden, m->at<float>(l.ln0), w.x_pk, nullptr, M, d, m->c.layer_norm_epsilon, 1.0f, st);
@@ -566,8 +569,8 @@ int mg_encode(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_
         AttnArgs t{};
         t.Q = w.q_pk; t.K = w.k_pk; t.Vt = w.vt_pk; t.ctx = w.ctx_pk; t.B = B; t.H = H; t.Sq = S; t.Sk = S;
         t.Sq_cap = S_cap; t.Sk_cap = S_cap; t.mode = ATT_ENC; t.kmask = w.mask;
-        t.tab1 = m->at<float>(m->tab1); t.tab1_len = 257; t.tabh = m->at<float>(m->tabh); t.tabv = m->at<float>(m->tabv);
-        t.cx = w.cx; t.cy = w.cy;
+        t.tab1 = m->at<float>(m->rb_raw[0]); t.tab1_len = 32; t.tabh = m->at<float>(m->rb_raw[1]); t.tabv = m->at<float>(m->rb_raw[2]);
+        t.bidx = w.bidx;
         attention(t, st);
         GemmArgs o = gemm_args(w.ctx_pk, m->at<uint16_t>(l.wo), M, d, inner);
         o.out_f32 = w.hidden; o.ldo = d;

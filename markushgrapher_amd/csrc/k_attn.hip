@@ -31,30 +31,23 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     const int h = bh % a.H, b = bh / a.H;
     const int Sk_pad = (a.Sk + AT_KEYS - 1) / AT_KEYS * AT_KEYS;
 
-    // LDS carve: [2 stages][tables: tab1 | tabh | tabv][kmask bytes][cx doubles][cy doubles]
+    // LDS carve: [2 stages][tables][key mask bytes (decoder modes)]
+    //   ATT_ENC:      t1[32] = 1-D table of head h, thv[1024] = horizontal[bh] + vertical[bv] of head h
+    //   ATT_DEC_SELF: tab1[tab1_len] = causal T5 table of head h by distance
     char* st_base = smem;
     float* tab1 = (float*)(smem + 2 * AT_STAGE_BYTES);
-    const int t1n = (MODE == ATT_CROSS) ? 0 : a.tab1_len;
-    float* tabh = tab1 + ((t1n + 3) & ~3);
-    float* tabv = tabh + 204;
-    double* kcx = (double*)(tabv + 204);
-    double* kcy = kcx + ((MODE == ATT_ENC) ? Sk_pad : 0);
-    unsigned char* kmk = (unsigned char*)(kcy + ((MODE == ATT_ENC) ? Sk_pad : 0));
+    const int t1n = (MODE == ATT_CROSS) ? 0 : (MODE == ATT_ENC ? 32 : a.tab1_len);
+    float* thv = tab1 + ((t1n + 3) & ~3);
+    unsigned char* kmk = (unsigned char*)(thv + (MODE == ATT_ENC ? 1024 : 0));
 
-    for (int i = tid; i < t1n; i += 256) tab1[i] = a.tab1[(size_t)i * a.H + h];
     if (MODE == ATT_ENC) {
-        for (int i = tid; i < 201; i += 256) {
-            tabh[i] = a.tabh[(size_t)i * a.H + h];
-            tabv[i] = a.tabv[(size_t)i * a.H + h];
-        }
-        for (int i = tid; i < Sk_pad; i += 256) {
-            const bool in = i < a.Sk;
-            kcx[i] = in ? a.cx[(size_t)b * a.Sk_cap + i] : 0.0;
-            kcy[i] = in ? a.cy[(size_t)b * a.Sk_cap + i] : 0.0;
-        }
+        for (int i = tid; i < 32; i += 256) tab1[i] = a.tab1[(size_t)i * a.H + h];
+        for (int i = tid; i < 1024; i += 256) thv[i] = a.tabh[(size_t)(i >> 5) * a.H + h] + a.tabv[(size_t)(i & 31) * a.H + h];
+    } else {
+        for (int i = tid; i < t1n; i += 256) tab1[i] = a.tab1[(size_t)i * a.H + h];
+        for (int i = tid; i < Sk_pad; i += 256)
+            kmk[i] = (i < a.Sk) ? (a.kmask ? a.kmask[(size_t)b * a.Sk_cap + i] : 1) : 0;
     }
-    for (int i = tid; i < Sk_pad; i += 256)
-        kmk[i] = (i < a.Sk) ? (a.kmask ? a.kmask[(size_t)b * a.Sk_cap + i] : 1) : 0;
 
     // this wave's 32 queries
     const int q0 = qb * 128 + w * 32;
@@ -66,13 +59,21 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) qf[kt] = ld16((const char*)(Qb + kt * TILE_ELEMS) + lane * 16);
     const int qi = q0 + l32;                 // this lane's query index
-    double qcx = 0.0, qcy = 0.0;
-    if (MODE == ATT_ENC) {
-        const int qc = qi < a.Sk_cap ? qi : a.Sk_cap - 1;
-        qcx = a.cx[(size_t)b * a.Sk_cap + qc];
-        qcy = a.cy[(size_t)b * a.Sk_cap + qc];
-    }
-
+    // ATT_ENC: per-(query, key) bucket indices precomputed once per batch (bias_index_kernel), 16 keys = 32 B per lane
+    // and 32-key tile, in accumulator-register order; prefetched one stage ahead
+    const int qcl = qi < a.Sk_cap ? qi : a.Sk_cap - 1;
+    const uint16_t* bix = (MODE == ATT_ENC)
+        ? a.bidx + ((size_t)b * (size_t)(a.Sk_cap >> 5) * (size_t)a.Sk_cap + (size_t)qcl) * 32 + half * 16 : nullptr;
+    const size_t bix_tile = (size_t)a.Sk_cap * 32;
+    uint4 bcur[4], bnxt[4];
+    auto load_bidx = [&](int st, uint4 (&d)[4]) {
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            const uint16_t* p = bix + (size_t)(st * 2 + t2) * bix_tile;
+            d[t2 * 2] = ld16(p);
+            d[t2 * 2 + 1] = ld16(p + 8);
+        }
+    };
     const uint16_t* Kb = a.K + ((size_t)b * a.H + h) * (size_t)(a.Sk_cap >> 5) * (4 * TILE_ELEMS);
     const uint16_t* Vb = a.Vt + ((size_t)b * a.H + h) * 2 * (size_t)(a.Sk_cap >> 4) * TILE_ELEMS;
     const int krt_max = (a.Sk_cap >> 5) - 1, vkt_max = (a.Sk_cap >> 4) - 1;
@@ -107,10 +108,16 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     float m_run = AT_NEG, l_run = 0.f;
 
     stage(0, 0);
+    if (MODE == ATT_ENC) load_bidx(0, bnxt);
     __syncthreads();
     for (int st = 0; st < nst; ++st) {
         const int cur = st & 1;
         if (st + 1 < nst) stage(cur ^ 1, st + 1);
+        if (MODE == ATT_ENC) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bcur[i] = bnxt[i];
+            if (st + 1 < nst) load_bidx(st + 1, bnxt);
+        }
         const char* kb = st_base + cur * AT_STAGE_BYTES + lane * 16;
         const char* vb = kb + 8 * TILE_BYTES;
         // S^T tiles: rows = keys, cols = queries
@@ -129,20 +136,20 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int key = st * AT_KEYS + t2 * 32 + acc_row(r, half);
                 float v = s[t2][r];
-                bool ok = kmk[key] != 0;
+                bool ok;
                 if (MODE == ATT_ENC) {
-                    int d1 = key - qi;
-                    d1 = d1 < -128 ? -128 : (d1 > 128 ? 128 : d1);
-                    const float fx = (float)(kcx[key] - qcx) * 100.0f;
-                    const float fy = (float)(kcy[key] - qcy) * 100.0f;
-                    int dx = (int)fmaxf(fminf(fx, 100.0f), -100.0f);
-                    int dy = (int)fmaxf(fminf(fy, 100.0f), -100.0f);
-                    v += tab1[d1 + 128] + tabh[dx + 100] + tabv[dy + 100];
+                    const uint4& wq = bcur[t2 * 2 + (r >> 3)];
+                    const uint32_t wd = ((r >> 1) & 3) == 0 ? wq.x : (((r >> 1) & 3) == 1 ? wq.y : (((r >> 1) & 3) == 2 ? wq.z : wq.w));
+                    const uint32_t e = (r & 1) ? (wd >> 16) : (wd & 0xFFFFu);
+                    ok = (e & 0x8000u) == 0;
+                    v += tab1[(e >> 10) & 31] + thv[e & 1023];
                 } else if (MODE == ATT_DEC_SELF) {
                     const int dist = qi - key;
-                    ok = ok && dist >= 0;
+                    ok = kmk[key] != 0 && dist >= 0;
                     const int di = dist < 0 ? 0 : (dist < t1n ? dist : t1n - 1);
                     v += tab1[di];
+                } else {
+                    ok = kmk[key] != 0;
                 }
                 v = ok ? v : AT_NEG;
                 s[t2][r] = v;
@@ -198,11 +205,47 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
 
 static size_t attn_smem(const AttnArgs& a) {
     const int Sk_pad = (a.Sk + AT_KEYS - 1) / AT_KEYS * AT_KEYS;
-    const int t1n = (a.mode == ATT_CROSS) ? 0 : a.tab1_len;
-    size_t sz = 2 * AT_STAGE_BYTES + (size_t)(((t1n + 3) & ~3) + 408) * 4;
-    if (a.mode == ATT_ENC) sz += (size_t)Sk_pad * 16;
-    sz += (size_t)Sk_pad + 16;
+    const int t1n = (a.mode == ATT_CROSS) ? 0 : (a.mode == ATT_ENC ? 32 : a.tab1_len);
+    size_t sz = 2 * AT_STAGE_BYTES + (size_t)((t1n + 3) & ~3) * 4;
+    if (a.mode == ATT_ENC) sz += 1024 * 4;
+    else sz += (size_t)Sk_pad + 16;
     return (sz + 15) & ~(size_t)15;
+}
+
+// Per-(image, query, key) bias bucket indices of the encoder, once per batch (the three relative biases are shared
+// by all layers and differ between heads only through the table values, stock:1215,1234-1235):
+//   entry = masked << 15 | bucket1d(key - query) << 10 | bucketH << 5 | bucketV          (stock:904-1009 semantics:
+//   box centres in float64, difference -> fp32, *100, truncation; 1-D distance in the combined sequence).
+// Layout [image][key tile of 32][query][32] with the 32 keys of a tile in MFMA accumulator order
+// (entry half*16 + r <-> key (r%4) + 8*(r/4) + 4*half), so a lane of the attention kernel reads its 16 keys as 32 B.
+__global__ __launch_bounds__(256) void bias_index_kernel(uint16_t* out, const double* cx, const double* cy, const uint8_t* kmask,
+                                                    const int* bk1, const int* bkhv, int B, int Sk, int S_cap) {
+    const size_t total = (size_t)B * (size_t)(S_cap >> 5) * (size_t)S_cap * 32;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int e = (int)(i & 31);
+        size_t rest = i >> 5;
+        const int q = (int)(rest % (size_t)S_cap);
+        rest /= (size_t)S_cap;
+        const int kt = (int)(rest % (size_t)(S_cap >> 5)), b = (int)(rest / (size_t)(S_cap >> 5));
+        const int r = e & 15, half = e >> 4;
+        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        uint32_t v = 0x8000u;
+        if (key < Sk && (kmask == nullptr || kmask[(size_t)b * S_cap + key] != 0)) {
+            int d1 = key - q;
+            d1 = d1 < -128 ? -128 : (d1 > 128 ? 128 : d1);
+            const double qx = cx[(size_t)b * S_cap + q], qy = cy[(size_t)b * S_cap + q];
+            const float fx = (float)(cx[(size_t)b * S_cap + key] - qx) * 100.0f;
+            const float fy = (float)(cy[(size_t)b * S_cap + key] - qy) * 100.0f;
+            const int dx = (int)fmaxf(fminf(fx, 100.0f), -100.0f);
+            const int dy = (int)fmaxf(fminf(fy, 100.0f), -100.0f);
+            v = ((uint32_t)bk1[d1 + 128] << 10) | ((uint32_t)bkhv[dx + 100] << 5) | (uint32_t)bkhv[dy + 100];
+        }
+        out[i] = (uint16_t)v;
+    }
+}
+void bias_index(uint16_t* out, const double* cx, const double* cy, const uint8_t* kmask, const int* bk1, const int* bkhv, int B,
+                int Sk, int S_cap, mgStream_t stream) {
+    MG_LAUNCH(bias_index_kernel, dim3(4096), dim3(256), 0, stream, out, cx, cy, kmask, bk1, bkhv, B, Sk, S_cap);
 }
 
 void attention(const AttnArgs& a, mgStream_t stream) {

@@ -133,14 +133,17 @@ struct AttnArgs {
     int B, H, Sq, Sk, Sq_cap, Sk_cap;
     int mode;
     const uint8_t* kmask;   // [B][Sk_cap] 1 = attended (nullable = all Sk attended)
-    // ATT_ENC bias: tab1[clamp(j-i)+128][H], tabh/tabv[trunc((c_j-c_i)*100)+100][H]
-    const float* tab1;      // [257][H]  (ENC)  or [Tmax][H] indexed by i-j >= 0 (DEC_SELF)
-    const float* tabh;      // [201][H]
-    const float* tabv;      // [201][H]
-    const double* cx;       // [B][Sk_cap]
-    const double* cy;
+    // ATT_ENC: tab1/tabh/tabv = RAW bucket tables [32][H] (1-D, horizontal, vertical) and bidx = per-(image, query, key)
+    //          bucket indices from bias_index();  ATT_DEC_SELF: tab1 = [tab1_len][H] indexed by distance i-j >= 0
+    const float* tab1;
+    const float* tabh;
+    const float* tabv;
+    const uint16_t* bidx;   // [B][Sk_cap/32][Sk_cap][32]
     int tab1_len;
 };
+// bucket indices of the encoder's relative biases, once per batch (see k_attn.hip)
+void bias_index(uint16_t* out, const double* cx, const double* cy, const uint8_t* kmask, const int* bk1, const int* bkhv, int B,
+                int Sk, int S_cap, mgStream_t stream);
 void attention(const AttnArgs& a, mgStream_t stream);
 
 // ---------------------------------------------------------------------------------------------

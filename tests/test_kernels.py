@@ -236,9 +236,12 @@ def test_attention_encoder_bias(be_name, S, S_cap):
             ref[b, h] = softmax_ref(sc) @ v[b, h, :S]
     Q, K, V = be.buf(pack_heads_rows(q)), be.buf(pack_heads_rows(k)), be.buf(pack_heads_t(v))
     ctx = be.zeros((B * S_cap * H * 64,), np.uint16)
+    bk1 = rpb(torch.arange(-128, 129), True, 32, 128).numpy().astype(np.int32)
+    bkhv = rpb(torch.arange(-100, 101), True, 32, 100).numpy().astype(np.int32)
+    bidx = be.zeros((B * S_cap * S_cap,), np.uint16)
     rc = be.lib.mgk_attention(be.stream, 0, be.p(Q), be.p(K), be.p(V), be.p(ctx), B, H, S, S, S_cap, S_cap,
-                              be.p(be.buf(mask)), be.p(be.buf(t1)), 257, be.p(be.buf(th)), be.p(be.buf(tv)),
-                              be.p(be.buf(cx)), be.p(be.buf(cy)))
+                              be.p(be.buf(mask)), be.p(be.buf(w1)), 32, be.p(be.buf(wh)), be.p(be.buf(wv)),
+                              be.p(be.buf(cx)), be.p(be.buf(cy)), be.p(be.buf(bk1)), be.p(be.buf(bkhv)), be.p(bidx))
     assert rc == 0
     got = pk.unpack_tiles(ctx.numpy(), B * S_cap, H * 64).reshape(B, S_cap, H, 64).transpose(0, 2, 1, 3)[:, :, :S]
     np.testing.assert_allclose(got, ref, rtol=0, atol=2e-2)
@@ -267,7 +270,7 @@ def test_attention_decoder_self_and_cross(be_name):
     Q, K, V = be.buf(pack_heads_rows(q)), be.buf(pack_heads_rows(k)), be.buf(pack_heads_t(v))
     ctx = be.zeros((B * T_cap * H * 64,), np.uint16)
     assert be.lib.mgk_attention(be.stream, 1, be.p(Q), be.p(K), be.p(V), be.p(ctx), B, H, T, T, T_cap, T_cap,
-                                be.p(be.buf(dmask)), be.p(be.buf(tab)), 64, None, None, None, None) == 0
+                                be.p(be.buf(dmask)), be.p(be.buf(tab)), 64, None, None, None, None, None, None, None) == 0
     got = pk.unpack_tiles(ctx.numpy(), B * T_cap, H * 64).reshape(B, T_cap, H, 64).transpose(0, 2, 1, 3)[:, :, :T]
     valid = np.ones((B, T), bool)
     valid[1, 30:] = True   # rows whose every key is masked still see key 0..i with dmask -> compare all defined rows
@@ -287,7 +290,7 @@ def test_attention_decoder_self_and_cross(be_name):
     KX, VX = be.buf(pack_heads_rows(kx)), be.buf(pack_heads_t(vx))
     ctx2 = be.zeros((B * T_cap * H * 64,), np.uint16)
     assert be.lib.mgk_attention(be.stream, 2, be.p(Q), be.p(KX), be.p(VX), be.p(ctx2), B, H, T, Sk, T_cap, Sk_cap,
-                                be.p(be.buf(xm)), None, 0, None, None, None, None) == 0
+                                be.p(be.buf(xm)), None, 0, None, None, None, None, None, None, None) == 0
     got2 = pk.unpack_tiles(ctx2.numpy(), B * T_cap, H * 64).reshape(B, T_cap, H, 64).transpose(0, 2, 1, 3)[:, :, :T]
     np.testing.assert_allclose(got2, refx, rtol=0, atol=2e-2)
 
