@@ -105,7 +105,11 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     }
 
     f32x16 o[2] = {acc_zero(), acc_zero()};
-    float m_run = AT_NEG, l_run = 0.f;
+    // row sums of the bf16 P tile come from the matrix pipe too (A = all-ones fragment): every register of `lsum`
+    // holds sum_keys P[key][query of this lane]; only register 0 is maintained across rescales
+    f32x16 lsum = acc_zero();
+    const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
+    float m_run = AT_NEG;
 
     stage(0, 0);
     if (MODE == ATT_ENC) load_bidx(0, bnxt);
@@ -160,33 +164,41 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
         const float m_new = fmaxf(m_run, mloc);
         const float alpha = fast_exp(m_run - m_new);
         m_run = m_new;
-        // P^T = exp(S^T - m), rounded to bf16; the row sum uses the ROUNDED values so that O/l is a convex combination
-        float psum = 0.f;
+        // P^T = exp(S^T - m), rounded to bf16; the row sum is taken over the ROUNDED values (ones-MFMA) so that O/l is a
+        // convex combination
         uint4 pch[4];
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
             f32x16 p;
 #pragma unroll
             for (int r = 0; r < 16; ++r) p[r] = fast_exp(s[t2][r] - m_new);
-            const PackedAcc pa = acc_pack(p);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) psum += (bf16lo(pa.p[g][0]) + bf16hi(pa.p[g][0])) + (bf16lo(pa.p[g][1]) + bf16hi(pa.p[g][1]));
-            packed_to_chunks(pa, half, &pch[2 * t2]);
+            acc_to_chunks(p, half, &pch[2 * t2]);
         }
-        psum += __shfl_xor(psum, 32);
-        l_run = l_run * alpha + psum;
+        // rescale only when some query of the wave raised its running max (rare after the first stages)
+#ifdef MG_EMU
+        const bool rescale = true;
+#else
+        const bool rescale = __any(alpha != 1.0f);
+#endif
+        if (rescale) {
+            lsum[0] *= alpha;
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
+            for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        }
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) o[dt] = mfma32(ld16(vb + (dt * 4 + kk) * TILE_BYTES), pch[kk], o[dt]);
+        for (int kk = 0; kk < 4; ++kk) {
+            const uint4 v0 = ld16(vb + (0 * 4 + kk) * TILE_BYTES), v1 = ld16(vb + (1 * 4 + kk) * TILE_BYTES);
+            o[0] = mfma32(v0, pch[kk], o[0]);
+            o[1] = mfma32(v1, pch[kk], o[1]);
+            lsum = mfma32(ones, pch[kk], lsum);
         }
         __syncthreads();
     }
 
     // O^T / l -> packed context rows [b*Sq_cap + q][h*64 + dim]
-    const float inv = 1.0f / l_run;
+    const float inv = 1.0f / lsum[0];
     const int HD = a.H * 64;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) {

@@ -85,7 +85,14 @@ MG_DEV uint16_t f32_to_bf16(float f) {
     return (uint16_t)(u >> 16);
 }
 MG_DEV uint32_t pack_bf16(float lo, float hi) {
+#ifdef MG_EMU
     return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+#else
+    // lowers to ONE v_cvt_pk_bf16_f32 (round-to-nearest-even), schedulable by the compiler unlike inline asm
+    typedef float mg_f32x2 __attribute__((ext_vector_type(2)));
+    const mg_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, mg_bf16x2));
+#endif
 }
 
 MG_DEV f32x16 acc_zero() {
