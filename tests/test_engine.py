@@ -154,3 +154,83 @@ def test_beam_search_random_weights_scores(be_name):
     assert ids.shape == g["beam_ids"].shape and np.all(ids[:, 0] == 0)
     # near-tied random-weight beams may swap, but the best score found must be as good as stock's within tolerance
     np.testing.assert_allclose(scores, g["beam_scores"], atol=5e-2)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# larger shapes (GPU only: the emulator is for index checks on tiny shapes)
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_mid_fixture_g1_on_gpu():
+    g = load_golden("g1_mid.npz")
+    shape, sd = _weights(g)
+    inp = _inputs(g, shape)
+    eng = make_engine("hip", shape, sd)
+    enc, mask = eng.encode(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"])
+    valid = g["enc_mask"].astype(bool)
+    err = np.abs(_np(eng, enc) - g["enc_out"])[valid]
+    assert err.max() < ENC_MAX and err.mean() < ENC_MEAN, (err.max(), err.mean())
+    from oracle.udop_oracle import Oracle
+    labels = g["labels"]
+    dec_ids = Oracle.shift_right(labels, shape.decoder_start_token_id, shape.pad_token_id).numpy()
+    logits, _, _ = eng.forward_logits(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"], dec_ids,
+                                      (labels != -100).astype(np.uint8))
+    assert np.abs(_np(eng, logits) - g["logits"]).max() < logit_tol(g["logits"])
+    ids, _, _ = eng.generate(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"], num_beams=1,
+                             max_length=int(g["max_length"]))
+    ids = _np(eng, ids)
+    for b in range(ids.shape[0]):
+        for t in range(1, ids.shape[1]):
+            if g["greedy_margin"][b, t - 1] < 4 * logit_tol(g["greedy_step_logits"]):
+                break
+            assert ids[b, t] == g["greedy_ids"][b, t]
+
+
+@pytest.mark.gpu
+def test_large_shape_fixture_g2_on_gpu():
+    """UDOP-large shape (the benchmark's model), B=1, L=64: encoder probe rows and checksums, the first 8 greedy steps'
+    top-8 logits, ids under the margin rule — against values minted from stock UDOP (tools/make_golden.py g2)."""
+    g = load_golden("g2_large.npz")
+    shape = synth.SHAPES["large"]
+    sd = synth.recipe_state_dict(shape, gain=float(g["gain"]))
+    inp = synth.synth_batch(shape, 1, seed=int(g["synth_seed"]), fixed_L=int(g["fixed_L"]))
+    eng = make_engine("hip", shape, sd, max_decode_len=64)
+    enc, mask = eng.encode(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"])
+    enc, mask = _np(eng, enc)[0], _np(eng, mask)[0]
+    assert np.array_equal(mask, g["enc_mask"][0].astype(np.uint8))
+    err = np.abs(enc[g["enc_rows"]] - g["enc_probe"])
+    assert err.max() < ENC_MAX and err.mean() < ENC_MEAN, (err.max(), err.mean())
+    valid = mask.astype(bool)
+    s_abs = np.abs(enc[valid]).astype(np.float64).sum()
+    assert abs(s_abs - float(g["enc_abs_sum"])) / float(g["enc_abs_sum"]) < 2e-3      # checksum over all valid rows
+    ids, _, top2 = eng.generate(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"], num_beams=1,
+                                max_length=9, return_top2=True)
+    ids, t2 = _np(eng, ids)[0], _np(eng, top2)
+    vals, idx = g["step_top_vals"], g["step_top_idx"]          # [8 steps][8]
+    tol = 0.015 * float(np.abs(vals).max()) + 0.02
+    for t in range(1, 9):
+        assert abs(t2[t, 0, 0] - vals[t - 1, 0]) < tol, (t, t2[t, 0, 0], vals[t - 1, 0])
+        if vals[t - 1, 0] - vals[t - 1, 1] < 4 * tol:
+            break
+        assert ids[t] == g["greedy_ids"][0, t]
+
+
+@pytest.mark.gpu
+def test_batch_independence_and_determinism_large():
+    """Size-independent properties at the benchmark's model shape: an image's encoder output and greedy ids do not depend
+    on what else is in the batch (same padded length), and two runs are bit-identical (deterministic reductions)."""
+    shape = synth.SHAPES["large"]
+    sd = synth.recipe_state_dict(shape, gain=1.0)
+    eng = make_engine("hip", shape, sd, max_decode_len=64)
+    inp = synth.synth_batch(shape, 4, L_min=40, L_max=90, seed=5)
+    enc4, _ = eng.encode(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"])
+    enc4 = _np(eng, enc4).copy()
+    ids4, _, _ = eng.generate(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"], max_length=12, min_length=12)
+    ids4 = _np(eng, ids4).copy()
+    ids4b, _, _ = eng.generate(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"], max_length=12, min_length=12)
+    assert np.array_equal(ids4, _np(eng, ids4b))
+    for b in (0, 3):
+        one = {k: v[b:b + 1] for k, v in inp.items()}
+        enc1, _ = eng.encode(one["input_ids"], one["bbox"], one["attention_mask"], one["pixel_values"])
+        assert np.array_equal(_np(eng, enc1)[0], enc4[b])
+        ids1, _, _ = eng.generate(one["input_ids"], one["bbox"], one["attention_mask"], one["pixel_values"], max_length=12, min_length=12)
+        assert np.array_equal(_np(eng, ids1)[0], ids4[b])
