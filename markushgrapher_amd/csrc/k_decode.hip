@@ -88,8 +88,8 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a) {
             kc = kc < nkeys ? kc : nkeys - 1;
             const int prow = a.anc ? a.anc[(size_t)kc * a.rows + owner] : owner;
             const size_t off = (((size_t)prow * a.H + h) * (size_t)a.cap + (size_t)kc) * 64 + sub * 8;
-            kv[u] = ld16(a.Kc + off);
-            vv[u] = ld16(a.Vc + off);
+            kv[u] = (NW >= 8) ? ld16_stream(a.Kc + off) : ld16(a.Kc + off);
+            vv[u] = (NW >= 8) ? ld16_stream(a.Vc + off) : ld16(a.Vc + off);
         }
     };
     uint4 kn[U], vn[U];

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_rows_kernel(GemmArgs a) {
     for (; kt + U <= k1; kt += U) {
         uint4 wf[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) wf[u] = wvalid ? ld16(wp + (size_t)(kt + u) * TILE_BYTES) : zero4;
+        for (int u = 0; u < U; ++u) wf[u] = wvalid ? ld16_stream(wp + (size_t)(kt + u) * TILE_BYTES) : zero4;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_rows_kernel(GemmArgs a) {
         }
     }
     for (; kt < k1; ++kt) {
-        const uint4 wf = wvalid ? ld16(wp + (size_t)kt * TILE_BYTES) : zero4;
+        const uint4 wf = wvalid ? ld16_stream(wp + (size_t)kt * TILE_BYTES) : zero4;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const uint4 xf = ld16(xp + ((size_t)i * kt16 + kt) * TILE_BYTES);
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256) void gemm_rows_splitk_kernel(const uint16_t* X
     for (; kt + U <= k1; kt += U) {
         uint4 wf[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) wf[u] = ld16(wp + (size_t)(kt + u) * TILE_BYTES);
+        for (int u = 0; u < U; ++u) wf[u] = ld16_stream(wp + (size_t)(kt + u) * TILE_BYTES);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void gemm_rows_splitk_kernel(const uint16_t* X
         }
     }
     for (; kt < k1; ++kt) {
-        const uint4 wf = ld16(wp + (size_t)kt * TILE_BYTES);
+        const uint4 wf = ld16_stream(wp + (size_t)kt * TILE_BYTES);
 #pragma unroll
         for (int i = 0; i < MT; ++i) acc[i] = mfma32(ld16(xp + ((size_t)i * kt16 + kt) * TILE_BYTES), wf, acc[i]);
     }
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_rows_resid_kernel(const uint16_t
     for (; kt + U <= k1; kt += U) {
         uint4 wf[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) wf[u] = wvalid ? ld16(wp + (size_t)(kt + u) * TILE_BYTES) : zero4;
+        for (int u = 0; u < U; ++u) wf[u] = wvalid ? ld16_stream(wp + (size_t)(kt + u) * TILE_BYTES) : zero4;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_rows_resid_kernel(const uint16_t
         }
     }
     for (; kt < k1; ++kt) {
-        const uint4 wf = wvalid ? ld16(wp + (size_t)kt * TILE_BYTES) : zero4;
+        const uint4 wf = wvalid ? ld16_stream(wp + (size_t)kt * TILE_BYTES) : zero4;
 #pragma unroll
         for (int i = 0; i < MT; ++i) acc[i] = mfma32(wf, ld16(xp + ((size_t)i * kt16 + kt) * TILE_BYTES), acc[i]);
     }

@@ -129,6 +129,16 @@ MG_DEV void glds16(const void* gsrc_lane, void* lds_wave_base) {
 }
 
 MG_DEV uint4 ld16(const void* p) { return *(const uint4*)p; }
+// streamed-once data (decode K/V, decode weights): non-temporal load, does not displace reusable lines
+MG_DEV uint4 ld16_stream(const void* p) {
+#ifdef MG_EMU
+    return *(const uint4*)p;
+#else
+    typedef unsigned int mg_u32x4 __attribute__((ext_vector_type(4)));
+    const mg_u32x4 v = __builtin_nontemporal_load((const mg_u32x4*)p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+#endif
+}
 MG_DEV void st16(void* p, const uint4& v) { *(uint4*)p = v; }
 
 // two packed bf16 pairs dotted into an fp32 accumulator

@@ -111,3 +111,24 @@ if __name__ == "__main__":
         bench_attn()
     if "norm" in what:
         bench_norm()
+
+
+def bench_reorder():
+    """configs[2]: KV-cache beam reorder. Physical index_select copy (reference behaviour) vs the ancestor-table form."""
+    layers, B, K, H, cap = 24, 32, 5, 16, 512
+    rows = B * K
+    for t in (32, 128):
+        src = torch.randint(-3000, 3000, (layers, 2, rows, H, cap, 64), dtype=torch.int16, device=dev)
+        dst = torch.empty_like(src)
+        idx = (torch.arange(rows, device=dev, dtype=torch.int32) // K) * K + torch.randint(0, K, (rows,), device=dev, dtype=torch.int32)
+
+        def f(i):
+            lib.mg_beam_reorder(stream(), P(src), P(dst), P(idx), layers, rows, H, cap, t)
+        us = timeit(f, iters=20, warm=3)
+        nbytes = layers * 2 * rows * H * t * 64 * 2 * 2
+        print(f"beam_reorder physical t={t:4d}: {us:9.1f} us  {nbytes / us / 1e3:7.1f} GB/s (read+write {nbytes / 1e6:.0f} MB); "
+              f"ancestor table moves {t * rows * 4 / 1e3:.0f} KB instead")
+
+
+if "reorder" in sys.argv[1:]:
+    bench_reorder()
