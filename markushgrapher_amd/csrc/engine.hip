@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void fill_ids_kernel(int64_t* next_ids, int64_
     if (threadIdx.x == 0) {
         next_ids[r] = start;
         unfinished[r] = 1;
-        if (r == 0) { counters[0] = rows; counters[1] = -1; counters[2] = 0; counters[3] = 0; }
+        if (r == 0) { counters[0] = rows; counters[1] = -1; counters[2] = 0; }   // [3] keeps the encoder's input-error count
     }
 }
 // counters: [0] n_unfinished, [1] done_step (first step after which every row had finished), [2] step, [3] input errors

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void beam_init_kernel(BeamPtrs p, int B, int K
     }
     if (tid == 0) {
         p.heur[b] = 1;
-        if (b == 0) { counters[0] = 1; counters[1] = -1; counters[2] = 0; counters[3] = 0; counters[4] = 0; }
+        if (b == 0) { counters[0] = 1; counters[1] = -1; counters[2] = 0; counters[4] = 0; }
     }
 }
 void beam_init(void* state, int B, int K, int max_len, int pad, int eos, int start, int64_t* next_ids, int* anc, int T_cap,

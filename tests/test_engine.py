@@ -234,3 +234,109 @@ def test_batch_independence_and_determinism_large():
         assert np.array_equal(_np(eng, enc1)[0], enc4[b])
         ids1, _, _ = eng.generate(one["input_ids"], one["bbox"], one["attention_mask"], one["pixel_values"], max_length=12, min_length=12)
         assert np.array_equal(_np(eng, ids1)[0], ids4[b])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# edge cases: shortest / longest inputs, single image, fully padded rows, maximum decode length
+# ---------------------------------------------------------------------------------------------------------
+def _oracle_ids(shape, sd, inp, max_length, beams=1):
+    from oracle.udop_oracle import Oracle
+    o = Oracle(shape, sd)
+    if beams == 1:
+        return o.greedy(inp["input_ids"], inp["bbox"], inp["pixel_values"], inp["attention_mask"], max_length=max_length)
+    return o.beam_search(inp["input_ids"], inp["bbox"], inp["pixel_values"], inp["attention_mask"], num_beams=beams,
+                         max_length=max_length)[0]
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+def test_edge_single_token_single_image(be_name):
+    """B=1, L=1 (one text token, box 0): shortest possible input; ids must equal the oracle's (trained weights)."""
+    g = load_golden("g3_trained_tiny.npz")
+    shape, sd = _weights(g)
+    inp = {"input_ids": np.array([[7]], np.int64), "bbox": np.zeros((1, 1, 4), np.float32),
+           "attention_mask": np.ones((1, 1), np.int64), "pixel_values": g["pixel_values"][:1]}
+    eng = make_engine(be_name, shape, sd)
+    ids, _, _ = eng.generate(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"], max_length=10)
+    ref = _oracle_ids(shape, sd, inp, 10)
+    enc, mask = eng.encode(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"])
+    from oracle.udop_oracle import Oracle
+    eo, mo = Oracle(shape, sd).encode(inp["input_ids"], inp["bbox"], inp["pixel_values"], inp["attention_mask"])
+    assert np.array_equal(_np(eng, mask), mo.numpy().astype(np.uint8))
+    assert np.abs(_np(eng, enc) - eo.numpy())[mo.numpy().astype(bool)].max() < ENC_MAX
+    assert _np(eng, ids).shape[1] == ref.shape[1]
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+def test_edge_fully_padded_row_and_ragged_batch(be_name):
+    """A ragged batch in which one row is ALL padding (mask 0 everywhere in the text part): the row still attends its
+    image patches; other rows are unaffected (compare with the oracle row by row)."""
+    g = load_golden("g3_trained_tiny.npz")
+    shape, sd = _weights(g)
+    inp = {k: g[k][:3].copy() for k in ("input_ids", "bbox", "attention_mask", "pixel_values")}
+    inp["input_ids"][1] = 0
+    inp["bbox"][1] = 0
+    inp["attention_mask"][1] = 0
+    eng = make_engine(be_name, shape, sd)
+    enc, mask = eng.encode(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"])
+    from oracle.udop_oracle import Oracle
+    eo, mo = Oracle(shape, sd).encode(inp["input_ids"], inp["bbox"], inp["pixel_values"], inp["attention_mask"])
+    assert np.array_equal(_np(eng, mask), mo.numpy().astype(np.uint8))
+    valid = mo.numpy().astype(bool)
+    assert np.abs(_np(eng, enc) - eo.numpy())[valid].max() < ENC_MAX
+    ids, _, _ = eng.generate(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"], max_length=16)
+    ref = _oracle_ids(shape, sd, inp, 16)
+    got = _np(eng, ids)
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[2], ref[2])     # trained rows: bit-exact
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+def test_edge_max_decode_length_and_early_stop(be_name):
+    """max_length = 512 (the reference's setting, ref: utils_evaluation.py:280) on the trained fixture: every row stops at
+    its EOS, the returned width is the longest row, not 512; beam-5 likewise."""
+    g = load_golden("g3_trained_tiny.npz")
+    shape, sd = _weights(g)
+    inp = _inputs(g, shape)
+    eng = make_engine(be_name, shape, sd, max_decode_len=512)
+    ids, _, _ = eng.generate(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"], max_length=512)
+    assert np.array_equal(_np(eng, ids), g["greedy_ids"])
+    if be_name == "hip":
+        bids, _, _ = eng.generate(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"], num_beams=5, max_length=512)
+        ref = _oracle_ids(shape, sd, inp, 512, beams=5)
+        assert np.array_equal(_np(eng, bids), ref)
+
+
+@pytest.mark.gpu
+def test_edge_longest_text_large_shape():
+    """L = 512 text tokens (the reference's max_seq_length, ref: config/predict.yaml:8) -> S = 1536 at the UDOP-large shape:
+    the longest sequence the path is specified for runs and stays finite; masks and compaction are consistent."""
+    shape = synth.SHAPES["large"]
+    sd = synth.recipe_state_dict(shape, gain=1.0)
+    eng = make_engine("hip", shape, sd, max_decode_len=64)
+    inp = synth.synth_batch(shape, 2, seed=3, fixed_L=512)
+    inp["attention_mask"][1, 300:] = 0
+    enc, mask = eng.encode(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"])
+    enc, mask = _np(eng, enc), _np(eng, mask)
+    assert enc.shape == (2, 1536, 1024) and np.isfinite(enc).all()
+    rms = np.sqrt((enc[mask.astype(bool)] ** 2).mean(-1))
+    assert np.all(rms > 0.5) and np.all(rms < 2.5)            # final RMSNorm with gains in [0.75, 1.25]
+    assert mask[1, 300:512].sum() == 0 and mask[0, :512].all()
+    ids, _, _ = eng.generate(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"], max_length=6, min_length=6)
+    ids = _np(eng, ids)
+    assert ids.shape == (2, 6) and ids.min() >= 0 and ids.max() < shape.vocab_size
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+def test_bad_inputs_are_rejected(be_name):
+    from markushgrapher_amd.engine import MgError
+    g = load_golden("g3_trained_tiny.npz")
+    shape, sd = _weights(g)
+    inp = _inputs(g, shape)
+    eng = make_engine(be_name, shape, sd)
+    bad = inp["input_ids"].copy()
+    bad[0, 0] = shape.vocab_size + 5
+    with pytest.raises(MgError, match="token ids"):
+        eng.generate(bad, inp["bbox"], inp["attention_mask"], inp["pixel_values"], max_length=8)
+    with pytest.raises(MgError, match="max_length"):
+        eng.generate(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"], max_length=100000)
+    with pytest.raises(ValueError):
+        eng.generate(inp["input_ids"], inp["bbox"][:, :3], inp["attention_mask"], inp["pixel_values"], max_length=8)
