@@ -139,6 +139,8 @@ int mgk_greedy_select(void* stream, const float* logits, int rows, int V, int ld
 int mgk_gemm_splitk(void* stream, const void* X_pk, const void* W_pk, float* P, int M, int N, int K, int ldp,
                     size_t slab_stride, int KS);
 int mgk_splitk_factor(int N, int K);
+/* A/B switch of the large-M GEMM kernel (0: 128x128 two-stage, 1: 256x128 three-stage, default) */
+int mgk_gemm_set_variant(int v);
 /* decode-step residual projection with the next RMSNorm folded in: h += X W^T (optionally scaled per row by the deferred
  * statistic rs_*), x_pk = bf16(h*gain*gscale) un-normalised, part[m][N/8] = per-block sums of h^2 */
 int mgk_gemm_resid(void* stream, const void* X_pk, const void* W_pk, float* h, const float* gain, float gscale, void* x_pk,

@@ -114,6 +114,7 @@ int mgk_gemm_splitk(void* stream, const void* X_pk, const void* W_pk, float* P, 
     return MG_OK;
 }
 int mgk_splitk_factor(int N, int K) { return splitk_factor(N, K); }
+int mgk_gemm_set_variant(int v) { gemm_set_variant(v); return MG_OK; }
 
 int mgk_gemm_resid(void* stream, const void* X_pk, const void* W_pk, float* h, const float* gain, float gscale, void* x_pk,
                    float* part, int M, int N, int K, const float* rs_part, int rs_nparts, float rs_inv_d, float rs_eps) {

@@ -228,7 +228,134 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs a) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// large-M GEMM, wide form: 256x128x64 block tile, 8 waves (4x2, 64x64 per wave), THREE LDS stages of 48 KiB filled by
+// global_load_lds with a prefetch distance of two K-steps.  One raw s_barrier per K-step and a COUNTED vmcnt: the
+// copies of the next stage stay in flight across the barrier (PMC on the 2-stage kernel: 58 % of wave cycles parked
+// at the barrier's vmcnt(0)).  Fragment-order LDS image => every ds_read_b128 is base + 16*lane, conflict-free.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int GW_M = 256, GW_N = 128, GW_K = 64;
+constexpr int GW_FRAGS = (GW_M + GW_N) / 32 * (GW_K / 16);      // 48 fragments per stage
+constexpr int GW_STAGE_BYTES = GW_FRAGS * TILE_BYTES;           // 48 KiB
+constexpr int GW_STAGES = 3;
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_wide_kernel(GemmArgs a) {
+    MG_DYN_SMEM(smem);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nbn = (a.N + GW_N - 1) / GW_N;
+    const int nbm = (a.M + GW_M - 1) / GW_M;
+    int bid = blockIdx.x;
+    const int nblk = nbm * nbn;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);   // XCD-contiguous tile ranges (speed only)
+    const int bm = bid / nbn, bn = bid - bm * nbn;
+    const int mt32 = (a.M + 31) >> 5, nt32 = (a.N + 31) >> 5;
+    const int nks = a.K / GW_K;
+
+    // loader: wave w copies fragments 6w .. 6w+5 of a stage; fragments 0..31 = X (row-tile f/4, k-tile f%4), 32..47 = W
+    const char* src[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int f = w * 6 + i;
+        const bool isW = f >= 32;
+        const int ff = isW ? f - 32 : f, rt = ff >> 2, kt = ff & 3;
+        int trow = isW ? (bn * 4 + rt) : (bm * 8 + rt);
+        const int tmax = isW ? nt32 - 1 : mt32 - 1;
+        trow = trow < tmax ? trow : tmax;
+        src[i] = (const char*)((isW ? a.W : a.X) + pk_tile_off(trow, kt, a.K)) + lane * 16;
+    }
+    auto stage = [&](int buf, int ks) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            glds16_async(src[i] + (size_t)ks * (4 * TILE_BYTES), smem + buf * GW_STAGE_BYTES + (w * 6 + i) * TILE_BYTES);
+    };
+
+    const int wr = w >> 1, wc = w & 1;
+    const int m0w = bm * GW_M + wr * 64, n0w = bn * GW_N + wc * 64;
+    bool tor;
+    if (EPI == EPI_F32_STORE || EPI == EPI_F32_RESID) tor = false;
+    else if (EPI == EPI_HEADS) tor = !heads_region_is_T(a.heads, n0w < a.N ? n0w : 0);
+    else tor = true;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = acc_zero();
+
+    stage(0, 0);
+    if (nks > 1) stage(1, 1);
+    int cur = 0;
+    for (int ks = 0; ks < nks; ++ks) {
+        // own copies of stage ks have landed (those of stage ks+1 may still be in flight) ...
+        if (ks + 1 < nks) MG_WAIT_VMCNT(6); else MG_WAIT_VMCNT(0);
+        // ... and after the barrier everybody's have, and everybody is done reading the buffer refilled below
+        MG_BARRIER_RAW();
+        if (ks + 2 < nks) { int nb = cur + 2; nb = nb >= GW_STAGES ? nb - GW_STAGES : nb; stage(nb, ks + 2); }
+        const char* xb = smem + cur * GW_STAGE_BYTES + lane * 16;
+        const char* wb = xb + 32 * TILE_BYTES;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            uint4 xf[2], wf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                xf[i] = ld16(xb + ((wr * 2 + i) * 4 + kt) * TILE_BYTES);
+                wf[i] = ld16(wb + ((wc * 2 + i) * 4 + kt) * TILE_BYTES);
+            }
+            if (tor) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(wf[j], xf[i], acc[i][j]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(xf[i], wf[j], acc[i][j]);
+            }
+        }
+        cur = cur + 1 >= GW_STAGES ? 0 : cur + 1;
+    }
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m0 = m0w + 32 * i, n0 = n0w + 32 * j;
+            if constexpr (EPI == EPI_F32_STORE || EPI == EPI_F32_RESID) {
+                tile_epilogue<EPI, false>(a, acc[i][j], m0, n0, lane);
+            } else if constexpr (EPI == EPI_HEADS) {
+                if (tor) tile_epilogue<EPI_HEADS, true>(a, acc[i][j], m0, n0, lane);
+                else tile_epilogue<EPI_HEADS, false>(a, acc[i][j], m0, n0, lane);
+            } else {
+                tile_epilogue<EPI, true>(a, acc[i][j], m0, n0, lane);
+            }
+        }
+}
+
+template <int EPI>
+static void launch_wide(const GemmArgs& a, mgStream_t stream) {
+    const int nblk = ((a.M + GW_M - 1) / GW_M) * ((a.N + GW_N - 1) / GW_N);
+    const size_t sh = (size_t)GW_STAGES * GW_STAGE_BYTES;
+    static bool once = false;
+    if (!once) { MG_SET_MAX_SMEM(&gemm_wide_kernel<EPI>, sh); once = true; }
+    MG_LAUNCH((gemm_wide_kernel<EPI>), dim3(nblk), dim3(512), sh, stream, a);
+}
+
+static int g_gemm_variant = 1;     // 0: 128x128 two-stage kernel, 1: 256x128 three-stage kernel for M >= 256
+void gemm_set_variant(int v) { g_gemm_variant = v; }
+
 void gemm(const GemmArgs& a, int epi, mgStream_t stream) {
+    if (g_gemm_variant == 1 && a.M >= GW_M) {
+        switch (epi) {
+            case EPI_F32_STORE: launch_wide<EPI_F32_STORE>(a, stream); break;
+            case EPI_F32_RESID: launch_wide<EPI_F32_RESID>(a, stream); break;
+            case EPI_PK_RELU: launch_wide<EPI_PK_RELU>(a, stream); break;
+            case EPI_PK: launch_wide<EPI_PK>(a, stream); break;
+            default: launch_wide<EPI_HEADS>(a, stream); break;
+        }
+        return;
+    }
     const int nblk = ((a.M + GB_M - 1) / GB_M) * ((a.N + GB_N - 1) / GB_N);
     const dim3 grid(nblk), block(256);
     const size_t sh = 2 * GB_STAGE_BYTES;

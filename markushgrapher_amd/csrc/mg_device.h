@@ -55,6 +55,20 @@ static inline float mg_event_elapsed_ms(mgEvent_t a, mgEvent_t b) { float ms = 0
 static inline void mg_event_destroy(mgEvent_t e) { (void)hipEventDestroy(e); }
 #endif
 
+// raw workgroup barrier / counted vector-memory wait: let direct global->LDS copies stay in flight ACROSS a barrier
+// (a __syncthreads() would drain them with vmcnt(0)); see cdna_hip_programming.md "Pipelining across barriers".
+#ifdef MG_EMU
+#define MG_BARRIER_RAW() __syncthreads()
+#define MG_WAIT_VMCNT(N) ((void)0)
+#define MG_WAIT_LGKM0() ((void)0)
+#define MG_SET_MAX_SMEM(kern, bytes) ((void)0)
+#else
+#define MG_BARRIER_RAW() __builtin_amdgcn_s_barrier()
+#define MG_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+#define MG_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define MG_SET_MAX_SMEM(kern, bytes) (void)hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))
+#endif
+
 #define MG_DEV __device__ __forceinline__
 #define MG_HD __host__ __device__ __forceinline__
 
@@ -125,6 +139,22 @@ MG_DEV void glds16(const void* gsrc_lane, void* lds_wave_base) {
 #else
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+#endif
+}
+
+// Same copy, but issued from inline asm so that hipcc does not know about it: the compiler treats a builtin
+// global_load_lds as a pending LDS write and inserts s_waitcnt vmcnt(0) before the next ds_read, which would drain a
+// multi-stage pipeline every K-step.  The caller orders it by hand: MG_WAIT_VMCNT(N) then MG_BARRIER_RAW() before any
+// wave reads the destination (cdna_hip_programming.md §5.7 "LDS-DMA recipe"; M0 is saved/restored in the statement).
+MG_DEV void glds16_async(const void* gsrc_lane, void* lds_wave_base) {
+#ifdef MG_EMU
+    emu::glds16(gsrc_lane, lds_wave_base);
+#else
+    const unsigned dst = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_wave_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc_lane), "s"(dst) : "memory");
 #endif
 }
 

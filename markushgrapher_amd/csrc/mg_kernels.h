@@ -55,6 +55,7 @@ struct GemmArgs {
     RowScale rs;           // decode-step kernels only
 };
 void gemm(const GemmArgs& a, int epi, mgStream_t stream);
+void gemm_set_variant(int v);   // 0: 128x128 two-stage tile kernel only; 1 (default): 256x128 three-stage kernel for M >= 256
 
 // small-M (decode step) GEMM: M <= 32*MT rows of live sequences, weights streamed once.
 void gemm_rows(const GemmArgs& a, int epi, mgStream_t stream);

@@ -41,7 +41,7 @@ def test_pack_weight(be_name):
 
 @pytest.mark.parametrize("be_name", BACKENDS)
 @pytest.mark.parametrize("mode,M,N,K", [(0, 160, 200, 128), (0, 128, 128, 64), (1, 32, 96, 256), (1, 20, 40, 64),
-                                        (1, 70, 64, 128)])
+                                        (1, 70, 64, 128), (0, 300, 200, 192), (0, 512, 128, 64), (0, 288, 136, 320)])
 def test_gemm_f32(be_name, mode, M, N, K):
     be = get_backend(be_name)
     x, w = rnd((M, K), 2), rnd((N, K), 3)
@@ -60,7 +60,7 @@ def test_gemm_f32(be_name, mode, M, N, K):
 
 
 @pytest.mark.parametrize("be_name", BACKENDS)
-@pytest.mark.parametrize("mode,M,N,K", [(0, 160, 192, 128), (1, 32, 128, 128), (1, 45, 64, 64)])
+@pytest.mark.parametrize("mode,M,N,K", [(0, 160, 192, 128), (1, 32, 128, 128), (1, 45, 64, 64), (0, 320, 256, 192)])
 def test_gemm_packed_relu(be_name, mode, M, N, K):
     be = get_backend(be_name)
     x, w = rnd((M, K), 6), rnd((N, K), 7)
@@ -74,10 +74,11 @@ def test_gemm_packed_relu(be_name, mode, M, N, K):
 
 
 @pytest.mark.parametrize("be_name", BACKENDS)
-def test_gemm_heads_flash_layout(be_name):
+@pytest.mark.parametrize("Bn", [2, 5])      # M = 128 -> 128x128 kernel, M = 320 -> 256x128 three-stage kernel
+def test_gemm_heads_flash_layout(be_name, Bn):
     """QKV projection of the encoder: Q,K packed rows, V packed transposed, per (b,h)."""
     be = get_backend(be_name)
-    B, S, H, K = 2, 64, 2, 64
+    B, S, H, K = Bn, 64, 2, 64
     inner = H * 64
     M, N = B * S, 3 * inner
     x, w = rnd((M, K), 8), rnd((N, K), 9, 0.2)
