@@ -32,17 +32,17 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     const int Sk_pad = (a.Sk + AT_KEYS - 1) / AT_KEYS * AT_KEYS;
 
     // LDS carve: [2 stages][tables][key mask bytes (decoder modes)]
-    //   ATT_ENC:      t1[32] = 1-D table of head h, thv[1024] = horizontal[bh] + vertical[bv] of head h
+    //   ATT_ENC:      t1[32], th[32], tv[32] = the three bucket tables of head h
     //   ATT_DEC_SELF: tab1[tab1_len] = causal T5 table of head h by distance
     char* st_base = smem;
     float* tab1 = (float*)(smem + 2 * AT_STAGE_BYTES);
     const int t1n = (MODE == ATT_CROSS) ? 0 : (MODE == ATT_ENC ? 32 : a.tab1_len);
-    float* thv = tab1 + ((t1n + 3) & ~3);
-    unsigned char* kmk = (unsigned char*)(thv + (MODE == ATT_ENC ? 1024 : 0));
+    float* thv = tab1 + ((t1n + 3) & ~3);      // ATT_ENC: th[32] | tv[32] (32-entry tables: one entry per LDS bank, no conflicts)
+    unsigned char* kmk = (unsigned char*)(thv + (MODE == ATT_ENC ? 64 : 0));
 
     if (MODE == ATT_ENC) {
         for (int i = tid; i < 32; i += 256) tab1[i] = a.tab1[(size_t)i * a.H + h];
-        for (int i = tid; i < 1024; i += 256) thv[i] = a.tabh[(size_t)(i >> 5) * a.H + h] + a.tabv[(size_t)(i & 31) * a.H + h];
+        for (int i = tid; i < 64; i += 256) thv[i] = i < 32 ? a.tabh[(size_t)i * a.H + h] : a.tabv[(size_t)(i - 32) * a.H + h];
     } else {
         for (int i = tid; i < t1n; i += 256) tab1[i] = a.tab1[(size_t)i * a.H + h];
         for (int i = tid; i < Sk_pad; i += 256)
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
                     const uint32_t wd = ((r >> 1) & 3) == 0 ? wq.x : (((r >> 1) & 3) == 1 ? wq.y : (((r >> 1) & 3) == 2 ? wq.z : wq.w));
                     const uint32_t e = (r & 1) ? (wd >> 16) : (wd & 0xFFFFu);
                     ok = (e & 0x8000u) == 0;
-                    v += tab1[(e >> 10) & 31] + thv[e & 1023];
+                    v += (tab1[(e >> 10) & 31] + thv[(e >> 5) & 31]) + thv[32 + (e & 31)];
                 } else if (MODE == ATT_DEC_SELF) {
                     const int dist = qi - key;
                     ok = kmk[key] != 0 && dist >= 0;
@@ -219,7 +219,7 @@ static size_t attn_smem(const AttnArgs& a) {
     const int Sk_pad = (a.Sk + AT_KEYS - 1) / AT_KEYS * AT_KEYS;
     const int t1n = (a.mode == ATT_CROSS) ? 0 : (a.mode == ATT_ENC ? 32 : a.tab1_len);
     size_t sz = 2 * AT_STAGE_BYTES + (size_t)((t1n + 3) & ~3) * 4;
-    if (a.mode == ATT_ENC) sz += 1024 * 4;
+    if (a.mode == ATT_ENC) sz += 64 * 4;
     else sz += (size_t)Sk_pad + 16;
     return (sz + 15) & ~(size_t)15;
 }
