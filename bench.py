@@ -3,9 +3,9 @@
 
 One "step" = one pass of the hot path over one batch of 32 synthetic pages per GPU: VTL encoder + cross-K/V
 projection + 256 greedy decode steps (EOS suppressed: min_length = max_length = 257) on the
-UDOP-large-shaped MarkushGrapher-2 model with recipe (random-init, bf16-exact) weights.  Inputs (pixel_values at the
-model's 512 px input resolution, produced from the 1024 px synthetic crops; token ids; boxes; masks) are resident in
-HBM when the timed region starts.  With --gpus N, every rank runs its own 32-image shard (weak scaling) and the
+UDOP-large-shaped MarkushGrapher-2 model with recipe (random-init, bf16-exact) weights.  Inputs (the 1024x1024 u8 RGB
+crops, token ids, boxes, masks) are resident in HBM when the timed region starts; the step includes the device-side
+LANCZOS resize to the model's 512 px input + normalisation (mg_preprocess_pages).  With --gpus N, every rank runs its own 32-image shard (weak scaling) and the
 decoded token ids are all-gathered over RCCL inside the timed region.
 
     python bench.py [--gpus N --steps K --warmup W]
@@ -96,14 +96,17 @@ def main():
     eng = Engine(shape, max_decode_len=max(512, max_length))
     eng.load_state_dict(sd)
     # each rank gets its own shard of the global batch (independent images, no data-path exchange)
-    inp = synth.synth_batch(shape, B, seed=20260928 + rank)
+    inp = synth.synth_batch(shape, B, seed=20260928 + rank, return_pages=True)
     dev = {k: eng.mem.asarray(v, {"input_ids": np.int64, "bbox": np.float32, "attention_mask": np.uint8,
-                                  "pixel_values": np.float32}[k]) for k, v in inp.items()}
+                                  "pixel_values": np.float32, "pages_u8": np.uint8}[k]) for k, v in inp.items()}
     L = inp["input_ids"].shape[1]
     gathered = torch.empty((world * B, max_length), dtype=torch.int64, device="cuda") if world > 1 else None
 
     def step():
-        ids, _, _ = eng.generate(dev["input_ids"], dev["bbox"], dev["attention_mask"], dev["pixel_values"],
+        # the 1024 px u8 crops are what is resident in HBM: LANCZOS resize to the 512 px model input + normalisation run
+        # on the device inside the step (bit-exact with the reference's Pillow preprocessing)
+        pix = eng.preprocess(dev["pages_u8"])
+        ids, _, _ = eng.generate(dev["input_ids"], dev["bbox"], dev["attention_mask"], pix,
                                  num_beams=args.beams, max_length=max_length, min_length=max_length)
         if world > 1:
             dist.all_gather_into_tensor(gathered, ids.contiguous())
@@ -158,7 +161,7 @@ def main():
             "metric": METRIC, "value": round(world * B * args.steps / dt, 3), "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "configs[1]: batch 32/GPU synthetic 1024x1024 crops -> 512px model input, greedy "
+            "config": {"workload": "configs[1]: batch 32/GPU synthetic 1024x1024 u8 crops -> device LANCZOS 512px model input, greedy "
                                    f"decode, {new_tokens} forced new tokens (EOS suppressed), UDOP-large-shaped "
                                    "MarkushGrapher-2 VTL encoder + CXSMILES decoder, recipe weights",
                        "shape": args.shape, "batch_per_gpu": B, "text_len_padded": int(L), "new_tokens": new_tokens,

@@ -104,6 +104,15 @@ int mg_profile_cross_attention(mg_model* m, int every, int max_samples);
 int mg_profile_read(mg_model* m, long* launches_host, double* total_ms_host, double* total_keys_host);
 int mg_debug_bucket_table(const mg_model* m, int which, int* out_host, int n);
 
+/* Page preprocessing on the device ("next" row f-3): replaces page_image.resize((512,512), Image.LANCZOS)
+ * (/root/reference/markushgrapher/core/datasets/mdu_dataset.py:118) + MarkushgrapherImageProcessor's rescale 1/255 and
+ * mean = std = 0.5 normalisation (/root/reference/markushgrapher/core/common/begin.py:105-109), bit-exactly (Pillow's
+ * 8-bit fixed-point resampler).  pages_u8 [B][Hs][Ws][3] (RGB, HWC) -> pixel_values [B][3][out][out] f32.
+ * scratch: mg_preprocess_scratch_bytes() of device memory. */
+size_t mg_preprocess_scratch_bytes(int B, int Hs, int Ws, int out_size);
+int mg_preprocess_pages(void* stream, const uint8_t* pages_u8, int B, int Hs, int Ws, int out_size, float* pixel_values,
+                        void* scratch, size_t scratch_bytes);
+
 /* Device self-test of the hardware assumptions the kernels rely on (MFMA fragment layout, global_load_lds
  * destination rule, cross-half shuffle). Synchronises. msg_host receives a short report. */
 int mg_selftest(void* stream, void* scratch_256k, char* msg_host, int msg_len);

@@ -139,4 +139,17 @@ int mgk_relu_pack(void* stream, const float* P, int KS, int ldp, size_t slab_str
     return MG_OK;
 }
 
+size_t mg_preprocess_scratch_bytes(int B, int Hs, int Ws, int out_size) {
+    if (B < 1 || Hs < 1 || Ws < 1 || out_size < 1) return 0;
+    return preprocess_scratch_bytes(B, Hs, Ws, out_size);
+}
+
+int mg_preprocess_pages(void* stream, const uint8_t* pages_u8, int B, int Hs, int Ws, int out_size, float* pixel_values,
+                        void* scratch, size_t scratch_bytes) {
+    if (!pages_u8 || !pixel_values || !scratch || B < 1 || Hs < 1 || Ws < 1 || out_size < 1) return MG_E_ARG;
+    if (scratch_bytes < preprocess_scratch_bytes(B, Hs, Ws, out_size)) return MG_E_WORKSPACE;
+    preprocess_pages(pages_u8, B, Hs, Ws, out_size, pixel_values, scratch, (mgStream_t)stream);
+    return MG_OK;
+}
+
 }  // extern "C"

@@ -206,6 +206,10 @@ void beam_reorder_anc(int* anc, int* anc_tmp, const int* beam_idx, int rows, int
 void beam_reorder_copy(const uint16_t* src, uint16_t* dst, const int* beam_idx, int nlk, int rows, int H, int t_cap, int t_used,
                        mgStream_t stream);
 
+// page preprocessing (k_prep.hip): u8 [B][Hs][Ws][3] -> f32 [B][3][out][out], Pillow-LANCZOS + 1/255 + (x-0.5)/0.5
+size_t preprocess_scratch_bytes(int B, int Hs, int Ws, int out_size);
+void preprocess_pages(const uint8_t* pages, int B, int Hs, int Ws, int out_size, float* pixel_values, void* scratch, mgStream_t stream);
+
 int selftest_device(char* msg, int msg_len, mgStream_t stream);
 
 }  // namespace mg

@@ -167,6 +167,28 @@ class Engine:
             self._ws_bytes = need.value
         return self._ws, self._ws_bytes
 
+    def preprocess(self, pages_u8):
+        """u8 pages [B][Hs][Ws][3] (RGB) -> pixel_values [B][3][I][I] f32 on the device: Pillow-LANCZOS resize to the
+        model's input size + 1/255 + (x-0.5)/0.5, bit-exact with the reference's host preprocessing
+        (ref: core/datasets/mdu_dataset.py:118, core/common/begin.py:105-109)."""
+        L = self.lib
+        L.mg_preprocess_scratch_bytes.restype = C.c_size_t
+        L.mg_preprocess_scratch_bytes.argtypes = [C.c_int] * 4
+        L.mg_preprocess_pages.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+        pg = self.mem.asarray(pages_u8, np.uint8)
+        B, Hs, Ws, ch = [int(v) for v in pg.shape]
+        if ch != self.shape.num_channels:
+            raise ValueError("pages must be [B, H, W, 3] uint8")
+        I = self.shape.image_size
+        nb = int(L.mg_preprocess_scratch_bytes(B, Hs, Ws, I))
+        if getattr(self, "_prep_bytes", 0) < nb:
+            self._prep = self.mem.empty((nb,), np.uint8)
+            self._prep_bytes = nb
+        out = self.mem.empty((B, ch, I, I), np.float32)
+        self._chk(L.mg_preprocess_pages(self.mem.stream(), self.mem.ptr(pg), B, Hs, Ws, I, self.mem.ptr(out),
+                                        self.mem.ptr(self._prep), self._prep_bytes))
+        return out
+
     def _inputs(self, input_ids, bbox, attention_mask, pixel_values):
         ids = self.mem.asarray(input_ids, np.int64)
         bb = self.mem.asarray(bbox, np.float32)

@@ -259,7 +259,7 @@ def pages_to_pixel_values(pages_u8: np.ndarray, image_size: int) -> np.ndarray:
 
 
 def synth_batch(s: ModelShape, B: int, L_min: int = 32, L_max: int = 256, seed: int = 20260928,
-                page_px: Optional[int] = None, fixed_L: Optional[int] = None):
+                page_px: Optional[int] = None, fixed_L: Optional[int] = None, return_pages: bool = False):
     """Batch of model inputs in the reference's contract:
     input_ids [B,L] i64, bbox [B,L,4] f32 in [0,1], attention_mask [B,L] i64, pixel_values [B,3,I,I] f32.
     Text: 12 question tokens with box 0, one sep with box 1, OCR sub-words with word boxes, one sep with
@@ -296,4 +296,7 @@ def synth_batch(s: ModelShape, B: int, L_min: int = 32, L_max: int = 256, seed: 
     px = page_px if page_px is not None else 2 * s.image_size
     pages = synth_pages_u8(B, px, seed)
     pixel_values = pages_to_pixel_values(pages, s.image_size)
-    return {"input_ids": ids, "bbox": bbox, "attention_mask": mask, "pixel_values": pixel_values}
+    out = {"input_ids": ids, "bbox": bbox, "attention_mask": mask, "pixel_values": pixel_values}
+    if return_pages:
+        out["pages_u8"] = pages
+    return out
