@@ -40,7 +40,7 @@ struct mg_model {
     int d, H, inner, dff, V, P, n_side, Kpatch, M2, T_cap;
     char* arena = nullptr;
     size_t arena_bytes = 0;
-    size_t tok_emb, lm_head, patch_w, patch_b, x_emb, y_emb, rb_raw[3], rb_dec_raw, tab1, tabh, tabv, dec_tab;
+    size_t tok_emb, lm_head, patch_w, patch_b, x_emb, y_emb, rb_raw[3], rb_dec_raw, dec_tab;
     size_t bk1, bkhv, bkdec, enc_ln, dec_ln;
     std::vector<EncLayer> enc;
     std::vector<DecLayer> dec;
@@ -148,7 +148,7 @@ struct Ws {
     float *dh, *logits, *slabs, *rs_part;
     size_t slab_stride;
     int64_t* next_ids;
-    int *unfinished, *anc, *anc_tmp, *beam_idx;
+    int *unfinished, *anc, *beam_idx;
     void* beam_state;
     // teacher-forced decoder
     int64_t* tf_ids;
@@ -219,7 +219,6 @@ void carve(const mg_model* m, char* base, int B, int L, int K, int max_len, int 
         w->next_ids = c.take<int64_t>(Rp);
         w->unfinished = c.take<int>(Rp);
         w->anc = c.take<int>((size_t)m->T_cap * R);
-        w->anc_tmp = c.take<int>((size_t)m->T_cap * R);
         w->beam_idx = c.take<int>(Rp);
         w->beam_state = c.take<char>(K > 1 ? beam_state_bytes(B, K, max_len) : 16);
     }
@@ -307,9 +306,6 @@ int mg_create(const mg_config* cfg, mg_model** out) {
     const int nb = c.relative_attention_num_buckets;
     for (int i = 0; i < 3; ++i) m->rb_raw[i] = take((size_t)nb * H * 4);
     m->rb_dec_raw = take((size_t)nb * H * 4);
-    m->tab1 = take((size_t)257 * H * 4);
-    m->tabh = take((size_t)201 * H * 4);
-    m->tabv = take((size_t)201 * H * 4);
     m->dec_tab = take((size_t)m->T_cap * H * 4);
     m->bk1 = take(257 * 4); m->bkhv = take(201 * 4); m->bkdec = take((size_t)m->T_cap * 4);
     m->enc_ln = take((size_t)d * 4); m->dec_ln = take((size_t)d * 4);
@@ -511,9 +507,6 @@ int mg_finalize(mg_model* m, void* stream) {
     mg_memcpy_async(m->at<int>(m->bk1), m->h_bk1.data(), 257 * 4, st);
     mg_memcpy_async(m->at<int>(m->bkhv), m->h_bkhv.data(), 201 * 4, st);
     mg_memcpy_async(m->at<int>(m->bkdec), m->h_bkdec.data(), (size_t)m->T_cap * 4, st);
-    MG_LAUNCH(build_table_kernel, dim3(8), dim3(256), 0, st, (const float*)m->at<float>(m->rb_raw[0]), (const int*)m->at<int>(m->bk1), m->at<float>(m->tab1), 257, H);
-    MG_LAUNCH(build_table_kernel, dim3(8), dim3(256), 0, st, (const float*)m->at<float>(m->rb_raw[1]), (const int*)m->at<int>(m->bkhv), m->at<float>(m->tabh), 201, H);
-    MG_LAUNCH(build_table_kernel, dim3(8), dim3(256), 0, st, (const float*)m->at<float>(m->rb_raw[2]), (const int*)m->at<int>(m->bkhv), m->at<float>(m->tabv), 201, H);
     MG_LAUNCH(build_table_kernel, dim3(8), dim3(256), 0, st, (const float*)m->at<float>(m->rb_dec_raw), (const int*)m->at<int>(m->bkdec), m->at<float>(m->dec_tab), m->T_cap, H);
     mg_stream_sync(st);    // the host tables above must outlive the copies
     const int rc = check_launch("mg_finalize");
@@ -731,7 +724,7 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
         } else {
             beam_step(w.beam_state, w.logits, ldl, m->V, B, K, max_length, t + 1, m->c.eos_token_id, min_length, length_penalty,
                       early_stopping, w.next_ids, w.beam_idx, counters, st);
-            beam_reorder_anc(w.anc, w.anc_tmp, w.beam_idx, R, t + 1, T_cap, counters, st);
+            beam_reorder_anc(w.anc, w.beam_idx, R, t + 1, counters, st);
         }
         MG_LAUNCH(step_end_kernel, dim3(1), dim3(64), 0, st, counters);
         steps_done = t + 1;

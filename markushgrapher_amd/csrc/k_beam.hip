@@ -359,9 +359,7 @@ __global__ __launch_bounds__(256) void beam_reorder_anc_kernel(int* anc, const i
     n = 0;
     for (int r = threadIdx.x; r < rows; r += 256) anc[(size_t)j * rows + r] = v[n++];
 }
-void beam_reorder_anc(int* anc, int* anc_tmp, const int* beam_idx, int rows, int t_written, int T_cap, const int* counters,
-                      mgStream_t stream) {
-    (void)anc_tmp; (void)T_cap;
+void beam_reorder_anc(int* anc, const int* beam_idx, int rows, int t_written, const int* counters, mgStream_t stream) {
     MG_LAUNCH(beam_reorder_anc_kernel, dim3(t_written), dim3(256), 0, stream, anc, beam_idx, rows, counters);
 }
 

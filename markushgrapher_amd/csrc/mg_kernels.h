@@ -200,8 +200,7 @@ void beam_step(void* state, const float* logits, int ldl, int V, int B, int K, i
                float length_penalty, int early_stopping, int64_t* next_ids, int* beam_idx, int* counters, mgStream_t stream);
 void beam_finalize(void* state, int B, int K, int max_len, int64_t* out_ids, int* out_cols, float* out_scores, mgStream_t stream);
 // ancestor-table form of the KV-cache reorder (cache_utils.py:100-104): anc[j][row] <- anc[j][beam_idx[row]], j < t_written
-void beam_reorder_anc(int* anc, int* anc_tmp, const int* beam_idx, int rows, int t_written, int T_cap, const int* counters,
-                      mgStream_t stream);
+void beam_reorder_anc(int* anc, const int* beam_idx, int rows, int t_written, const int* counters, mgStream_t stream);
 // physical form: dst[lk][row] = src[lk][beam_idx[row]] for nlk = layers*2 K/V planes of [rows][H][t_cap][64] bf16
 void beam_reorder_copy(const uint16_t* src, uint16_t* dst, const int* beam_idx, int nlk, int rows, int H, int t_cap, int t_used,
                        mgStream_t stream);
@@ -210,6 +209,5 @@ void beam_reorder_copy(const uint16_t* src, uint16_t* dst, const int* beam_idx, 
 size_t preprocess_scratch_bytes(int B, int Hs, int Ws, int out_size);
 void preprocess_pages(const uint8_t* pages, int B, int Hs, int Ws, int out_size, float* pixel_values, void* scratch, mgStream_t stream);
 
-int selftest_device(char* msg, int msg_len, mgStream_t stream);
 
 }  // namespace mg
