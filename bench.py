@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--beams", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-every", type=int, default=16)
+    ap.add_argument("--decode-graph", type=int, default=1, help="1: replay the captured decode-step HIP graph; 0: eager launches")
     args = ap.parse_args()
 
     import torch
@@ -95,6 +96,7 @@ def main():
     t_weights = time.time() - t0
     eng = Engine(shape, max_decode_len=max(512, max_length))
     eng.load_state_dict(sd)
+    eng.set_decode_graph(args.decode_graph)
     # each rank gets its own shard of the global batch (independent images, no data-path exchange)
     inp = synth.synth_batch(shape, B, seed=20260928 + rank, return_pages=True)
     dev = {k: eng.mem.asarray(v, {"input_ids": np.int64, "bbox": np.float32, "attention_mask": np.uint8,
@@ -165,7 +167,7 @@ def main():
                                    f"decode, {new_tokens} forced new tokens (EOS suppressed), UDOP-large-shaped "
                                    "MarkushGrapher-2 VTL encoder + CXSMILES decoder, recipe weights",
                        "shape": args.shape, "batch_per_gpu": B, "text_len_padded": int(L), "new_tokens": new_tokens,
-                       "num_beams": args.beams, "parallelism": f"dp{world} (independent image shards, one RCCL all-gather of token ids)"},
+                       "num_beams": args.beams, "decode_graph": args.decode_graph, "parallelism": f"dp{world} (independent image shards, one RCCL all-gather of token ids)"},
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:

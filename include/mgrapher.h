@@ -104,6 +104,16 @@ int mg_profile_cross_attention(mg_model* m, int every, int max_samples);
 int mg_profile_read(mg_model* m, long* launches_host, double* total_ms_host, double* total_keys_host);
 int mg_debug_bucket_table(const mg_model* m, int which, int* out_host, int n);
 
+/* Decode-step replay. The ~200 launches of one decode step (the body of the reference's generation loop,
+ * transformers generation/utils.py `_sample` / `_beam_search` while-loop) are captured once as a HIP graph whose
+ * kernels read the step index from device memory; later steps - and later calls with the same buffers and
+ * generation arguments - replay it with one hipGraphLaunch. enable = 0 launches every kernel eagerly (same kernels,
+ * same results); enable = 2 launches the graph's device-counter form of the kernels eagerly (test hook). Default: 1.
+ * Returns the previous setting. */
+int mg_set_decode_graph(mg_model* m, int enable);
+/* 1 if the last mg_generate replayed a captured graph, 0 if it launched eagerly (mode 0/2, capture unavailable). */
+int mg_decode_graph_active(const mg_model* m);
+
 /* Page preprocessing on the device ("next" row f-3): replaces page_image.resize((512,512), Image.LANCZOS)
  * (/root/reference/markushgrapher/core/datasets/mdu_dataset.py:118) + MarkushgrapherImageProcessor's rescale 1/255 and
  * mean = std = 0.5 normalisation (/root/reference/markushgrapher/core/common/begin.py:105-109), bit-exactly (Pillow's

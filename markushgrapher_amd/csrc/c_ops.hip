@@ -102,6 +102,7 @@ int mgk_greedy_select(void* stream, const float* logits, int rows, int V, int ld
     a.logits = logits; a.rows = rows; a.V = V; a.ldl = ldl; a.eos = eos; a.pad = pad; a.min_len = min_len;
     a.next_ids = next_ids; a.out_ids = out_ids; a.max_len = max_len; a.pos = pos; a.unfinished = unfinished;
     a.n_unfinished = n_unfinished; a.top2 = top2;
+    mg_memset_async(n_unfinished, 0, sizeof(int), (mgStream_t)stream);   // the kernel accumulates
     greedy_select(a, (mgStream_t)stream);
     return MG_OK;
 }

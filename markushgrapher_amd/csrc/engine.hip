@@ -35,6 +35,29 @@ struct DecLayer { size_t wqkv, wo, ln0, xq, xkv, xo, ln1, wi, wo2, ln2; };
 
 }  // namespace
 
+// A captured decode step.  Every step-dependent value (cache position, key count, output column) is read from the
+// device step counter, so one executable graph serves all steps of a call — and later calls with the same buffers.
+struct StepGraph {
+    struct Key {
+        const void *ws, *out_ids, *top2, *stream;
+        int B, L, K, max_length, min_length, early_stopping;
+        float length_penalty;
+        bool operator==(const Key& o) const {
+            return ws == o.ws && out_ids == o.out_ids && top2 == o.top2 && stream == o.stream && B == o.B && L == o.L && K == o.K &&
+                   max_length == o.max_length && min_length == o.min_length && early_stopping == o.early_stopping &&
+                   length_penalty == o.length_penalty;
+        }
+    };
+    Key key{};
+    bool valid = false;
+#ifndef MG_EMU
+    hipGraphExec_t exec = nullptr;
+    void reset() { if (exec) (void)hipGraphExecDestroy(exec); exec = nullptr; valid = false; }
+#else
+    void reset() { valid = false; }
+#endif
+};
+
 struct mg_model {
     mg_config c;
     int d, H, inner, dff, V, P, n_side, Kpatch, M2, T_cap;
@@ -57,6 +80,22 @@ struct mg_model {
     double prof_ms = 0.0;
     long prof_n = 0;
     double prof_keys = 0.0;   // sum over timed launches of the number of (image, key) pairs streamed
+    // one decode step captured as a HIP graph (greedy and beam); replayed while its key matches the call
+    StepGraph step_graph;
+    std::vector<float> beam_div_host;
+    int use_graph = 1;
+    bool graph_active = false;
+#ifndef MG_EMU
+    hipStream_t own_stream = nullptr;
+    hipEvent_t fork_ev = nullptr;
+#endif
+    ~mg_model() {
+        step_graph.reset();
+#ifndef MG_EMU
+        if (own_stream) (void)hipStreamDestroy(own_stream);
+        if (fork_ev) (void)hipEventDestroy(fork_ev);
+#endif
+    }
 
     template <typename T> T* at(size_t off) const { return (T*)(arena + off); }
 };
@@ -98,12 +137,14 @@ __global__ __launch_bounds__(256) void fill_ids_kernel(int64_t* next_ids, int64_
     if (threadIdx.x == 0) {
         next_ids[r] = start;
         unfinished[r] = 1;
-        if (r == 0) { counters[0] = rows; counters[1] = -1; counters[2] = 0; }   // [3] keeps the encoder's input-error count
+        if (r == 0) { counters[0] = rows; counters[1] = -1; counters[2] = 0; counters[5] = 0; }   // [3] keeps the encoder's input-error count
     }
 }
-// counters: [0] n_unfinished, [1] done_step (first step after which every row had finished), [2] step, [3] input errors
-__global__ void step_end_kernel(int* counters) {
+// counters: [0] n_unfinished, [1] done_step (first step after which every row had finished), [2] step, [3] input errors,
+// [4] beam output columns, [5] greedy: unfinished rows counted by this step's selection (published to [0] here)
+__global__ void step_end_kernel(int* counters, int greedy) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (greedy) { counters[0] = counters[5]; counters[5] = 0; }
         if (counters[0] == 0 && counters[1] < 0) counters[1] = counters[2];
         counters[2] += 1;
     }
@@ -149,6 +190,7 @@ struct Ws {
     size_t slab_stride;
     int64_t* next_ids;
     int *unfinished, *anc, *beam_idx;
+    float* beam_div;          // [T_cap + 1] length-penalty divisor per cur_len
     void* beam_state;
     // teacher-forced decoder
     int64_t* tf_ids;
@@ -220,6 +262,7 @@ void carve(const mg_model* m, char* base, int B, int L, int K, int max_len, int 
         w->unfinished = c.take<int>(Rp);
         w->anc = c.take<int>((size_t)m->T_cap * R);
         w->beam_idx = c.take<int>(Rp);
+        w->beam_div = c.take<float>((size_t)m->T_cap + 1);
         w->beam_state = c.take<char>(K > 1 ? beam_state_bytes(B, K, max_len) : 16);
     }
     if (T > 0) {
@@ -658,10 +701,25 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
     }
     int* counters = w.counters;
     const int64_t start = m->c.decoder_start_token_id, pad = m->c.pad_token_id;
+#ifndef MG_EMU
+    // The legacy null stream cannot be captured: the decode phase then runs on a stream the model owns, ordered after
+    // the caller's stream by an event (the call ends with a host synchronisation of that stream, which orders it
+    // before anything the caller enqueues later).
+    if (m->use_graph == 1 && st == nullptr) {
+        if (!m->own_stream && hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking) != hipSuccess) m->own_stream = nullptr;
+        if (!m->fork_ev && hipEventCreateWithFlags(&m->fork_ev, hipEventDisableTiming) != hipSuccess) m->fork_ev = nullptr;
+        if (m->own_stream && m->fork_ev && hipEventRecord(m->fork_ev, st) == hipSuccess &&
+            hipStreamWaitEvent(m->own_stream, m->fork_ev, 0) == hipSuccess)
+            st = m->own_stream;
+    }
+#endif
     if (K == 1) {
         MG_LAUNCH(fill_ids_kernel, dim3(R), dim3(64), 0, st, w.next_ids, out_ids, w.unfinished, counters, R, max_length, start, pad);
     } else {
         beam_init(w.beam_state, B, K, max_length, (int)pad, m->c.eos_token_id, (int)start, w.next_ids, w.anc, T_cap, counters, st);
+        m->beam_div_host.resize((size_t)max_length + 1);
+        for (int c = 0; c <= max_length; ++c) m->beam_div_host[c] = beam_length_divisor(c, length_penalty);
+        mg_memcpy_async(w.beam_div, m->beam_div_host.data(), m->beam_div_host.size() * sizeof(float), st);
     }
     int steps_done = 0;
     int host_flag[4] = {0, 0, 0, 0};
@@ -674,7 +732,9 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
     auto slabs = [&](int KS, int ldp) { Slabs sl; sl.P = w.slabs; sl.KS = KS; sl.ldp = ldp; sl.stride = w.slab_stride; return sl; };
     RowScale none{};
     RowScale rsd{w.rs_part, d / 8, 1.0f / (float)d, eps};
-    for (int t = 0; t + 1 < max_length; ++t) {
+    // One decode step.  tdev == nullptr: step-dependent values are passed by value (eager launches); otherwise the
+    // kernels read the step from the device counter, which makes the launch sequence capturable as a graph.
+    auto decode_step = [&](int t, const int* tdev) {
         embed_rows(w.next_ids, m->at<uint16_t>(m->tok_emb), w.dh, R, d, m->V, counters + 3, st);
         rmsnorm_pack(w.dh, m->at<float>(m->dec[0].ln0), w.dx_pk, nullptr, R, d, eps, 1.0f, st);
         for (size_t li = 0; li < nl; ++li) {
@@ -684,13 +744,13 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
             {
                 GemmArgs a = gemm_args(w.dx_pk, m->at<uint16_t>(l.wqkv), R, 3 * inner, d);
                 set_heads(a, H, R, T_cap, w.dq, HF_STEP_Q, sk, HF_STEP_KV, sv, HF_STEP_KV);
-                a.heads.pos = t;
+                a.heads.pos = t; a.heads.pos_dev = tdev;
                 a.rs = li == 0 ? none : rsd;      // layer 0 reads the explicitly normalised embedding
                 gemm_rows(a, EPI_HEADS, st);      // q -> dq, k/v appended to the cache at position t
             }
             AttnStepArgs s{};
             s.q = w.dq; s.Kc = sk; s.Vc = sv; s.ctx = w.dctx_pk; s.rows = R; s.H = H; s.group = 1; s.cap = T_cap;
-            s.n_keys = t + 1; s.bias = m->at<float>(m->dec_tab); s.anc = K > 1 ? w.anc : nullptr; s.t = t;
+            s.n_keys = t + 1; s.bias = m->at<float>(m->dec_tab); s.anc = K > 1 ? w.anc : nullptr; s.t = t; s.t_dev = tdev;
             attention_step(s, st);
             gemm_rows_resid(w.dctx_pk, m->at<uint16_t>(l.wo), w.dh, m->at<float>(l.ln1), 1.0f, w.dx_pk, w.rs_part, R, d, inner, none, st);
             // cross-attention over the image's compacted K/V stream (all beams of an image share one pass)
@@ -698,7 +758,7 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
             AttnStepArgs x{};
             x.Kc = w.xk + li * xkv_stride; x.Vc = w.xv + li * xkv_stride; x.ctx = w.dctx_pk; x.rows = R; x.H = H;
             x.group = K; x.cap = S_cap; x.len = w.xlen; x.qkv = slabs(ks_xq, inner); x.self_append = 0;
-            const bool timed = m->prof_every > 0 && (t % m->prof_every) == 0 && m->prof_used + 2 <= m->prof_ev.size();
+            const bool timed = !tdev && m->prof_every > 0 && (t % m->prof_every) == 0 && m->prof_used + 2 <= m->prof_ev.size();
             if (timed) mg_event_record(m->prof_ev[m->prof_used], st);
             attention_step(x, st);
             if (timed) { mg_event_record(m->prof_ev[m->prof_used + 1], st); m->prof_used += 2; }
@@ -718,15 +778,56 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
         if (K == 1) {
             ArgmaxArgs g{};
             g.logits = w.logits; g.rows = R; g.V = m->V; g.ldl = ldl; g.eos = m->c.eos_token_id; g.pad = (int)pad;
-            g.min_len = min_length; g.next_ids = w.next_ids; g.out_ids = out_ids; g.max_len = max_length; g.pos = t + 1;
-            g.unfinished = w.unfinished; g.n_unfinished = counters; g.top2 = step_top2 ? step_top2 + (size_t)(t + 1) * R * 2 : nullptr;
+            g.min_len = min_length; g.next_ids = w.next_ids; g.out_ids = out_ids; g.max_len = max_length;
+            g.pos = tdev ? 1 : t + 1; g.pos_dev = tdev;
+            g.unfinished = w.unfinished; g.n_unfinished = counters + 5;
+            g.top2 = step_top2 ? (tdev ? step_top2 : step_top2 + (size_t)(t + 1) * R * 2) : nullptr;
             greedy_select(g, st);
         } else {
-            beam_step(w.beam_state, w.logits, ldl, m->V, B, K, max_length, t + 1, m->c.eos_token_id, min_length, length_penalty,
-                      early_stopping, w.next_ids, w.beam_idx, counters, st);
-            beam_reorder_anc(w.anc, w.beam_idx, R, t + 1, counters, st);
+            beam_step(w.beam_state, w.logits, ldl, m->V, B, K, max_length, t + 1, tdev, w.beam_div, m->c.eos_token_id, min_length,
+                      length_penalty, early_stopping, w.next_ids, w.beam_idx, counters, st);
+            beam_reorder_anc(w.anc, w.beam_idx, R, tdev ? max_length - 1 : t + 1, tdev, counters, st);
         }
-        MG_LAUNCH(step_end_kernel, dim3(1), dim3(64), 0, st, counters);
+        MG_LAUNCH(step_end_kernel, dim3(1), dim3(64), 0, st, counters, K == 1 ? 1 : 0);
+    };
+    bool graphed = false;
+#ifndef MG_EMU
+    if (m->use_graph == 1) {
+        const StepGraph::Key key{ws, out_ids, step_top2, (const void*)st, B, L, K, max_length, min_length, early_stopping, length_penalty};
+        StepGraph& sg = m->step_graph;
+        if (!(sg.valid && sg.key == key)) {
+            sg.reset();
+            hipGraph_t graph = nullptr;
+            hipError_t e1 = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal), e2 = hipSuccess, e3 = hipSuccess;
+            if (e1 == hipSuccess) {
+                decode_step(0, counters + 2);
+                e2 = hipStreamEndCapture(st, &graph);
+                if (e2 == hipSuccess && graph) {
+                    e3 = hipGraphInstantiate(&sg.exec, graph, nullptr, nullptr, 0);
+                    if (e3 == hipSuccess) { sg.key = key; sg.valid = true; }
+                }
+                if (graph) (void)hipGraphDestroy(graph);
+            }
+            if (!sg.valid && getenv("MG_DEBUG"))
+                fprintf(stderr, "mg_generate: decode-step capture failed (begin %s, end %s, instantiate %s); launching eagerly\n",
+                        hipGetErrorName(e1), hipGetErrorName(e2), hipGetErrorName(e3));
+            (void)hipGetLastError();
+        }
+        graphed = sg.valid;
+    }
+#endif
+    m->graph_active = graphed;
+    for (int t = 0; t + 1 < max_length; ++t) {
+        const bool timed_step = m->prof_every > 0 && (t % m->prof_every) == 0;
+#ifndef MG_EMU
+        if (graphed && !timed_step) {
+            if (hipGraphLaunch(m->step_graph.exec, st) != hipSuccess) return fail(MG_E_HIP, "mg_generate: hipGraphLaunch failed");
+        } else
+#endif
+        {
+            // use_graph == 2: the device-counter form launched eagerly (what the graph replays; testable without HIP graphs)
+            decode_step(t, (m->use_graph == 2 && !timed_step) ? counters + 2 : nullptr);
+        }
         steps_done = t + 1;
         // termination is checked every 8 steps (and at the end): overrunning only appends pad columns, which are
         // trimmed with the device-recorded `done_step`
@@ -776,6 +877,14 @@ int mg_profile_cross_attention(mg_model* m, int every, int max_samples) {
     }
     return MG_OK;
 }
+int mg_set_decode_graph(mg_model* m, int enable) {
+    if (!m) return fail(MG_E_ARG, "mg_set_decode_graph: null model");
+    const int prev = m->use_graph;
+    m->use_graph = enable < 0 ? 0 : (enable > 2 ? 1 : enable);
+    if (m->use_graph != 1) m->step_graph.reset();
+    return prev;
+}
+int mg_decode_graph_active(const mg_model* m) { return m && m->graph_active ? 1 : 0; }
 // launches timed, their summed duration, and the summed number of (image, key) rows streamed per launch
 int mg_profile_read(mg_model* m, long* launches, double* total_ms, double* total_keys) {
     if (!m) return fail(MG_E_ARG, "mg_profile_read: null model");

@@ -116,9 +116,10 @@ MG_DEV float block_sum(float v, float* red, int tid) {
 
 // a. log-probs + running scores, b. top-2K over K*V by 2K rounds of block-wide selection
 template <int KMAX>
-__global__ __launch_bounds__(256) void beam_topk_kernel(BeamPtrs p, const float* logits, int ldl, int V, int K, int cur_len, int eos,
-                                                   int min_len, const int* counters) {
+__global__ __launch_bounds__(256) void beam_topk_kernel(BeamPtrs p, const float* logits, int ldl, int V, int K, int cur_len_arg, int eos,
+                                                   int min_len, const int* counters, const int* tdev) {
     if (counters[0] == 0) return;
+    const int cur_len = tdev ? *tdev + 1 : cur_len_arg;
     MG_DYN_SMEM(smem);
     float* red = (float*)smem;            // [4]
     float* rmax = red + 4;                // [KMAX]
@@ -173,10 +174,15 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(BeamPtrs p, const float*
 }
 
 // c.-g. bookkeeping for one image (K <= 8, 2K <= 16 candidates)
-__global__ __launch_bounds__(256) void beam_update_kernel(BeamPtrs p, int B, int K, int V, int max_len, int cur_len, int eos,
-                                                     float fin_div, float heur_div, int early_stopping, int64_t* next_ids,
-                                                     int* beam_idx, const int* counters) {
+__global__ __launch_bounds__(256) void beam_update_kernel(BeamPtrs p, int B, int K, int V, int max_len, int cur_len_arg, int eos,
+                                                     float div_arg, const float* div_table, int early_stopping, int64_t* next_ids,
+                                                     int* beam_idx, const int* counters, const int* tdev) {
     if (counters[0] == 0) return;
+    const int cur_len = tdev ? *tdev + 1 : cur_len_arg;
+    // (cur_len + 1 - prompt_len)^length_penalty with prompt_len = 1: the divisor of the finished-beam score
+    // (utils.py:3182) and, after the increment of cur_len, of the early-stop heuristic (utils.py:3047-3052)
+    const float fin_div = div_table ? div_table[cur_len] : div_arg;
+    const float heur_div = fin_div;
     MG_DYN_SMEM(smem);
     const int b = blockIdx.x, tid = threadIdx.x;
     const int keep = 2 * K, ml = max_len, il = max_len - 1;
@@ -312,14 +318,18 @@ __global__ void beam_flags_kernel(BeamPtrs p, int B, int early_stopping, int* co
     counters[0] = (any_h && !(all_fin && early_stopping) && !all_hit) ? 1 : 0;
 }
 
-void beam_step(void* state, const float* logits, int ldl, int V, int B, int K, int max_len, int cur_len, int eos, int min_len,
-               float length_penalty, int early_stopping, int64_t* next_ids, int* beam_idx, int* counters, mgStream_t stream) {
+float beam_length_divisor(int cur_len, float length_penalty) { return (float)pow((double)cur_len, (double)length_penalty); }
+
+// tdev != nullptr (graph capture): cur_len = *tdev + 1 and the divisor comes from div_table[cur_len] (device memory,
+// filled on the host with beam_length_divisor so both forms use bit-identical values)
+void beam_step(void* state, const float* logits, int ldl, int V, int B, int K, int max_len, int cur_len, const int* tdev,
+               const float* div_table, int eos, int min_len, float length_penalty, int early_stopping, int64_t* next_ids,
+               int* beam_idx, int* counters, mgStream_t stream) {
     const BeamPtrs p = beam_ptrs(state, B, K, max_len);
-    MG_LAUNCH((beam_topk_kernel<8>), dim3(B), dim3(256), 256, stream, p, logits, ldl, V, K, cur_len, eos, min_len, (const int*)counters);
-    const float fin_div = (float)pow((double)cur_len, (double)length_penalty);    // (cur_len + 1 - prompt_len)^lp, prompt = 1
-    const float heur_div = (float)pow((double)cur_len, (double)length_penalty);   // ((cur_len+1) - prompt_len)^lp after the increment
-    MG_LAUNCH(beam_update_kernel, dim3(B), dim3(256), 1024, stream, p, B, K, V, max_len, cur_len, eos, fin_div, heur_div, early_stopping,
-              next_ids, beam_idx, (const int*)counters);
+    MG_LAUNCH((beam_topk_kernel<8>), dim3(B), dim3(256), 256, stream, p, logits, ldl, V, K, cur_len, eos, min_len, (const int*)counters, tdev);
+    const float div = beam_length_divisor(cur_len, length_penalty);
+    MG_LAUNCH(beam_update_kernel, dim3(B), dim3(256), 1024, stream, p, B, K, V, max_len, cur_len, eos, div, tdev ? div_table : nullptr,
+              early_stopping, next_ids, beam_idx, (const int*)counters, tdev);
     MG_LAUNCH(beam_flags_kernel, dim3(1), dim3(64), 0, stream, p, B, early_stopping, counters);
 }
 
@@ -349,9 +359,11 @@ void beam_finalize(void* state, int B, int K, int max_len, int64_t* out_ids, int
 }
 
 // ancestor-table reorder: one workgroup per cached position j < t_written, in place
-__global__ __launch_bounds__(256) void beam_reorder_anc_kernel(int* anc, const int* beam_idx, int rows, const int* counters) {
+__global__ __launch_bounds__(256) void beam_reorder_anc_kernel(int* anc, const int* beam_idx, int rows, const int* counters,
+                                                          const int* tdev) {
     if (counters[0] == 0) return;
     const int j = blockIdx.x;
+    if (tdev && j > *tdev) return;      // graph form: launched over every position, only the written ones are permuted
     int v[4];
     int n = 0;
     for (int r = threadIdx.x; r < rows; r += 256) v[n++] = anc[(size_t)j * rows + beam_idx[r]];
@@ -359,8 +371,8 @@ __global__ __launch_bounds__(256) void beam_reorder_anc_kernel(int* anc, const i
     n = 0;
     for (int r = threadIdx.x; r < rows; r += 256) anc[(size_t)j * rows + r] = v[n++];
 }
-void beam_reorder_anc(int* anc, const int* beam_idx, int rows, int t_written, const int* counters, mgStream_t stream) {
-    MG_LAUNCH(beam_reorder_anc_kernel, dim3(t_written), dim3(256), 0, stream, anc, beam_idx, rows, counters);
+void beam_reorder_anc(int* anc, const int* beam_idx, int rows, int t_written, const int* tdev, const int* counters, mgStream_t stream) {
+    MG_LAUNCH(beam_reorder_anc_kernel, dim3(t_written), dim3(256), 0, stream, anc, beam_idx, rows, counters, tdev);
 }
 
 // physical reorder (cache_utils.py:100-104): dst[lk][r] = src[lk][beam_idx[r]], 16-byte copies, HBM-bound

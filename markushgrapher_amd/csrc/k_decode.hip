@@ -241,7 +241,7 @@ __global__ __launch_bounds__(GS_THREADS) void greedy_select_kernel(ArgmaxArgs a)
     MG_DYN_SMEM(smem);
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const float* lg = a.logits + (size_t)row * a.ldl;
-    const int pos = a.pos_dev ? *a.pos_dev : a.pos;
+    const int pos = a.pos_dev ? *a.pos_dev + a.pos : a.pos;
     const bool no_eos = a.suppress_eos || pos < a.min_len;
     float b1 = -3.0e38f, b2 = -3.0e38f;
     int i1 = 0x7fffffff;
@@ -277,12 +277,14 @@ __global__ __launch_bounds__(GS_THREADS) void greedy_select_kernel(ArgmaxArgs a)
         const int still = unf && tok != a.eos;
         a.unfinished[row] = still;
         if (still) atomicAdd(a.n_unfinished, 1);
-        if (a.top2) { a.top2[row * 2] = b1; a.top2[row * 2 + 1] = b2; }
+        if (a.top2) {
+            float* tp = a.top2 + (a.pos_dev ? (size_t)pos * a.rows * 2 : 0);
+            tp[row * 2] = b1; tp[row * 2 + 1] = b2;
+        }
     }
 }
 
 void greedy_select(const ArgmaxArgs& a, mgStream_t stream) {
-    mg_memset_async(a.n_unfinished, 0, sizeof(int), stream);
     MG_LAUNCH(greedy_select_kernel, dim3(a.rows), dim3(GS_THREADS), 256, stream, a);
 }
 

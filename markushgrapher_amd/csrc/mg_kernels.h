@@ -184,10 +184,11 @@ struct ArgmaxArgs {
     int64_t* next_ids;       // [rows] token fed to the next step
     int64_t* out_ids;        // [rows][max_len]
     int max_len, pos;        // column written
-    const int* pos_dev;      // if non-null the column is *pos_dev
+    const int* pos_dev;      // if non-null the column is *pos_dev + pos (graph replay: the step counter lives on the device)
+                             // and `top2` is the base of a [max_len][rows][2] array indexed by that column
     int min_len;             // EOS is suppressed while pos < min_len (MinLengthLogitsProcessor)
     int* unfinished;         // [rows]
-    int* n_unfinished;       // [1] recomputed
+    int* n_unfinished;       // [1] accumulated here; the step-end kernel publishes and clears it
     float* top2;             // [rows][2] (nullable) top-1 / top-2 logit of this step
 };
 void greedy_select(const ArgmaxArgs& a, mgStream_t stream);
@@ -196,11 +197,13 @@ void greedy_select(const ArgmaxArgs& a, mgStream_t stream);
 size_t beam_state_bytes(int B, int K, int max_len);
 void beam_init(void* state, int B, int K, int max_len, int pad, int eos, int start, int64_t* next_ids, int* anc, int T_cap,
                int* counters, mgStream_t stream);
-void beam_step(void* state, const float* logits, int ldl, int V, int B, int K, int max_len, int cur_len, int eos, int min_len,
-               float length_penalty, int early_stopping, int64_t* next_ids, int* beam_idx, int* counters, mgStream_t stream);
+float beam_length_divisor(int cur_len, float length_penalty);
+void beam_step(void* state, const float* logits, int ldl, int V, int B, int K, int max_len, int cur_len, const int* tdev,
+               const float* div_table, int eos, int min_len, float length_penalty, int early_stopping, int64_t* next_ids,
+               int* beam_idx, int* counters, mgStream_t stream);
 void beam_finalize(void* state, int B, int K, int max_len, int64_t* out_ids, int* out_cols, float* out_scores, mgStream_t stream);
 // ancestor-table form of the KV-cache reorder (cache_utils.py:100-104): anc[j][row] <- anc[j][beam_idx[row]], j < t_written
-void beam_reorder_anc(int* anc, const int* beam_idx, int rows, int t_written, const int* counters, mgStream_t stream);
+void beam_reorder_anc(int* anc, const int* beam_idx, int rows, int t_written, const int* tdev, const int* counters, mgStream_t stream);
 // physical form: dst[lk][row] = src[lk][beam_idx[row]] for nlk = layers*2 K/V planes of [rows][H][t_cap][64] bf16
 void beam_reorder_copy(const uint16_t* src, uint16_t* dst, const int* beam_idx, int nlk, int rows, int H, int t_cap, int t_used,
                        mgStream_t stream);

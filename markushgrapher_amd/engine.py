@@ -64,6 +64,9 @@ class TorchMem:
             x = x.view(t.int16)
         return x.to(device=self.device, dtype=want, non_blocking=True).contiguous()
 
+    def copy(self, h):
+        return h.clone()
+
     def ptr(self, h):
         return C.c_void_p(h.data_ptr())
 
@@ -96,6 +99,7 @@ class Engine:
         self._chk(self.lib.mg_bind_weights(self.model, self.mem.ptr(self.arena)))
         self._ws = None
         self._ws_bytes = 0
+        self._gen_out = {}
         self.ignored_keys = []
 
     def _declare(self):
@@ -107,6 +111,8 @@ class Engine:
         L.mg_bind_weights.argtypes = [C.c_void_p, C.c_void_p]
         L.mg_finalize.argtypes = [C.c_void_p, C.c_void_p]
         L.mg_load_tensor.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]
+        L.mg_set_decode_graph.argtypes = [C.c_void_p, C.c_int]
+        L.mg_decode_graph_active.argtypes = [C.c_void_p]
         L.mg_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
         L.mg_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
@@ -121,6 +127,13 @@ class Engine:
         if rc < 0:
             raise MgError(f"libmgrapher error {rc}: {self.lib.mg_last_error().decode()}")
         return rc
+
+    def set_decode_graph(self, mode):
+        """0: eager launches; 1: captured decode-step HIP graph (default); 2: the graph's device-counter kernels, eager."""
+        return int(self.lib.mg_set_decode_graph(self.model, int(mode)))
+
+    def decode_graph_active(self):
+        return bool(self.lib.mg_decode_graph_active(self.model))
 
     def close(self):
         if self.model:
@@ -229,7 +242,13 @@ class Engine:
                  length_penalty=1.0, early_stopping=False, return_top2=False):
         ids, bb, am, pv, B, L = self._inputs(input_ids, bbox, attention_mask, pixel_values)
         ws, nb = self.workspace(B, L, num_beams, max_length, 0)
-        out = self.mem.empty((B, max_length), np.int64)
+        # the id buffer is persistent per (B, max_length): the captured decode-step graph holds its address, so a stable
+        # buffer lets later calls replay the graph instead of re-capturing; callers get a copy
+        okey = (B, max_length)
+        out = self._gen_out.get(okey)
+        if out is None:
+            self._gen_out.clear()
+            out = self._gen_out[okey] = self.mem.empty((B, max_length), np.int64)
         scores = self.mem.zeros((B,), np.float32)
         top2 = self.mem.zeros((max_length, B * num_beams, 2), np.float32) if (return_top2 and num_beams == 1) else None
         cols = C.c_int(0)
@@ -238,4 +257,4 @@ class Engine:
                                        max_length, min_length, C.c_float(length_penalty), 1 if early_stopping is True else 0,
                                        self.mem.ptr(out), C.byref(cols), self.mem.ptr(scores),
                                        self.mem.ptr(top2) if top2 is not None else None))
-        return out[:, :cols.value], scores, top2
+        return self.mem.copy(out[:, :cols.value]), scores, top2

@@ -100,6 +100,9 @@ class NumpyMem:
             x = x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
         return np.ascontiguousarray(x).astype(dtype, copy=True)
 
+    def copy(self, h):
+        return np.array(h, copy=True)
+
     def ptr(self, h):
         return ctypes.c_void_p(h.ctypes.data)
 
