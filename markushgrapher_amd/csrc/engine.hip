@@ -31,7 +31,8 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 int round_up(int x, int a) { return (x + a - 1) / a * a; }
 
 struct EncLayer { size_t wqkv, wo, ln0, wi, wo2, ln1; };
-struct DecLayer { size_t wqkv, wo, ln0, xq, xkv, xo, ln1, wi, wo2, ln2; };
+// xq2 / wi2: product weights of the decode step (built by mg_finalize): [Wxq·G1 | Wxq·G1·Wo] and [Wi·G2 | Wi·G2·Wxo]
+struct DecLayer { size_t wqkv, wo, ln0, xq, xkv, xo, ln1, wi, wo2, ln2, xq2, wi2; };
 
 }  // namespace
 
@@ -81,6 +82,7 @@ struct mg_model {
     long prof_n = 0;
     double prof_keys = 0.0;   // sum over timed launches of the number of (image, key) pairs streamed
     // one decode step captured as a HIP graph (greedy and beam); replayed while its key matches the call
+    size_t fin_a = 0, fin_b = 0, fin_c = 0;
     StepGraph step_graph;
     std::vector<float> beam_div_host;
     int use_graph = 1;
@@ -185,8 +187,9 @@ struct Ws {
     uint8_t* mask;
     int *xrow, *xlen, *counters;
     // decode (generate)
-    uint16_t *xk, *xv, *sk, *sv, *dq, *dx_pk, *dctx_pk, *dy_pk;
-    float *dh, *logits, *slabs, *rs_part;
+    uint16_t *xk, *xv, *sk, *sv, *dq, *dx_pk, *dy_pk;
+    uint16_t *xa, *xb;        // packed [rows][d + inner] operand windows of the pair projections: [bf16(h) | attention context]
+    float *dh, *logits, *slabs, *rs_part, *rs_part1, *rs_part2;
     size_t slab_stride;
     int64_t* next_ids;
     int *unfinished, *anc, *beam_idx;
@@ -246,7 +249,6 @@ void carve(const mg_model* m, char* base, int B, int L, int K, int max_len, int 
         w->sv = c.take<uint16_t>(nl * R * H * (size_t)m->T_cap * 64);
         w->dq = c.take<uint16_t>((size_t)Rp * inner);
         w->dx_pk = c.take<uint16_t>((size_t)Rp * d);
-        w->dctx_pk = c.take<uint16_t>((size_t)Rp * inner);
         w->dy_pk = c.take<uint16_t>((size_t)Rp * m->dff);
         w->dh = c.take<float>((size_t)Rp * d);
         w->logits = c.take<float>((size_t)Rp * round_up(m->V, 32));
@@ -257,6 +259,10 @@ void carve(const mg_model* m, char* base, int B, int L, int K, int max_len, int 
             w->slab_stride = (size_t)Rp * ldmax;
             w->slabs = c.take<float>(16 * w->slab_stride);
             w->rs_part = c.take<float>((size_t)Rp * (d / 8));
+            w->rs_part1 = c.take<float>((size_t)Rp * (d / 8));
+            w->rs_part2 = c.take<float>((size_t)Rp * (d / 8));
+            w->xa = c.take<uint16_t>((size_t)Rp * (d + inner));
+            w->xb = c.take<uint16_t>((size_t)Rp * (d + inner));
         }
         w->next_ids = c.take<int64_t>(Rp);
         w->unfinished = c.take<int>(Rp);
@@ -364,7 +370,12 @@ int mg_create(const mg_config* cfg, mg_model** out) {
         l.xq = take(pk_elems(inner, d) * 2); l.xkv = take(pk_elems(2 * inner, d) * 2); l.xo = take(pk_elems(d, inner) * 2);
         l.ln1 = take((size_t)d * 4);
         l.wi = take(pk_elems(dff, d) * 2); l.wo2 = take(pk_elems(d, dff) * 2); l.ln2 = take((size_t)d * 4);
+        l.xq2 = take(pk_elems(inner, d + inner) * 2); l.wi2 = take(pk_elems(dff, d + inner) * 2);
         m->dec.push_back(l);
+    }
+    {   // fp32 scratch of mg_finalize (unpacked factors and one product)
+        const size_t nmax = (size_t)(dff > inner ? dff : inner);
+        m->fin_a = take(nmax * d * 4); m->fin_b = take((size_t)d * inner * 4); m->fin_c = take(nmax * (d + inner) * 4);
     }
     m->arena_bytes = align_up(off, 256);
     // host bucket tables
@@ -551,6 +562,28 @@ int mg_finalize(mg_model* m, void* stream) {
     mg_memcpy_async(m->at<int>(m->bkhv), m->h_bkhv.data(), 201 * 4, st);
     mg_memcpy_async(m->at<int>(m->bkdec), m->h_bkdec.data(), (size_t)m->T_cap * 4, st);
     MG_LAUNCH(build_table_kernel, dim3(8), dim3(256), 0, st, (const float*)m->at<float>(m->rb_dec_raw), (const int*)m->at<int>(m->bkdec), m->at<float>(m->dec_tab), m->T_cap, H);
+    // Product weights of the decode step.  With h1 = h + Wo·ctx the cross-attention query is
+    //   Wxq·G1·h1 = (Wxq·G1)·h + (Wxq·G1·Wo)·ctx          (G1 = diag of the cross-attention layer-norm gain, stock:611-640)
+    // and likewise the FFN input projection over h2 = h1 + Wxo·ctx_x is (Wi·G2)·h1 + (Wi·G2·Wxo)·ctx_x (stock:313-325),
+    // both up to the per-row RMSNorm scalar, which the consumers apply (RowScale).  One GEMM over [bf16(h) | ctx] with
+    // the concatenated weight then runs NEXT TO the residual projection instead of after it: 6 launches per decoder
+    // layer instead of 8.  Products are formed in fp32 from the bf16 weights and rounded to bf16 once.
+    {
+        const int d = m->d, inner = m->inner, dff = m->dff, K2 = d + inner;
+        float *A = m->at<float>(m->fin_a), *Bm = m->at<float>(m->fin_b), *C = m->at<float>(m->fin_c);
+        for (DecLayer& l : m->dec) {
+            unpack_weight(m->at<uint16_t>(l.wo), Bm, d, inner, st);
+            unpack_weight(m->at<uint16_t>(l.xq), A, inner, d, st);
+            scale_cols_f32(A, m->at<float>(l.ln1), C, inner, d, K2, st);
+            gemm_f32_scaled(A, m->at<float>(l.ln1), Bm, C + d, inner, d, inner, K2, st);
+            pack_weight(C, 0, inner, K2, m->at<uint16_t>(l.xq2), round_up(inner, 32), st);
+            unpack_weight(m->at<uint16_t>(l.xo), Bm, d, inner, st);
+            unpack_weight(m->at<uint16_t>(l.wi), A, dff, d, st);
+            scale_cols_f32(A, m->at<float>(l.ln2), C, dff, d, K2, st);
+            gemm_f32_scaled(A, m->at<float>(l.ln2), Bm, C + d, dff, d, inner, K2, st);
+            pack_weight(C, 0, dff, K2, m->at<uint16_t>(l.wi2), round_up(dff, 32), st);
+        }
+    }
     mg_stream_sync(st);    // the host tables above must outlive the copies
     const int rc = check_launch("mg_finalize");
     if (rc != MG_OK) return rc;
@@ -723,19 +756,23 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
     }
     int steps_done = 0;
     int host_flag[4] = {0, 0, 0, 0};
-    // Decode step, 8 launches per layer.  Residual projections (O, cross-O, FFN wo) run with complete sums per
-    // workgroup and fold the NEXT sub-layer's RMSNorm in: they leave bf16(h*gain) un-normalised plus per-row partial
-    // sums of squares, and the consuming projection multiplies its outputs by rsqrt(mean(h^2)+eps) (RowScale).
-    const int ks_xq = splitk_factor(inner, d);
+    // Decode step, 6 launches per layer: QKV -> self-attention -> [O residual | cross-Q] -> cross-attention ->
+    // [cross-O residual | FFN wi] -> FFN wo residual.  Residual projections run with complete sums per workgroup and
+    // leave per-row partial sums of squares; RMSNorm being a per-row scalar, every consumer applies
+    // rsqrt(mean(h^2)+eps) itself (RowScale) — there are no norm launches.  The two bracketed pairs use the product
+    // weights built by mg_finalize: the second projection of a pair reads [bf16(h before the residual) | context]
+    // and so does not wait for the residual projection next to it.
     const float eps = m->c.layer_norm_epsilon;
     const int ldl = round_up(m->V, 32);
-    auto slabs = [&](int KS, int ldp) { Slabs sl; sl.P = w.slabs; sl.KS = KS; sl.ldp = ldp; sl.stride = w.slab_stride; return sl; };
+    const int K2 = d + inner, kts2 = K2 >> 4, kt_ctx = d >> 4;
     RowScale none{};
-    RowScale rsd{w.rs_part, d / 8, 1.0f / (float)d, eps};
+    RowScale rs0{w.rs_part, d / 8, 1.0f / (float)d, eps};     // after the FFN output (next layer's ln0 / final norm)
+    RowScale rs1{w.rs_part1, d / 8, 1.0f / (float)d, eps};    // after the self-attention output (cross-attention norm)
+    RowScale rs2{w.rs_part2, d / 8, 1.0f / (float)d, eps};    // after the cross-attention output (FFN norm)
     // One decode step.  tdev == nullptr: step-dependent values are passed by value (eager launches); otherwise the
     // kernels read the step from the device counter, which makes the launch sequence capturable as a graph.
     auto decode_step = [&](int t, const int* tdev) {
-        embed_rows(w.next_ids, m->at<uint16_t>(m->tok_emb), w.dh, R, d, m->V, counters + 3, st);
+        embed_rows(w.next_ids, m->at<uint16_t>(m->tok_emb), w.dh, R, d, m->V, counters + 3, st, w.xa, K2, 0);
         rmsnorm_pack(w.dh, m->at<float>(m->dec[0].ln0), w.dx_pk, nullptr, R, d, eps, 1.0f, st);
         for (size_t li = 0; li < nl; ++li) {
             const DecLayer& l = m->dec[li];
@@ -745,36 +782,48 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
                 GemmArgs a = gemm_args(w.dx_pk, m->at<uint16_t>(l.wqkv), R, 3 * inner, d);
                 set_heads(a, H, R, T_cap, w.dq, HF_STEP_Q, sk, HF_STEP_KV, sv, HF_STEP_KV);
                 a.heads.pos = t; a.heads.pos_dev = tdev;
-                a.rs = li == 0 ? none : rsd;      // layer 0 reads the explicitly normalised embedding
+                a.rs = li == 0 ? none : rs0;      // layer 0 reads the explicitly normalised embedding
                 gemm_rows(a, EPI_HEADS, st);      // q -> dq, k/v appended to the cache at position t
             }
             AttnStepArgs s{};
-            s.q = w.dq; s.Kc = sk; s.Vc = sv; s.ctx = w.dctx_pk; s.rows = R; s.H = H; s.group = 1; s.cap = T_cap;
-            s.n_keys = t + 1; s.bias = m->at<float>(m->dec_tab); s.anc = K > 1 ? w.anc : nullptr; s.t = t; s.t_dev = tdev;
+            s.q = w.dq; s.Kc = sk; s.Vc = sv; s.ctx = w.xa; s.ctx_ld = K2; s.ctx_col0 = d; s.rows = R; s.H = H; s.group = 1;
+            s.cap = T_cap; s.n_keys = t + 1; s.bias = m->at<float>(m->dec_tab); s.anc = K > 1 ? w.anc : nullptr; s.t = t; s.t_dev = tdev;
             attention_step(s, st);
-            gemm_rows_resid(w.dctx_pk, m->at<uint16_t>(l.wo), w.dh, m->at<float>(l.ln1), 1.0f, w.dx_pk, w.rs_part, R, d, inner, none, st);
+            {   // h += Wo·ctx (partials of sum h^2 -> rs1, bf16(h) -> xb)   |   cross-attention q (un-normalised) -> dq
+                ResidArgs r{};
+                r.X = w.xa; r.x_kts = kts2; r.x_k0 = kt_ctx; r.W = m->at<uint16_t>(l.wo); r.h = w.dh; r.x2_pk = w.xb; r.x2_ld = K2;
+                r.part = w.rs_part1; r.M = R; r.N = d; r.K = inner;
+                GemmArgs g = gemm_args(w.xa, m->at<uint16_t>(l.xq2), R, inner, K2);
+                set_heads(g, H, R, T_cap, w.dq, HF_STEP_Q, nullptr, HF_NONE, nullptr, HF_NONE);
+                gemm_rows_pair(r, g, EPI_HEADS, st);
+            }
             // cross-attention over the image's compacted K/V stream (all beams of an image share one pass)
-            gemm_rows_splitk(w.dx_pk, m->at<uint16_t>(l.xq), w.slabs, R, inner, d, inner, w.slab_stride, ks_xq, rsd, st);
             AttnStepArgs x{};
-            x.Kc = w.xk + li * xkv_stride; x.Vc = w.xv + li * xkv_stride; x.ctx = w.dctx_pk; x.rows = R; x.H = H;
-            x.group = K; x.cap = S_cap; x.len = w.xlen; x.qkv = slabs(ks_xq, inner); x.self_append = 0;
+            x.q = w.dq; x.qrs = rs1; x.Kc = w.xk + li * xkv_stride; x.Vc = w.xv + li * xkv_stride; x.ctx = w.xb; x.ctx_ld = K2;
+            x.ctx_col0 = d; x.rows = R; x.H = H; x.group = K; x.cap = S_cap; x.len = w.xlen;
             const bool timed = !tdev && m->prof_every > 0 && (t % m->prof_every) == 0 && m->prof_used + 2 <= m->prof_ev.size();
             if (timed) mg_event_record(m->prof_ev[m->prof_used], st);
             attention_step(x, st);
             if (timed) { mg_event_record(m->prof_ev[m->prof_used + 1], st); m->prof_used += 2; }
-            gemm_rows_resid(w.dctx_pk, m->at<uint16_t>(l.xo), w.dh, m->at<float>(l.ln2), 1.0f, w.dx_pk, w.rs_part, R, d, inner, none, st);
-            {
-                GemmArgs a = gemm_args(w.dx_pk, m->at<uint16_t>(l.wi), R, m->dff, d);
-                a.out_pk = w.dy_pk;
-                a.rs = rsd;
-                gemm_rows(a, EPI_PK_RELU, st);
+            {   // h += Wxo·ctx_x (partials -> rs2)   |   y = relu(wi·...) un-normalised -> dy_pk
+                ResidArgs r{};
+                r.X = w.xb; r.x_kts = kts2; r.x_k0 = kt_ctx; r.W = m->at<uint16_t>(l.xo); r.h = w.dh; r.part = w.rs_part2;
+                r.M = R; r.N = d; r.K = inner;
+                GemmArgs g = gemm_args(w.xb, m->at<uint16_t>(l.wi2), R, m->dff, K2);
+                g.out_pk = w.dy_pk;
+                gemm_rows_pair(r, g, EPI_PK_RELU, st);
             }
-            // FFN output; folded norm = next layer's ln0, or the final norm with the d_model^-0.5 of the tied head
-            const bool last = li + 1 == nl;
-            gemm_rows_resid(w.dy_pk, m->at<uint16_t>(l.wo2), w.dh, m->at<float>(last ? m->dec_ln : m->dec[li + 1].ln0),
-                            last ? 1.0f / sqrtf((float)d) : 1.0f, w.dx_pk, w.rs_part, R, d, m->dff, none, st);
+            {   // FFN output (input scaled by rs2); leaves bf16(h·gain) for the next QKV / lm_head (gain = next layer's ln0,
+                // or the final norm with the d_model^-0.5 of the tied head), bf16(h) for the next pair, partials -> rs0
+                const bool last = li + 1 == nl;
+                ResidArgs r{};
+                r.X = w.dy_pk; r.W = m->at<uint16_t>(l.wo2); r.h = w.dh; r.gain = m->at<float>(last ? m->dec_ln : m->dec[li + 1].ln0);
+                r.gscale = last ? 1.0f / sqrtf((float)d) : 1.0f; r.x_pk = w.dx_pk; r.x2_pk = w.xa; r.x2_ld = K2; r.part = w.rs_part;
+                r.M = R; r.N = d; r.K = m->dff; r.rs = rs2;
+                gemm_rows_resid(r, st);
+            }
         }
-        gemm_rows_splitk(w.dx_pk, m->at<uint16_t>(m->lm_head), w.logits, R, m->V, d, ldl, 0, 1, rsd, st);
+        gemm_rows_splitk(w.dx_pk, m->at<uint16_t>(m->lm_head), w.logits, R, m->V, d, ldl, 0, 1, rs0, st);
         if (K == 1) {
             ArgmaxArgs g{};
             g.logits = w.logits; g.rows = R; g.V = m->V; g.ldl = ldl; g.eos = m->c.eos_token_id; g.pad = (int)pad;

@@ -58,6 +58,22 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a) {
         row = row < a.rows ? row : a.rows - 1;
         q[g] = a.qkv.P ? slab_chunk(row, h * 64 + sub * 8) : ld16(a.q + ((size_t)row * a.H + h) * 64 + sub * 8);
     }
+    // deferred RMSNorm of the query rows: q was projected from the un-normalised bf16(h), the row scale r(row) is applied
+    // to the scores (q·k is linear in q); every wave sums the row's partials itself (fixed order: deterministic)
+    float qs[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        qs[g] = 1.0f;
+        if (a.qrs.part) {
+            int row = owner * G + g;
+            row = row < a.rows ? row : a.rows - 1;
+            float t = 0.f;
+            for (int i = lane; i < a.qrs.nparts; i += 64) t += a.qrs.part[(size_t)row * a.qrs.nparts + i];
+#pragma unroll
+            for (int step = 1; step < 64; step <<= 1) t += __shfl_xor(t, step);
+            qs[g] = rsqrtf(t * a.qrs.inv_d + a.qrs.eps);
+        }
+    }
     // self-attention with split-K projections: this workgroup also owns the new position's k, v (kept in registers
     // for its own use and appended to the cache for later steps)
     uint4 knew = make_uint4(0, 0, 0, 0), vnew = make_uint4(0, 0, 0, 0);
@@ -116,7 +132,7 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a) {
                 p = dot2_bf16(q[g].z, kv[u].z, p);
                 p = dot2_bf16(q[g].w, kv[u].w, p);
                 p = sum8(p);
-                s[u][g] = key[u] < nkeys ? p + bias : DC_NEG;
+                s[u][g] = key[u] < nkeys ? p * qs[g] + bias : DC_NEG;
             }
         }
 #pragma unroll
@@ -148,7 +164,7 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a) {
         p = dot2_bf16(q[0].w, knew.w, p);
         p = sum8(p);
         if (ks == 0) {
-            const float sc = p + (a.bias ? a.bias[h] : 0.f);
+            const float sc = p * qs[0] + (a.bias ? a.bias[h] : 0.f);
             const float mn = fmaxf(m[0], sc);
             const float al = fast_exp(m[0] - mn), pe = fast_exp(sc - mn);
             m[0] = mn;
@@ -201,7 +217,7 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a) {
             const float inv = L > 0.f ? 1.0f / L : 0.f;
             const int row = owner * G + g;
             if (row < a.rows)
-                st16(a.ctx + pk_off(row, h * 64 + sub * 8, a.H * 64),
+                st16(a.ctx + pk_off(row, a.ctx_col0 + h * 64 + sub * 8, a.ctx_ld ? a.ctx_ld : a.H * 64),
                      make_uint4(pack_bf16(o[0] * inv, o[1] * inv), pack_bf16(o[2] * inv, o[3] * inv),
                                 pack_bf16(o[4] * inv, o[5] * inv), pack_bf16(o[6] * inv, o[7] * inv)));
         }

@@ -154,7 +154,7 @@ void embed_assemble(const EmbedArgs& a, void* meta_ws, mgStream_t stream) {
 
 // decoder token embedding: h[row] = shared[ids[row]]  (stock:1140)
 __global__ __launch_bounds__(256) void embed_rows_kernel(const int64_t* ids, const uint16_t* tok_emb, float* h, int rows, int d, int V,
-                                                    int* err) {
+                                                    int* err, uint16_t* x_pk, int x_ld, int x_col0) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int row = blockIdx.x * 4 + w; row < rows; row += gridDim.x * 4) {
         long long id = ids[row];
@@ -162,13 +162,15 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(const int64_t* ids, con
         for (int c = lane * 4; c < d; c += 256) {
             const uint2 t = *(const uint2*)(tok_emb + (size_t)id * d + c);
             *(float4*)(h + (size_t)row * d + c) = make_float4(bf16lo(t.x), bf16hi(t.x), bf16lo(t.y), bf16hi(t.y));
+            if (x_pk) *(uint2*)(x_pk + pk_off(row, x_col0 + c, x_ld)) = t;      // 4 consecutive k of one packed row
         }
     }
 }
-void embed_rows(const int64_t* ids, const uint16_t* tok_emb, float* h, int rows, int d, int V, int* err, mgStream_t stream) {
+void embed_rows(const int64_t* ids, const uint16_t* tok_emb, float* h, int rows, int d, int V, int* err, mgStream_t stream,
+                uint16_t* x_pk, int x_ld, int x_col0) {
     int blocks = (rows + 3) / 4;
     if (blocks > 4096) blocks = 4096;
-    MG_LAUNCH(embed_rows_kernel, dim3(blocks), dim3(256), 0, stream, ids, tok_emb, h, rows, d, V, err);
+    MG_LAUNCH(embed_rows_kernel, dim3(blocks), dim3(256), 0, stream, ids, tok_emb, h, rows, d, V, err, x_pk, x_ld, x_col0);
 }
 
 }  // namespace mg

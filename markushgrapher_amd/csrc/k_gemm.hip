@@ -376,12 +376,11 @@ void gemm(const GemmArgs& a, int epi, mgStream_t stream) {
 // ---------------------------------------------------------------------------------------------------------
 // HALF: one workgroup per 16 output features (half a weight tile; the other half's lanes feed zeros to the MFMA) —
 // doubles the number of workgroups for projections whose epilogue must see complete sums (relu, bf16 per-head stores).
-template <int EPI, int MT, bool HALF, int NW = 4>
-__global__ __launch_bounds__(NW * 64) void gemm_rows_kernel(GemmArgs a) {
-    MG_DYN_SMEM(smem);
+template <int EPI, int MT, bool HALF, int NW, int U>
+MG_DEV void rows_block(const GemmArgs& a, int bid, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int nt = HALF ? (blockIdx.x >> 1) : blockIdx.x;
-    const int sub = HALF ? (blockIdx.x & 1) : 0;
+    const int nt = HALF ? (bid >> 1) : bid;
+    const int sub = HALF ? (bid & 1) : 0;
     const bool wvalid = !HALF || (((lane & 31) >> 4) == sub);
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
     const int kt16 = a.K >> 4;
@@ -395,8 +394,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_rows_kernel(GemmArgs a) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) acc[i] = acc_zero();
     const char* wp = (const char*)(a.W + pk_tile_off(nt, 0, a.K)) + lane * 16;
-    const char* xp = (const char*)a.X + lane * 16;
-    constexpr int U = 8;
+    const int xkts = a.x_kts ? a.x_kts : kt16;
+    const char* xp = (const char*)a.X + ((size_t)a.x_k0 * TILE_BYTES + lane * 16);
     int kt = k0;
     for (; kt + U <= k1; kt += U) {
         uint4 wf[U];
@@ -406,7 +405,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_rows_kernel(GemmArgs a) {
         for (int u = 0; u < U; ++u) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                const uint4 xf = ld16(xp + ((size_t)i * kt16 + (kt + u)) * TILE_BYTES);
+                const uint4 xf = ld16(xp + ((size_t)i * xkts + (kt + u)) * TILE_BYTES);
                 acc[i] = TOR ? mfma32(wf[u], xf, acc[i]) : mfma32(xf, wf[u], acc[i]);
             }
         }
@@ -415,7 +414,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_rows_kernel(GemmArgs a) {
         const uint4 wf = wvalid ? ld16_stream(wp + (size_t)kt * TILE_BYTES) : zero4;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            const uint4 xf = ld16(xp + ((size_t)i * kt16 + kt) * TILE_BYTES);
+            const uint4 xf = ld16(xp + ((size_t)i * xkts + kt) * TILE_BYTES);
             acc[i] = TOR ? mfma32(wf, xf, acc[i]) : mfma32(xf, wf, acc[i]);
         }
     }
@@ -439,6 +438,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_rows_kernel(GemmArgs a) {
         }
         __syncthreads();
     }
+}
+template <int EPI, int MT, bool HALF, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void gemm_rows_kernel(GemmArgs a) {
+    MG_DYN_SMEM(smem);
+    rows_block<EPI, MT, HALF, NW, 8>(a, blockIdx.x, smem);
 }
 
 template <int EPI>
@@ -532,24 +536,24 @@ __global__ __launch_bounds__(256) void gemm_rows_splitk_kernel(const uint16_t* X
 // workgroup = NW waves, 8 output features (a quarter weight tile; other lanes feed zeros), all M rows.
 // ---------------------------------------------------------------------------------------------------------
 template <int MT, int NW>
-__global__ __launch_bounds__(NW * 64) void gemm_rows_resid_kernel(const uint16_t* X, const uint16_t* W, float* h, const float* gain, float gscale,
-                                                             uint16_t* x_pk, float* part, int M, int N, int K, RowScale rs) {
-    MG_DYN_SMEM(smem);
+MG_DEV void resid_block(const ResidArgs& a, int bid, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int half = lane >> 5, l32 = lane & 31;
-    const int nt = blockIdx.x >> 2, sub = blockIdx.x & 3;
+    const int nt = bid >> 2, sub = bid & 3;
     const bool wvalid = (l32 >> 3) == sub;
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
-    const int kt16 = K >> 4;
+    const int M = a.M, N = a.N;
+    const int kt16 = a.K >> 4;
     const int per = (kt16 + NW - 1) / NW;
     const int k0 = w * per, k1 = (k0 + per) < kt16 ? (k0 + per) : kt16;
     float* rsl = (float*)(smem + NW * 4 * 64 * sizeof(float));     // [32*MT]
-    block_row_scales(rs, M, 32 * MT, rsl, tid, NW * 64);
+    block_row_scales(a.rs, M, 32 * MT, rsl, tid, NW * 64);
     f32x16 acc[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) acc[i] = acc_zero();
-    const char* wp = (const char*)(W + pk_tile_off(nt, 0, K)) + lane * 16;
-    const char* xp = (const char*)X + lane * 16;
+    const char* wp = (const char*)(a.W + pk_tile_off(nt, 0, a.K)) + lane * 16;
+    const int xkts = a.x_kts ? a.x_kts : kt16;
+    const char* xp = (const char*)a.X + ((size_t)a.x_k0 * TILE_BYTES + lane * 16);
     constexpr int U = (NW >= 16) ? 16 : 8;       // the wide (K = d_ff) form keeps its whole K share in flight at once
     int kt = k0;
     for (; kt + U <= k1; kt += U) {
@@ -559,19 +563,20 @@ __global__ __launch_bounds__(NW * 64) void gemm_rows_resid_kernel(const uint16_t
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) acc[i] = mfma32(wf[u], ld16(xp + ((size_t)i * kt16 + (kt + u)) * TILE_BYTES), acc[i]);
+            for (int i = 0; i < MT; ++i) acc[i] = mfma32(wf[u], ld16(xp + ((size_t)i * xkts + (kt + u)) * TILE_BYTES), acc[i]);
         }
     }
     for (; kt < k1; ++kt) {
         const uint4 wf = wvalid ? ld16_stream(wp + (size_t)kt * TILE_BYTES) : zero4;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) acc[i] = mfma32(wf, ld16(xp + ((size_t)i * kt16 + kt) * TILE_BYTES), acc[i]);
+        for (int i = 0; i < MT; ++i) acc[i] = mfma32(wf, ld16(xp + ((size_t)i * xkts + kt) * TILE_BYTES), acc[i]);
     }
     // D rows = features of the tile; the valid 8 (8*sub .. +7) sit in registers 4*sub .. 4*sub+3:
     // lane (row m = l32, half) holds features 8*sub + 4*half + j.  Reduce those 4 registers over the NW waves.
     float* slab = (float*)smem;                         // [NW][4][64]
     const int n0 = nt * 32 + sub * 8 + half * 4;
     const int nparts = N >> 3;
+    const int x_ld = a.x_ld ? a.x_ld : N, x2_ld = a.x2_ld ? a.x2_ld : N;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -593,39 +598,137 @@ __global__ __launch_bounds__(NW * 64) void gemm_rows_resid_kernel(const uint16_t
             const int m = 32 * i + l32;
             float ss = 0.f;
             if (m < M) {
-                float4 hv = *(const float4*)(h + (size_t)m * N + n0);
+                float4 hv = *(const float4*)(a.h + (size_t)m * N + n0);
                 hv.x += v[0]; hv.y += v[1]; hv.z += v[2]; hv.w += v[3];
-                *(float4*)(h + (size_t)m * N + n0) = hv;
+                *(float4*)(a.h + (size_t)m * N + n0) = hv;
                 ss = (hv.x * hv.x + hv.y * hv.y) + (hv.z * hv.z + hv.w * hv.w);
-                const float4 g = *(const float4*)(gain + n0);
-                *(uint2*)(x_pk + pk_off(m, n0, N)) =
-                    make_uint2(pack_bf16(hv.x * g.x * gscale, hv.y * g.y * gscale), pack_bf16(hv.z * g.z * gscale, hv.w * g.w * gscale));
+                if (a.x_pk) {
+                    const float4 g = *(const float4*)(a.gain + n0);
+                    const float gs = a.gscale;
+                    *(uint2*)(a.x_pk + pk_off(m, a.x_col0 + n0, x_ld)) =
+                        make_uint2(pack_bf16(hv.x * g.x * gs, hv.y * g.y * gs), pack_bf16(hv.z * g.z * gs, hv.w * g.w * gs));
+                }
+                if (a.x2_pk)
+                    *(uint2*)(a.x2_pk + pk_off(m, a.x2_col0 + n0, x2_ld)) = make_uint2(pack_bf16(hv.x, hv.y), pack_bf16(hv.z, hv.w));
             }
             ss += __shfl_xor(ss, 32);
-            if (m < M && half == 0) part[(size_t)m * nparts + blockIdx.x] = ss;
+            if (m < M && half == 0) a.part[(size_t)m * nparts + bid] = ss;
         }
         __syncthreads();
     }
 }
+template <int MT, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_rows_resid_kernel(ResidArgs a) {
+    MG_DYN_SMEM(smem);
+    resid_block<MT, NW>(a, blockIdx.x, smem);
+}
 
-void gemm_rows_resid(const uint16_t* X, const uint16_t* W, float* h, const float* gain, float gscale, uint16_t* x_pk, float* part,
-                     int M, int N, int K, const RowScale& rs, mgStream_t stream) {
-    const int mt = (M + 31) / 32;
-    const dim3 grid(N / 8);
-    const bool wide = K > 2048;
+void gemm_rows_resid(const ResidArgs& r, mgStream_t stream) {
+    const int mt = (r.M + 31) / 32;
+    const dim3 grid(r.N / 8);
+    const bool wide = r.K > 2048;
     const int NW = wide ? 16 : 8;
     const dim3 block(NW * 64);
     const size_t sh = (size_t)NW * 4 * 64 * sizeof(float) + (size_t)32 * mt * sizeof(float);
-#define MG_RR(MTV)                                                                                                        \
-    case MTV:                                                                                                             \
-        if (wide) MG_LAUNCH((gemm_rows_resid_kernel<MTV, 16>), grid, block, sh, stream, X, W, h, gain, gscale, x_pk, part, M, N, K, rs); \
-        else MG_LAUNCH((gemm_rows_resid_kernel<MTV, 8>), grid, block, sh, stream, X, W, h, gain, gscale, x_pk, part, M, N, K, rs);       \
+#define MG_RR(MTV)                                                                                 \
+    case MTV:                                                                                      \
+        if (wide) MG_LAUNCH((gemm_rows_resid_kernel<MTV, 16>), grid, block, sh, stream, r);        \
+        else MG_LAUNCH((gemm_rows_resid_kernel<MTV, 8>), grid, block, sh, stream, r);              \
         break;
     switch (mt) {
         MG_RR(1) MG_RR(2) MG_RR(3) MG_RR(4) MG_RR(5) MG_RR(6) MG_RR(7) MG_RR(8)
         default: break;
     }
 #undef MG_RR
+}
+void gemm_rows_resid(const uint16_t* X, const uint16_t* W, float* h, const float* gain, float gscale, uint16_t* x_pk, float* part,
+                     int M, int N, int K, const RowScale& rs, mgStream_t stream) {
+    ResidArgs r{};
+    r.X = X; r.W = W; r.h = h; r.gain = gain; r.gscale = gscale; r.x_pk = x_pk; r.part = part; r.M = M; r.N = N; r.K = K; r.rs = rs;
+    gemm_rows_resid(r, stream);
+}
+
+// Residual projection and a half-tile projection side by side in one grid (8 waves per workgroup; the second
+// projection keeps up to 16 k-tiles per wave in flight: K = d_model + inner of the product weights in one round).
+template <int EPI, int MT>
+__global__ __launch_bounds__(512) void gemm_rows_pair_kernel(ResidArgs r, GemmArgs g, int nres) {
+    MG_DYN_SMEM(smem);
+    if ((int)blockIdx.x < nres) resid_block<MT, 8>(r, blockIdx.x, smem);
+    else rows_block<EPI, MT, true, 8, 16>(g, (int)blockIdx.x - nres, smem);
+}
+void gemm_rows_pair(const ResidArgs& r, const GemmArgs& g, int epi, mgStream_t stream) {
+    const int mt = (r.M + 31) / 32;
+    const int nres = r.N / 8, nrows = ((g.N + 31) / 32) * 2;
+    const dim3 grid(nres + nrows), block(512);
+    const size_t sh = (size_t)8 * 16 * 64 * sizeof(float) + (size_t)32 * mt * sizeof(float);
+#define MG_RP(MTV)                                                                                                   \
+    case MTV:                                                                                                        \
+        if (epi == EPI_PK_RELU) MG_LAUNCH((gemm_rows_pair_kernel<EPI_PK_RELU, MTV>), grid, block, sh, stream, r, g, nres); \
+        else MG_LAUNCH((gemm_rows_pair_kernel<EPI_HEADS, MTV>), grid, block, sh, stream, r, g, nres);                \
+        break;
+    switch (mt) {
+        MG_RP(1) MG_RP(2) MG_RP(3) MG_RP(4) MG_RP(5) MG_RP(6) MG_RP(7) MG_RP(8)
+        default: break;
+    }
+#undef MG_RP
+}
+
+// fp32 helpers for product weights (finalize time, not on the hot path)
+__global__ __launch_bounds__(256) void unpack_weight_kernel(const uint16_t* W, float* out, int N, int K) {
+    const size_t n_el = (size_t)N * K;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_el; i += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / K), k = (int)(i - (size_t)n * K);
+        out[i] = bf16_to_f32(W[pk_off(n, k, K)]);
+    }
+}
+void unpack_weight(const uint16_t* W_pk, float* out, int N, int K, mgStream_t stream) {
+    MG_LAUNCH(unpack_weight_kernel, dim3(1024), dim3(256), 0, stream, W_pk, out, N, K);
+}
+// 32x32 output tile per workgroup, 16x16 threads with 2x2 outputs each, k staged through LDS in chunks of 32
+__global__ __launch_bounds__(256) void gemm_f32_scaled_kernel(const float* A, const float* gain, const float* B, float* C, int N, int K,
+                                                         int J, int ldc) {
+    MG_DYN_SMEM(smem);
+    float* As = (float*)smem;            // [32][33]
+    float* Bs = As + 32 * 33;            // [32][33]
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int tiles_j = (J + 31) / 32;
+    const int n0 = (blockIdx.x / tiles_j) * 32, j0 = (blockIdx.x % tiles_j) * 32;
+    float c00 = 0.f, c01 = 0.f, c10 = 0.f, c11 = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        for (int e = threadIdx.x; e < 1024; e += 256) {
+            const int r = e >> 5, c = e & 31;
+            const int n = n0 + r, k = k0 + c;
+            As[r * 33 + c] = (n < N && k < K) ? A[(size_t)n * K + k] * gain[k] : 0.f;
+            const int kb = k0 + r, j = j0 + c;
+            Bs[r * 33 + c] = (kb < K && j < J) ? B[(size_t)kb * J + j] : 0.f;
+        }
+        __syncthreads();
+        for (int kk = 0; kk < 32; ++kk) {
+            const float a0 = As[(2 * ty) * 33 + kk], a1 = As[(2 * ty + 1) * 33 + kk];
+            const float b0 = Bs[kk * 33 + 2 * tx], b1 = Bs[kk * 33 + 2 * tx + 1];
+            c00 += a0 * b0; c01 += a0 * b1; c10 += a1 * b0; c11 += a1 * b1;
+        }
+        __syncthreads();
+    }
+    const int n = n0 + 2 * ty, j = j0 + 2 * tx;
+    if (n < N && j < J) C[(size_t)n * ldc + j] = c00;
+    if (n < N && j + 1 < J) C[(size_t)n * ldc + j + 1] = c01;
+    if (n + 1 < N && j < J) C[(size_t)(n + 1) * ldc + j] = c10;
+    if (n + 1 < N && j + 1 < J) C[(size_t)(n + 1) * ldc + j + 1] = c11;
+}
+void gemm_f32_scaled(const float* A, const float* gain, const float* B, float* C, int N, int K, int J, int ldc, mgStream_t stream) {
+    const int blocks = ((N + 31) / 32) * ((J + 31) / 32);
+    MG_LAUNCH(gemm_f32_scaled_kernel, dim3(blocks), dim3(256), 2 * 32 * 33 * sizeof(float), stream, A, gain, B, C, N, K, J, ldc);
+}
+__global__ __launch_bounds__(256) void scale_cols_f32_kernel(const float* A, const float* gain, float* C, int N, int J, int ldc) {
+    const size_t n_el = (size_t)N * J;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_el; i += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / J), j = (int)(i - (size_t)n * J);
+        C[(size_t)n * ldc + j] = A[i] * gain[j];
+    }
+}
+void scale_cols_f32(const float* A, const float* gain, float* C, int N, int J, int ldc, mgStream_t stream) {
+    MG_LAUNCH(scale_cols_f32_kernel, dim3(1024), dim3(256), 0, stream, A, gain, C, N, J, ldc);
 }
 
 int splitk_factor(int N, int K) {

@@ -53,6 +53,9 @@ struct GemmArgs {
     uint16_t* out_pk;
     HeadsOut heads;
     RowScale rs;           // decode-step kernels only
+    // decode-step kernels: X may be a column window of a wider packed buffer: x_kts = 16-wide k-tiles per row tile of
+    // the buffer (0 = K/16), x_k0 = first k-tile of the window
+    int x_kts, x_k0;
 };
 void gemm(const GemmArgs& a, int epi, mgStream_t stream);
 void gemm_set_variant(int v);   // 0: 128x128 two-stage tile kernel only; 1 (default): 256x128 three-stage kernel for M >= 256
@@ -70,6 +73,35 @@ void gemm_rows_splitk(const uint16_t* X, const uint16_t* W, float* P, int M, int
 // One workgroup per 8 output features (complete sums, deterministic), K split over the workgroup's waves.
 void gemm_rows_resid(const uint16_t* X, const uint16_t* W, float* h, const float* gain, float gscale, uint16_t* x_pk, float* part,
                      int M, int N, int K, const RowScale& rs, mgStream_t stream);
+// general form: X as a column window (x_kts / x_k0 as in GemmArgs); two optional packed bf16 outputs, each a column
+// window (ld = columns of the destination buffer, col0 = first column): x_pk = bf16(h * gain * gscale), x2_pk = bf16(h)
+struct ResidArgs {
+    const uint16_t* X;
+    int x_kts, x_k0;
+    const uint16_t* W;
+    float* h;
+    const float* gain;
+    float gscale;
+    uint16_t* x_pk;
+    int x_ld, x_col0;      // x_ld = 0: N
+    uint16_t* x2_pk;
+    int x2_ld, x2_col0;
+    float* part;
+    int M, N, K;
+    RowScale rs;
+};
+void gemm_rows_resid(const ResidArgs& r, mgStream_t stream);
+// Two independent decode projections that read the same inputs in ONE launch (they sit side by side in the grid):
+// the residual projection `r` and the projection `g` (epilogue EPI_HEADS or EPI_PK_RELU, half-tile workgroups).
+// Used with product weights: g's X is the window [bf16(h_before) | ctx] and its W = [Wn·G | Wn·G·Wr], so that
+// g = Wn·G·(h_before + Wr·ctx) = Wn·G·h_after without waiting for r's result (see engine.hip, decode step).
+void gemm_rows_pair(const ResidArgs& r, const GemmArgs& g, int epi, mgStream_t stream);
+// fp32 helpers for building product weights at finalize time
+void unpack_weight(const uint16_t* W_pk, float* out, int N, int K, mgStream_t stream);          // out[n][k] row-major
+// C[n][j] (ldc) = sum_k A[n][k] * gain[k] * B[k][j]   (A: [N][K] row-major, B: [K][J] row-major, fp32)
+void gemm_f32_scaled(const float* A, const float* gain, const float* B, float* C, int N, int K, int J, int ldc, mgStream_t stream);
+// C[n][j] (ldc) = A[n][j] * gain[j]
+void scale_cols_f32(const float* A, const float* gain, float* C, int N, int J, int ldc, mgStream_t stream);
 // a row-major fp32 matrix given as KS split-K partial slabs
 struct Slabs {
     const float* P;        // null = not used
@@ -163,6 +195,8 @@ struct AttnStepArgs {
     const int* anc;           // self with beams: [T_cap][rows] physical row holding position j (nullable)
     int t;                    // current position (self)
     const int* t_dev;         // if non-null: t (and n_keys = t+1 for self-attention) are read from device memory
+    RowScale qrs;             // deferred RMSNorm scale of the query rows (scores are multiplied by r(row)); part = null: none
+    int ctx_ld, ctx_col0;     // ctx as a column window of a wider packed buffer (ctx_ld = 0: H*64 columns, offset 0)
     // split-K form of the projections feeding this step: q (and for self-attention k, v of the new position) are
     // given as fp32 partial slabs [rows][ldp] with q | k | v at column offsets 0 | inner | 2*inner; the kernel sums
     // them, rounds to bf16, appends k, v to the cache at position t and attends over [0, t] (self) or the cross keys.
@@ -174,8 +208,9 @@ struct AttnStepArgs {
 void attention_step(const AttnStepArgs& a, mgStream_t stream);
 
 // h[rows][d] = tok_emb[ids[row]]
+// optionally also x_pk (packed bf16 window, x_ld columns, first column x_col0) = the embedding rows themselves
 void embed_rows(const int64_t* ids, const uint16_t* tok_emb, float* h, int rows, int d, int V, int* err,
-                mgStream_t stream);
+                mgStream_t stream, uint16_t* x_pk = nullptr, int x_ld = 0, int x_col0 = 0);
 
 struct ArgmaxArgs {
     const float* logits;     // [rows][ldl]
