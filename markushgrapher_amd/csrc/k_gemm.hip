@@ -388,19 +388,28 @@ MG_DEV void rows_block(const GemmArgs& a, int bid, char* smem) {
     const int k0 = w * per, k1 = (k0 + per) < kt16 ? (k0 + per) : kt16;
     constexpr bool TOR = !(EPI == EPI_F32_STORE || EPI == EPI_F32_RESID);
     float* rsl = (float*)(smem + NW * 16 * 64 * sizeof(float));     // [32*MT] deferred RMSNorm scale per row
+    const char* wp = (const char*)(a.W + pk_tile_off(nt, 0, a.K)) + lane * 16;
+    const int xkts = a.x_kts ? a.x_kts : kt16;
+    const char* xp = (const char*)a.X + ((size_t)a.x_k0 * TILE_BYTES + lane * 16);
+    // the first round of the weight stream (HBM) is issued before anything else, so that the L2 round trip of the row
+    // scales overlaps it instead of preceding it
+    int kt = k0;
+    uint4 wf[U];
+    const bool first_full = kt + U <= k1;
+    if (first_full) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) wf[u] = wvalid ? ld16_stream(wp + (size_t)(kt + u) * TILE_BYTES) : zero4;
+    }
     if (TOR) block_row_scales(a.rs, a.M, 32 * MT, rsl, tid, NW * 64);
 
     f32x16 acc[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) acc[i] = acc_zero();
-    const char* wp = (const char*)(a.W + pk_tile_off(nt, 0, a.K)) + lane * 16;
-    const int xkts = a.x_kts ? a.x_kts : kt16;
-    const char* xp = (const char*)a.X + ((size_t)a.x_k0 * TILE_BYTES + lane * 16);
-    int kt = k0;
-    for (; kt + U <= k1; kt += U) {
-        uint4 wf[U];
+    for (bool first = true; kt + U <= k1; kt += U, first = false) {
+        if (!first) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) wf[u] = wvalid ? ld16_stream(wp + (size_t)(kt + u) * TILE_BYTES) : zero4;
+            for (int u = 0; u < U; ++u) wf[u] = wvalid ? ld16_stream(wp + (size_t)(kt + u) * TILE_BYTES) : zero4;
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
@@ -547,19 +556,32 @@ MG_DEV void resid_block(const ResidArgs& a, int bid, char* smem) {
     const int per = (kt16 + NW - 1) / NW;
     const int k0 = w * per, k1 = (k0 + per) < kt16 ? (k0 + per) : kt16;
     float* rsl = (float*)(smem + NW * 4 * 64 * sizeof(float));     // [32*MT]
-    block_row_scales(a.rs, M, 32 * MT, rsl, tid, NW * 64);
-    f32x16 acc[MT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) acc[i] = acc_zero();
     const char* wp = (const char*)(a.W + pk_tile_off(nt, 0, a.K)) + lane * 16;
     const int xkts = a.x_kts ? a.x_kts : kt16;
     const char* xp = (const char*)a.X + ((size_t)a.x_k0 * TILE_BYTES + lane * 16);
     constexpr int U = (NW >= 16) ? 16 : 8;       // the wide (K = d_ff) form keeps its whole K share in flight at once
+    // first round of the weight stream (HBM) first; the row scales' and the residual's L2 round trips overlap it
     int kt = k0;
-    for (; kt + U <= k1; kt += U) {
-        uint4 wf[U];
+    uint4 wf[U];
+    const bool first_full = kt + U <= k1;
+    if (first_full) {
 #pragma unroll
         for (int u = 0; u < U; ++u) wf[u] = wvalid ? ld16_stream(wp + (size_t)(kt + u) * TILE_BYTES) : zero4;
+    }
+    // the wave that finishes m-tile i (i % NW == w; MT <= NW so at most one) fetches its slice of the residual now
+    const int n0 = nt * 32 + sub * 8 + half * 4;
+    const int my_i = w < MT ? w : -1;
+    float4 h_pre = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (my_i >= 0 && 32 * my_i + l32 < M) h_pre = *(const float4*)(a.h + (size_t)(32 * my_i + l32) * N + n0);
+    block_row_scales(a.rs, M, 32 * MT, rsl, tid, NW * 64);
+    f32x16 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = acc_zero();
+    for (bool first = true; kt + U <= k1; kt += U, first = false) {
+        if (!first) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) wf[u] = wvalid ? ld16_stream(wp + (size_t)(kt + u) * TILE_BYTES) : zero4;
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
@@ -574,7 +596,6 @@ MG_DEV void resid_block(const ResidArgs& a, int bid, char* smem) {
     // D rows = features of the tile; the valid 8 (8*sub .. +7) sit in registers 4*sub .. 4*sub+3:
     // lane (row m = l32, half) holds features 8*sub + 4*half + j.  Reduce those 4 registers over the NW waves.
     float* slab = (float*)smem;                         // [NW][4][64]
-    const int n0 = nt * 32 + sub * 8 + half * 4;
     const int nparts = N >> 3;
     const int x_ld = a.x_ld ? a.x_ld : N, x2_ld = a.x2_ld ? a.x2_ld : N;
 #pragma unroll
@@ -598,7 +619,7 @@ MG_DEV void resid_block(const ResidArgs& a, int bid, char* smem) {
             const int m = 32 * i + l32;
             float ss = 0.f;
             if (m < M) {
-                float4 hv = *(const float4*)(a.h + (size_t)m * N + n0);
+                float4 hv = h_pre;
                 hv.x += v[0]; hv.y += v[1]; hv.z += v[2]; hv.w += v[3];
                 *(float4*)(a.h + (size_t)m * N + n0) = hv;
                 ss = (hv.x * hv.x + hv.y * hv.y) + (hv.z * hv.z + hv.w * hv.w);
