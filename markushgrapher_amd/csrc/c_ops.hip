@@ -120,8 +120,11 @@ int mgk_gemm_set_variant(int v) { gemm_set_variant(v); return MG_OK; }
 int mgk_gemm_resid(void* stream, const void* X_pk, const void* W_pk, float* h, const float* gain, float gscale, void* x_pk,
                    float* part, int M, int N, int K, const float* rs_part, int rs_nparts, float rs_inv_d, float rs_eps) {
     if ((K & 63) || (N & 31) || M > 256) return MG_E_SHAPE;
-    RowScale rs{rs_part, rs_nparts, rs_inv_d, rs_eps};
-    gemm_rows_resid((const uint16_t*)X_pk, (const uint16_t*)W_pk, h, gain, gscale, (uint16_t*)x_pk, part, M, N, K, rs, (mgStream_t)stream);
+    ResidArgs r{};
+    r.X = (const uint16_t*)X_pk; r.W = (const uint16_t*)W_pk; r.h = h; r.gain = gain; r.gscale = gscale; r.x_pk = (uint16_t*)x_pk;
+    r.part = part; r.M = M; r.N = N; r.K = K; r.rs = RowScale{rs_part, rs_nparts, rs_inv_d, rs_eps};
+    if (const char* e = getenv("MG_KPROBE_DBG")) r.dbg = atoi(e);      // timing experiments (tools/kprobe.py)
+    gemm_rows_resid(r, (mgStream_t)stream);
     return MG_OK;
 }
 

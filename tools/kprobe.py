@@ -1,5 +1,5 @@
-"""Probe of candidate decode-GEMM shapes under rocprofv3 (kernel durations, not host-side timing): every case is
-launched 100 times over rotating weight copies (HBM-cold); read the result with tools/rocpd_stats.py --by-grid.
+"""Probe of decode-GEMM variants under rocprofv3 (kernel durations, not host-side timing): every case is launched 100
+times over rotating weight copies (HBM-cold).  tools/kprobe_report.py prints the per-case averages.
    cd /tmp && rocprofv3 --kernel-trace -d $OUT -o probe -- python tools/kprobe.py
 """
 import ctypes as C
@@ -14,7 +14,6 @@ from markushgrapher_amd import _lib  # noqa: E402
 
 lib = _lib.load()
 dev = torch.device("cuda:0")
-EPI_F32_STORE, EPI_F32_RESID, EPI_PK_RELU, EPI_PK = 0, 1, 2, 3
 
 
 def P(t):
@@ -25,31 +24,30 @@ def st():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+CASES = [("wo2 resid full", 0), ("wo2 resid no W loads", 1), ("wo2 resid no X loads", 2), ("wo2 resid empty", 3),
+         ("wo2 resid no epilogue", 4), ("wo2 resid with rs", 10)]
+
+
 def main():
-    M = 32
-    cases = [("wi      rows relu", 4096, 1024, "rows"), ("wi'     rows relu", 4096, 2048, "rows"), ("xq'     rows pk", 1024, 2048, "rows"),
-             ("xq      rows pk", 1024, 1024, "rows"), ("o       resid", 1024, 1024, "resid"), ("o K2048 resid", 1024, 2048, "resid"),
-             ("wo2     resid", 1024, 4096, "resid")]
-    for name, N, K, kind in cases:
-        wbytes = N * K * 2
-        ncopy = max(2, min(128, int(600e6 // wbytes)))
-        W = torch.randint(-3000, 3000, (ncopy, wbytes // 2), dtype=torch.int16, device=dev)
-        X = torch.randint(-3000, 3000, (M * K,), dtype=torch.int16, device=dev)
-        out_pk = torch.empty((M * N,), dtype=torch.int16, device=dev)
-        h = torch.zeros((M, N), dtype=torch.float32, device=dev)
-        gain = torch.ones((N,), dtype=torch.float32, device=dev)
-        part = torch.zeros((M * (N // 8),), dtype=torch.float32, device=dev)
+    M, N, K = 32, 1024, 4096
+    wbytes = N * K * 2
+    ncopy = 64
+    W = torch.randint(-3000, 3000, (ncopy, wbytes // 2), dtype=torch.int16, device=dev)
+    X = torch.randint(-3000, 3000, (M * K,), dtype=torch.int16, device=dev)
+    out_pk = torch.empty((M * N,), dtype=torch.int16, device=dev)
+    h = torch.zeros((M, N), dtype=torch.float32, device=dev)
+    gain = torch.ones((N,), dtype=torch.float32, device=dev)
+    part = torch.ones((M * (N // 8),), dtype=torch.float32, device=dev)
+    part_in = torch.ones((M * (N // 8),), dtype=torch.float32, device=dev)
+    for name, dbg in CASES:
+        os.environ["MG_KPROBE_DBG"] = str(dbg if dbg < 10 else 0)
         torch.cuda.synchronize()
         for i in range(100):
-            if kind == "rows":
-                epi = EPI_PK_RELU if "relu" in name else EPI_PK
-                rc = lib.mgk_gemm(st(), 1, epi, P(X), P(W[i % ncopy]), M, N, K, None, 0, None, P(out_pk))
-            else:
-                rc = lib.mgk_gemm_resid(st(), P(X), P(W[i % ncopy]), P(h), P(gain), C.c_float(1.0), P(out_pk), P(part), M, N, K, None, 0,
-                                        C.c_float(0.0), C.c_float(0.0))
+            rs = (P(part_in), N // 8, C.c_float(1.0 / N), C.c_float(1e-6)) if dbg == 10 else (None, 0, C.c_float(0.0), C.c_float(0.0))
+            rc = lib.mgk_gemm_resid(st(), P(X), P(W[i % ncopy]), P(h), P(gain), C.c_float(1.0), P(out_pk), P(part), M, N, K, *rs)
             assert rc == 0, (name, rc)
         torch.cuda.synchronize()
-        print(name, "grid-id N", N, "K", K)
+    print("done")
 
 
 if __name__ == "__main__":
