@@ -333,6 +333,114 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmArgs a) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// large-M GEMM, 256x256x64 block tile, 8 waves as 2 (M) x 4 (N), 128x64 per wave (4x2 MFMA tiles, 128 accumulator
+// registers).  Per K-step a wave issues 24 ds_read_b128 for 32 MFMAs (0.75 LDS reads per MFMA; the 256x128 kernel
+// with 64x64 per wave needs 1.0 and is LDS-bandwidth-bound: 8 waves x 16 KiB per K-step = 1024 cycles of the CU's
+// 128 B/clk LDS port against 1024 cycles of MFMA per SIMD).  Two LDS stages of 64 KiB; the copies of K-step ks+1 are
+// issued right after the barrier of step ks and have a whole compute phase (~2048 MFMA cycles) to land.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int GX_M = 256, GX_N = 256, GX_K = 64;
+constexpr int GX_FRAGS = (GX_M + GX_N) / 32 * (GX_K / 16);      // 64 fragments per stage
+constexpr int GX_STAGE_BYTES = GX_FRAGS * TILE_BYTES;           // 64 KiB
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_xl_kernel(GemmArgs a) {
+    MG_DYN_SMEM(smem);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nbn = (a.N + GX_N - 1) / GX_N;
+    const int nbm = (a.M + GX_M - 1) / GX_M;
+    int bid = blockIdx.x;
+    const int nblk = nbm * nbn;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);   // XCD-contiguous tile ranges (speed only)
+    const int bm = bid / nbn, bn = bid - bm * nbn;
+    const int mt32 = (a.M + 31) >> 5, nt32 = (a.N + 31) >> 5;
+    const int nks = a.K / GX_K;
+
+    // loader: wave w copies fragments 8w .. 8w+7 of a stage; fragments 0..31 = X (row-tile f/4, k-tile f%4), 32..63 = W
+    const char* src[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int f = w * 8 + i;
+        const bool isW = f >= 32;
+        const int ff = isW ? f - 32 : f, rt = ff >> 2, kt = ff & 3;
+        int trow = isW ? (bn * 8 + rt) : (bm * 8 + rt);
+        const int tmax = isW ? nt32 - 1 : mt32 - 1;
+        trow = trow < tmax ? trow : tmax;
+        src[i] = (const char*)((isW ? a.W : a.X) + pk_tile_off(trow, kt, a.K)) + lane * 16;
+    }
+    auto stage = [&](int buf, int ks) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            glds16_async(src[i] + (size_t)ks * (4 * TILE_BYTES), smem + buf * GX_STAGE_BYTES + (w * 8 + i) * TILE_BYTES);
+    };
+
+    const int wr = w >> 2, wc = w & 3;
+    const int m0w = bm * GX_M + wr * 128, n0w = bn * GX_N + wc * 64;
+    bool tor;
+    if (EPI == EPI_F32_STORE || EPI == EPI_F32_RESID) tor = false;
+    else if (EPI == EPI_HEADS) tor = !heads_region_is_T(a.heads, n0w < a.N ? n0w : 0);
+    else tor = true;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = acc_zero();
+
+    stage(0, 0);
+    for (int ks = 0; ks < nks; ++ks) {
+        const int cur = ks & 1;
+        MG_WAIT_VMCNT(0);        // own copies of stage ks (issued one compute phase ago) have landed ...
+        MG_BARRIER_RAW();        // ... everybody's have, and everybody finished reading the other buffer
+        if (ks + 1 < nks) stage(cur ^ 1, ks + 1);
+        const char* xb = smem + cur * GX_STAGE_BYTES + lane * 16;
+        const char* wb = xb + 32 * TILE_BYTES;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            uint4 xf[4], wf[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) wf[j] = ld16(wb + ((wc * 2 + j) * 4 + kt) * TILE_BYTES);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xf[i] = ld16(xb + ((wr * 4 + i) * 4 + kt) * TILE_BYTES);
+            if (tor) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(wf[j], xf[i], acc[i][j]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(xf[i], wf[j], acc[i][j]);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m0 = m0w + 32 * i, n0 = n0w + 32 * j;
+            if constexpr (EPI == EPI_F32_STORE || EPI == EPI_F32_RESID) {
+                tile_epilogue<EPI, false>(a, acc[i][j], m0, n0, lane);
+            } else if constexpr (EPI == EPI_HEADS) {
+                if (tor) tile_epilogue<EPI_HEADS, true>(a, acc[i][j], m0, n0, lane);
+                else tile_epilogue<EPI_HEADS, false>(a, acc[i][j], m0, n0, lane);
+            } else {
+                tile_epilogue<EPI, true>(a, acc[i][j], m0, n0, lane);
+            }
+        }
+}
+template <int EPI>
+static void launch_xl(const GemmArgs& a, mgStream_t stream) {
+    const int nblk = ((a.M + GX_M - 1) / GX_M) * ((a.N + GX_N - 1) / GX_N);
+    const size_t sh = (size_t)2 * GX_STAGE_BYTES;
+    static bool once = false;
+    if (!once) { MG_SET_MAX_SMEM(&gemm_xl_kernel<EPI>, sh); once = true; }
+    MG_LAUNCH((gemm_xl_kernel<EPI>), dim3(nblk), dim3(512), sh, stream, a);
+}
+
 template <int EPI>
 static void launch_wide(const GemmArgs& a, mgStream_t stream) {
     const int nblk = ((a.M + GW_M - 1) / GW_M) * ((a.N + GW_N - 1) / GW_N);
@@ -342,11 +450,26 @@ static void launch_wide(const GemmArgs& a, mgStream_t stream) {
     MG_LAUNCH((gemm_wide_kernel<EPI>), dim3(nblk), dim3(512), sh, stream, a);
 }
 
-static int g_gemm_variant = 1;     // 0: 128x128 two-stage kernel, 1: 256x128 three-stage kernel for M >= 256
+// 0: 128x128 two-stage kernel only; 1: + 256x128 three-stage kernel for M >= 256; 2: + 256x256 kernel wherever it fits;
+// 3 (default): 256x256 for wide outputs (N >= 2048: QKV, FFN wi, cross-K/V), 256x128 for N = d_model (measured:
+// 0.90-1.06 vs 0.73-0.91 PFLOP/s on the wide ones, 0.43-0.68 vs 0.46-0.70 on the narrow ones)
+static int g_gemm_variant = 3;
 void gemm_set_variant(int v) { g_gemm_variant = v; }
 
 void gemm(const GemmArgs& a, int epi, mgStream_t stream) {
-    if (g_gemm_variant == 1 && a.M >= GW_M) {
+    static bool env_read = false;
+    if (!env_read) { env_read = true; if (const char* e = getenv("MG_GEMM_VARIANT")) g_gemm_variant = atoi(e); }   // A/B runs
+    if ((g_gemm_variant == 2 || (g_gemm_variant == 3 && a.N >= 2048)) && a.M >= GX_M && a.N >= GX_N) {
+        switch (epi) {
+            case EPI_F32_STORE: launch_xl<EPI_F32_STORE>(a, stream); break;
+            case EPI_F32_RESID: launch_xl<EPI_F32_RESID>(a, stream); break;
+            case EPI_PK_RELU: launch_xl<EPI_PK_RELU>(a, stream); break;
+            case EPI_PK: launch_xl<EPI_PK>(a, stream); break;
+            default: launch_xl<EPI_HEADS>(a, stream); break;
+        }
+        return;
+    }
+    if (g_gemm_variant >= 1 && a.M >= GW_M) {
         switch (epi) {
             case EPI_F32_STORE: launch_wide<EPI_F32_STORE>(a, stream); break;
             case EPI_F32_RESID: launch_wide<EPI_F32_RESID>(a, stream); break;

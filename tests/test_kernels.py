@@ -74,6 +74,45 @@ def test_gemm_packed_relu(be_name, mode, M, N, K):
 
 
 @pytest.mark.parametrize("be_name", BACKENDS)
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 520, 128), (512, 384, 192)])
+def test_gemm_256x256_tile_kernel(be_name, M, N, K):
+    """variant 2: the 256x256x64 two-stage kernel (ragged edges in M and N, several K-steps), all epilogue families."""
+    be = get_backend(be_name)
+    be.lib.mgk_gemm_set_variant(2)
+    try:
+        x, w = rnd((M, K), 31), rnd((N, K), 32, 0.3)
+        bias = rnd((N,), 33)
+        ref = pk.bf16_round(x) @ pk.bf16_round(w).T
+        X, W = be.buf(pk.pack_tiles(x)), be.buf(pk.pack_tiles(w))
+        out = be.zeros((M, N), np.float32)
+        bb = be.buf(bias)
+        assert be.lib.mgk_gemm(be.stream, 0, EPI_F32_STORE, be.p(X), be.p(W), M, N, K, be.p(out), N, be.p(bb), None) == 0
+        np.testing.assert_allclose(out.numpy(), ref + bias, rtol=1e-4, atol=1e-4)
+        h0 = rnd((M, N), 34)
+        h = be.buf(h0)
+        assert be.lib.mgk_gemm(be.stream, 0, EPI_F32_RESID, be.p(X), be.p(W), M, N, K, be.p(h), N, None, None) == 0
+        np.testing.assert_allclose(h.numpy(), h0 + ref, rtol=1e-4, atol=1e-4)
+        Mp = (M + 31) // 32 * 32
+        if N % 16 == 0:
+            outp = be.zeros((Mp * N,), np.uint16)
+            assert be.lib.mgk_gemm(be.stream, 0, EPI_PK_RELU, be.p(X), be.p(W), M, N, K, None, 0, None, be.p(outp)) == 0
+            np.testing.assert_allclose(pk.unpack_tiles(outp.numpy(), M, N), np.maximum(ref, 0), rtol=1.0 / 128, atol=1e-3)
+        if M % 64 == 0 and N % 384 == 0:      # per-head epilogue: Q, K packed rows, V packed transposed
+            S, H = 64, N // 192
+            B = M // S
+            q, k, v = (be.zeros((B * H * S * 64,), np.uint16) for _ in range(3))
+            rc = be.lib.mgk_gemm_heads(be.stream, 0, be.p(X), be.p(W), M, N, K, be.p(q), be.p(k), be.p(v),
+                                       HF_PK_ROWS, HF_PK_ROWS, HF_PK_T, H, S, S, None, 0)
+            assert rc == 0
+            r5 = ref.reshape(B, S, 3, H, 64).transpose(2, 0, 3, 1, 4)
+            np.testing.assert_allclose(pk.unpack_heads_rows(q.numpy(), B, H, S), r5[0], rtol=1 / 128, atol=1e-3)
+            np.testing.assert_allclose(pk.unpack_heads_rows(k.numpy(), B, H, S), r5[1], rtol=1 / 128, atol=1e-3)
+            np.testing.assert_allclose(pk.unpack_heads_t(v.numpy(), B, H, S), r5[2], rtol=1 / 128, atol=1e-3)
+    finally:
+        be.lib.mgk_gemm_set_variant(3)
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
 @pytest.mark.parametrize("Bn", [2, 5])      # M = 128 -> 128x128 kernel, M = 320 -> 256x128 three-stage kernel
 def test_gemm_heads_flash_layout(be_name, Bn):
     """QKV projection of the encoder: Q,K packed rows, V packed transposed, per (b,h)."""

@@ -60,6 +60,24 @@ def bench_gemm():
                   f"{us:7.2f} us  {wbytes / us / 1e3:7.1f} GB/s")
 
 
+def bench_encgemm():
+    """Encoder-sized GEMMs (M = 32 images x 1280 positions): 256x128 three-stage kernel (variant 1) vs 256x256 (variant 2)."""
+    M = 40960
+    for name, N, K, epi in [("qkv", 3072, 1024, 3), ("o", 1024, 1024, 1), ("wi", 4096, 1024, 2), ("wo", 1024, 4096, 1), ("xkv", 2048, 1024, 3)]:
+        X = torch.randint(-3000, 3000, (M * K,), dtype=torch.int16, device=dev)
+        W = torch.randint(-3000, 3000, (N * K,), dtype=torch.int16, device=dev)
+        out_pk = torch.empty((M * N,), dtype=torch.int16, device=dev)
+        out_f = torch.zeros((M, N), dtype=torch.float32, device=dev) if epi == 1 else None
+        for variant in (1, 2):
+            lib.mgk_gemm_set_variant(variant)
+
+            def f(i):
+                lib.mgk_gemm(stream(), 0, epi, P(X), P(W), M, N, K, P(out_f), N, None, P(out_pk))
+            us = timeit(f, iters=20, warm=3)
+            print(f"enc gemm {name:4s} M={M} N={N:5d} K={K:4d} variant {variant}: {us:8.1f} us  {2.0 * M * N * K / us / 1e9:7.3f} PFLOP/s")
+    lib.mgk_gemm_set_variant(3)
+
+
 def bench_attn():
     B, H, cap = 32, 16, 1280
     for name, group, lens in [("cross", 1, 1072), ("cross-warm", 1, 1072), ("cross-full", 1, 1280), ("self t=128", 0, 129), ("self t=400", 0, 401)]:
@@ -107,6 +125,8 @@ if __name__ == "__main__":
     what = sys.argv[1:] or ["gemm", "attn", "norm"]
     if "gemm" in what:
         bench_gemm()
+    if "encgemm" in sys.argv:
+        bench_encgemm()
     if "attn" in what:
         bench_attn()
     if "norm" in what:
