@@ -123,7 +123,6 @@ int mgk_gemm_resid(void* stream, const void* X_pk, const void* W_pk, float* h, c
     ResidArgs r{};
     r.X = (const uint16_t*)X_pk; r.W = (const uint16_t*)W_pk; r.h = h; r.gain = gain; r.gscale = gscale; r.x_pk = (uint16_t*)x_pk;
     r.part = part; r.M = M; r.N = N; r.K = K; r.rs = RowScale{rs_part, rs_nparts, rs_inv_d, rs_eps};
-    if (const char* e = getenv("MG_KPROBE_DBG")) r.dbg = atoi(e);      // timing experiments (tools/kprobe.py)
     gemm_rows_resid(r, (mgStream_t)stream);
     return MG_OK;
 }

@@ -672,8 +672,7 @@ MG_DEV void resid_block(const ResidArgs& a, int bid, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int half = lane >> 5, l32 = lane & 31;
     const int nt = bid >> 2, sub = bid & 3;
-    if (a.dbg == 3) return;
-    const bool wvalid = ((l32 >> 3) == sub) && a.dbg != 1;
+    const bool wvalid = (l32 >> 3) == sub;
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
     const int M = a.M, N = a.N;
     const int kt16 = a.K >> 4;
@@ -709,8 +708,7 @@ MG_DEV void resid_block(const ResidArgs& a, int bid, char* smem) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
-                acc[i] = mfma32(wf[u], a.dbg == 2 ? zero4 : ld16(xp + ((size_t)i * xkts + (kt + u)) * TILE_BYTES), acc[i]);
+            for (int i = 0; i < MT; ++i) acc[i] = mfma32(wf[u], ld16(xp + ((size_t)i * xkts + (kt + u)) * TILE_BYTES), acc[i]);
         }
     }
     for (; kt < k1; ++kt) {
@@ -718,7 +716,6 @@ MG_DEV void resid_block(const ResidArgs& a, int bid, char* smem) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) acc[i] = mfma32(wf, ld16(xp + ((size_t)i * xkts + kt) * TILE_BYTES), acc[i]);
     }
-    if (a.dbg == 4) { if (acc[0][0] == 12345.f) a.part[0] = 1.f; return; }
     // D rows = features of the tile; the valid 8 (8*sub .. +7) sit in registers 4*sub .. 4*sub+3:
     // lane (row m = l32, half) holds features 8*sub + 4*half + j.  Reduce those 4 registers over the NW waves.
     float* slab = (float*)smem;                         // [NW][4][64]

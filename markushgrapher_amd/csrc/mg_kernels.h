@@ -89,7 +89,6 @@ struct ResidArgs {
     float* part;
     int M, N, K;
     RowScale rs;
-    int dbg;               // timing experiments only (tools/kprobe.py): 1 no weight loads, 2 no X loads, 3 empty, 4 no epilogue
 };
 void gemm_rows_resid(const ResidArgs& r, mgStream_t stream);
 // Two independent decode projections that read the same inputs in ONE launch (they sit side by side in the grid):
