@@ -102,6 +102,9 @@ int mg_beam_reorder(void* stream, const void* kv_src, void* kv_dst, const int32_
  * summed duration and the summed number of (image, key) rows each of them streamed (bytes = rows * H * 64 * 2 * 2). */
 int mg_profile_cross_attention(mg_model* m, int every, int max_samples);
 int mg_profile_read(mg_model* m, long* launches_host, double* total_ms_host, double* total_keys_host);
+/* Calibration of the bracket: after every timed launch a third event is recorded right behind the second; this returns
+ * the summed duration of those EMPTY brackets (what two hipEventRecord cost on the stream with nothing in between). */
+int mg_profile_read_overhead(mg_model* m, double* empty_ms_host);
 int mg_debug_bucket_table(const mg_model* m, int which, int* out_host, int n);
 
 /* Decode-step replay. The ~200 launches of one decode step (the body of the reference's generation loop,

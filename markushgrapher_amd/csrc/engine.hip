@@ -79,6 +79,7 @@ struct mg_model {
     std::vector<mgEvent_t> prof_ev;
     size_t prof_used = 0;
     double prof_ms = 0.0;
+    double prof_empty_ms = 0.0;   // summed duration of the empty event brackets recorded right after each timed launch
     long prof_n = 0;
     double prof_keys = 0.0;   // sum over timed launches of the number of (image, key) pairs streamed
     // one decode step captured as a HIP graph (greedy and beam); replayed while its key matches the call
@@ -801,10 +802,14 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
             AttnStepArgs x{};
             x.q = w.dq; x.qrs = rs1; x.Kc = w.xk + li * xkv_stride; x.Vc = w.xv + li * xkv_stride; x.ctx = w.xb; x.ctx_ld = K2;
             x.ctx_col0 = d; x.rows = R; x.H = H; x.group = K; x.cap = S_cap; x.len = w.xlen;
-            const bool timed = !tdev && m->prof_every > 0 && (t % m->prof_every) == 0 && m->prof_used + 2 <= m->prof_ev.size();
+            const bool timed = !tdev && m->prof_every > 0 && (t % m->prof_every) == 0 && m->prof_used + 3 <= m->prof_ev.size();
             if (timed) mg_event_record(m->prof_ev[m->prof_used], st);
             attention_step(x, st);
-            if (timed) { mg_event_record(m->prof_ev[m->prof_used + 1], st); m->prof_used += 2; }
+            if (timed) {   // third event right behind the second: the empty bracket calibrates what two records alone cost
+                mg_event_record(m->prof_ev[m->prof_used + 1], st);
+                mg_event_record(m->prof_ev[m->prof_used + 2], st);
+                m->prof_used += 3;
+            }
             {   // h += Wxo·ctx_x (partials -> rs2)   |   y = relu(wi·...) un-normalised -> dy_pk
                 ResidArgs r{};
                 r.X = w.xb; r.x_kts = kts2; r.x_k0 = kt_ctx; r.W = m->at<uint16_t>(l.xo); r.h = w.dh; r.part = w.rs_part2;
@@ -898,8 +903,9 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
     if (m->prof_used) {
         double keys = 0.0;
         for (int b = 0; b < B; ++b) keys += xlen_host[b];
-        for (size_t i = 0; i + 1 < m->prof_used; i += 2) {
+        for (size_t i = 0; i + 2 < m->prof_used; i += 3) {
             m->prof_ms += mg_event_elapsed_ms(m->prof_ev[i], m->prof_ev[i + 1]);
+            m->prof_empty_ms += mg_event_elapsed_ms(m->prof_ev[i + 1], m->prof_ev[i + 2]);
             m->prof_n += 1;
             m->prof_keys += keys;
         }
@@ -918,8 +924,8 @@ int mg_profile_cross_attention(mg_model* m, int every, int max_samples) {
     for (mgEvent_t e : m->prof_ev) mg_event_destroy(e);
     m->prof_ev.clear();
     m->prof_every = every;
-    m->prof_used = 0; m->prof_ms = 0.0; m->prof_n = 0; m->prof_keys = 0.0;
-    for (int i = 0; every > 0 && i < 2 * max_samples; ++i) {
+    m->prof_used = 0; m->prof_ms = 0.0; m->prof_empty_ms = 0.0; m->prof_n = 0; m->prof_keys = 0.0;
+    for (int i = 0; every > 0 && i < 3 * max_samples; ++i) {
         mgEvent_t e;
         if (mg_event_create(&e) != 0) return fail(MG_E_HIP, "hipEventCreate failed");
         m->prof_ev.push_back(e);
@@ -940,6 +946,13 @@ int mg_profile_read(mg_model* m, long* launches, double* total_ms, double* total
     if (launches) *launches = m->prof_n;
     if (total_ms) *total_ms = m->prof_ms;
     if (total_keys) *total_keys = m->prof_keys;
+    return MG_OK;
+}
+// summed duration of the EMPTY event brackets (two hipEventRecord back to back) recorded after each timed launch:
+// what the bracket itself costs on this stream, to be subtracted from total_ms for the kernel's own duration
+int mg_profile_read_overhead(mg_model* m, double* empty_ms) {
+    if (!m || !empty_ms) return fail(MG_E_ARG, "mg_profile_read_overhead: null argument");
+    *empty_ms = m->prof_empty_ms;
     return MG_OK;
 }
 
