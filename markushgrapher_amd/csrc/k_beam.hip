@@ -11,7 +11,7 @@ namespace mg {
 
 struct BeamLayout {
     size_t running_seq, sequences, top_seq, tmp_seq, tmp_idx, running_scores, beam_scores, topv, topi, is_fin, heur, run_idx, beam_idx_out,
-        top_run_idx, flags, total;
+        top_run_idx, flags, rowv, rowi, total;
 };
 static BeamLayout beam_layout(int B, int K, int max_len) {
     BeamLayout l;
@@ -33,6 +33,8 @@ static BeamLayout beam_layout(int B, int K, int max_len) {
     l.beam_idx_out = take((size_t)B * K * il * 4);
     l.top_run_idx = take((size_t)B * 2 * K * il * 4);
     l.flags = take((size_t)B * 4 * 4);
+    l.rowv = take((size_t)B * K * 2 * K * 4);      // per (image, beam) row: its own top-2K candidates
+    l.rowi = take((size_t)B * K * 2 * K * 4);
     l.total = (off + 255) / 256 * 256;
     return l;
 }
@@ -45,6 +47,8 @@ struct BeamPtrs {
     int* topi;
     uint8_t *is_fin, *heur;
     int *run_idx, *beam_idx_out, *top_run_idx, *flags;
+    float* rowv;
+    int* rowi;
 };
 static BeamPtrs beam_ptrs(void* state, int B, int K, int max_len) {
     const BeamLayout l = beam_layout(B, K, max_len);
@@ -55,7 +59,7 @@ static BeamPtrs beam_ptrs(void* state, int B, int K, int max_len) {
     p.running_scores = (float*)(s + l.running_scores); p.beam_scores = (float*)(s + l.beam_scores); p.topv = (float*)(s + l.topv);
     p.topi = (int*)(s + l.topi); p.is_fin = (uint8_t*)(s + l.is_fin); p.heur = (uint8_t*)(s + l.heur);
     p.run_idx = (int*)(s + l.run_idx); p.beam_idx_out = (int*)(s + l.beam_idx_out); p.top_run_idx = (int*)(s + l.top_run_idx);
-    p.flags = (int*)(s + l.flags);
+    p.flags = (int*)(s + l.flags); p.rowv = (float*)(s + l.rowv); p.rowi = (int*)(s + l.rowi);
     return p;
 }
 
@@ -96,59 +100,88 @@ void beam_init(void* state, int B, int K, int max_len, int pad, int eos, int sta
 
 MG_DEV bool cand_before(float v1, int i1, float v2, int i2) { return v1 > v2 || (v1 == v2 && i1 < i2); }
 
-// block-wide reductions through LDS (256 threads)
-MG_DEV float block_max(float v, float* red, int tid) {
+// a. log-probs + running scores (utils.py:3388-3396), b. top-2K over K*V (utils.py:3077-3130), in two steps:
+//  1. one workgroup of 1024 threads per (image, beam) row: log-softmax statistics, then that row's own top-2K by 2K
+//     rounds of block-wide selection over values held in registers (at most 2K of the image's top-2K come from one row);
+//  2. one workgroup per image ranks the K*2K row candidates (value descending, flat index ascending - torch.topk's
+//     order for distinct values) and keeps the first 2K.
+constexpr int BT_THREADS = 1024, BT_NPT = 40;     // register-resident path for V <= 40960, generic loop beyond
+MG_DEV float block_max16(float v, float* red, int tid) {
     v = wave_max(v);
     if ((tid & 63) == 0) red[tid >> 6] = v;
     __syncthreads();
-    const float r = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float r = red[0];
+    for (int i = 1; i < BT_THREADS / 64; ++i) r = fmaxf(r, red[i]);
     __syncthreads();
     return r;
 }
-MG_DEV float block_sum(float v, float* red, int tid) {
+MG_DEV float block_sum16(float v, float* red, int tid) {
     v = wave_sum(v);
     if ((tid & 63) == 0) red[tid >> 6] = v;
     __syncthreads();
-    const float r = (red[0] + red[1]) + (red[2] + red[3]);
+    float r = 0.f;
+    for (int i = 0; i < BT_THREADS / 64; ++i) r += red[i];
     __syncthreads();
     return r;
 }
-
-// a. log-probs + running scores, b. top-2K over K*V by 2K rounds of block-wide selection
-template <int KMAX>
-__global__ __launch_bounds__(256) void beam_topk_kernel(BeamPtrs p, const float* logits, int ldl, int V, int K, int cur_len_arg, int eos,
-                                                   int min_len, const int* counters, const int* tdev) {
+__global__ __launch_bounds__(BT_THREADS) void beam_row_topk_kernel(BeamPtrs p, const float* logits, int ldl, int V, int K, int cur_len_arg,
+                                                              int eos, int min_len, const int* counters, const int* tdev) {
     if (counters[0] == 0) return;
     const int cur_len = tdev ? *tdev + 1 : cur_len_arg;
     MG_DYN_SMEM(smem);
-    float* red = (float*)smem;            // [4]
-    float* rmax = red + 4;                // [KMAX]
-    float* rlse = rmax + KMAX;            // [KMAX]
-    float* selv = rlse + KMAX;            // [4]
-    int* seli = (int*)(selv + 4);         // [4]
-    const int b = blockIdx.x, tid = threadIdx.x;
+    float* red = (float*)smem;            // [16]
+    float* selv = red + 16;               // [16]
+    int* seli = (int*)(selv + 16);        // [16]
+    const int row = blockIdx.x, k = row % K, tid = threadIdx.x;
     const bool no_eos = cur_len < min_len;
-    for (int k = 0; k < K; ++k) {
-        const float* lg = logits + (size_t)(b * K + k) * ldl;
-        float mx = -3.0e38f;
-        for (int v = tid; v < V; v += 256) mx = fmaxf(mx, lg[v]);
-        mx = block_max(mx, red, tid);
-        float s = 0.f;
-        for (int v = tid; v < V; v += 256) s += expf(lg[v] - mx);
-        s = block_sum(s, red, tid);
-        if (tid == 0) { rmax[k] = mx; rlse[k] = logf(s); }
+    const float* lg = logits + (size_t)row * ldl;
+    const bool in_regs = V <= BT_THREADS * BT_NPT;
+    float x[BT_NPT];
+    float mx = -3.0e38f;
+    if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < BT_NPT; ++j) {
+            const int v = tid + j * BT_THREADS;
+            x[j] = v < V ? lg[v] : -3.0e38f;
+            mx = fmaxf(mx, x[j]);
+        }
+    } else {
+        for (int v = tid; v < V; v += BT_THREADS) mx = fmaxf(mx, lg[v]);
     }
-    __syncthreads();
+    mx = block_max16(mx, red, tid);
+    float s = 0.f;
+    if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < BT_NPT; ++j) s += (tid + j * BT_THREADS < V) ? expf(x[j] - mx) : 0.f;
+    } else {
+        for (int v = tid; v < V; v += BT_THREADS) s += expf(lg[v] - mx);
+    }
+    s = block_sum16(s, red, tid);
+    const float lse = logf(s), rs = p.running_scores[row];
+    if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < BT_NPT; ++j) {
+            const int v = tid + j * BT_THREADS;
+            float lp = (x[j] - mx) - lse;
+            if (no_eos && v == eos) lp = -INFINITY;
+            x[j] = v < V ? lp + rs : -INFINITY;
+        }
+    }
     float lastv = 3.0e38f;
     int lasti = -1;
     const int keep = 2 * K;
     for (int round = 0; round < keep; ++round) {
-        float bv = -3.0e38f;
+        float bv = -INFINITY;
         int bi = 0x7fffffff;
-        for (int k = 0; k < K; ++k) {
-            const float* lg = logits + (size_t)(b * K + k) * ldl;
-            const float mx = rmax[k], lse = rlse[k], rs = p.running_scores[b * K + k];
-            for (int v = tid; v < V; v += 256) {
+        if (in_regs) {
+#pragma unroll
+            for (int j = 0; j < BT_NPT; ++j) {
+                const int v = tid + j * BT_THREADS;
+                const int idx = k * V + v;
+                if (v < V && cand_before(lastv, lasti, x[j], idx) && cand_before(x[j], idx, bv, bi)) { bv = x[j]; bi = idx; }
+            }
+        } else {
+            for (int v = tid; v < V; v += BT_THREADS) {
                 float lp = (lg[v] - mx) - lse;
                 if (no_eos && v == eos) lp = -INFINITY;
                 const float val = lp + rs;
@@ -156,7 +189,6 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(BeamPtrs p, const float*
                 if (cand_before(lastv, lasti, val, idx) && cand_before(val, idx, bv, bi)) { bv = val; bi = idx; }
             }
         }
-        // wave then block argmax in (value desc, index asc) order
 #pragma unroll
         for (int step = 1; step < 64; step <<= 1) {
             const float ov = __shfl_xor(bv, step);
@@ -165,11 +197,26 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(BeamPtrs p, const float*
         }
         if ((tid & 63) == 0) { selv[tid >> 6] = bv; seli[tid >> 6] = bi; }
         __syncthreads();
-        for (int ww = 0; ww < 4; ++ww)
+        for (int ww = 0; ww < BT_THREADS / 64; ++ww)
             if (cand_before(selv[ww], seli[ww], bv, bi)) { bv = selv[ww]; bi = seli[ww]; }
         __syncthreads();
         lastv = bv; lasti = bi;
-        if (tid == 0) { p.topv[b * keep + round] = bv; p.topi[b * keep + round] = bi; }
+        if (tid == 0) { p.rowv[(size_t)row * keep + round] = bv; p.rowi[(size_t)row * keep + round] = bi; }
+    }
+}
+// rank of every row candidate among the image's K*2K; ranks < 2K are the image's top-2K in order
+__global__ __launch_bounds__(128) void beam_merge_topk_kernel(BeamPtrs p, int K, const int* counters) {
+    if (counters[0] == 0) return;
+    MG_DYN_SMEM(smem);
+    const int b = blockIdx.x, tid = threadIdx.x, keep = 2 * K, n = K * keep;
+    float* cv = (float*)smem;             // [128]
+    int* ci = (int*)(cv + 128);           // [128]
+    if (tid < n) { cv[tid] = p.rowv[(size_t)b * n + tid]; ci[tid] = p.rowi[(size_t)b * n + tid]; }
+    __syncthreads();
+    if (tid < n) {
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += cand_before(cv[j], ci[j], cv[tid], ci[tid]) ? 1 : 0;
+        if (rank < keep) { p.topv[b * keep + rank] = cv[tid]; p.topi[b * keep + rank] = ci[tid]; }
     }
 }
 
@@ -326,7 +373,8 @@ void beam_step(void* state, const float* logits, int ldl, int V, int B, int K, i
                const float* div_table, int eos, int min_len, float length_penalty, int early_stopping, int64_t* next_ids,
                int* beam_idx, int* counters, mgStream_t stream) {
     const BeamPtrs p = beam_ptrs(state, B, K, max_len);
-    MG_LAUNCH((beam_topk_kernel<8>), dim3(B), dim3(256), 256, stream, p, logits, ldl, V, K, cur_len, eos, min_len, (const int*)counters, tdev);
+    MG_LAUNCH(beam_row_topk_kernel, dim3(B * K), dim3(BT_THREADS), 256, stream, p, logits, ldl, V, K, cur_len, eos, min_len, (const int*)counters, tdev);
+    MG_LAUNCH(beam_merge_topk_kernel, dim3(B), dim3(128), 1024, stream, p, K, (const int*)counters);
     const float div = beam_length_divisor(cur_len, length_penalty);
     MG_LAUNCH(beam_update_kernel, dim3(B), dim3(256), 1024, stream, p, B, K, V, max_len, cur_len, eos, div, tdev ? div_table : nullptr,
               early_stopping, next_ids, beam_idx, (const int*)counters, tdev);

@@ -228,15 +228,17 @@ void attention_step(const AttnStepArgs& a, mgStream_t stream) {
     const int G = a.group;
     const int owners = (a.rows + G - 1) / G;
     const dim3 grid(owners * a.H);
-    // long streams (cross-attention over ~1000+ keys) use 8 waves per (image, head) for more loads in flight per CU;
-    // the short self-attention streams (<= 512 keys) use 4
-    const bool wide = a.len != nullptr;
-    const int NW = wide ? 8 : 4;
+    // 8 waves per (row or image, head) - 128 keys per round, more loads in flight per CU - unless the grid alone fills
+    // the chip with the short self-attention streams (beam search: rows x heads >= 1024 workgroups), where 4 waves
+    // win.  Measured end to end: greedy B=32 (512 workgroups) 8 waves +1.2 % over 4, 16 waves -3 %; beam-5 (2560
+    // workgroups) 4 waves +4 % over 8.
+    const bool eight = a.len != nullptr || grid.x < 1024;
+    const int NW = eight ? 8 : 4;
     const dim3 block(NW * 64);
     const size_t sh = (size_t)NW * G * 8 * 10 * sizeof(float);
 #define MG_AS(GG)                                                                                         \
     case GG:                                                                                              \
-        if (wide) MG_LAUNCH((attn_step_kernel<GG, 8>), grid, block, sh, stream, a);                       \
+        if (eight) MG_LAUNCH((attn_step_kernel<GG, 8>), grid, block, sh, stream, a);                      \
         else MG_LAUNCH((attn_step_kernel<GG, 4>), grid, block, sh, stream, a);                            \
         break;
     switch (G) {

@@ -682,7 +682,9 @@ MG_DEV void resid_block(const ResidArgs& a, int bid, char* smem) {
     const char* wp = (const char*)(a.W + pk_tile_off(nt, 0, a.K)) + lane * 16;
     const int xkts = a.x_kts ? a.x_kts : kt16;
     const char* xp = (const char*)a.X + ((size_t)a.x_k0 * TILE_BYTES + lane * 16);
-    constexpr int U = (NW >= 16) ? 16 : 8;       // the wide (K = d_ff) form keeps its whole K share in flight at once
+    // the wide (K = d_ff) form keeps its whole K share in flight at once - while the accumulators of the live m-tiles
+    // leave room for it (1024 threads: 128 registers per lane; with 3+ m-tiles sixteen fragments spill to scratch)
+    constexpr int U = (NW >= 16 && MT <= 2) ? 16 : 8;
     // first round of the weight stream (HBM) first; the row scales' and the residual's L2 round trips overlap it
     int kt = k0;
     uint4 wf[U];
@@ -770,7 +772,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_rows_resid_kernel(ResidArgs a) {
 void gemm_rows_resid(const ResidArgs& r, mgStream_t stream) {
     const int mt = (r.M + 31) / 32;
     const dim3 grid(r.N / 8);
-    const bool wide = r.K > 2048;
+    // 16 waves for the long K = d_ff stream, unless 3+ live m-tiles need the registers (1024 threads: 128 per lane,
+    // 80 of them accumulators at 5 m-tiles -> measured 52 us with scratch spills)
+    const bool wide = r.K > 2048 && mt <= 2;
     const int NW = wide ? 16 : 8;
     const dim3 block(NW * 64);
     const size_t sh = (size_t)NW * 4 * 64 * sizeof(float) + (size_t)32 * mt * sizeof(float);
