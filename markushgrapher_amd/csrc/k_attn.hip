@@ -36,12 +36,14 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     //   ATT_DEC_SELF: tab1[tab1_len] = causal T5 table of head h by distance
     char* st_base = smem;
     float* tab1 = (float*)(smem + 2 * AT_STAGE_BYTES);
-    const int t1n = (MODE == ATT_CROSS) ? 0 : (MODE == ATT_ENC ? 32 : a.tab1_len);
+    // ATT_ENC: t1 has 64 entries - the mask bit of a bucket-index word sits right above its 5-bit 1-D bucket, so
+    // (e >> 10) & 63 selects entries 32..63 = AT_NEG for masked keys and the mask costs no instructions
+    const int t1n = (MODE == ATT_CROSS) ? 0 : (MODE == ATT_ENC ? 64 : a.tab1_len);
     float* thv = tab1 + ((t1n + 3) & ~3);      // ATT_ENC: th[32] | tv[32] (32-entry tables: one entry per LDS bank, no conflicts)
     unsigned char* kmk = (unsigned char*)(thv + (MODE == ATT_ENC ? 64 : 0));
 
     if (MODE == ATT_ENC) {
-        for (int i = tid; i < 32; i += 256) tab1[i] = a.tab1[(size_t)i * a.H + h];
+        for (int i = tid; i < 64; i += 256) tab1[i] = i < 32 ? a.tab1[(size_t)i * a.H + h] : AT_NEG;
         for (int i = tid; i < 64; i += 256) thv[i] = i < 32 ? a.tabh[(size_t)i * a.H + h] : a.tabv[(size_t)(i - 32) * a.H + h];
     } else {
         for (int i = tid; i < t1n; i += 256) tab1[i] = a.tab1[(size_t)i * a.H + h];
@@ -144,9 +146,10 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
                 if (MODE == ATT_ENC) {
                     const uint4& wq = bcur[t2 * 2 + (r >> 3)];
                     const uint32_t wd = ((r >> 1) & 3) == 0 ? wq.x : (((r >> 1) & 3) == 1 ? wq.y : (((r >> 1) & 3) == 2 ? wq.z : wq.w));
-                    const uint32_t e = (r & 1) ? (wd >> 16) : (wd & 0xFFFFu);
-                    ok = (e & 0x8000u) == 0;
-                    v += (tab1[(e >> 10) & 31] + thv[(e >> 5) & 31]) + thv[32 + (e & 31)];
+                    const uint32_t e = (r & 1) ? (wd >> 16) : wd;        // the upper half of the word is masked off below
+                    ok = true;
+                    // masked key: tab1 entry = AT_NEG, which absorbs the other terms exactly (|score| << ulp(1e30))
+                    v += (tab1[(e >> 10) & 63] + thv[(e >> 5) & 31]) + thv[32 + (e & 31)];
                 } else if (MODE == ATT_DEC_SELF) {
                     const int dist = qi - key;
                     ok = kmk[key] != 0 && dist >= 0;
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
                 } else {
                     ok = kmk[key] != 0;
                 }
-                v = ok ? v : AT_NEG;
+                if (MODE != ATT_ENC) v = ok ? v : AT_NEG;
                 s[t2][r] = v;
                 mloc = fmaxf(mloc, v);
             }
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
 
 static size_t attn_smem(const AttnArgs& a) {
     const int Sk_pad = (a.Sk + AT_KEYS - 1) / AT_KEYS * AT_KEYS;
-    const int t1n = (a.mode == ATT_CROSS) ? 0 : (a.mode == ATT_ENC ? 32 : a.tab1_len);
+    const int t1n = (a.mode == ATT_CROSS) ? 0 : (a.mode == ATT_ENC ? 64 : a.tab1_len);
     size_t sz = 2 * AT_STAGE_BYTES + (size_t)((t1n + 3) & ~3) * 4;
     if (a.mode == ATT_ENC) sz += 64 * 4;
     else sz += (size_t)Sk_pad + 16;
