@@ -798,21 +798,26 @@ void gemm_rows_resid(const uint16_t* X, const uint16_t* W, float* h, const float
 
 // Residual projection and a half-tile projection side by side in one grid (8 waves per workgroup; the second
 // projection keeps up to 16 k-tiles per wave in flight: K = d_model + inner of the product weights in one round).
-template <int EPI, int MT>
+template <int EPI, int MT, bool HALF>
 __global__ __launch_bounds__(512) void gemm_rows_pair_kernel(ResidArgs r, GemmArgs g, int nres) {
     MG_DYN_SMEM(smem);
     if ((int)blockIdx.x < nres) resid_block<MT, 8>(r, blockIdx.x, smem);
-    else rows_block<EPI, MT, true, 8, 16>(g, (int)blockIdx.x - nres, smem);
+    else rows_block<EPI, MT, HALF, 8, 16>(g, (int)blockIdx.x - nres, smem);
 }
 void gemm_rows_pair(const ResidArgs& r, const GemmArgs& g, int epi, mgStream_t stream) {
     const int mt = (r.M + 31) / 32;
-    const int nres = r.N / 8, nrows = ((g.N + 31) / 32) * 2;
+    // every workgroup of the second projection reads ALL of its activation window (rows x K) from L2: with many output
+    // features (FFN wi: 128 tiles) whole 32-feature tiles halve that traffic (+0.8 % end to end), with few (cross-Q:
+    // 32 tiles) half tiles give the workgroups that keep the weight stream wide
+    const bool full = g.N >= 2048;
+    const int nres = r.N / 8, nrows = ((g.N + 31) / 32) * (full ? 1 : 2);
     const dim3 grid(nres + nrows), block(512);
     const size_t sh = (size_t)8 * 16 * 64 * sizeof(float) + (size_t)32 * mt * sizeof(float);
 #define MG_RP(MTV)                                                                                                   \
     case MTV:                                                                                                        \
-        if (epi == EPI_PK_RELU) MG_LAUNCH((gemm_rows_pair_kernel<EPI_PK_RELU, MTV>), grid, block, sh, stream, r, g, nres); \
-        else MG_LAUNCH((gemm_rows_pair_kernel<EPI_HEADS, MTV>), grid, block, sh, stream, r, g, nres);                \
+        if (epi == EPI_PK_RELU && full) MG_LAUNCH((gemm_rows_pair_kernel<EPI_PK_RELU, MTV, false>), grid, block, sh, stream, r, g, nres); \
+        else if (epi == EPI_PK_RELU) MG_LAUNCH((gemm_rows_pair_kernel<EPI_PK_RELU, MTV, true>), grid, block, sh, stream, r, g, nres); \
+        else MG_LAUNCH((gemm_rows_pair_kernel<EPI_HEADS, MTV, true>), grid, block, sh, stream, r, g, nres);          \
         break;
     switch (mt) {
         MG_RP(1) MG_RP(2) MG_RP(3) MG_RP(4) MG_RP(5) MG_RP(6) MG_RP(7) MG_RP(8)
