@@ -164,7 +164,7 @@ def main():
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
                     "traffic_source": traffic_src,
-                    "kernel": "attn_step_kernel<1, 8> (decoder cross-attention, single query per image/head)",
+                    "kernel": "attn_step_kernel<1, 8, true> (decoder cross-attention, single query per image/head)",
                     "bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(dur_s * 1e6, 2),
                     "empty_bracket_us": round(empty_s * 1e6, 2),
                     "timing": "HIP events on the launch stream: (record, launch, record, record); avg_launch_us = first "

@@ -14,7 +14,9 @@ constexpr float DC_NEG = -1.0e30f;
 // instructions in flight for K and V each; scores are reduced over the 8 lanes of a key by xor-shuffles;
 // every lane keeps an online-softmax partial (m, l, acc[8 dims]) per query which is merged across key slots by
 // shuffles and across the 4 waves through LDS in a fixed order (deterministic).
-template <int G, int NW>
+// XA = cross-attention form (per-image key counts from `len`, no positional bias, no beam ancestor table): a distinct
+// symbol, so that kernel traces keep the bandwidth-sized cross-attention apart from the short self-attention launches
+template <int G, int NW, bool XA>
 __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a) {
     MG_DYN_SMEM(smem);
     // keys per wave per round = 8*U: the 8-wave (long-stream) form uses U = 2 so the last, partially filled round of a
@@ -24,7 +26,7 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a) {
     const int sub = lane & 7, ks = lane >> 3;
     const int owner = blockIdx.x / a.H, h = blockIdx.x - owner * a.H;
     const int tcur = a.t_dev ? *a.t_dev : a.t;
-    const int nkeys_all = a.len ? a.len[owner] : (a.t_dev ? tcur + 1 : a.n_keys);
+    const int nkeys_all = XA ? a.len[owner] : (a.t_dev ? tcur + 1 : a.n_keys);
     // with an in-kernel append the newest key (position t) comes from registers, the cache holds [0, t)
     const bool app0 = (G == 1) && a.qkv.P && a.self_append;
     const int nkeys = app0 ? nkeys_all - 1 : nkeys_all;
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a) {
         for (int u = 0; u < U; ++u) {
             int kc = kb + u * 8 + ks;
             kc = kc < nkeys ? kc : nkeys - 1;
-            const int prow = a.anc ? a.anc[(size_t)kc * a.rows + owner] : owner;
+            const int prow = (!XA && a.anc) ? a.anc[(size_t)kc * a.rows + owner] : owner;
             const size_t off = (((size_t)prow * a.H + h) * (size_t)a.cap + (size_t)kc) * 64 + sub * 8;
             kv[u] = (NW >= 8) ? ld16_stream(a.Kc + off) : ld16(a.Kc + off);
             vv[u] = (NW >= 8) ? ld16_stream(a.Vc + off) : ld16(a.Vc + off);
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             float bias = 0.f;
-            if (a.bias) {
+            if (!XA && a.bias) {
                 int dist = tcur - key[u];
                 dist = dist < 0 ? 0 : dist;
                 bias = a.bias[(size_t)dist * a.H + h];
@@ -238,8 +240,9 @@ void attention_step(const AttnStepArgs& a, mgStream_t stream) {
     const size_t sh = (size_t)NW * G * 8 * 10 * sizeof(float);
 #define MG_AS(GG)                                                                                         \
     case GG:                                                                                              \
-        if (eight) MG_LAUNCH((attn_step_kernel<GG, 8>), grid, block, sh, stream, a);                      \
-        else MG_LAUNCH((attn_step_kernel<GG, 4>), grid, block, sh, stream, a);                            \
+        if (a.len) MG_LAUNCH((attn_step_kernel<GG, 8, true>), grid, block, sh, stream, a);               \
+        else if (eight) MG_LAUNCH((attn_step_kernel<GG, 8, false>), grid, block, sh, stream, a);          \
+        else MG_LAUNCH((attn_step_kernel<GG, 4, false>), grid, block, sh, stream, a);                     \
         break;
     switch (G) {
         MG_AS(1) MG_AS(2) MG_AS(3) MG_AS(4) MG_AS(5) MG_AS(6) MG_AS(7) MG_AS(8)
