@@ -26,8 +26,17 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int half = lane >> 5, l32 = lane & 31;
     const int nqb = (a.Sq_cap + 127) / 128;
-    const int qb = blockIdx.x % nqb;
-    const int bh = blockIdx.x / nqb;
+    // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  All heads and query
+    // blocks of one image go to the same XCD, so an image's per-(query, key) bucket-index array (2 B per pair, shared by
+    // the 16 heads) and its K/V tiles are fetched into ONE L2 instead of eight (PMC: 0.97 GB fetched per launch
+    // before, mostly that array eight times over).
+    int bid = blockIdx.x;
+    if ((a.B & 7) == 0) {
+        const int per_img = a.H * nqb, xcd = bid & 7, j = bid >> 3;
+        bid = ((j / per_img) * 8 + xcd) * per_img + (j % per_img);
+    }
+    const int qb = bid % nqb;
+    const int bh = bid / nqb;
     const int h = bh % a.H, b = bh / a.H;
     const int Sk_pad = (a.Sk + AT_KEYS - 1) / AT_KEYS * AT_KEYS;
 
