@@ -150,7 +150,7 @@ def main():
             raw_s = ms.value / n_l.value * 1e-3            # e0 -> e1 around the launch
             empty_s = empty_ms.value / n_l.value * 1e-3    # e1 -> e2 with nothing in between: cost of the bracket itself
             # The bracket over-reads the kernel by the dispatch latency behind the first record (rocprofv3 kernel trace:
-            # 25.1 us, profiles/r01_n_kernel_stats.md); the empty bracket (5.3 us) over-corrects, so the conservative raw
+            # 24.2 us, profiles/r01_p_kernel_stats.md); the empty bracket (5.2 us) over-corrects, so the conservative raw
             # bracket is what `achieved` uses and the empty one is reported for reference only.
             dur_s = raw_s
             ach = bytes_per_launch / dur_s / 1e9
