@@ -60,22 +60,6 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a) {
         row = row < a.rows ? row : a.rows - 1;
         q[g] = a.qkv.P ? slab_chunk(row, h * 64 + sub * 8) : ld16(a.q + ((size_t)row * a.H + h) * 64 + sub * 8);
     }
-    // deferred RMSNorm of the query rows: q was projected from the un-normalised bf16(h), the row scale r(row) is applied
-    // to the scores (q·k is linear in q); every wave sums the row's partials itself (fixed order: deterministic)
-    float qs[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        qs[g] = 1.0f;
-        if (a.qrs.part) {
-            int row = owner * G + g;
-            row = row < a.rows ? row : a.rows - 1;
-            float t = 0.f;
-            for (int i = lane; i < a.qrs.nparts; i += 64) t += a.qrs.part[(size_t)row * a.qrs.nparts + i];
-#pragma unroll
-            for (int step = 1; step < 64; step <<= 1) t += __shfl_xor(t, step);
-            qs[g] = rsqrtf(t * a.qrs.inv_d + a.qrs.eps);
-        }
-    }
     // self-attention with split-K projections: this workgroup also owns the new position's k, v (kept in registers
     // for its own use and appended to the cache for later steps)
     uint4 knew = make_uint4(0, 0, 0, 0), vnew = make_uint4(0, 0, 0, 0);
@@ -112,6 +96,23 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a) {
     };
     uint4 kn[U], vn[U];
     if (w * 8 * U < nkeys) issue(w * 8 * U, kn, vn);
+    // (after the first K/V round is in flight: the partial-sum round trip below overlaps it)
+    // deferred RMSNorm of the query rows: q was projected from the un-normalised bf16(h), the row scale r(row) is applied
+    // to the scores (q·k is linear in q); every wave sums the row's partials itself (fixed order: deterministic)
+    float qs[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        qs[g] = 1.0f;
+        if (a.qrs.part) {
+            int row = owner * G + g;
+            row = row < a.rows ? row : a.rows - 1;
+            float t = 0.f;
+            for (int i = lane; i < a.qrs.nparts; i += 64) t += a.qrs.part[(size_t)row * a.qrs.nparts + i];
+#pragma unroll
+            for (int step = 1; step < 64; step <<= 1) t += __shfl_xor(t, step);
+            qs[g] = rsqrtf(t * a.qrs.inv_d + a.qrs.eps);
+        }
+    }
     for (int kb = w * 8 * U; kb < nkeys; kb += NW * 8 * U) {
         uint4 kv[U], vv[U];
         int key[U];
