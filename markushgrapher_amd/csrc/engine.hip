@@ -140,11 +140,12 @@ __global__ __launch_bounds__(256) void fill_ids_kernel(int64_t* next_ids, int64_
     if (threadIdx.x == 0) {
         next_ids[r] = start;
         unfinished[r] = 1;
-        if (r == 0) { counters[0] = rows; counters[1] = -1; counters[2] = 0; counters[5] = 0; }   // [3] keeps the encoder's input-error count
+        if (r == 0) { counters[0] = rows; counters[1] = -1; counters[2] = 0; counters[5] = 0; counters[6] = 0; }   // [3] keeps the encoder's input-error count
     }
 }
 // counters: [0] n_unfinished, [1] done_step (first step after which every row had finished), [2] step, [3] input errors,
-// [4] beam output columns, [5] greedy: unfinished rows counted by this step's selection (published to [0] here)
+// [4] beam output columns, [5] greedy: unfinished rows counted by this step's selection (published to [0] by the last
+// selection workgroup), [6] greedy: arrival counter of the selection workgroups
 __global__ void step_end_kernel(int* counters, int greedy) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         if (greedy) { counters[0] = counters[5]; counters[5] = 0; }
@@ -773,8 +774,8 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
     // One decode step.  tdev == nullptr: step-dependent values are passed by value (eager launches); otherwise the
     // kernels read the step from the device counter, which makes the launch sequence capturable as a graph.
     auto decode_step = [&](int t, const int* tdev) {
-        embed_rows(w.next_ids, m->at<uint16_t>(m->tok_emb), w.dh, R, d, m->V, counters + 3, st, w.xa, K2, 0);
-        rmsnorm_pack(w.dh, m->at<float>(m->dec[0].ln0), w.dx_pk, nullptr, R, d, eps, 1.0f, st);
+        embed_norm_rows(w.next_ids, m->at<uint16_t>(m->tok_emb), w.dh, m->at<float>(m->dec[0].ln0), w.dx_pk, w.xa, K2, 0, R, d, m->V,
+                        counters + 3, eps, st);
         for (size_t li = 0; li < nl; ++li) {
             const DecLayer& l = m->dec[li];
             uint16_t* sk = w.sk + li * skv_stride;
@@ -836,13 +837,14 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
             g.pos = tdev ? 1 : t + 1; g.pos_dev = tdev;
             g.unfinished = w.unfinished; g.n_unfinished = counters + 5;
             g.top2 = step_top2 ? (tdev ? step_top2 : step_top2 + (size_t)(t + 1) * R * 2) : nullptr;
+            g.step_ctr = counters;      // the last workgroup to finish does the step bookkeeping (no step_end launch)
             greedy_select(g, st);
         } else {
             beam_step(w.beam_state, w.logits, ldl, m->V, B, K, max_length, t + 1, tdev, w.beam_div, m->c.eos_token_id, min_length,
                       length_penalty, early_stopping, w.next_ids, w.beam_idx, counters, st);
             beam_reorder_anc(w.anc, w.beam_idx, R, tdev ? max_length - 1 : t + 1, tdev, counters, st);
         }
-        MG_LAUNCH(step_end_kernel, dim3(1), dim3(64), 0, st, counters, K == 1 ? 1 : 0);
+        if (K > 1) MG_LAUNCH(step_end_kernel, dim3(1), dim3(64), 0, st, counters, 0);
     };
     bool graphed = false;
 #ifndef MG_EMU

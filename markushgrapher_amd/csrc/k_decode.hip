@@ -303,6 +303,18 @@ __global__ __launch_bounds__(GS_THREADS) void greedy_select_kernel(ArgmaxArgs a)
             float* tp = a.top2 + (a.pos_dev ? (size_t)pos * a.rows * 2 : 0);
             tp[row * 2] = b1; tp[row * 2 + 1] = b2;
         }
+        if (a.step_ctr) {
+            int* c = a.step_ctr;
+            __threadfence();
+            if (atomicAdd(c + 6, 1) == a.rows - 1) {        // every other workgroup has finished (and read the step index)
+                const int unf_total = atomicAdd(a.n_unfinished, 0);
+                *a.n_unfinished = 0;       // plain stores: nobody else touches the counters until the next launch
+                c[0] = unf_total;
+                if (unf_total == 0 && c[1] < 0) c[1] = c[2];
+                c[2] += 1;
+                c[6] = 0;
+            }
+        }
     }
 }
 

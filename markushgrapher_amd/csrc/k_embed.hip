@@ -173,4 +173,45 @@ void embed_rows(const int64_t* ids, const uint16_t* tok_emb, float* h, int rows,
     MG_LAUNCH(embed_rows_kernel, dim3(blocks), dim3(256), 0, stream, ids, tok_emb, h, rows, d, V, err, x_pk, x_ld, x_col0);
 }
 
+// Decode step, first launch: token embedding (stock:1140) + the first decoder layer's RMSNorm (stock:611-616) in one
+// pass.  Same arithmetic and summation order as embed_rows followed by rmsnorm_pack (one wave per row, 8 features per
+// lane and step).  Writes h (fp32), x_pk = bf16(RMSNorm(h) * gain) and x2_pk = the embedding row itself (packed window).
+__global__ __launch_bounds__(256) void embed_norm_rows_kernel(const int64_t* ids, const uint16_t* tok_emb, float* h, const float* gain,
+                                                         uint16_t* x_pk, uint16_t* x2_pk, int x2_ld, int x2_col0, int rows, int d, int V,
+                                                         int* err, float eps) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nch = d >> 3;
+    for (int m = blockIdx.x * 4 + w; m < rows; m += gridDim.x * 4) {
+        long long id = ids[m];
+        if (id < 0 || id >= V) { if (lane == 0) atomicAdd(err, 1); id = 0; }
+        const uint16_t* src = tok_emb + (size_t)id * d;
+        float ss = 0.f;
+        for (int c = lane; c < nch; c += 64) {
+            const uint4 t = ld16(src + c * 8);
+            const float a0 = bf16lo(t.x), a1 = bf16hi(t.x), a2 = bf16lo(t.y), a3 = bf16hi(t.y);
+            const float b0 = bf16lo(t.z), b1 = bf16hi(t.z), b2 = bf16lo(t.w), b3 = bf16hi(t.w);
+            ss += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3 + b0 * b0 + b1 * b1 + b2 * b2 + b3 * b3;
+        }
+        ss = wave_sum(ss);
+        const float r = rsqrtf(ss / (float)d + eps);
+        for (int c = lane; c < nch; c += 64) {
+            const uint4 t = ld16(src + c * 8);
+            const float a[8] = {bf16lo(t.x), bf16hi(t.x), bf16lo(t.y), bf16hi(t.y), bf16lo(t.z), bf16hi(t.z), bf16lo(t.w), bf16hi(t.w)};
+            const float4 g0 = *(const float4*)(gain + c * 8), g1 = *(const float4*)(gain + c * 8 + 4);
+            *(float4*)(h + (size_t)m * d + c * 8) = make_float4(a[0], a[1], a[2], a[3]);
+            *(float4*)(h + (size_t)m * d + c * 8 + 4) = make_float4(a[4], a[5], a[6], a[7]);
+            st16(x_pk + pk_off(m, c * 8, d),
+                 make_uint4(pack_bf16(g0.x * (a[0] * r), g0.y * (a[1] * r)), pack_bf16(g0.z * (a[2] * r), g0.w * (a[3] * r)),
+                            pack_bf16(g1.x * (a[4] * r), g1.y * (a[5] * r)), pack_bf16(g1.z * (a[6] * r), g1.w * (a[7] * r))));
+            if (x2_pk) st16(x2_pk + pk_off(m, x2_col0 + c * 8, x2_ld), t);
+        }
+    }
+}
+void embed_norm_rows(const int64_t* ids, const uint16_t* tok_emb, float* h, const float* gain, uint16_t* x_pk, uint16_t* x2_pk, int x2_ld,
+                     int x2_col0, int rows, int d, int V, int* err, float eps, mgStream_t stream) {
+    int blocks = (rows + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    MG_LAUNCH(embed_norm_rows_kernel, dim3(blocks), dim3(256), 0, stream, ids, tok_emb, h, gain, x_pk, x2_pk, x2_ld, x2_col0, rows, d, V, err, eps);
+}
+
 }  // namespace mg

@@ -208,6 +208,9 @@ struct AttnStepArgs {
 void attention_step(const AttnStepArgs& a, mgStream_t stream);
 
 // h[rows][d] = tok_emb[ids[row]]
+// embed_rows + rmsnorm_pack(h, gain, x_pk) in one launch (decode step); x2_pk (nullable) = the embedding rows, packed window
+void embed_norm_rows(const int64_t* ids, const uint16_t* tok_emb, float* h, const float* gain, uint16_t* x_pk, uint16_t* x2_pk, int x2_ld,
+                     int x2_col0, int rows, int d, int V, int* err, float eps, mgStream_t stream);
 // optionally also x_pk (packed bf16 window, x_ld columns, first column x_col0) = the embedding rows themselves
 void embed_rows(const int64_t* ids, const uint16_t* tok_emb, float* h, int rows, int d, int V, int* err,
                 mgStream_t stream, uint16_t* x_pk = nullptr, int x_ld = 0, int x_col0 = 0);
@@ -225,6 +228,10 @@ struct ArgmaxArgs {
     int* unfinished;         // [rows]
     int* n_unfinished;       // [1] accumulated here; the step-end kernel publishes and clears it
     float* top2;             // [rows][2] (nullable) top-1 / top-2 logit of this step
+    // step bookkeeping folded into the selection (engine decode loop): when non-null, the LAST workgroup to finish
+    // publishes the unfinished count, records the first all-finished step and advances the step counter
+    // (counters layout: engine.hip); step_ctr[6] is the arrival counter
+    int* step_ctr;
 };
 void greedy_select(const ArgmaxArgs& a, mgStream_t stream);
 
