@@ -167,6 +167,13 @@ int mgk_gemm_set_variant(int v);
  * statistic rs_*), x_pk = bf16(h*gain*gscale) un-normalised, part[m][N/8] = per-block sums of h^2 */
 int mgk_gemm_resid(void* stream, const void* X_pk, const void* W_pk, float* h, const float* gain, float gscale, void* x_pk,
                    float* part, int M, int N, int K, const float* rs_part, int rs_nparts, float rs_inv_d, float rs_eps);
+/* Pair projection of the decode step with its product weight (test entry for gemm_rows_pair / the mg_finalize helpers):
+ *   W2_pk  <- pack([Wn*diag(gain) | Wn*diag(gain)*Wr])   built on the device from Wn_pk [N2][d], Wr_pk [d][inner]
+ *             (scratch_f32: at least N2*(2*d+inner) + d*inner floats);
+ *   one launch: h[M][d] += ctx*Wr^T, hb_out_pk = pack(bf16(h_new)), part = per-row partial sums of h_new^2   |
+ *               out2_pk = pack(relu?(W2 * [hb ; ctx]))     with xwin_pk = packed [rows][d+inner] = [bf16(h_old) | ctx]. */
+int mgk_gemm_pair(void* stream, const void* Wn_pk, const void* Wr_pk, const float* gain, int N2, int d, int inner, void* W2_pk,
+                  float* scratch_f32, const void* xwin_pk, float* h, void* hb_out_pk, float* part, void* out2_pk, int M, int relu);
 int mgk_add_norm_pack(void* stream, float* h, const float* P, int KS, int ldp, size_t slab_stride, const float* gain,
                       void* x_pk, int M, int d, float eps, float scale);
 int mgk_relu_pack(void* stream, const float* P, int KS, int ldp, size_t slab_stride, void* y_pk, int M, int N);

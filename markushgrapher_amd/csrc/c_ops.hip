@@ -127,6 +127,27 @@ int mgk_gemm_resid(void* stream, const void* X_pk, const void* W_pk, float* h, c
     return MG_OK;
 }
 
+int mgk_gemm_pair(void* stream, const void* Wn_pk, const void* Wr_pk, const float* gain, int N2, int d, int inner, void* W2_pk,
+                  float* scratch_f32, const void* xwin_pk, float* h, void* hb_out_pk, float* part, void* out2_pk, int M, int relu) {
+    if ((d & 63) || (inner & 63) || (N2 & 31) || M > 256) return MG_E_SHAPE;
+    mgStream_t st = (mgStream_t)stream;
+    const int K2 = d + inner;
+    float *A = scratch_f32, *Bm = A + (size_t)N2 * d, *Cm = Bm + (size_t)d * inner;
+    unpack_weight((const uint16_t*)Wr_pk, Bm, d, inner, st);
+    unpack_weight((const uint16_t*)Wn_pk, A, N2, d, st);
+    scale_cols_f32(A, gain, Cm, N2, d, K2, st);
+    gemm_f32_scaled(A, gain, Bm, Cm + d, N2, d, inner, K2, st);
+    pack_weight(Cm, 0, N2, K2, (uint16_t*)W2_pk, N2, st);
+    ResidArgs r{};
+    r.X = (const uint16_t*)xwin_pk; r.x_kts = K2 >> 4; r.x_k0 = d >> 4; r.W = (const uint16_t*)Wr_pk; r.h = h;
+    r.x2_pk = (uint16_t*)hb_out_pk; r.part = part; r.M = M; r.N = d; r.K = inner;
+    GemmArgs g{};
+    g.X = (const uint16_t*)xwin_pk; g.W = (const uint16_t*)W2_pk; g.M = M; g.N = N2; g.K = K2; g.out_pk = (uint16_t*)out2_pk;
+    if (!relu) return MG_E_UNSUPPORTED;      // the per-head form is covered through mg_generate
+    gemm_rows_pair(r, g, EPI_PK_RELU, st);
+    return MG_OK;
+}
+
 int mgk_add_norm_pack(void* stream, float* h, const float* P, int KS, int ldp, size_t slab_stride, const float* gain,
                       void* x_pk, int M, int d, float eps, float scale) {
     if ((d & 15) || d > 4096 || KS < 0 || KS > 16) return MG_E_SHAPE;

@@ -511,3 +511,45 @@ def test_gemm_resid_deferred_norm(be_name, M, N, K):
                                  be.p(part2), M, 64, N, be.p(part), N // 8, 1.0 / N, 1e-6) == 0
     xn = pk.bf16_round(ref_h * g * 0.5) / np.sqrt((ref_h ** 2).mean(-1, keepdims=True) + 1e-6)
     np.testing.assert_allclose(h2.numpy(), xn @ pk.bf16_round(w2).T, rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+@pytest.mark.parametrize("M,N2,d,inner", [(32, 128, 64, 128), (45, 2048, 64, 64), (70, 256, 128, 64)])
+def test_gemm_pair_product_weights(be_name, M, N2, d, inner):
+    """Pair projection: the residual projection h += ctx Wr^T and, in the same launch, relu(Wn G (h + ctx Wr^T))
+    computed as [Wn G | Wn G Wr] [bf16(h) ; ctx] from the product weight.  N2 = 2048 takes the whole-tile workgroup form,
+    the others the half-tile form; M = 45 / 70 cover two and three row tiles."""
+    be = get_backend(be_name)
+    be.lib.mgk_gemm_pair.argtypes = [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p] * 7 + [C.c_int, C.c_int]
+    Wn, Wr = rnd((N2, d), 200, 0.3), rnd((d, inner), 201, 0.3)
+    gain = 1 + 0.2 * rnd((d,), 202)
+    h0, ctx = rnd((M, d), 203), rnd((M, inner), 204)
+    Wn_b, Wr_b, ctx_b, hb = pk.bf16_round(Wn), pk.bf16_round(Wr), pk.bf16_round(ctx), pk.bf16_round(h0)
+    Mp = (M + 31) // 32 * 32
+    xwin = np.zeros((Mp, d + inner), np.float32)
+    xwin[:M, :d], xwin[:M, d:] = hb, ctx_b
+    W2 = be.zeros((N2 * (d + inner),), np.uint16)
+    scratch = be.zeros((N2 * (2 * d + inner) + d * inner,), np.float32)
+    h = be.buf(h0)
+    hb_out = be.zeros((Mp * d,), np.uint16)
+    part = be.zeros((Mp, d // 8), np.float32)
+    out2 = be.zeros((Mp * N2,), np.uint16)
+    rc = be.lib.mgk_gemm_pair(be.stream, be.p(be.buf(pk.pack_tiles(Wn))), be.p(be.buf(pk.pack_tiles(Wr))), be.p(be.buf(gain)), N2, d, inner,
+                              be.p(W2), be.p(scratch), be.p(be.buf(pk.pack_tiles(xwin))), be.p(h), be.p(hb_out), be.p(part), be.p(out2), M, 1)
+    assert rc == 0
+    # product weight: fp32 product of the bf16 factors, rounded to bf16 once
+    w2_ref = np.concatenate([Wn_b * gain, (Wn_b * gain) @ Wr_b], axis=1)
+    np.testing.assert_allclose(pk.unpack_tiles(W2.numpy(), N2, d + inner), w2_ref, rtol=1 / 200, atol=1e-4)
+    # residual projection, its bf16 copy and the partial sums of squares
+    h_ref = h0 + ctx_b @ Wr_b.T
+    np.testing.assert_allclose(h.numpy(), h_ref, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(pk.unpack_tiles(hb_out.numpy(), M, d), h_ref, rtol=1 / 200, atol=1e-3)
+    np.testing.assert_allclose(part.numpy()[:M].sum(1), (h_ref ** 2).sum(1), rtol=1e-4)
+    # second projection == the sequential form relu(Wn G h_new) up to the bf16 roundings of h, ctx and the product weight
+    seq = np.maximum((h0 + ctx @ Wr.T) @ (Wn * gain).T, 0)
+    got = pk.unpack_tiles(out2.numpy(), M, N2)
+    scale = np.abs(seq).max()
+    assert np.abs(got - seq).max() < 0.03 * scale, np.abs(got - seq).max() / scale
+    # and exactly (to bf16 output rounding) the product form on the rounded operands
+    exact = np.maximum(xwin[:M] @ pk.bf16_round(w2_ref).T, 0)
+    np.testing.assert_allclose(got, exact, rtol=1 / 100, atol=2e-3 * scale)
