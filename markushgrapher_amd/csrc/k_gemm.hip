@@ -571,10 +571,104 @@ MG_DEV void rows_block(const GemmArgs& a, int bid, char* smem) {
         __syncthreads();
     }
 }
+// Half-tile projections (16 output features per workgroup) on v_mfma_f32_16x16x32_bf16: no zero-padded feature rows, one
+// MFMA per two k-tiles and token group, every lane of a weight wave-load carries data.  Epilogues: packed bf16 rows
+// (optionally relu) or per-head stores; a lane holds 4 consecutive features of one token, two lanes (l, l^16) make one
+// 16-byte chunk.  Operand addressing as in resid_block16.
+template <int EPI, int MT, int NW, int U>
+MG_DEV void rows_block16(const GemmArgs& a, int bid, char* smem) {
+    static_assert(EPI == EPI_PK || EPI == EPI_PK_RELU || EPI == EPI_HEADS, "half-tile form has packed / per-head epilogues only");
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int nt = bid >> 1, sub = bid & 1;
+    const int kt16 = a.K >> 4, kp = kt16 >> 1;
+    const int per = (kp + NW - 1) / NW;
+    const int p0 = w * per, p1 = (p0 + per) < kp ? (p0 + per) : kp;
+    float* rsl = (float*)(smem + NW * 8 * 64 * sizeof(float));     // [32*MT] deferred RMSNorm scale per row
+    const size_t lane_off = (size_t)(kg >> 1) * TILE_BYTES + (size_t)(kg & 1) * 512;
+    const char* wp = (const char*)(a.W + pk_tile_off(nt, 0, a.K)) + lane_off + (size_t)(16 * sub + r16) * 16;
+    const int xkts = a.x_kts ? a.x_kts : kt16;
+    const char* xp = (const char*)a.X + (size_t)a.x_k0 * TILE_BYTES + lane_off + (size_t)r16 * 16;
+    int p = p0;
+    uint4 wf[U];
+    if (p + U <= p1) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) wf[u] = ld16_stream(wp + (size_t)(p + u) * (2 * TILE_BYTES));
+    }
+    block_row_scales(a.rs, a.M, 32 * MT, rsl, tid, NW * 64);
+    f32x4 acc[MT][2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) { acc[i][0] = acc4_zero(); acc[i][1] = acc4_zero(); }
+    for (bool first = true; p + U <= p1; p += U, first = false) {
+        if (!first) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) wf[u] = ld16_stream(wp + (size_t)(p + u) * (2 * TILE_BYTES));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const char* xt = xp + ((size_t)i * xkts + 2 * (p + u)) * TILE_BYTES;
+                acc[i][0] = mfma16(wf[u], ld16(xt), acc[i][0]);
+                acc[i][1] = mfma16(wf[u], ld16(xt + 256), acc[i][1]);
+            }
+        }
+    }
+    for (; p < p1; ++p) {
+        const uint4 w1 = ld16_stream(wp + (size_t)p * (2 * TILE_BYTES));
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const char* xt = xp + ((size_t)i * xkts + 2 * p) * TILE_BYTES;
+            acc[i][0] = mfma16(w1, ld16(xt), acc[i][0]);
+            acc[i][1] = mfma16(w1, ld16(xt + 256), acc[i][1]);
+        }
+    }
+    float* slab = (float*)smem;                                  // [NW][8][64]
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) slab[(w * 8 + g * 4 + j) * 64 + lane] = acc[i][g][j];
+        __syncthreads();
+        if ((i % NW) == w) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int m = 32 * i + 16 * g + r16;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float t = 0.f;
+                    for (int ww = 0; ww < NW; ++ww) t += slab[(ww * 8 + g * 4 + j) * 64 + lane];
+                    t *= rsl[32 * i + 16 * g + r16];
+                    v[j] = (EPI == EPI_PK_RELU) ? fmaxf(t, 0.f) : t;
+                }
+                // features 4*kg .. 4*kg+3 of token m here; lanes with even kg collect the partner's four (kg + 1)
+                const uint32_t lo = pack_bf16(v[0], v[1]), hi = pack_bf16(v[2], v[3]);
+                const uint32_t plo = __shfl_xor(lo, 16), phi = __shfl_xor(hi, 16);
+                if ((kg & 1) == 0 && m < a.M) {
+                    const uint4 ch = make_uint4(lo, hi, plo, phi);
+                    const int n = nt * 32 + 16 * sub + 4 * kg;        // 8 consecutive features from n
+                    if (n < a.N) {
+                        if constexpr (EPI == EPI_HEADS) {
+                            const HeadsOut& ho = a.heads;
+                            const int ri = n / ho.inner, nn = n - ri * ho.inner;
+                            heads_store(ho, ri, nn >> 6, m, nn & 63, ch);
+                        } else {
+                            st16(a.out_pk + pk_off(m, n, a.N), ch);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
 template <int EPI, int MT, bool HALF, int NW = 4>
 __global__ __launch_bounds__(NW * 64) void gemm_rows_kernel(GemmArgs a) {
     MG_DYN_SMEM(smem);
-    rows_block<EPI, MT, HALF, NW, 8>(a, blockIdx.x, smem);
+    if constexpr (HALF && (EPI == EPI_PK || EPI == EPI_PK_RELU || EPI == EPI_HEADS)) rows_block16<EPI, MT, NW, 4>(a, blockIdx.x, smem);
+    else rows_block<EPI, MT, HALF, NW, 8>(a, blockIdx.x, smem);
 }
 
 template <int EPI>
@@ -763,10 +857,122 @@ MG_DEV void resid_block(const ResidArgs& a, int bid, char* smem) {
         __syncthreads();
     }
 }
+// The same residual projection on v_mfma_f32_16x16x32_bf16: the workgroup's 8 output features fill half of the 16
+// feature rows of the tile (a quarter of the 32 rows of the 32x32x16 form), one MFMA spans two k-tiles and costs about
+// half the matrix-pipe time, and one wave-load of weights carries 512 useful bytes instead of 256.
+//   A operand (weights): lane (r16 = l%16, kg = l/16) <- chunk (row 8*sub + r16, k-half kg&1) of k-tile 2p + kg/2
+//   B operand (tokens 16g .. 16g+15 of an m-tile): same chunk addressing on the activation tile
+//   D: lane holds features 4*kg + j (valid: kg < 2) of token 16g + r16
+template <int MT, int NW, int U>
+MG_DEV void resid_block16(const ResidArgs& a, int bid, char* smem) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int nt = bid >> 2, sub = bid & 3;
+    const bool wvalid = r16 < 8;
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    const int M = a.M, N = a.N;
+    const int kt16 = a.K >> 4, kp = kt16 >> 1;                 // pairs of k-tiles
+    const int per = (kp + NW - 1) / NW;
+    const int p0 = w * per, p1 = (p0 + per) < kp ? (p0 + per) : kp;
+    float* rsl = (float*)(smem + NW * 8 * 64 * sizeof(float));     // [32*MT]
+    const size_t lane_off = (size_t)(kg >> 1) * TILE_BYTES + (size_t)(kg & 1) * 512;
+    const char* wp = (const char*)(a.W + pk_tile_off(nt, 0, a.K)) + lane_off + (size_t)(8 * sub + r16) * 16;
+    const int xkts = a.x_kts ? a.x_kts : kt16;
+    const char* xp = (const char*)a.X + (size_t)a.x_k0 * TILE_BYTES + lane_off + (size_t)r16 * 16;
+    // first round of the weight stream (HBM) first; the row scales' and the residual's L2 round trips overlap it
+    int p = p0;
+    uint4 wf[U];
+    if (p + U <= p1) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) wf[u] = wvalid ? ld16_stream(wp + (size_t)(p + u) * (2 * TILE_BYTES)) : zero4;
+    }
+    const int n0 = nt * 32 + sub * 8 + kg * 4;                  // this lane's 4 features (kg < 2)
+    const int my_i = w < MT ? w : -1;                           // m-tile this wave finishes (MT <= NW)
+    float4 h_pre[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    if (my_i >= 0 && kg < 2) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int m = 32 * my_i + 16 * g + r16;
+            if (m < M) h_pre[g] = *(const float4*)(a.h + (size_t)m * N + n0);
+        }
+    }
+    block_row_scales(a.rs, M, 32 * MT, rsl, tid, NW * 64);
+    f32x4 acc[MT][2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) { acc[i][0] = acc4_zero(); acc[i][1] = acc4_zero(); }
+    for (bool first = true; p + U <= p1; p += U, first = false) {
+        if (!first) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) wf[u] = wvalid ? ld16_stream(wp + (size_t)(p + u) * (2 * TILE_BYTES)) : zero4;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const char* xt = xp + ((size_t)i * xkts + 2 * (p + u)) * TILE_BYTES;
+                acc[i][0] = mfma16(wf[u], ld16(xt), acc[i][0]);
+                acc[i][1] = mfma16(wf[u], ld16(xt + 256), acc[i][1]);
+            }
+        }
+    }
+    for (; p < p1; ++p) {
+        const uint4 w1 = wvalid ? ld16_stream(wp + (size_t)p * (2 * TILE_BYTES)) : zero4;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const char* xt = xp + ((size_t)i * xkts + 2 * p) * TILE_BYTES;
+            acc[i][0] = mfma16(w1, ld16(xt), acc[i][0]);
+            acc[i][1] = mfma16(w1, ld16(xt + 256), acc[i][1]);
+        }
+    }
+    // reduce the NW K-slices: slab[w][g*4 + j][lane]
+    float* slab = (float*)smem;
+    const int nparts = N >> 3;
+    const int x_ld = a.x_ld ? a.x_ld : N, x2_ld = a.x2_ld ? a.x2_ld : N;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) slab[(w * 8 + g * 4 + j) * 64 + lane] = acc[i][g][j];
+        __syncthreads();
+        if (i == w) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int m = 32 * i + 16 * g + r16;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float t = 0.f;
+                    for (int ww = 0; ww < NW; ++ww) t += slab[(ww * 8 + g * 4 + j) * 64 + lane];
+                    v[j] = t * rsl[32 * i + 16 * g + r16];
+                }
+                float ss = 0.f;
+                if (m < M && kg < 2) {
+                    float4 hv = h_pre[g];
+                    hv.x += v[0]; hv.y += v[1]; hv.z += v[2]; hv.w += v[3];
+                    *(float4*)(a.h + (size_t)m * N + n0) = hv;
+                    ss = (hv.x * hv.x + hv.y * hv.y) + (hv.z * hv.z + hv.w * hv.w);
+                    if (a.x_pk) {
+                        const float4 gn = *(const float4*)(a.gain + n0);
+                        const float gs = a.gscale;
+                        *(uint2*)(a.x_pk + pk_off(m, a.x_col0 + n0, x_ld)) =
+                            make_uint2(pack_bf16(hv.x * gn.x * gs, hv.y * gn.y * gs), pack_bf16(hv.z * gn.z * gs, hv.w * gn.w * gs));
+                    }
+                    if (a.x2_pk)
+                        *(uint2*)(a.x2_pk + pk_off(m, a.x2_col0 + n0, x2_ld)) = make_uint2(pack_bf16(hv.x, hv.y), pack_bf16(hv.z, hv.w));
+                }
+                ss += __shfl_xor(ss, 16);                        // features 0-3 (kg 0) + 4-7 (kg 1)
+                if (m < M && kg == 0) a.part[(size_t)m * nparts + bid] = ss;
+            }
+        }
+        __syncthreads();
+    }
+}
 template <int MT, int NW>
 __global__ __launch_bounds__(NW * 64) void gemm_rows_resid_kernel(ResidArgs a) {
     MG_DYN_SMEM(smem);
-    resid_block<MT, NW>(a, blockIdx.x, smem);
+    // pairs of k-tiles per wave and round: 8 covers K = 4096 over 16 waves, 4 covers K = 1024 over 8 waves, in one round
+    resid_block16<MT, NW, (NW >= 16 ? 8 : 4)>(a, blockIdx.x, smem);
 }
 
 void gemm_rows_resid(const ResidArgs& r, mgStream_t stream) {
@@ -777,7 +983,7 @@ void gemm_rows_resid(const ResidArgs& r, mgStream_t stream) {
     const bool wide = r.K > 2048 && mt <= 2;
     const int NW = wide ? 16 : 8;
     const dim3 block(NW * 64);
-    const size_t sh = (size_t)NW * 4 * 64 * sizeof(float) + (size_t)32 * mt * sizeof(float);
+    const size_t sh = (size_t)NW * 8 * 64 * sizeof(float) + (size_t)32 * mt * sizeof(float);
 #define MG_RR(MTV)                                                                                 \
     case MTV:                                                                                      \
         if (wide) MG_LAUNCH((gemm_rows_resid_kernel<MTV, 16>), grid, block, sh, stream, r);        \
@@ -801,8 +1007,9 @@ void gemm_rows_resid(const uint16_t* X, const uint16_t* W, float* h, const float
 template <int EPI, int MT, bool HALF>
 __global__ __launch_bounds__(512) void gemm_rows_pair_kernel(ResidArgs r, GemmArgs g, int nres) {
     MG_DYN_SMEM(smem);
-    if ((int)blockIdx.x < nres) resid_block<MT, 8>(r, blockIdx.x, smem);
-    else rows_block<EPI, MT, HALF, 8, 16>(g, (int)blockIdx.x - nres, smem);
+    if ((int)blockIdx.x < nres) resid_block16<MT, 8, 4>(r, blockIdx.x, smem);
+    else if constexpr (HALF) rows_block16<EPI, MT, 8, 8>(g, (int)blockIdx.x - nres, smem);     // K = d + inner: 8 pairs per wave
+    else rows_block<EPI, MT, false, 8, 16>(g, (int)blockIdx.x - nres, smem);
 }
 void gemm_rows_pair(const ResidArgs& r, const GemmArgs& g, int epi, mgStream_t stream) {
     const int mt = (r.M + 31) / 32;

@@ -16,6 +16,11 @@ struct f32x16 {
     float& operator[](int i) { return v[i]; }
     const float& operator[](int i) const { return v[i]; }
 };
+struct f32x4 {
+    float v[4];
+    float& operator[](int i) { return v[i]; }
+    const float& operator[](int i) const { return v[i]; }
+};
 #else
 #include <hip/hip_runtime.h>
 #define MG_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
@@ -23,6 +28,7 @@ struct f32x16 {
     hipLaunchKernelGGL(kern, grid, block, shmem, stream, __VA_ARGS__)
 typedef hipStream_t mgStream_t;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 mg_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 mg_bf16x2 __attribute__((ext_vector_type(2)));
 #endif
@@ -127,6 +133,24 @@ MG_DEV f32x16 mfma32(const uint4& a, const uint4& b, const f32x16& c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mg_bf16x8, a), __builtin_bit_cast(mg_bf16x8, b),
                                                    c, 0, 0, 0);
 #endif
+}
+// D = A·B + C for one 16x16x32 bf16 tile.  a: lane holds A[row = l%16][k = 8*(l/16)+0..7];
+// b: lane holds B[k = 8*(l/16)+0..7][col = l%16];  result: lane holds D[row = 4*(l/16)+j][col = l%16], j = 0..3.
+// In the packed fragment-tile format one operand = the 16-byte chunks (row, k-half) of TWO consecutive 16-wide k-tiles.
+MG_DEV f32x4 mfma16(const uint4& a, const uint4& b, const f32x4& c) {
+#ifdef MG_EMU
+    f32x4 d = c;
+    emu::mfma_16x16x32_bf16((const uint16_t*)&a, (const uint16_t*)&b, d.v);
+    return d;
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mg_bf16x8, a), __builtin_bit_cast(mg_bf16x8, b), c, 0, 0, 0);
+#endif
+}
+MG_DEV f32x4 acc4_zero() {
+    f32x4 c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c[i] = 0.f;
+    return c;
 }
 // row of D held in accumulator register r by this lane
 MG_DEV int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }

@@ -140,6 +140,29 @@ void mfma_32x32x16_bf16(const uint16_t* a8, const uint16_t* b8, float* c16) {
     wave_sync();
 }
 
+// v_mfma_f32_16x16x32_bf16: A[i][k] in lane i+16*(k/8) elem k%8; B[k][j] in lane j+16*(k/8) elem k%8;
+// D[i][j] in lane j+16*(i/4), reg i%4   (cdna_hip_programming.md §3 "Fragment layout").
+void mfma_16x16x32_bf16(const uint16_t* a8, const uint16_t* b8, float* c4) {
+    Wave& w = B.waves[cur->lin_tid >> 6];
+    int lane = cur->lin_tid & 63;
+    if (w.nlanes != 64) { fprintf(stderr, "emu: mfma in a partial wave\n"); abort(); }
+    memcpy(w.slot[lane], a8, 16);
+    memcpy(w.slot[lane] + 16, b8, 16);
+    wave_sync();
+    int j = lane & 15, q = lane >> 4;
+    for (int r = 0; r < 4; ++r) {
+        int i = 4 * q + r;
+        float s = c4[r];
+        for (int k = 0; k < 32; ++k) {
+            const uint16_t* pa = (const uint16_t*)(w.slot[i + 16 * (k >> 3)]);
+            const uint16_t* pb = (const uint16_t*)(w.slot[j + 16 * (k >> 3)] + 16);
+            s += bf2f(pa[k & 7]) * bf2f(pb[k & 7]);
+        }
+        c4[r] = s;
+    }
+    wave_sync();
+}
+
 // global_load_lds_dwordx4: LDS destination = wave-uniform base + lane*16 (cdna_hip_programming.md §5 caveat)
 void glds16(const void* gsrc_lane, void* lds_wave_base) {
     int lane = cur->lin_tid & 63;

@@ -29,6 +29,7 @@ void syncthreads();
 char* smem();
 uint32_t shfl_u32(uint32_t v, int src_lane);
 void mfma_32x32x16_bf16(const uint16_t* a8, const uint16_t* b8, float* c16);
+void mfma_16x16x32_bf16(const uint16_t* a8, const uint16_t* b8, float* c4);
 void glds16(const void* gsrc_lane, void* lds_wave_base);
 }  // namespace emu
 
