@@ -22,6 +22,9 @@ import os
 import sys
 import time
 
+# before torch loads the HIP runtime: kernel arguments in device memory (see markushgrapher_amd/__init__.py)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

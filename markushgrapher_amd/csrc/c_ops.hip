@@ -127,6 +127,15 @@ int mgk_gemm_resid(void* stream, const void* X_pk, const void* W_pk, float* h, c
     return MG_OK;
 }
 
+int mgk_gemm_resid_trace(void* stream, const void* X_pk, const void* W_pk, float* h, const float* gain, void* x_pk, float* part, int N,
+                         int K, const float* rs_part, long long* trace) {
+    ResidArgs r{};
+    r.X = (const uint16_t*)X_pk; r.W = (const uint16_t*)W_pk; r.h = h; r.gain = gain; r.gscale = 1.0f; r.x_pk = (uint16_t*)x_pk;
+    r.part = part; r.M = 32; r.N = N; r.K = K; r.rs = RowScale{rs_part, N / 8, 1.0f / (float)N, 1e-6f};
+    gemm_rows_resid_trace(r, trace, (mgStream_t)stream);
+    return MG_OK;
+}
+
 int mgk_gemm_pair(void* stream, const void* Wn_pk, const void* Wr_pk, const float* gain, int N2, int d, int inner, void* W2_pk,
                   float* scratch_f32, const void* xwin_pk, float* h, void* hb_out_pk, float* part, void* out2_pk, int M, int relu) {
     if ((d & 63) || (inner & 63) || (N2 & 31) || M > 256) return MG_E_SHAPE;

@@ -863,9 +863,17 @@ MG_DEV void resid_block(const ResidArgs& a, int bid, char* smem) {
 //   A operand (weights): lane (r16 = l%16, kg = l/16) <- chunk (row 8*sub + r16, k-half kg&1) of k-tile 2p + kg/2
 //   B operand (tokens 16g .. 16g+15 of an m-tile): same chunk addressing on the activation tile
 //   D: lane holds features 4*kg + j (valid: kg < 2) of token 16g + r16
-template <int MT, int NW, int U>
-MG_DEV void resid_block16(const ResidArgs& a, int bid, char* smem) {
+template <int MT, int NW, int U, bool TRACE = false>
+MG_DEV void resid_block16(const ResidArgs& a, int bid, char* smem, long long* trace = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // TRACE (tools/trace_resid.py only): shader-clock stamps of wave phases -> trace[(bid*NW + w)*8 + k]
+    auto stamp = [&](int k) {
+#ifndef MG_EMU
+        if constexpr (TRACE) { if (lane == 0) trace[((size_t)bid * NW + w) * 8 + k] = (long long)__builtin_readcyclecounter(); }
+#endif
+        (void)k;
+    };
+    stamp(0);
     const int r16 = lane & 15, kg = lane >> 4;
     const int nt = bid >> 2, sub = bid & 3;
     const bool wvalid = r16 < 8;
@@ -886,6 +894,7 @@ MG_DEV void resid_block16(const ResidArgs& a, int bid, char* smem) {
 #pragma unroll
         for (int u = 0; u < U; ++u) wf[u] = wvalid ? ld16_stream(wp + (size_t)(p + u) * (2 * TILE_BYTES)) : zero4;
     }
+    stamp(1);
     const int n0 = nt * 32 + sub * 8 + kg * 4;                  // this lane's 4 features (kg < 2)
     const int my_i = w < MT ? w : -1;                           // m-tile this wave finishes (MT <= NW)
     float4 h_pre[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
@@ -897,6 +906,7 @@ MG_DEV void resid_block16(const ResidArgs& a, int bid, char* smem) {
         }
     }
     block_row_scales(a.rs, M, 32 * MT, rsl, tid, NW * 64);
+    stamp(2);
     f32x4 acc[MT][2];
 #pragma unroll
     for (int i = 0; i < MT; ++i) { acc[i][0] = acc4_zero(); acc[i][1] = acc4_zero(); }
@@ -924,6 +934,8 @@ MG_DEV void resid_block16(const ResidArgs& a, int bid, char* smem) {
             acc[i][1] = mfma16(w1, ld16(xt + 256), acc[i][1]);
         }
     }
+    if constexpr (TRACE) { if (acc[0][0][0] == 123456.f) a.part[0] = 0.f; }      // MFMA results are in
+    stamp(3);
     // reduce the NW K-slices: slab[w][g*4 + j][lane]
     float* slab = (float*)smem;
     const int nparts = N >> 3;
@@ -935,6 +947,7 @@ MG_DEV void resid_block16(const ResidArgs& a, int bid, char* smem) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) slab[(w * 8 + g * 4 + j) * 64 + lane] = acc[i][g][j];
         __syncthreads();
+        stamp(4);
         if (i == w) {
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
@@ -964,15 +977,27 @@ MG_DEV void resid_block16(const ResidArgs& a, int bid, char* smem) {
                 ss += __shfl_xor(ss, 16);                        // features 0-3 (kg 0) + 4-7 (kg 1)
                 if (m < M && kg == 0) a.part[(size_t)m * nparts + bid] = ss;
             }
+            stamp(5);
         }
         __syncthreads();
     }
+    stamp(6);
 }
 template <int MT, int NW>
 __global__ __launch_bounds__(NW * 64) void gemm_rows_resid_kernel(ResidArgs a) {
     MG_DYN_SMEM(smem);
     // pairs of k-tiles per wave and round: 8 covers K = 4096 over 16 waves, 4 covers K = 1024 over 8 waves, in one round
     resid_block16<MT, NW, (NW >= 16 ? 8 : 4)>(a, blockIdx.x, smem);
+}
+
+// instrumented copy of the 16-wave, one-row-tile form (tools/trace_resid.py)
+__global__ __launch_bounds__(1024) void gemm_rows_resid_trace_kernel(ResidArgs a, long long* trace) {
+    MG_DYN_SMEM(smem);
+    resid_block16<1, 16, 8, true>(a, blockIdx.x, smem, trace);
+}
+void gemm_rows_resid_trace(const ResidArgs& r, long long* trace, mgStream_t stream) {
+    const size_t sh = (size_t)16 * 8 * 64 * sizeof(float) + 32 * sizeof(float);
+    MG_LAUNCH(gemm_rows_resid_trace_kernel, dim3(r.N / 8), dim3(1024), sh, stream, r, trace);
 }
 
 void gemm_rows_resid(const ResidArgs& r, mgStream_t stream) {

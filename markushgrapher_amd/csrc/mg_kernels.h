@@ -91,6 +91,7 @@ struct ResidArgs {
     RowScale rs;
 };
 void gemm_rows_resid(const ResidArgs& r, mgStream_t stream);
+void gemm_rows_resid_trace(const ResidArgs& r, long long* trace, mgStream_t stream);   // phase stamps, M <= 32, K = d_ff form
 // Two independent decode projections that read the same inputs in ONE launch (they sit side by side in the grid):
 // the residual projection `r` and the projection `g` (epilogue EPI_HEADS or EPI_PK_RELU, half-tile workgroups).
 // Used with product weights: g's X is the window [bf16(h_before) | ctx] and its W = [Wn·G | Wn·G·Wr], so that

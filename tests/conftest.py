@@ -1,6 +1,7 @@
 import os
 import sys
 
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # before torch loads the HIP runtime (markushgrapher_amd/__init__.py)
 import numpy as np
 import pytest
 
