@@ -31,6 +31,37 @@ MG_DEV void block_row_scales(const RowScale& rs, int M, int nrows, float* out, i
     }
 }
 
+// Split form of block_row_scales for the common decode shape (all rows in one pass, <= 16 partials per thread): the
+// partial sums are FETCHED first of all (rs_issue), the weight and activation streams are issued behind them, and the
+// reduction (rs_finish) then waits only for these earliest loads - a wait on a later load would drain the whole in-order
+// vector-memory queue, i.e. serialise the row scales behind the HBM round trip of the weights.
+struct RsRegs { float4 v[4]; bool fast; };
+MG_DEV void rs_issue(const RowScale& rs, int M, int nrows, int tid, int nthreads, RsRegs& r) {
+    const int per = rs.nparts >> 3;
+    r.fast = rs.part && nrows <= (nthreads >> 3) && per <= 16 && (per & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r.fast) {
+        const int row = tid >> 3, j = tid & 7;
+        if (row < nrows) {
+            const int mr = row < M ? row : M - 1;
+            const float* p = rs.part + (size_t)mr * rs.nparts + j * per;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (4 * i < per) r.v[i] = *(const float4*)(p + 4 * i);
+        }
+    }
+}
+MG_DEV void rs_finish(const RowScale& rs, int M, int nrows, float* out, int tid, int nthreads, const RsRegs& r) {
+    if (!r.fast) { block_row_scales(rs, M, nrows, out, tid, nthreads); return; }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += (r.v[i].x + r.v[i].y) + (r.v[i].z + r.v[i].w);
+    s = sum8(s);
+    const int row = tid >> 3;
+    if ((tid & 7) == 0 && row < nrows) out[row] = rsqrtf(s * rs.inv_d + rs.eps);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // epilogue helpers
 // ---------------------------------------------------------------------------------------------------------
@@ -589,13 +620,24 @@ MG_DEV void rows_block16(const GemmArgs& a, int bid, char* smem) {
     const char* wp = (const char*)(a.W + pk_tile_off(nt, 0, a.K)) + lane_off + (size_t)(16 * sub + r16) * 16;
     const int xkts = a.x_kts ? a.x_kts : kt16;
     const char* xp = (const char*)a.X + (size_t)a.x_k0 * TILE_BYTES + lane_off + (size_t)r16 * 16;
+    RsRegs rsr;                                                  // load order = wait order, see resid_block16
+    rs_issue(a.rs, a.M, 32 * MT, tid, NW * 64, rsr);
     int p = p0;
     uint4 wf[U];
+    constexpr bool XPF = MT == 1;                                // see resid_block16
+    uint4 xf[XPF ? U : 1][2];
     if (p + U <= p1) {
 #pragma unroll
         for (int u = 0; u < U; ++u) wf[u] = ld16_stream(wp + (size_t)(p + u) * (2 * TILE_BYTES));
+        if constexpr (XPF) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const char* xt = xp + (size_t)(2 * (p + u)) * TILE_BYTES;
+                xf[u][0] = ld16(xt); xf[u][1] = ld16(xt + 256);
+            }
+        }
     }
-    block_row_scales(a.rs, a.M, 32 * MT, rsl, tid, NW * 64);
+    rs_finish(a.rs, a.M, 32 * MT, rsl, tid, NW * 64, rsr);
     f32x4 acc[MT][2];
 #pragma unroll
     for (int i = 0; i < MT; ++i) { acc[i][0] = acc4_zero(); acc[i][1] = acc4_zero(); }
@@ -609,8 +651,13 @@ MG_DEV void rows_block16(const GemmArgs& a, int bid, char* smem) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const char* xt = xp + ((size_t)i * xkts + 2 * (p + u)) * TILE_BYTES;
-                acc[i][0] = mfma16(wf[u], ld16(xt), acc[i][0]);
-                acc[i][1] = mfma16(wf[u], ld16(xt + 256), acc[i][1]);
+                if (XPF && first) {
+                    acc[i][0] = mfma16(wf[u], xf[XPF ? u : 0][0], acc[i][0]);
+                    acc[i][1] = mfma16(wf[u], xf[XPF ? u : 0][1], acc[i][1]);
+                } else {
+                    acc[i][0] = mfma16(wf[u], ld16(xt), acc[i][0]);
+                    acc[i][1] = mfma16(wf[u], ld16(xt + 256), acc[i][1]);
+                }
             }
         }
     }
@@ -631,9 +678,10 @@ MG_DEV void rows_block16(const GemmArgs& a, int bid, char* smem) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) slab[(w * 8 + g * 4 + j) * 64 + lane] = acc[i][g][j];
         __syncthreads();
-        if ((i % NW) == w) {
+        // unit f = 2*i + g (m-tile, token group) is finished by wave f % NW: two waves share a tile's epilogue
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
+        for (int g = 0; g < 2; ++g) {
+            if (((2 * i + g) % NW) == w) {
                 const int m = 32 * i + 16 * g + r16;
                 float v[4];
 #pragma unroll
@@ -865,6 +913,7 @@ MG_DEV void resid_block(const ResidArgs& a, int bid, char* smem) {
 //   D: lane holds features 4*kg + j (valid: kg < 2) of token 16g + r16
 template <int MT, int NW, int U, bool TRACE = false>
 MG_DEV void resid_block16(const ResidArgs& a, int bid, char* smem, long long* trace = nullptr) {
+    static_assert(MT <= NW, "at most two finishing units per wave");
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     // TRACE (tools/trace_resid.py only): shader-clock stamps of wave phases -> trace[(bid*NW + w)*8 + k]
     auto stamp = [&](int k) {
@@ -887,25 +936,42 @@ MG_DEV void resid_block16(const ResidArgs& a, int bid, char* smem, long long* tr
     const char* wp = (const char*)(a.W + pk_tile_off(nt, 0, a.K)) + lane_off + (size_t)(8 * sub + r16) * 16;
     const int xkts = a.x_kts ? a.x_kts : kt16;
     const char* xp = (const char*)a.X + (size_t)a.x_k0 * TILE_BYTES + lane_off + (size_t)r16 * 16;
-    // first round of the weight stream (HBM) first; the row scales' and the residual's L2 round trips overlap it
+    // load order = wait order (the vector-memory queue retires in order): row-scale partials and the residual slice
+    // first (small, L2), then the weight stream (HBM); the activation fragments follow in the MFMA loop
+    RsRegs rsr;
+    rs_issue(a.rs, M, 32 * MT, tid, NW * 64, rsr);
+    const int n0 = nt * 32 + sub * 8 + kg * 4;                  // this lane's 4 features (kg < 2)
+    // the (m-tile, token group) unit this wave finishes: unit f = 2*i + g goes to wave f (2*MT <= NW), so the two token
+    // groups of a tile are reduced and stored by two waves in parallel
+    // (with more than NW/2 row tiles a wave takes a second unit, f + NW)
+    float4 h_pre[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int f = w + q * NW;
+        if (f < 2 * MT && kg < 2) {
+            const int m = 32 * (f >> 1) + 16 * (f & 1) + r16;
+            if (m < M) h_pre[q] = *(const float4*)(a.h + (size_t)m * N + n0);
+        }
+    }
     int p = p0;
     uint4 wf[U];
+    // one row tile, 8 waves: the activation fragments of the first round are fetched up front as well (the 16-wave form
+    // has 64 registers per lane, where that spills: measured 7.8 -> 15.5 us)
+    constexpr bool XPF = MT == 1 && NW <= 8;
+    uint4 xf[XPF ? U : 1][2];
     if (p + U <= p1) {
 #pragma unroll
         for (int u = 0; u < U; ++u) wf[u] = wvalid ? ld16_stream(wp + (size_t)(p + u) * (2 * TILE_BYTES)) : zero4;
-    }
-    stamp(1);
-    const int n0 = nt * 32 + sub * 8 + kg * 4;                  // this lane's 4 features (kg < 2)
-    const int my_i = w < MT ? w : -1;                           // m-tile this wave finishes (MT <= NW)
-    float4 h_pre[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-    if (my_i >= 0 && kg < 2) {
+        if constexpr (XPF) {
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const int m = 32 * my_i + 16 * g + r16;
-            if (m < M) h_pre[g] = *(const float4*)(a.h + (size_t)m * N + n0);
+            for (int u = 0; u < U; ++u) {
+                const char* xt = xp + (size_t)(2 * (p + u)) * TILE_BYTES;
+                xf[u][0] = ld16(xt); xf[u][1] = ld16(xt + 256);
+            }
         }
     }
-    block_row_scales(a.rs, M, 32 * MT, rsl, tid, NW * 64);
+    stamp(1);
+    rs_finish(a.rs, M, 32 * MT, rsl, tid, NW * 64, rsr);
     stamp(2);
     f32x4 acc[MT][2];
 #pragma unroll
@@ -920,8 +986,13 @@ MG_DEV void resid_block16(const ResidArgs& a, int bid, char* smem, long long* tr
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const char* xt = xp + ((size_t)i * xkts + 2 * (p + u)) * TILE_BYTES;
-                acc[i][0] = mfma16(wf[u], ld16(xt), acc[i][0]);
-                acc[i][1] = mfma16(wf[u], ld16(xt + 256), acc[i][1]);
+                if (XPF && first) {
+                    acc[i][0] = mfma16(wf[u], xf[XPF ? u : 0][0], acc[i][0]);
+                    acc[i][1] = mfma16(wf[u], xf[XPF ? u : 0][1], acc[i][1]);
+                } else {
+                    acc[i][0] = mfma16(wf[u], ld16(xt), acc[i][0]);
+                    acc[i][1] = mfma16(wf[u], ld16(xt + 256), acc[i][1]);
+                }
             }
         }
     }
@@ -948,9 +1019,11 @@ MG_DEV void resid_block16(const ResidArgs& a, int bid, char* smem, long long* tr
             for (int j = 0; j < 4; ++j) slab[(w * 8 + g * 4 + j) * 64 + lane] = acc[i][g][j];
         __syncthreads();
         stamp(4);
-        if (i == w) {
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
+        for (int q = 0; q < 2; ++q) {
+            const int f = w + q * NW;
+            if (f < 2 * MT && (f >> 1) == i) {
+                const int g = f & 1;
                 const int m = 32 * i + 16 * g + r16;
                 float v[4];
 #pragma unroll
@@ -961,7 +1034,7 @@ MG_DEV void resid_block16(const ResidArgs& a, int bid, char* smem, long long* tr
                 }
                 float ss = 0.f;
                 if (m < M && kg < 2) {
-                    float4 hv = h_pre[g];
+                    float4 hv = h_pre[q];
                     hv.x += v[0]; hv.y += v[1]; hv.z += v[2]; hv.w += v[3];
                     *(float4*)(a.h + (size_t)m * N + n0) = hv;
                     ss = (hv.x * hv.x + hv.y * hv.y) + (hv.z * hv.z + hv.w * hv.w);
