@@ -79,6 +79,15 @@ int mgk_attention_step(void* stream, const void* q, const void* Kc, const void* 
     return MG_OK;
 }
 
+int mgk_attention_step_trace(void* stream, const void* q, const void* Kc, const void* Vc, void* ctx_pk, int rows, int H, int cap,
+                             const int* len, long long* trace) {
+    AttnStepArgs a{};
+    a.q = (const uint16_t*)q; a.Kc = (const uint16_t*)Kc; a.Vc = (const uint16_t*)Vc; a.ctx = (uint16_t*)ctx_pk;
+    a.rows = rows; a.H = H; a.group = 1; a.cap = cap; a.len = len;
+    attention_step_trace(a, trace, (mgStream_t)stream);
+    return MG_OK;
+}
+
 size_t mgk_embed_meta_bytes(int B, int S_cap) { return embed_meta_bytes(B, S_cap); }
 
 int mgk_embed_assemble(void* stream, void* meta_ws, const int64_t* input_ids, const float* bbox,

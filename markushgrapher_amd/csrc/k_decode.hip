@@ -16,9 +16,17 @@ constexpr float DC_NEG = -1.0e30f;
 // shuffles and across the 4 waves through LDS in a fixed order (deterministic).
 // XA = cross-attention form (per-image key counts from `len`, no positional bias, no beam ancestor table): a distinct
 // symbol, so that kernel traces keep the bandwidth-sized cross-attention apart from the short self-attention launches
-template <int G, int NW, bool XA>
-__global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a) {
+template <int G, int NW, bool XA, bool TRACE = false>
+__global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a, long long* trace = nullptr) {
     MG_DYN_SMEM(smem);
+    // TRACE (tools/trace_attn.py only): shader-clock stamps of wave phases -> trace[(workgroup*NW + wave)*8 + k]
+    auto stamp = [&](int k) {
+#ifndef MG_EMU
+        if constexpr (TRACE) { if ((threadIdx.x & 63) == 0) trace[((size_t)blockIdx.x * NW + (threadIdx.x >> 6)) * 8 + k] = (long long)__builtin_readcyclecounter(); }
+#endif
+        (void)k;
+    };
+    stamp(0);
     // keys per wave per round = 8*U: the 8-wave (long-stream) form uses U = 2 so the last, partially filled round of a
     // ~1000-key stream wastes < 10 % of the wave-rounds instead of ~20 %
     constexpr int U = (NW >= 8) ? 2 : 4;
@@ -96,6 +104,7 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a) {
     };
     uint4 kn[U], vn[U];
     if (w * 8 * U < nkeys) issue(w * 8 * U, kn, vn);
+    stamp(1);
     // (after the first K/V round is in flight: the partial-sum round trip below overlaps it)
     // deferred RMSNorm of the query rows: q was projected from the un-normalised bf16(h), the row scale r(row) is applied
     // to the scores (q·k is linear in q); every wave sums the row's partials itself (fixed order: deterministic)
@@ -159,6 +168,7 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a) {
                 acc[g][6] += p * bf16lo(vv[u].w); acc[g][7] += p * bf16hi(vv[u].w);
             }
         }
+        if constexpr (TRACE) { if (kb == w * 8 * U) stamp(2); }
     }
     if (append && w == 0) {   // the new position (distance 0), handled by key slot 0 of wave 0; whole wave runs the shuffles
         float p = dot2_bf16(q[0].x, knew.x, 0.f);
@@ -178,6 +188,7 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a) {
             acc[0][6] = acc[0][6] * al + pe * bf16lo(vnew.w); acc[0][7] = acc[0][7] * al + pe * bf16hi(vnew.w);
         }
     }
+    stamp(3);
     // merge the 8 key slots of the wave
 #pragma unroll
     for (int step = 8; step <= 32; step <<= 1) {
@@ -192,6 +203,7 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a) {
             m[g] = M;
         }
     }
+    stamp(4);
     // merge the NW waves: red[w][g][sub][10]
     float* red = (float*)smem;
     if (ks == 0) {
@@ -204,6 +216,7 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a) {
         }
     }
     __syncthreads();
+    stamp(5);
     if (w == 0 && ks == 0) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -225,6 +238,13 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a) {
                                 pack_bf16(o[4] * inv, o[5] * inv), pack_bf16(o[6] * inv, o[7] * inv)));
         }
     }
+    stamp(6);
+}
+
+// instrumented cross-attention (G = 1), tools/trace_attn.py
+void attention_step_trace(const AttnStepArgs& a, long long* trace, mgStream_t stream) {
+    const dim3 grid(a.rows * a.H), block(512);
+    MG_LAUNCH((attn_step_kernel<1, 8, true, true>), grid, block, (size_t)8 * 8 * 10 * sizeof(float), stream, a, trace);
 }
 
 void attention_step(const AttnStepArgs& a, mgStream_t stream) {
@@ -241,9 +261,9 @@ void attention_step(const AttnStepArgs& a, mgStream_t stream) {
     const size_t sh = (size_t)NW * G * 8 * 10 * sizeof(float);
 #define MG_AS(GG)                                                                                         \
     case GG:                                                                                              \
-        if (a.len) MG_LAUNCH((attn_step_kernel<GG, 8, true>), grid, block, sh, stream, a);               \
-        else if (eight) MG_LAUNCH((attn_step_kernel<GG, 8, false>), grid, block, sh, stream, a);          \
-        else MG_LAUNCH((attn_step_kernel<GG, 4, false>), grid, block, sh, stream, a);                     \
+        if (a.len) MG_LAUNCH((attn_step_kernel<GG, 8, true>), grid, block, sh, stream, a, (long long*)nullptr);               \
+        else if (eight) MG_LAUNCH((attn_step_kernel<GG, 8, false>), grid, block, sh, stream, a, (long long*)nullptr);          \
+        else MG_LAUNCH((attn_step_kernel<GG, 4, false>), grid, block, sh, stream, a, (long long*)nullptr);                     \
         break;
     switch (G) {
         MG_AS(1) MG_AS(2) MG_AS(3) MG_AS(4) MG_AS(5) MG_AS(6) MG_AS(7) MG_AS(8)

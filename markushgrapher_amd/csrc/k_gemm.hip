@@ -588,7 +588,24 @@ MG_DEV void rows_block(const GemmArgs& a, int bid, char* smem) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) slab[(w * 16 + r) * 64 + lane] = acc[i][r];
         __syncthreads();
-        if ((i % NW) == w) {
+        if constexpr (TOR && !HALF) {
+            // whole tile, token-major epilogue: the two 16-feature halves (registers 0-7 / 8-15, one 16-byte chunk per
+            // lane each) are reduced and stored by two waves in parallel
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                if (((2 * i + q) % NW) == w) {
+                    f32x16 s = acc_zero();
+#pragma unroll
+                    for (int r = 8 * q; r < 8 * q + 8; ++r) {
+                        float v = 0.f;
+#pragma unroll
+                        for (int ww = 0; ww < NW; ++ww) v += slab[(ww * 16 + r) * 64 + lane];
+                        s[r] = v * rsl[32 * i + (lane & 31)];
+                    }
+                    tile_epilogue<EPI, TOR>(a, s, 32 * i, 32 * nt, lane, 1 << q);
+                }
+            }
+        } else if ((i % NW) == w) {
             f32x16 s;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {

@@ -207,6 +207,7 @@ struct AttnStepArgs {
     uint16_t* Vc_w;
 };
 void attention_step(const AttnStepArgs& a, mgStream_t stream);
+void attention_step_trace(const AttnStepArgs& a, long long* trace, mgStream_t stream);   // phase stamps, cross form, group 1
 
 // h[rows][d] = tok_emb[ids[row]]
 // embed_rows + rmsnorm_pack(h, gain, x_pk) in one launch (decode step); x2_pk (nullable) = the embedding rows, packed window
