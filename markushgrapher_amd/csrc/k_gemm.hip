@@ -371,16 +371,21 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmArgs a) {
 // 128 B/clk LDS port against 1024 cycles of MFMA per SIMD).  Two LDS stages of 64 KiB; the copies of K-step ks+1 are
 // issued right after the barrier of step ks and have a whole compute phase (~2048 MFMA cycles) to land.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int GX_M = 256, GX_N = 256, GX_K = 64;
-constexpr int GX_FRAGS = (GX_M + GX_N) / 32 * (GX_K / 16);      // 64 fragments per stage
-constexpr int GX_STAGE_BYTES = GX_FRAGS * TILE_BYTES;           // 64 KiB
+constexpr int GX_N = 256, GX_K = 64;
 
-template <int EPI>
+// TI = row tiles (of 32) per wave: TI = 4 -> 256x256 block tile; TI = 5 -> 320x256 (0.7 LDS reads per MFMA, 160
+// accumulator registers, two 72 KiB stages), used where it makes the tile count a whole number of rounds over the 256 CUs
+// (M = 40960, N = 1024: 128 x 4 = 512 tiles instead of 640).
+template <int EPI, int TI>
 __global__ __launch_bounds__(512) void gemm_xl_kernel(GemmArgs a) {
     MG_DYN_SMEM(smem);
+    constexpr int BM = 64 * TI, XT = 2 * TI;                   // X row tiles per block (2 wave rows x TI)
+    constexpr int FRAGS = (XT + 8) * 4;                        // fragments per stage
+    constexpr int STAGE_BYTES = FRAGS * TILE_BYTES;
+    constexpr int PER_WAVE = (FRAGS + 7) / 8;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nbn = (a.N + GX_N - 1) / GX_N;
-    const int nbm = (a.M + GX_M - 1) / GX_M;
+    const int nbm = (a.M + BM - 1) / BM;
     int bid = blockIdx.x;
     const int nblk = nbm * nbn;
     if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);   // XCD-contiguous tile ranges (speed only)
@@ -388,34 +393,36 @@ __global__ __launch_bounds__(512) void gemm_xl_kernel(GemmArgs a) {
     const int mt32 = (a.M + 31) >> 5, nt32 = (a.N + 31) >> 5;
     const int nks = a.K / GX_K;
 
-    // loader: wave w copies fragments 8w .. 8w+7 of a stage; fragments 0..31 = X (row-tile f/4, k-tile f%4), 32..63 = W
-    const char* src[8];
+    // loader: wave w copies fragments PER_WAVE*w ..; fragments 0 .. 4*XT-1 = X (row-tile f/4, k-tile f%4), then W
+    const char* src[PER_WAVE];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int f = w * 8 + i;
-        const bool isW = f >= 32;
-        const int ff = isW ? f - 32 : f, rt = ff >> 2, kt = ff & 3;
-        int trow = isW ? (bn * 8 + rt) : (bm * 8 + rt);
+    for (int i = 0; i < PER_WAVE; ++i) {
+        int f = w * PER_WAVE + i;
+        f = f < FRAGS ? f : FRAGS - 1;                          // (FRAGS % 8 == 0 for TI = 4, 5: no clamping happens)
+        const bool isW = f >= 4 * XT;
+        const int ff = isW ? f - 4 * XT : f, rt = ff >> 2, kt = ff & 3;
+        int trow = isW ? (bn * 8 + rt) : (bm * XT + rt);
         const int tmax = isW ? nt32 - 1 : mt32 - 1;
         trow = trow < tmax ? trow : tmax;
         src[i] = (const char*)((isW ? a.W : a.X) + pk_tile_off(trow, kt, a.K)) + lane * 16;
     }
     auto stage = [&](int buf, int ks) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            glds16_async(src[i] + (size_t)ks * (4 * TILE_BYTES), smem + buf * GX_STAGE_BYTES + (w * 8 + i) * TILE_BYTES);
+        for (int i = 0; i < PER_WAVE; ++i)
+            if (w * PER_WAVE + i < FRAGS)
+                glds16_async(src[i] + (size_t)ks * (4 * TILE_BYTES), smem + buf * STAGE_BYTES + (w * PER_WAVE + i) * TILE_BYTES);
     };
 
     const int wr = w >> 2, wc = w & 3;
-    const int m0w = bm * GX_M + wr * 128, n0w = bn * GX_N + wc * 64;
+    const int m0w = bm * BM + wr * (32 * TI), n0w = bn * GX_N + wc * 64;
     bool tor;
     if (EPI == EPI_F32_STORE || EPI == EPI_F32_RESID) tor = false;
     else if (EPI == EPI_HEADS) tor = !heads_region_is_T(a.heads, n0w < a.N ? n0w : 0);
     else tor = true;
 
-    f32x16 acc[4][2];
+    f32x16 acc[TI][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = acc_zero();
 
@@ -425,23 +432,23 @@ __global__ __launch_bounds__(512) void gemm_xl_kernel(GemmArgs a) {
         MG_WAIT_VMCNT(0);        // own copies of stage ks (issued one compute phase ago) have landed ...
         MG_BARRIER_RAW();        // ... everybody's have, and everybody finished reading the other buffer
         if (ks + 1 < nks) stage(cur ^ 1, ks + 1);
-        const char* xb = smem + cur * GX_STAGE_BYTES + lane * 16;
-        const char* wb = xb + 32 * TILE_BYTES;
+        const char* xb = smem + cur * STAGE_BYTES + lane * 16;
+        const char* wb = xb + 4 * XT * TILE_BYTES;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            uint4 xf[4], wf[2];
+            uint4 xf[TI], wf[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) wf[j] = ld16(wb + ((wc * 2 + j) * 4 + kt) * TILE_BYTES);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) xf[i] = ld16(xb + ((wr * 4 + i) * 4 + kt) * TILE_BYTES);
+            for (int i = 0; i < TI; ++i) xf[i] = ld16(xb + ((wr * TI + i) * 4 + kt) * TILE_BYTES);
             if (tor) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < TI; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(wf[j], xf[i], acc[i][j]);
             } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < TI; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(xf[i], wf[j], acc[i][j]);
             }
@@ -449,7 +456,7 @@ __global__ __launch_bounds__(512) void gemm_xl_kernel(GemmArgs a) {
     }
 
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int m0 = m0w + 32 * i, n0 = n0w + 32 * j;
@@ -463,13 +470,14 @@ __global__ __launch_bounds__(512) void gemm_xl_kernel(GemmArgs a) {
             }
         }
 }
-template <int EPI>
+template <int EPI, int TI>
 static void launch_xl(const GemmArgs& a, mgStream_t stream) {
-    const int nblk = ((a.M + GX_M - 1) / GX_M) * ((a.N + GX_N - 1) / GX_N);
-    const size_t sh = (size_t)2 * GX_STAGE_BYTES;
+    constexpr int BM = 64 * TI;
+    const int nblk = ((a.M + BM - 1) / BM) * ((a.N + GX_N - 1) / GX_N);
+    const size_t sh = (size_t)2 * (2 * TI + 8) * 4 * TILE_BYTES;
     static bool once = false;
-    if (!once) { MG_SET_MAX_SMEM(&gemm_xl_kernel<EPI>, sh); once = true; }
-    MG_LAUNCH((gemm_xl_kernel<EPI>), dim3(nblk), dim3(512), sh, stream, a);
+    if (!once) { MG_SET_MAX_SMEM((&gemm_xl_kernel<EPI, TI>), sh); once = true; }
+    MG_LAUNCH((gemm_xl_kernel<EPI, TI>), dim3(nblk), dim3(512), sh, stream, a);
 }
 
 template <int EPI>
@@ -482,23 +490,38 @@ static void launch_wide(const GemmArgs& a, mgStream_t stream) {
 }
 
 // 0: 128x128 two-stage kernel only; 1: + 256x128 three-stage kernel for M >= 256; 2: + 256x256 kernel wherever it fits;
-// 3 (default): 256x256 for wide outputs (N >= 2048: QKV, FFN wi, cross-K/V), 256x128 for N = d_model (measured:
-// 0.90-1.06 vs 0.73-0.91 PFLOP/s on the wide ones, 0.43-0.68 vs 0.46-0.70 on the narrow ones)
+// 4: + 320x256; 3 (default): by shape (currently = 4)
 static int g_gemm_variant = 3;
 void gemm_set_variant(int v) { g_gemm_variant = v; }
 
 void gemm(const GemmArgs& a, int epi, mgStream_t stream) {
     static bool env_read = false;
     if (!env_read) { env_read = true; if (const char* e = getenv("MG_GEMM_VARIANT")) g_gemm_variant = atoi(e); }   // A/B runs
-    if ((g_gemm_variant == 2 || (g_gemm_variant == 3 && a.N >= 2048)) && a.M >= GX_M && a.N >= GX_N) {
-        switch (epi) {
-            case EPI_F32_STORE: launch_xl<EPI_F32_STORE>(a, stream); break;
-            case EPI_F32_RESID: launch_xl<EPI_F32_RESID>(a, stream); break;
-            case EPI_PK_RELU: launch_xl<EPI_PK_RELU>(a, stream); break;
-            case EPI_PK: launch_xl<EPI_PK>(a, stream); break;
-            default: launch_xl<EPI_HEADS>(a, stream); break;
+    if (g_gemm_variant >= 2 && a.M >= 320 && a.N >= GX_N) {
+        // measured at M = 40960 (PFLOP/s, 256x128 / 256x256 / 320x256): QKV 0.72 / 0.92 / 1.01, O 0.47 / 0.45 / 0.53,
+        // wi 0.78 / 0.99 / 1.04, wo 0.73 / 0.69 / 0.80, cross-KV 0.97 / 1.10 / 1.09 -> the 320-row tile by default
+        const bool five = g_gemm_variant == 4 || g_gemm_variant == 3;
+        const bool four = g_gemm_variant == 2;
+        if (five) {
+            switch (epi) {
+                case EPI_F32_STORE: launch_xl<EPI_F32_STORE, 5>(a, stream); break;
+                case EPI_F32_RESID: launch_xl<EPI_F32_RESID, 5>(a, stream); break;
+                case EPI_PK_RELU: launch_xl<EPI_PK_RELU, 5>(a, stream); break;
+                case EPI_PK: launch_xl<EPI_PK, 5>(a, stream); break;
+                default: launch_xl<EPI_HEADS, 5>(a, stream); break;
+            }
+            return;
         }
-        return;
+        if (four) {
+            switch (epi) {
+                case EPI_F32_STORE: launch_xl<EPI_F32_STORE, 4>(a, stream); break;
+                case EPI_F32_RESID: launch_xl<EPI_F32_RESID, 4>(a, stream); break;
+                case EPI_PK_RELU: launch_xl<EPI_PK_RELU, 4>(a, stream); break;
+                case EPI_PK: launch_xl<EPI_PK, 4>(a, stream); break;
+                default: launch_xl<EPI_HEADS, 4>(a, stream); break;
+            }
+            return;
+        }
     }
     if (g_gemm_variant >= 1 && a.M >= GW_M) {
         switch (epi) {

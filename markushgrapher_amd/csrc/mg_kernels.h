@@ -58,7 +58,7 @@ struct GemmArgs {
     int x_kts, x_k0;
 };
 void gemm(const GemmArgs& a, int epi, mgStream_t stream);
-void gemm_set_variant(int v);   // 0: 128x128 kernel only; 1: + 256x128 three-stage; 2: + 256x256 wherever it fits; 3 (default): by shape
+void gemm_set_variant(int v);   // 0: 128x128 kernel only; 1: + 256x128 three-stage; 2: + 256x256; 4: + 320x256 wherever it fits; 3 (default): by shape
 
 // small-M (decode step) GEMM: M <= 32*MT rows of live sequences, weights streamed once.
 void gemm_rows(const GemmArgs& a, int epi, mgStream_t stream);

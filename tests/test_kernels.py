@@ -74,11 +74,13 @@ def test_gemm_packed_relu(be_name, mode, M, N, K):
 
 
 @pytest.mark.parametrize("be_name", BACKENDS)
-@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 520, 128), (512, 384, 192)])
-def test_gemm_256x256_tile_kernel(be_name, M, N, K):
-    """variant 2: the 256x256x64 two-stage kernel (ragged edges in M and N, several K-steps), all epilogue families."""
+@pytest.mark.parametrize("variant", [2, 4])
+@pytest.mark.parametrize("M,N,K", [(320, 256, 64), (300, 520, 128), (512, 384, 192), (700, 256, 128)])
+def test_gemm_256x256_tile_kernel(be_name, M, N, K, variant):
+    """variants 2 / 4: the 256x256x64 and 320x256x64 two-stage kernels (ragged edges in M and N, several K-steps), all
+    epilogue families."""
     be = get_backend(be_name)
-    be.lib.mgk_gemm_set_variant(2)
+    be.lib.mgk_gemm_set_variant(variant)
     try:
         x, w = rnd((M, K), 31), rnd((N, K), 32, 0.3)
         bias = rnd((N,), 33)
