@@ -148,7 +148,7 @@ void embed_assemble(const EmbedArgs& a, void* meta_ws, mgStream_t stream) {
     const size_t sh = ((a.P + 15) & ~15) + 256 * sizeof(int);
     MG_LAUNCH(embed_index_kernel, dim3(a.B), dim3(256), sh, stream, a, meta);
     int blocks = (a.B * a.S_cap + 3) / 4;
-    if (blocks > 8192) blocks = 8192;
+    if (blocks > 65536) blocks = 65536;
     MG_LAUNCH(embed_gather_kernel, dim3(blocks), dim3(256), 0, stream, a, (const EmbedMeta*)meta);
 }
 

@@ -119,14 +119,14 @@ __global__ __launch_bounds__(256) void rmsnorm_pack_kernel(const float* h, const
 void rmsnorm_pack(const float* h, const float* gain, uint16_t* x_pk, float* out_f32, int M, int d, float eps,
                   float scale, mgStream_t stream) {
     int blocks = (M + 3) / 4;
-    if (blocks > 8192) blocks = 8192;
+    if (blocks > 65536) blocks = 65536;     // one row per wave up to 256 K rows
     if (blocks < 1) blocks = 1;
     MG_LAUNCH(rmsnorm_pack_kernel, dim3(blocks), dim3(256), 0, stream, h, gain, x_pk, out_f32, (const int*)nullptr, M, d, eps, scale);
 }
 void rmsnorm_pack_rows(const float* h, const float* gain, uint16_t* x_pk, const int* dst_row, int M, int d, float eps,
                        float scale, mgStream_t stream) {
     int blocks = (M + 3) / 4;
-    if (blocks > 8192) blocks = 8192;
+    if (blocks > 65536) blocks = 65536;     // one row per wave up to 256 K rows
     if (blocks < 1) blocks = 1;
     MG_LAUNCH(rmsnorm_pack_kernel, dim3(blocks), dim3(256), 0, stream, h, gain, x_pk, (float*)nullptr, dst_row, M, d, eps, scale);
 }
