@@ -1103,6 +1103,90 @@ __global__ __launch_bounds__(NW * 64) void gemm_rows_resid_kernel(ResidArgs a) {
     resid_block16<MT, NW, (NW >= 16 ? 8 : 4)>(a, blockIdx.x, smem);
 }
 
+// FFN-wo form (K = d_ff) for ONE row tile, split by token group: a workgroup owns 8 output features and 16 of the 32
+// rows, so that 2*N/8 workgroups cover all 256 CUs and each pulls 64 KB of weights + 128 KB of activations through its
+// CU's L1 instead of 64 + 256 KB (the per-CU ingest at 64 B/clk is what bounds this projection).  The
+// two workgroups of a feature slice sit 8 apart in the grid = on the same XCD, so the slice's weights reach that L2 once.
+template <int NW, int U>
+__global__ __launch_bounds__(NW * 64) void gemm_rows_resid_split_kernel(ResidArgs a) {
+    MG_DYN_SMEM(smem);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int bid = blockIdx.x;
+    const int g = (bid >> 3) & 1, slice = (bid >> 4) * 8 + (bid & 7);
+    const int nt = slice >> 2, sub = slice & 3;
+    const bool wvalid = r16 < 8;
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    const int M = a.M, N = a.N;
+    const int kt16 = a.K >> 4, kp = kt16 >> 1;
+    const int per = (kp + NW - 1) / NW;
+    const int p0 = w * per, p1 = (p0 + per) < kp ? (p0 + per) : kp;
+    float* rsl = (float*)(smem + NW * 4 * 64 * sizeof(float));     // [32]
+    const size_t lane_off = (size_t)(kg >> 1) * TILE_BYTES + (size_t)(kg & 1) * 512;
+    const char* wp = (const char*)(a.W + pk_tile_off(nt, 0, a.K)) + lane_off + (size_t)(8 * sub + r16) * 16;
+    const int xkts = a.x_kts ? a.x_kts : kt16;
+    (void)xkts;
+    const char* xp = (const char*)a.X + (size_t)a.x_k0 * TILE_BYTES + lane_off + (size_t)(16 * g + r16) * 16;
+    RsRegs rsr;
+    rs_issue(a.rs, M, 32, tid, NW * 64, rsr);
+    const int n0 = nt * 32 + sub * 8 + kg * 4;
+    const int m = 16 * g + r16;
+    float4 h_pre = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (w == 0 && kg < 2 && m < M) h_pre = *(const float4*)(a.h + (size_t)m * N + n0);
+    int p = p0;
+    uint4 wf[U];
+    if (p + U <= p1) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) wf[u] = wvalid ? ld16_stream(wp + (size_t)(p + u) * (2 * TILE_BYTES)) : zero4;
+    }
+    rs_finish(a.rs, M, 32, rsl, tid, NW * 64, rsr);
+    f32x4 acc = acc4_zero();
+    for (bool first = true; p + U <= p1; p += U, first = false) {
+        if (!first) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) wf[u] = wvalid ? ld16_stream(wp + (size_t)(p + u) * (2 * TILE_BYTES)) : zero4;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = mfma16(wf[u], ld16(xp + (size_t)(2 * (p + u)) * TILE_BYTES), acc);
+    }
+    for (; p < p1; ++p) {
+        const uint4 w1 = wvalid ? ld16_stream(wp + (size_t)p * (2 * TILE_BYTES)) : zero4;
+        acc = mfma16(w1, ld16(xp + (size_t)(2 * p) * TILE_BYTES), acc);
+    }
+    float* slab = (float*)smem;                                  // [NW][4][64]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) slab[(w * 4 + j) * 64 + lane] = acc[j];
+    __syncthreads();
+    if (w == 0) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float t = 0.f;
+            for (int ww = 0; ww < NW; ++ww) t += slab[(ww * 4 + j) * 64 + lane];
+            v[j] = t * rsl[m];
+        }
+        const int nparts = N >> 3;
+        const int x_ld = a.x_ld ? a.x_ld : N, x2_ld = a.x2_ld ? a.x2_ld : N;
+        float ss = 0.f;
+        if (m < M && kg < 2) {
+            float4 hv = h_pre;
+            hv.x += v[0]; hv.y += v[1]; hv.z += v[2]; hv.w += v[3];
+            *(float4*)(a.h + (size_t)m * N + n0) = hv;
+            ss = (hv.x * hv.x + hv.y * hv.y) + (hv.z * hv.z + hv.w * hv.w);
+            if (a.x_pk) {
+                const float4 gn = *(const float4*)(a.gain + n0);
+                const float gs = a.gscale;
+                *(uint2*)(a.x_pk + pk_off(m, a.x_col0 + n0, x_ld)) =
+                    make_uint2(pack_bf16(hv.x * gn.x * gs, hv.y * gn.y * gs), pack_bf16(hv.z * gn.z * gs, hv.w * gn.w * gs));
+            }
+            if (a.x2_pk)
+                *(uint2*)(a.x2_pk + pk_off(m, a.x2_col0 + n0, x2_ld)) = make_uint2(pack_bf16(hv.x, hv.y), pack_bf16(hv.z, hv.w));
+        }
+        ss += __shfl_xor(ss, 16);
+        if (m < M && kg == 0) a.part[(size_t)m * nparts + slice] = ss;
+    }
+}
+
 // instrumented copy of the 16-wave, one-row-tile form (tools/trace_resid.py)
 __global__ __launch_bounds__(1024) void gemm_rows_resid_trace_kernel(ResidArgs a, long long* trace) {
     MG_DYN_SMEM(smem);
@@ -1119,6 +1203,11 @@ void gemm_rows_resid(const ResidArgs& r, mgStream_t stream) {
     // 16 waves for the long K = d_ff stream, unless 3+ live m-tiles need the registers (1024 threads: 128 per lane,
     // 80 of them accumulators at 5 m-tiles -> measured 52 us with scratch spills)
     const bool wide = r.K > 2048 && mt <= 2;
+    if (wide && mt == 1 && r.M > 16 && ((r.N >> 3) & 7) == 0 && r.x_kts == 0) {      // one row tile: split by token group
+        const size_t shs = (size_t)16 * 4 * 64 * sizeof(float) + 32 * sizeof(float);
+        MG_LAUNCH((gemm_rows_resid_split_kernel<16, 8>), dim3(2 * (r.N >> 3)), dim3(1024), shs, stream, r);
+        return;
+    }
     const int NW = wide ? 16 : 8;
     const dim3 block(NW * 64);
     const size_t sh = (size_t)NW * 8 * 64 * sizeof(float) + (size_t)32 * mt * sizeof(float);

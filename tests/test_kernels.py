@@ -484,7 +484,7 @@ def test_beam_reorder_physical_copy(be_name):
 
 
 @pytest.mark.parametrize("be_name", BACKENDS)
-@pytest.mark.parametrize("M,N,K", [(32, 64, 128), (20, 128, 256), (70, 64, 4096)])
+@pytest.mark.parametrize("M,N,K", [(32, 64, 128), (20, 128, 256), (70, 64, 4096), (32, 64, 4096), (20, 128, 4096)])
 def test_gemm_resid_deferred_norm(be_name, M, N, K):
     """h += X W^T; x = bf16(h*gain*gscale) un-normalised; per-row partial sums of squares; and a consumer that applies
     the deferred rsqrt(mean(h^2)+eps) must reproduce RMSNorm(h)*gain followed by the projection."""
