@@ -752,6 +752,72 @@ MG_DEV void rows_block16(const GemmArgs& a, int bid, char* smem) {
         __syncthreads();
     }
 }
+// One-row-tile form of rows_block16 split by token group: a unit = (16 output features, 16 of the 32 rows); the two units
+// of a feature slice are `pair_stride` apart in the unit numbering (callers place them on the same XCD).  Halves the
+// activation bytes a workgroup pulls through its CU's L1 (see gemm_rows_resid_split_kernel).
+template <int EPI, int NW, int U>
+MG_DEV void rows_split_block(const GemmArgs& a, int ht, int g, char* smem) {
+    static_assert(EPI == EPI_PK || EPI == EPI_PK_RELU || EPI == EPI_HEADS, "packed / per-head epilogues only");
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int nt = ht >> 1, sub = ht & 1;
+    const int kt16 = a.K >> 4, kp = kt16 >> 1;
+    const int per = (kp + NW - 1) / NW;
+    const int p0 = w * per, p1 = (p0 + per) < kp ? (p0 + per) : kp;
+    float* rsl = (float*)(smem + NW * 4 * 64 * sizeof(float));     // [32]
+    const size_t lane_off = (size_t)(kg >> 1) * TILE_BYTES + (size_t)(kg & 1) * 512;
+    const char* wp = (const char*)(a.W + pk_tile_off(nt, 0, a.K)) + lane_off + (size_t)(16 * sub + r16) * 16;
+    const char* xp = (const char*)a.X + (size_t)a.x_k0 * TILE_BYTES + lane_off + (size_t)(16 * g + r16) * 16;
+    RsRegs rsr;
+    rs_issue(a.rs, a.M, 32, tid, NW * 64, rsr);
+    int p = p0;
+    uint4 wf[U], xf[U];
+    const bool full = p + U <= p1;
+    if (full) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) wf[u] = ld16_stream(wp + (size_t)(p + u) * (2 * TILE_BYTES));
+#pragma unroll
+        for (int u = 0; u < U; ++u) xf[u] = ld16(xp + (size_t)(2 * (p + u)) * TILE_BYTES);
+    }
+    rs_finish(a.rs, a.M, 32, rsl, tid, NW * 64, rsr);
+    f32x4 acc = acc4_zero();
+    if (full) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = mfma16(wf[u], xf[u], acc);
+        p += U;
+    }
+    for (; p < p1; ++p) acc = mfma16(ld16_stream(wp + (size_t)p * (2 * TILE_BYTES)), ld16(xp + (size_t)(2 * p) * TILE_BYTES), acc);
+    float* slab = (float*)smem;                                  // [NW][4][64]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) slab[(w * 4 + j) * 64 + lane] = acc[j];
+    __syncthreads();
+    if (w == 0) {
+        const int m = 16 * g + r16;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float t = 0.f;
+            for (int ww = 0; ww < NW; ++ww) t += slab[(ww * 4 + j) * 64 + lane];
+            t *= rsl[m];
+            v[j] = (EPI == EPI_PK_RELU) ? fmaxf(t, 0.f) : t;
+        }
+        const uint32_t lo = pack_bf16(v[0], v[1]), hi = pack_bf16(v[2], v[3]);
+        const uint32_t plo = __shfl_xor(lo, 16), phi = __shfl_xor(hi, 16);
+        if ((kg & 1) == 0 && m < a.M) {
+            const uint4 ch = make_uint4(lo, hi, plo, phi);
+            const int n = nt * 32 + 16 * sub + 4 * kg;
+            if (n < a.N) {
+                if constexpr (EPI == EPI_HEADS) {
+                    const HeadsOut& ho = a.heads;
+                    const int ri = n / ho.inner, nn = n - ri * ho.inner;
+                    heads_store(ho, ri, nn >> 6, m, nn & 63, ch);
+                } else {
+                    st16(a.out_pk + pk_off(m, n, a.N), ch);
+                }
+            }
+        }
+    }
+}
 template <int EPI, int MT, bool HALF, int NW = 4>
 __global__ __launch_bounds__(NW * 64) void gemm_rows_kernel(GemmArgs a) {
     MG_DYN_SMEM(smem);
@@ -1231,6 +1297,16 @@ void gemm_rows_resid(const uint16_t* X, const uint16_t* W, float* h, const float
 
 // Residual projection and a half-tile projection side by side in one grid (8 waves per workgroup; the second
 // projection keeps up to 16 k-tiles per wave in flight: K = d_model + inner of the product weights in one round).
+// [residual projection | half-tile projection split by token group], one row tile: nres + 2*(N2/16) workgroups laid out so
+// that every aligned group of 16 consecutive workgroup ids holds 8 residual workgroups... (simple form: the second
+// projection's units follow the residual ones; unit u -> slice (u>>4)*8 + (u&7), group (u>>3)&1: same XCD for a slice)
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_rows_pair_split_kernel(ResidArgs r, GemmArgs g, int nres) {
+    MG_DYN_SMEM(smem);
+    if ((int)blockIdx.x < nres) { resid_block16<1, 8, 4>(r, blockIdx.x, smem); return; }
+    const int u = (int)blockIdx.x - nres;
+    rows_split_block<EPI, 8, 8>(g, (u >> 4) * 8 + (u & 7), (u >> 3) & 1, smem);
+}
 template <int EPI, int MT, bool HALF>
 __global__ __launch_bounds__(512) void gemm_rows_pair_kernel(ResidArgs r, GemmArgs g, int nres) {
     MG_DYN_SMEM(smem);
@@ -1244,6 +1320,15 @@ void gemm_rows_pair(const ResidArgs& r, const GemmArgs& g, int epi, mgStream_t s
     // features (FFN wi: 128 tiles) whole 32-feature tiles halve that traffic (+0.8 % end to end), with few (cross-Q:
     // 32 tiles) half tiles give the workgroups that keep the weight stream wide
     const bool full = g.N >= 2048;
+    const int nhalf = (g.N + 15) / 16;
+    if (!full && mt == 1 && r.M > 16 && (nhalf & 7) == 0 && (r.N & 63) == 0 && epi == EPI_HEADS) {
+        // one row tile, few output features (cross-Q): the second projection split by token group, 2*nhalf units; with
+        // nres a multiple of 8 the two units of a slice keep the same XCD
+        const int nres_s = r.N / 8;
+        const size_t shs = (size_t)8 * 8 * 64 * sizeof(float) + 32 * sizeof(float);
+        MG_LAUNCH((gemm_rows_pair_split_kernel<EPI_HEADS>), dim3(nres_s + 2 * nhalf), dim3(512), shs, stream, r, g, nres_s);
+        return;
+    }
     const int nres = r.N / 8, nrows = ((g.N + 31) / 32) * (full ? 1 : 2);
     const dim3 grid(nres + nrows), block(512);
     const size_t sh = (size_t)8 * 16 * 64 * sizeof(float) + (size_t)32 * mt * sizeof(float);
