@@ -856,7 +856,8 @@ __global__ __launch_bounds__(256) void gemm_rows_splitk_kernel(const uint16_t* X
     MG_DYN_SMEM(smem);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     float* rsl = (float*)(smem + 4 * 16 * 64 * sizeof(float));     // [32*MT] deferred RMSNorm scale per row
-    block_row_scales(rs, M, 32 * MT, rsl, tid, 256);
+    RsRegs rsr;                                                    // load order = wait order (see resid_block16)
+    rs_issue(rs, M, 32 * MT, tid, 256, rsr);
     const int ntiles = (N + 31) >> 5;
     const int nt = blockIdx.x % ntiles, ks = blockIdx.x / ntiles;
     const int kt16 = K >> 4;
@@ -870,12 +871,20 @@ __global__ __launch_bounds__(256) void gemm_rows_splitk_kernel(const uint16_t* X
     for (int i = 0; i < MT; ++i) acc[i] = acc_zero();
     const char* wp = (const char*)(W + pk_tile_off(nt, 0, K)) + lane * 16;
     const char* xp = (const char*)X + lane * 16;
-    constexpr int U = 8;
+    constexpr int U = MT <= 2 ? 16 : 8;           // K = 1024 over 4 waves: 16 k-tiles per wave in one round
     int kt = k0;
-    for (; kt + U <= k1; kt += U) {
-        uint4 wf[U];
+    uint4 wf[U];
+    const bool first_full = kt + U <= k1;
+    if (first_full) {
 #pragma unroll
         for (int u = 0; u < U; ++u) wf[u] = ld16_stream(wp + (size_t)(kt + u) * TILE_BYTES);
+    }
+    rs_finish(rs, M, 32 * MT, rsl, tid, 256, rsr);
+    for (bool first = true; kt + U <= k1; kt += U, first = false) {
+        if (!first) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) wf[u] = ld16_stream(wp + (size_t)(kt + u) * TILE_BYTES);
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
