@@ -187,7 +187,8 @@ struct Ws {
     void* meta;
     double *cx, *cy;
     uint8_t* mask;
-    int *xrow, *xlen, *counters;
+    int *xrow, *xlen, *counters, *att_kst;
+    uint8_t* att_qbv;
     // decode (generate)
     uint16_t *xk, *xv, *sk, *sv, *dq, *dx_pk, *dy_pk;
     uint16_t *xa, *xb;        // packed [rows][d + inner] operand windows of the pair projections: [bf16(h) | attention context]
@@ -242,6 +243,8 @@ void carve(const mg_model* m, char* base, int B, int L, int K, int max_len, int 
     w->xrow = c.take<int>(M);
     w->xlen = c.take<int>(B);
     w->counters = c.take<int>(16);
+    w->att_kst = c.take<int>((size_t)B * (1 + (S_cap >> 6)));
+    w->att_qbv = c.take<uint8_t>((size_t)B * ((S_cap + 127) / 128));
     if (max_len > 0) {
         const int R = B * K, Rp = round_up(R, 32);
         const size_t nl = m->dec.size();
@@ -631,6 +634,7 @@ int mg_encode(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_
     }
     // bucket indices of the three relative biases: shared by all layers and heads, computed once per batch
     bias_index(w.bidx, w.cx, w.cy, w.mask, m->at<int>(m->bk1), m->at<int>(m->bkhv), B, S, S_cap, st);
+    attn_lists(w.mask, B, S, S_cap, w.att_kst, w.att_qbv, st);
     for (size_t li = 0; li < m->enc.size(); ++li) {
         const EncLayer& l = m->enc[li];
         rmsnorm_pack(w.hidden, m->at<float>(l.ln0), w.x_pk, nullptr, M, d, m->c.layer_norm_epsilon, 1.0f, st);
@@ -641,7 +645,7 @@ int mg_encode(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_
         t.Q = w.q_pk; t.K = w.k_pk; t.Vt = w.vt_pk; t.ctx = w.ctx_pk; t.B = B; t.H = H; t.Sq = S; t.Sk = S;
         t.Sq_cap = S_cap; t.Sk_cap = S_cap; t.mode = ATT_ENC; t.kmask = w.mask;
         t.tab1 = m->at<float>(m->rb_raw[0]); t.tab1_len = 32; t.tabh = m->at<float>(m->rb_raw[1]); t.tabv = m->at<float>(m->rb_raw[2]);
-        t.bidx = w.bidx;
+        t.bidx = w.bidx; t.kst = w.att_kst; t.qbv = w.att_qbv;
         attention(t, st);
         GemmArgs o = gemm_args(w.ctx_pk, m->at<uint16_t>(l.wo), M, d, inner);
         o.out_f32 = w.hidden; o.ldo = d;

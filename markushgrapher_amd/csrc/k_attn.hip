@@ -39,6 +39,18 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     const int bh = bid / nqb;
     const int h = bh % a.H, b = bh / a.H;
     const int Sk_pad = (a.Sk + AT_KEYS - 1) / AT_KEYS * AT_KEYS;
+    // padded positions are never attended and their own outputs are never used: query blocks without an attended
+    // position only clear their context rows (later GEMMs must see finite values), key stages without an attended key
+    // are not visited
+    const int* kst = (MODE == ATT_ENC && a.kst) ? a.kst + (size_t)b * (1 + (a.Sk_cap >> 6)) : nullptr;
+    if (MODE == ATT_ENC && a.qbv && !a.qbv[(size_t)b * nqb + qb]) {
+        const int HDz = a.H * 64;
+        for (int i = tid; i < 128 * 8; i += 256) {
+            const int q = qb * 128 + (i >> 3), c = (i & 7) * 8;
+            if (q < a.Sq_cap) st16(a.ctx + pk_off(b * a.Sq_cap + q, h * 64 + c, HDz), make_uint4(0, 0, 0, 0));
+        }
+        return;
+    }
 
     // LDS carve: [2 stages][tables][key mask bytes (decoder modes)]
     //   ATT_ENC:      t1[32], th[32], tv[32] = the three bucket tables of head h
@@ -108,7 +120,8 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
         }
     };
 
-    int nst = Sk_pad / AT_KEYS;
+    int nst = kst ? kst[0] : Sk_pad / AT_KEYS;
+    auto sid = [&](int i) { return kst ? kst[1 + i] : i; };       // i-th visited key stage
     if (MODE == ATT_DEC_SELF) {   // keys beyond the workgroup's last query are all causally masked
         const int last_q = qb * 128 + 127;
         const int lim = last_q / AT_KEYS + 1;
@@ -122,16 +135,17 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);
     float m_run = AT_NEG;
 
-    stage(0, 0);
-    if (MODE == ATT_ENC) load_bidx(0, bnxt);
+    stage(0, sid(0));
+    if (MODE == ATT_ENC) load_bidx(sid(0), bnxt);
     __syncthreads();
-    for (int st = 0; st < nst; ++st) {
-        const int cur = st & 1;
-        if (st + 1 < nst) stage(cur ^ 1, st + 1);
+    for (int sti = 0; sti < nst; ++sti) {
+        const int cur = sti & 1;
+        const int st = sid(sti);                                      // key stage (64 keys) processed this iteration
+        if (sti + 1 < nst) stage(cur ^ 1, sid(sti + 1));
         if (MODE == ATT_ENC) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) bcur[i] = bnxt[i];
-            if (st + 1 < nst) load_bidx(st + 1, bnxt);
+            if (sti + 1 < nst) load_bidx(sid(sti + 1), bnxt);
         }
         const char* kb = st_base + cur * AT_STAGE_BYTES + lane * 16;
         const char* vb = kb + 8 * TILE_BYTES;
@@ -270,6 +284,33 @@ __global__ __launch_bounds__(256) void bias_index_kernel(uint16_t* out, const do
 void bias_index(uint16_t* out, const double* cx, const double* cy, const uint8_t* kmask, const int* bk1, const int* bkhv, int B,
                 int Sk, int S_cap, mgStream_t stream) {
     MG_LAUNCH(bias_index_kernel, dim3(4096), dim3(256), 0, stream, out, cx, cy, kmask, bk1, bkhv, B, Sk, S_cap);
+}
+
+// one workgroup per image: which 64-key stages / 128-query blocks contain an attended position
+__global__ __launch_bounds__(64) void attn_lists_kernel(const uint8_t* kmask, int Sk, int S_cap, int* kst, uint8_t* qbv) {
+    MG_DYN_SMEM(smem);
+    unsigned char* flag = (unsigned char*)smem;              // [S_cap/64]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int nstg = S_cap >> 6, nqb = (S_cap + 127) / 128;
+    const uint8_t* mk = kmask + (size_t)b * S_cap;
+    for (int s = tid; s < nstg; s += 64) {
+        int any = 0;
+        for (int k = s * 64; k < s * 64 + 64 && k < Sk; ++k) any |= mk[k];
+        flag[s] = any ? 1 : 0;
+    }
+    __syncthreads();
+    for (int q = tid; q < nqb; q += 64) qbv[(size_t)b * nqb + q] = (flag[2 * q] | ((2 * q + 1 < nstg) ? flag[2 * q + 1] : 0)) ? 1 : 0;
+    if (tid == 0) {
+        int* out = kst + (size_t)b * (1 + nstg);
+        int n = 0;
+        for (int s = 0; s < nstg; ++s)
+            if (flag[s]) out[1 + n++] = s;
+        if (n == 0) { out[1] = 0; n = 1; }                   // nothing attended: keep one stage so the softmax stays finite
+        out[0] = n;
+    }
+}
+void attn_lists(const uint8_t* kmask, int B, int Sk, int S_cap, int* kst, uint8_t* qbv, mgStream_t stream) {
+    MG_LAUNCH(attn_lists_kernel, dim3(B), dim3(64), (size_t)((S_cap >> 6) + 16), stream, kmask, Sk, S_cap, kst, qbv);
 }
 
 void attention(const AttnArgs& a, mgStream_t stream) {

@@ -174,10 +174,16 @@ struct AttnArgs {
     const float* tabv;
     const uint16_t* bidx;   // [B][Sk_cap/32][Sk_cap][32]
     int tab1_len;
+    // ATT_ENC, optional (attn_lists): per image the 64-key stages that hold at least one attended key, and which
+    // 128-query blocks hold at least one attended position; fully padded stages / blocks are skipped
+    const int* kst;         // [B][1 + Sk_cap/64]: count, stage ids
+    const uint8_t* qbv;     // [B][Sq_cap/128 rounded up]
 };
 // bucket indices of the encoder's relative biases, once per batch (see k_attn.hip)
 void bias_index(uint16_t* out, const double* cx, const double* cy, const uint8_t* kmask, const int* bk1, const int* bkhv, int B,
                 int Sk, int S_cap, mgStream_t stream);
+// stage / query-block lists for AttnArgs::kst / qbv from the key mask (one launch per batch)
+void attn_lists(const uint8_t* kmask, int B, int Sk, int S_cap, int* kst, uint8_t* qbv, mgStream_t stream);
 void attention(const AttnArgs& a, mgStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
