@@ -146,6 +146,12 @@ int mgk_attention(void* stream, int mode, const void* Q, const void* K, const vo
                   int Sq, int Sk, int Sq_cap, int Sk_cap, const uint8_t* kmask, const float* tab1, int tab1_len,
                   const float* tabh, const float* tabv, const double* cx, const double* cy, const int* bk1, const int* bkhv,
                   void* bidx_scratch);
+/* mgk_attention(mode 0) with the skip lists mg_encode uses: 64-key stages / 128-query blocks without an attended position
+ * are not visited (kst_scratch: B*(1+S_cap/64) ints, qbv_scratch: B*ceil(S_cap/128) bytes). */
+int mgk_attention_enc_skip(void* stream, const void* Q, const void* K, const void* Vt, void* ctx_pk, int B, int H, int S, int S_cap,
+                           const uint8_t* kmask, const float* tab1, const float* tabh, const float* tabv, const double* cx,
+                           const double* cy, const int* bk1, const int* bkhv, void* bidx_scratch, int* kst_scratch,
+                           uint8_t* qbv_scratch);
 int mgk_attention_step(void* stream, const void* q, const void* Kc, const void* Vc, void* ctx_pk, int rows, int H,
                        int group, int cap, const int* len, int n_keys, const float* bias, const int* anc, int t);
 int mgk_embed_assemble(void* stream, void* meta_ws, const int64_t* input_ids, const float* bbox,

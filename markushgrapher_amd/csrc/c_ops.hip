@@ -68,6 +68,23 @@ int mgk_attention(void* stream, int mode, const void* Q, const void* K, const vo
     return MG_OK;
 }
 
+// encoder attention with the padded-stage / padded-block skip lists built from the key mask (as mg_encode runs it)
+int mgk_attention_enc_skip(void* stream, const void* Q, const void* K, const void* Vt, void* ctx_pk, int B, int H, int S, int S_cap,
+                           const uint8_t* kmask, const float* tab1, const float* tabh, const float* tabv, const double* cx,
+                           const double* cy, const int* bk1, const int* bkhv, void* bidx_scratch, int* kst_scratch,
+                           uint8_t* qbv_scratch) {
+    if ((S_cap & 63) || S > S_cap || !kmask || !bidx_scratch || !kst_scratch || !qbv_scratch) return MG_E_ARG;
+    AttnArgs a{};
+    a.Q = (const uint16_t*)Q; a.K = (const uint16_t*)K; a.Vt = (const uint16_t*)Vt; a.ctx = (uint16_t*)ctx_pk;
+    a.B = B; a.H = H; a.Sq = S; a.Sk = S; a.Sq_cap = S_cap; a.Sk_cap = S_cap; a.mode = ATT_ENC; a.kmask = kmask;
+    a.tab1 = tab1; a.tab1_len = 32; a.tabh = tabh; a.tabv = tabv;
+    bias_index((uint16_t*)bidx_scratch, cx, cy, kmask, bk1, bkhv, B, S, S_cap, (mgStream_t)stream);
+    attn_lists(kmask, B, S, S_cap, kst_scratch, qbv_scratch, (mgStream_t)stream);
+    a.bidx = (const uint16_t*)bidx_scratch; a.kst = kst_scratch; a.qbv = qbv_scratch;
+    attention(a, (mgStream_t)stream);
+    return MG_OK;
+}
+
 int mgk_attention_step(void* stream, const void* q, const void* Kc, const void* Vc, void* ctx_pk, int rows, int H,
                        int group, int cap, const int* len, int n_keys, const float* bias, const int* anc, int t) {
     if (group < 1 || group > 8) return MG_E_SHAPE;

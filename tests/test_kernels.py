@@ -555,3 +555,53 @@ def test_gemm_pair_product_weights(be_name, M, N2, d, inner):
     # and exactly (to bf16 output rounding) the product form on the rounded operands
     exact = np.maximum(xwin[:M] @ pk.bf16_round(w2_ref).T, 0)
     np.testing.assert_allclose(got, exact, rtol=1 / 100, atol=2e-3 * scale)
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+def test_attention_encoder_skips_padded_stages(be_name):
+    """Encoder attention as mg_encode runs it: key stages (64 keys) and query blocks (128 queries) without an attended
+    position are skipped.  Attended query rows must match the masked reference; rows of a skipped query block are zero."""
+    import torch
+    from oracle.udop_oracle import relative_position_bucket as rpb
+    be = get_backend(be_name)
+    B, H, S, S_cap = 2, 2, 300, 320
+    q, k, v = [pk.bf16_round(rnd((B, H, S_cap, 64), 120 + i, 0.5)) for i in range(3)]
+    rs = np.random.RandomState(15)
+    cx, cy = np.round(rs.rand(B, S_cap) * 64) / 64.0, rs.rand(B, S_cap)
+    mask = np.ones((B, S_cap), np.uint8)
+    mask[0, 40:200] = 0          # stages 1 and 2 (keys 64..191) fully padded, stages 0 and 3 partly; query block 0 partly
+    mask[1, 128:256] = 0         # stages 2, 3 and the whole query block 1 padded
+    mask[:, S:] = 0
+    w1, wh, wv = [rnd((32, H), 130 + i) for i in range(3)]
+    pos = np.arange(S)
+    b1 = rpb(torch.from_numpy(pos[None, :] - pos[:, None]), True, 32, 128).numpy()
+    ref = np.zeros((B, H, S, 64), np.float32)
+    for b in range(B):
+        dx = ((torch.from_numpy(cx[b, None, :S] - cx[b, :S, None]).float() * 100).to(torch.long))
+        dy = ((torch.from_numpy(cy[b, None, :S] - cy[b, :S, None]).float() * 100).to(torch.long))
+        bh, bv = rpb(dx, True, 32, 100).numpy(), rpb(dy, True, 32, 100).numpy()
+        for h in range(H):
+            sc = q[b, h, :S] @ k[b, h, :S].T + w1[b1, h] + wh[bh, h] + wv[bv, h]
+            sc = np.where(mask[b, None, :S] != 0, sc, -1e30)
+            ref[b, h] = softmax_ref(sc) @ v[b, h, :S]
+    Q, K, V = be.buf(pack_heads_rows(q)), be.buf(pack_heads_rows(k)), be.buf(pack_heads_t(v))
+    ctx = be.buf(np.full((B * S_cap * H * 64,), 0x7FC0, np.uint16))       # NaN pattern: skipped blocks must clear it
+    bk1 = rpb(torch.arange(-128, 129), True, 32, 128).numpy().astype(np.int32)
+    bkhv = rpb(torch.arange(-100, 101), True, 32, 100).numpy().astype(np.int32)
+    bidx = be.zeros((B * S_cap * S_cap,), np.uint16)
+    kst = be.zeros((B * (1 + S_cap // 64),), np.int32)
+    qbv = be.zeros((B * ((S_cap + 127) // 128),), np.uint8)
+    be.lib.mgk_attention_enc_skip.argtypes = [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p] * 11
+    rc = be.lib.mgk_attention_enc_skip(be.stream, be.p(Q), be.p(K), be.p(V), be.p(ctx), B, H, S, S_cap, be.p(be.buf(mask)),
+                                       be.p(be.buf(w1)), be.p(be.buf(wh)), be.p(be.buf(wv)), be.p(be.buf(cx)), be.p(be.buf(cy)),
+                                       be.p(be.buf(bk1)), be.p(be.buf(bkhv)), be.p(bidx), be.p(kst), be.p(qbv))
+    assert rc == 0
+    ks = kst.numpy().reshape(B, 1 + S_cap // 64)
+    assert ks[0, 0] == 3 and ks[0, 1:4].tolist() == [0, 3, 4] and ks[1, 0] == 3 and ks[1, 1:4].tolist() == [0, 1, 4]
+    assert qbv.numpy().reshape(B, 3).tolist() == [[1, 1, 1], [1, 0, 1]]
+    got = pk.unpack_tiles(ctx.numpy(), B * S_cap, H * 64).reshape(B, S_cap, H, 64).transpose(0, 2, 1, 3)
+    for b in range(B):
+        rows = np.nonzero(mask[b, :S])[0]
+        np.testing.assert_allclose(got[b][:, rows], ref[b][:, rows], rtol=0, atol=2e-2)
+    assert np.all(got[1][:, 128:256] == 0)            # the skipped query block was cleared
+    assert np.all(np.isfinite(got[:, :, :S]))
