@@ -95,13 +95,13 @@ def main():
     B, new_tokens = args.batch, args.new_tokens
     max_length = new_tokens + 1
     t0 = time.time()
-    sd = synth.recipe_state_dict(shape, gain=1.0)
+    sd = synth.recipe_state_dict(shape, **synth.BENCH_RECIPE)
     t_weights = time.time() - t0
     eng = Engine(shape, max_decode_len=max(512, max_length))
     eng.load_state_dict(sd)
     eng.set_decode_graph(args.decode_graph)
     # each rank gets its own shard of the global batch (independent images, no data-path exchange)
-    inp = synth.synth_batch(shape, B, seed=20260928 + rank, return_pages=True)
+    inp = synth.synth_batch(shape, B, seed=synth.BENCH_SEED + rank, return_pages=True)
     dev = {k: eng.mem.asarray(v, {"input_ids": np.int64, "bbox": np.float32, "attention_mask": np.uint8,
                                   "pixel_values": np.float32, "pages_u8": np.uint8}[k]) for k, v in inp.items()}
     L = inp["input_ids"].shape[1]

@@ -43,6 +43,9 @@ typedef struct mg_config {
     int pad_token_id, eos_token_id, decoder_start_token_id;
     float layer_norm_epsilon;
     int max_decode_len;          /* capacity of the decoder self-attention cache / bias table (>= max_length) */
+    int tie_word_embeddings;     /* 1 (UDOP / MarkushGrapher default): lm_head = shared.weight, logits scaled by d_model^-0.5
+                                    (stock modeling_udop.py:1405-1413,1554-1557) and a checkpoint's lm_head.weight is ignored,
+                                    as HF's tie_weights() does; 0: lm_head.weight is a required tensor, no scale */
 } mg_config;
 
 typedef struct mg_model mg_model;
@@ -90,6 +93,15 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
                 int min_length, float length_penalty, int early_stopping, int64_t* out_ids, int* out_cols_host,
                 float* out_scores, float* step_top2);
 
+/* Limits: B * num_beams <= 256 live sequences per call (MG_E_UNSUPPORTED beyond; split the batch), num_beams <= 8. */
+
+/* Parity-test instrumentation of mg_generate (tests only; while set, the decode steps are launched eagerly with by-value
+ * arguments instead of replaying the captured graph - the same kernels).  logits_capture [capture_steps][B*num_beams][vocab]
+ * fp32 (device) receives the pre-argmax logits of decode steps 0 .. capture_steps-1.  forced_ids [B][max_length] i64
+ * (device, greedy only): the token fed into step t+1 is forced_ids[b][t+1] instead of step t's argmax, i.e. teacher
+ * forcing THROUGH the KV-cached decode path; out_ids / step_top2 still record every step's own selection.  NULL clears. */
+int mg_debug_decode_capture(mg_model* m, float* logits_capture, int capture_steps, const int64_t* forced_ids);
+
 /* Beam-search KV-cache reorder, physical form: for every decoder layer, dst K/V rows [r] = src rows [beam_idx[r]]
  * (cache_utils.py:100-104 index_select).  kv_src/kv_dst: [layers][2][rows][H][t_cap][64] bf16; only the first
  * `t_used` positions of every row are copied. */
@@ -105,6 +117,10 @@ int mg_profile_read(mg_model* m, long* launches_host, double* total_ms_host, dou
 /* Calibration of the bracket: after every timed launch a third event is recorded right behind the second; this returns
  * the summed duration of those EMPTY brackets (what two hipEventRecord cost on the stream with nothing in between). */
 int mg_profile_read_overhead(mg_model* m, double* empty_ms_host);
+/* Phase timing of mg_generate: three HIP events per call bracket [encoder + cross-K/V precompute] and [decode loop];
+ * mg_profile_phases_read returns the number of calls and the summed durations since it was enabled. */
+int mg_profile_phases(mg_model* m, int enable);
+int mg_profile_phases_read(mg_model* m, long* calls_host, double* enc_ms_host, double* dec_ms_host);
 int mg_debug_bucket_table(const mg_model* m, int which, int* out_host, int n);
 
 /* Decode-step replay. The ~200 launches of one decode step (the body of the reference's generation loop,

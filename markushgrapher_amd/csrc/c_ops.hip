@@ -63,6 +63,7 @@ int mgk_attention(void* stream, int mode, const void* Q, const void* K, const vo
         if (!bidx_scratch || !bk1 || !bkhv || !cx || !cy || Sq_cap != Sk_cap) return MG_E_ARG;
         bias_index((uint16_t*)bidx_scratch, cx, cy, kmask, bk1, bkhv, B, Sk, Sk_cap, (mgStream_t)stream);
         a.bidx = (const uint16_t*)bidx_scratch;
+        a.bk1 = bk1;
     }
     attention(a, (mgStream_t)stream);
     return MG_OK;
@@ -80,7 +81,7 @@ int mgk_attention_enc_skip(void* stream, const void* Q, const void* K, const voi
     a.tab1 = tab1; a.tab1_len = 32; a.tabh = tabh; a.tabv = tabv;
     bias_index((uint16_t*)bidx_scratch, cx, cy, kmask, bk1, bkhv, B, S, S_cap, (mgStream_t)stream);
     attn_lists(kmask, B, S, S_cap, kst_scratch, qbv_scratch, (mgStream_t)stream);
-    a.bidx = (const uint16_t*)bidx_scratch; a.kst = kst_scratch; a.qbv = qbv_scratch;
+    a.bidx = (const uint16_t*)bidx_scratch; a.bk1 = bk1; a.kst = kst_scratch; a.qbv = qbv_scratch;
     attention(a, (mgStream_t)stream);
     return MG_OK;
 }

@@ -88,6 +88,16 @@ struct mg_model {
     std::vector<float> beam_div_host;
     int use_graph = 1;
     bool graph_active = false;
+    // optional phase timing of mg_generate (HIP events): [start, encoder + cross-K/V done, decode loop done]
+    bool phase_on = false;
+    mgEvent_t phase_ev[3] = {};
+    long phase_n = 0;
+    double phase_enc_ms = 0.0, phase_dec_ms = 0.0;
+    // parity-test instrumentation of the greedy decode loop (mg_debug_decode_capture)
+    float* dbg_logits = nullptr;
+    int dbg_steps = 0;
+    const int64_t* dbg_forced = nullptr;
+    bool tied = true;          // tie_word_embeddings: lm_head = shared.weight and logits scaled by d_model^-0.5 (stock:1554-1557)
 #ifndef MG_EMU
     hipStream_t own_stream = nullptr;
     hipEvent_t fork_ev = nullptr;
@@ -98,6 +108,7 @@ struct mg_model {
         if (own_stream) (void)hipStreamDestroy(own_stream);
         if (fork_ev) (void)hipEventDestroy(fork_ev);
 #endif
+        for (mgEvent_t e : phase_ev) if (e) mg_event_destroy(e);
     }
 
     template <typename T> T* at(size_t off) const { return (T*)(arena + off); }
@@ -152,6 +163,17 @@ __global__ void step_end_kernel(int* counters, int greedy) {
         if (counters[0] == 0 && counters[1] < 0) counters[1] = counters[2];
         counters[2] += 1;
     }
+}
+// parity-test instrumentation (mg_debug_decode_capture): copy the step's logits / overwrite the token fed to the next step
+__global__ __launch_bounds__(256) void capture_logits_kernel(const float* logits, int ldl, float* out, int rows, int V) {
+    const size_t n = (size_t)rows * V;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / V, c = i - r * V;
+        out[i] = logits[r * ldl + c];
+    }
+}
+__global__ __launch_bounds__(64) void force_ids_kernel(int64_t* next_ids, const int64_t* forced, int rows, int max_len, int pos) {
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += gridDim.x * blockDim.x) next_ids[r] = forced[(size_t)r * max_len + pos];
 }
 // teacher-forced decoder: pad [B][T] ids to [B][T_cap] rows and build the compact-row map of the valid positions
 __global__ __launch_bounds__(256) void pad_dec_inputs_kernel(const int64_t* ids, const uint8_t* mask, int64_t* ids_pad, uint8_t* mask_pad,
@@ -347,6 +369,7 @@ int mg_create(const mg_config* cfg, mg_model** out) {
     m->n_side = c.image_size / c.patch_size; m->P = m->n_side * m->n_side; m->Kpatch = Kpatch;
     m->M2 = c.max_2d_position_embeddings;
     m->T_cap = round_up(c.max_decode_len > 0 ? c.max_decode_len : 512, 64);
+    m->tied = c.tie_word_embeddings != 0;
     // arena layout
     size_t off = 0;
     auto take = [&](size_t bytes) { off = align_up(off, 256); size_t o = off; off += bytes; return o; };
@@ -437,11 +460,14 @@ int mg_load_tensor(mg_model* m, void* stream, const char* hf_key, const void* sr
     if (key == "shared.weight" || key == "encoder.embed_tokens.weight" || key == "decoder.embed_tokens.weight") {
         if (!want({m->V, d})) return bad_shape();
         convert_to_bf16(src, dtype, m->at<uint16_t>(m->tok_emb), (size_t)m->V * d, st);
-        if (!m->lm_head_loaded) packw(m->lm_head, 0, m->V, d);    // tied unless lm_head.weight is loaded explicitly
+        if (m->tied) packw(m->lm_head, 0, m->V, d);               // tied head (stock:1405-1413)
         return mark("shared.weight");
     }
     if (key == "lm_head.weight") {
         if (!want({m->V, d})) return bad_shape();
+        // tie_word_embeddings: the checkpoint's lm_head.weight is discarded and the head re-tied to shared.weight, as
+        // HF's tie_weights() does after loading; only an untied config uses it (then without the d_model^-0.5 scale)
+        if (m->tied) return MG_KEY_IGNORED;
         packw(m->lm_head, 0, m->V, d);
         m->lm_head_loaded = true;
         return mark("lm_head.weight");
@@ -560,6 +586,7 @@ int mg_finalize(mg_model* m, void* stream) {
             need.push_back(buf);
         }
     }
+    if (!m->tied) need.push_back("lm_head.weight");
     for (const std::string& k : need)
         if (!m->loaded.count(k)) return fail(MG_E_STATE, "mg_finalize: tensor %s was never loaded", k.c_str());
     const int H = m->H;
@@ -645,7 +672,7 @@ int mg_encode(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_
         t.Q = w.q_pk; t.K = w.k_pk; t.Vt = w.vt_pk; t.ctx = w.ctx_pk; t.B = B; t.H = H; t.Sq = S; t.Sk = S;
         t.Sq_cap = S_cap; t.Sk_cap = S_cap; t.mode = ATT_ENC; t.kmask = w.mask;
         t.tab1 = m->at<float>(m->rb_raw[0]); t.tab1_len = 32; t.tabh = m->at<float>(m->rb_raw[1]); t.tabv = m->at<float>(m->rb_raw[2]);
-        t.bidx = w.bidx; t.kst = w.att_kst; t.qbv = w.att_qbv;
+        t.bidx = w.bidx; t.bk1 = m->at<int>(m->bk1); t.kst = w.att_kst; t.qbv = w.att_qbv;
         attention(t, st);
         GemmArgs o = gemm_args(w.ctx_pk, m->at<uint16_t>(l.wo), M, d, inner);
         o.out_f32 = w.hidden; o.ldo = d;
@@ -706,11 +733,19 @@ int mg_decoder_forward(mg_model* m, void* stream, void* ws, size_t ws_bytes, con
     }
     // final norm, d_model^-0.5 (tied head, stock:1554-1555), lm_head on the B*T real positions only
     rmsnorm_pack_rows(w.tf_hidden, m->at<float>(m->dec_ln), w.tf_xc, w.tf_rowmap, MT, d, m->c.layer_norm_epsilon,
-                      1.0f / sqrtf((float)d), st);
+                      m->tied ? 1.0f / sqrtf((float)d) : 1.0f, st);
     GemmArgs lg = gemm_args(w.tf_xc, m->at<uint16_t>(m->lm_head), B * T, m->V, d);
     lg.out_f32 = logits; lg.ldo = m->V;
     gemm(lg, EPI_F32_STORE, st);
-    return check_launch("mg_decoder_forward");
+    // out-of-range token ids (encoder or decoder side) were replaced by id 0 and counted: report them, as the
+    // reference's embedding lookup would raise (SYNCHRONISES)
+    int bad_ids = 0;
+    mg_memcpy_async(&bad_ids, w.counters + 3, sizeof(int), st);
+    mg_stream_sync(st);
+    const int rc = check_launch("mg_decoder_forward");
+    if (rc != MG_OK) return rc;
+    if (bad_ids != 0) return fail(MG_E_INPUT, "mg_decoder_forward: %d token ids outside [0, vocab)", bad_ids);
+    return MG_OK;
 }
 
 int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* input_ids, const float* bbox,
@@ -720,11 +755,16 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
     if (!m || !out_ids || !out_cols_host) return fail(MG_E_ARG, "mg_generate: null argument");
     if (max_length < 2 || max_length > m->T_cap) return fail(MG_E_SHAPE, "mg_generate: max_length must be in [2, %d]", m->T_cap);
     if (num_beams < 1 || num_beams > 8) return fail(MG_E_UNSUPPORTED, "mg_generate: num_beams must be in [1, 8]");
+    // the decode-step projections keep all live rows of a workgroup's feature slice in registers: at most 8 row tiles
+    if ((long)B * num_beams > 256)
+        return fail(MG_E_UNSUPPORTED, "mg_generate: B * num_beams = %ld live sequences exceeds the supported 256; split the batch",
+                    (long)B * num_beams);
     mgStream_t st = (mgStream_t)stream;
     const int K = num_beams;
     Ws w;
     carve(m, (char*)ws, B, L, K, max_length, 0, &w);
     if (w.total > ws_bytes) return fail(MG_E_WORKSPACE, "mg_generate: workspace too small (%zu < %zu)", ws_bytes, w.total);
+    if (m->phase_on) mg_event_record(m->phase_ev[0], st);
     int rc = mg_encode(m, stream, ws, ws_bytes, input_ids, bbox, attention_mask, pixel_values, B, L, nullptr, nullptr);
     if (rc != MG_OK) return rc;
     const int d = m->d, H = m->H, inner = m->inner, S_cap = m->st_Scap, M = B * S_cap;
@@ -738,6 +778,7 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
         kv.heads.row_map = w.xrow;
         gemm(kv, EPI_HEADS, st);
     }
+    if (m->phase_on) mg_event_record(m->phase_ev[1], st);
     int* counters = w.counters;
     const int64_t start = m->c.decoder_start_token_id, pad = m->c.pad_token_id;
 #ifndef MG_EMU
@@ -777,7 +818,7 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
     RowScale rs2{w.rs_part2, d / 8, 1.0f / (float)d, eps};    // after the cross-attention output (FFN norm)
     // One decode step.  tdev == nullptr: step-dependent values are passed by value (eager launches); otherwise the
     // kernels read the step from the device counter, which makes the launch sequence capturable as a graph.
-    auto decode_step = [&](int t, const int* tdev) {
+    auto decode_step = [&](int t, const int* tdev, bool time_cross) {
         embed_norm_rows(w.next_ids, m->at<uint16_t>(m->tok_emb), w.dh, m->at<float>(m->dec[0].ln0), w.dx_pk, w.xa, K2, 0, R, d, m->V,
                         counters + 3, eps, st);
         for (size_t li = 0; li < nl; ++li) {
@@ -807,7 +848,7 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
             AttnStepArgs x{};
             x.q = w.dq; x.qrs = rs1; x.Kc = w.xk + li * xkv_stride; x.Vc = w.xv + li * xkv_stride; x.ctx = w.xb; x.ctx_ld = K2;
             x.ctx_col0 = d; x.rows = R; x.H = H; x.group = K; x.cap = S_cap; x.len = w.xlen;
-            const bool timed = !tdev && m->prof_every > 0 && (t % m->prof_every) == 0 && m->prof_used + 3 <= m->prof_ev.size();
+            const bool timed = time_cross && m->prof_used + 3 <= m->prof_ev.size();
             if (timed) mg_event_record(m->prof_ev[m->prof_used], st);
             attention_step(x, st);
             if (timed) {   // third event right behind the second: the empty bracket calibrates what two records alone cost
@@ -828,12 +869,15 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
                 const bool last = li + 1 == nl;
                 ResidArgs r{};
                 r.X = w.dy_pk; r.W = m->at<uint16_t>(l.wo2); r.h = w.dh; r.gain = m->at<float>(last ? m->dec_ln : m->dec[li + 1].ln0);
-                r.gscale = last ? 1.0f / sqrtf((float)d) : 1.0f; r.x_pk = w.dx_pk; r.x2_pk = w.xa; r.x2_ld = K2; r.part = w.rs_part;
+                r.gscale = (last && m->tied) ? 1.0f / sqrtf((float)d) : 1.0f; r.x_pk = w.dx_pk; r.x2_pk = w.xa; r.x2_ld = K2; r.part = w.rs_part;
                 r.M = R; r.N = d; r.K = m->dff; r.rs = rs2;
                 gemm_rows_resid(r, st);
             }
         }
         gemm_rows_splitk(w.dx_pk, m->at<uint16_t>(m->lm_head), w.logits, R, m->V, d, ldl, 0, 1, rs0, st);
+        if (m->dbg_logits && t < m->dbg_steps)
+            MG_LAUNCH(capture_logits_kernel, dim3(1024), dim3(256), 0, st, (const float*)w.logits, ldl,
+                      m->dbg_logits + (size_t)t * R * m->V, R, m->V);
         if (K == 1) {
             ArgmaxArgs g{};
             g.logits = w.logits; g.rows = R; g.V = m->V; g.ldl = ldl; g.eos = m->c.eos_token_id; g.pad = (int)pad;
@@ -843,6 +887,8 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
             g.top2 = step_top2 ? (tdev ? step_top2 : step_top2 + (size_t)(t + 1) * R * 2) : nullptr;
             g.step_ctr = counters;      // the last workgroup to finish does the step bookkeeping (no step_end launch)
             greedy_select(g, st);
+            if (m->dbg_forced && t + 1 < max_length)
+                MG_LAUNCH(force_ids_kernel, dim3((R + 63) / 64), dim3(64), 0, st, w.next_ids, m->dbg_forced, R, max_length, t + 1);
         } else {
             beam_step(w.beam_state, w.logits, ldl, m->V, B, K, max_length, t + 1, tdev, w.beam_div, m->c.eos_token_id, min_length,
                       length_penalty, early_stopping, w.next_ids, w.beam_idx, counters, st);
@@ -851,8 +897,9 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
         if (K > 1) MG_LAUNCH(step_end_kernel, dim3(1), dim3(64), 0, st, counters, 0);
     };
     bool graphed = false;
+    const bool instrumented = m->dbg_logits || m->dbg_forced;      // by-value eager launches of the same kernels
 #ifndef MG_EMU
-    if (m->use_graph == 1) {
+    if (m->use_graph == 1 && !instrumented) {
         const StepGraph::Key key{ws, out_ids, step_top2, (const void*)st, B, L, K, max_length, min_length, early_stopping, length_penalty};
         StepGraph& sg = m->step_graph;
         if (!(sg.valid && sg.key == key)) {
@@ -860,7 +907,7 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
             hipGraph_t graph = nullptr;
             hipError_t e1 = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal), e2 = hipSuccess, e3 = hipSuccess;
             if (e1 == hipSuccess) {
-                decode_step(0, counters + 2);
+                decode_step(0, counters + 2, false);
                 e2 = hipStreamEndCapture(st, &graph);
                 if (e2 == hipSuccess && graph) {
                     e3 = hipGraphInstantiate(&sg.exec, graph, nullptr, nullptr, 0);
@@ -885,19 +932,24 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
         } else
 #endif
         {
-            // use_graph == 2: the device-counter form launched eagerly (what the graph replays; testable without HIP graphs)
-            decode_step(t, (m->use_graph == 2 && !timed_step) ? counters + 2 : nullptr);
+            // use_graph == 2: the device-counter form launched eagerly (what the graph replays; testable without HIP graphs).
+            // A timed step of a graphed call launches that same device-counter form, so the bracketed launches are the
+            // kernels the graph replays (the step counter lives on the device and advances identically).
+            const bool dev_form = !instrumented && (m->use_graph == 2 || graphed);
+            decode_step(t, dev_form ? counters + 2 : nullptr, timed_step);
         }
         steps_done = t + 1;
         // termination is checked every 8 steps (and at the end): overrunning only appends pad columns, which are
-        // trimmed with the device-recorded `done_step`
-        if ((t & 7) == 7 || t + 2 >= max_length) {
+        // trimmed with the device-recorded `done_step`.  With min_length >= max_length EOS is suppressed at every
+        // position, no row can finish early and the host never looks.
+        if (min_length < max_length && ((t & 7) == 7 || t + 2 >= max_length)) {
             mg_memcpy_async(host_flag, counters, sizeof host_flag, st);
             mg_stream_sync(st);
             if (host_flag[0] == 0) break;
         }
     }
     if (K > 1) beam_finalize(w.beam_state, B, K, max_length, out_ids, counters + 4, out_scores, st);
+    if (m->phase_on) mg_event_record(m->phase_ev[2], st);
     std::vector<int> xlen_host;
     if (m->prof_used) { xlen_host.resize(B); mg_memcpy_async(xlen_host.data(), w.xlen, (size_t)B * sizeof(int), st); }
     mg_memcpy_async(host_flag, counters, sizeof host_flag, st);
@@ -916,6 +968,11 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
             m->prof_keys += keys;
         }
         m->prof_used = 0;
+    }
+    if (m->phase_on) {
+        m->phase_enc_ms += mg_event_elapsed_ms(m->phase_ev[0], m->phase_ev[1]);
+        m->phase_dec_ms += mg_event_elapsed_ms(m->phase_ev[1], m->phase_ev[2]);
+        m->phase_n += 1;
     }
     if (host_flag[3] != 0) return fail(MG_E_INPUT, "mg_generate: %d token ids outside [0, vocab)", host_flag[3]);
     if (K == 1) *out_cols_host = 1 + (host_flag[1] >= 0 ? host_flag[1] + 1 : steps_done);
@@ -936,6 +993,32 @@ int mg_profile_cross_attention(mg_model* m, int every, int max_samples) {
         if (mg_event_create(&e) != 0) return fail(MG_E_HIP, "hipEventCreate failed");
         m->prof_ev.push_back(e);
     }
+    return MG_OK;
+}
+// Parity-test instrumentation of mg_generate (see mgrapher.h); cleared by passing null pointers.
+int mg_debug_decode_capture(mg_model* m, float* logits_capture, int capture_steps, const int64_t* forced_ids) {
+    if (!m) return fail(MG_E_ARG, "mg_debug_decode_capture: null model");
+    m->dbg_logits = logits_capture;
+    m->dbg_steps = logits_capture ? capture_steps : 0;
+    m->dbg_forced = forced_ids;
+    return MG_OK;
+}
+// Phase timing of mg_generate with three HIP events per call: [encoder + cross-K/V precompute | decode loop].
+int mg_profile_phases(mg_model* m, int enable) {
+    if (!m) return fail(MG_E_ARG, "mg_profile_phases: null model");
+    if (enable && !m->phase_ev[0]) {
+        for (int i = 0; i < 3; ++i)
+            if (mg_event_create(&m->phase_ev[i]) != 0) return fail(MG_E_HIP, "hipEventCreate failed");
+    }
+    m->phase_on = enable != 0;
+    m->phase_n = 0; m->phase_enc_ms = 0.0; m->phase_dec_ms = 0.0;
+    return MG_OK;
+}
+int mg_profile_phases_read(mg_model* m, long* calls, double* enc_ms, double* dec_ms) {
+    if (!m) return fail(MG_E_ARG, "mg_profile_phases_read: null model");
+    if (calls) *calls = m->phase_n;
+    if (enc_ms) *enc_ms = m->phase_enc_ms;
+    if (dec_ms) *dec_ms = m->phase_dec_ms;
     return MG_OK;
 }
 int mg_set_decode_graph(mg_model* m, int enable) {

@@ -241,6 +241,283 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Encoder attention (ATT_ENC), second form.  Workgroup = 8 waves = 256 consecutive queries of one (image, head), 32 per wave;
+// one raw barrier per 64-key stage, K / V^T stages double-buffered by inline-asm LDS-DMA that stays in flight across the
+// barrier (the builtin form makes hipcc drain vmcnt(0) in front of every ds_read, i.e. it serialised each stage behind the
+// prefetch of the next one).  What is new against attention_kernel<ATT_ENC> is the cost of a score (VALU and LDS are the
+// co-critical pipes of this kernel next to the matrix pipe: 16 scores per lane and 32x32 tile against 8 MFMAs):
+//   * horizontal + vertical bias from ONE lookup: a per-head [vertical bucket][horizontal bucket] table of 1024 sums in LDS
+//     (+ one entry = AT_NEG for masked keys); the per-pair index array holds the BYTE address of the entry (u16), so a
+//     score costs one and/shift and one ds_read_b32.  Horizontal bucket minor = LDS bank: the 32 queries of a wave that lie
+//     in one patch row share the vertical bucket of a key and hit 32 different banks or the same word;
+//   * 1-D bias by distance: all pairs of a (32-query, 32-key) tile further apart than 128 positions share one bucket
+//     (stock:422-468 saturates at max_distance), so the term is a per-tile constant folded into the running-max
+//     bookkeeping (zero instructions per score); only the ~5 tiles around the diagonal read a distance-indexed table, with
+//     the register's key offset as the instruction's immediate offset (no address arithmetic per score);
+//   * exp2 with log2(e) folded into the score fma and into the tables; row sums of the rounded weights by v_dot2 on the
+//     packed pairs (half an instruction per score; the ones-MFMA of the first form cost 20 % of the matrix pipe).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int AE_WAVES = 8;
+constexpr int AE_QB = 32 * AE_WAVES;                 // queries per workgroup
+constexpr int AE_HV = 1024;                          // [bv][bh] entries; entry AE_HV = masked key
+constexpr int AE_D1 = 192;                           // distance table covers key - query in [-AE_D1, AE_D1]
+constexpr int AE_DEPTH = 2;                          // stages in flight ahead of the one being computed
+constexpr int AE_RING = AE_DEPTH + 1;                // K / V^T stage buffers (a slot is refilled one barrier after its last read)
+constexpr int AE_IDX_BYTES = AE_WAVES * 4 * TILE_BYTES;   // index words of one stage: 4 KiB per wave, read back by that wave only
+constexpr float AE_LOG2E = 1.4426950408889634f;
+constexpr int AE_MAXST = 64;                         // visited-stage list kept in LDS (S_cap <= 4096)
+constexpr int AE_SMEM = AE_RING * AT_STAGE_BYTES + AE_DEPTH * AE_IDX_BYTES + (AE_HV + 4) * 4 + (2 * AE_D1 + 4) * 4 + AE_MAXST * 4;
+
+MG_DEV float fast_exp2(float x) {
+#ifdef MG_EMU
+    return exp2f(x);
+#else
+    return __builtin_amdgcn_exp2f(x);
+#endif
+}
+
+// Pipeline: the registers of a workgroup (170+ per lane) allow one workgroup per CU, so all memory-level parallelism is the
+// prefetch depth: K / V^T stages and the wave's index words all travel by LDS-DMA (inline asm, invisible to hipcc's
+// s_waitcnt insertion) AE_DEPTH stages ahead; every wave waits with a COUNTED vmcnt for its own copies of the current stage
+// and one raw barrier per stage makes the K / V^T fragments visible to the other waves.  6 copies per wave and stage
+// (4 x 1 KiB of index words, 2 fragments; waves without an attended query issue only the 2 fragments).  Inside the stage
+// loop there must be NO compiler-tracked vector-memory access: a compiler-inserted vmcnt(0) would drain the pipeline
+// (the stage list therefore lives in LDS, and the loads of the prologue are retired by hand before the loop).
+__global__ __launch_bounds__(512) void attention_enc_kernel(AttnArgs a) {
+    MG_DYN_SMEM(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+#ifdef MG_EMU
+    const int w = tid >> 6;
+#else
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: tile distances below are scalar branches
+#endif
+    const int half = lane >> 5, l32 = lane & 31;
+    const int nqb = (a.Sq_cap + AE_QB - 1) / AE_QB;
+    int bid = blockIdx.x;
+    if ((a.B & 7) == 0) {          // an image's heads and query blocks on one XCD: its index array and K/V reach one L2
+        const int per_img = a.H * nqb, xcd = bid & 7, j = bid >> 3;
+        bid = ((j / per_img) * 8 + xcd) * per_img + (j % per_img);
+    }
+    const int qb = bid % nqb;
+    const int bh = bid / nqb;
+    const int h = bh % a.H, b = bh / a.H;
+    const int HD = a.H * 64;
+    const int* kst = a.kst ? a.kst + (size_t)b * (1 + (a.Sk_cap >> 6)) : nullptr;
+    if (a.qbv) {                   // query block without an attended position: clear its context rows, nothing else
+        const int n128 = (a.Sq_cap + 127) / 128;
+        const uint8_t* qv = a.qbv + (size_t)b * n128;
+        const bool any = qv[2 * qb] | ((2 * qb + 1 < n128) ? qv[2 * qb + 1] : 0);
+        if (!any) {
+            for (int i = tid; i < AE_QB * 8; i += 512) {
+                const int q = qb * AE_QB + (i >> 3), c = (i & 7) * 8;
+                if (q < a.Sq_cap) st16(a.ctx + pk_off(b * a.Sq_cap + q, h * 64 + c, HD), make_uint4(0, 0, 0, 0));
+            }
+            return;
+        }
+    }
+    char* st_base = smem;
+    char* ix_base = smem + AE_RING * AT_STAGE_BYTES + w * (4 * TILE_BYTES);      // + slot * AE_IDX_BYTES
+    float* hv = (float*)(smem + AE_RING * AT_STAGE_BYTES + AE_DEPTH * AE_IDX_BYTES);
+    float* t1d = hv + AE_HV + 4;
+    int* ksl = (int*)(t1d + 2 * AE_D1 + 4);
+    const int nst = kst ? kst[0] : (a.Sk + AT_KEYS - 1) / AT_KEYS;
+    for (int i = tid; i < nst && i < AE_MAXST; i += 512) ksl[i] = kst ? kst[1 + i] : i;
+    for (int i = tid; i < AE_HV; i += 512)
+        hv[i] = (a.tabh[(size_t)(i & 31) * a.H + h] + a.tabv[(size_t)(i >> 5) * a.H + h]) * AE_LOG2E;
+    if (tid < 4) hv[AE_HV + tid] = AT_NEG;
+    for (int i = tid; i < 2 * AE_D1 + 1; i += 512) {
+        int d = i - AE_D1;
+        d = d < -128 ? -128 : (d > 128 ? 128 : d);
+        t1d[i] = a.tab1[(size_t)a.bk1[d + 128] * a.H + h] * AE_LOG2E;
+    }
+
+    const int q0 = qb * AE_QB + w * 32;
+    int qrt = q0 >> 5;
+    const int qrt_max = (a.Sq_cap >> 5) - 1;
+    if (qrt > qrt_max) qrt = qrt_max;
+    const uint16_t* Qb = a.Q + (((size_t)b * a.H + h) * (size_t)(a.Sq_cap >> 5) + (size_t)qrt) * (4 * TILE_ELEMS);
+    mg_raw16 qr[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) gld16_async(qr[kt], (const char*)(Qb + kt * TILE_ELEMS) + lane * 16);
+    const int qi = q0 + l32;
+    const int qcl = qi < a.Sk_cap ? qi : a.Sk_cap - 1;
+    // a wave in a 128-query block without an attended position (the granularity of attn_lists, and what the first form of
+    // the kernel skipped: padded rows next to attended ones are still computed, as the reference does) keeps loading its
+    // share of the stages and meeting the barriers, but computes nothing; its context rows are cleared (later GEMMs must
+    // see finite values)
+    int act = q0 < a.Sq_cap ? 1 : 0;
+    if (a.qbv && act) act = a.qbv[(size_t)b * ((a.Sq_cap + 127) / 128) + (q0 >> 7)] ? 1 : 0;
+    __syncthreads();               // tables and stage list complete
+    // retire every load of the prologue by hand (the Q fragments were raw loads: nothing may touch them before this wait):
+    // from here on the vector-memory queue holds only the hand-counted copies below
+    MG_WAIT_VMCNT_TIE4(0, qr[0], qr[1], qr[2], qr[3]);
+    uint4 qf[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) qf[kt] = raw16_get(qr[kt]);
+    // 1-D term of a tile whose pairs are all >= 128 positions apart (saturated bucket, stock:455-466): keys left / right
+    const float c_left = t1d[0], c_right = t1d[2 * AE_D1];
+
+    const uint16_t* bix = a.bidx + ((size_t)b * (size_t)(a.Sk_cap >> 5) * (size_t)a.Sk_cap + (size_t)qcl) * 32 + half * 16;
+    const size_t bix_tile = (size_t)a.Sk_cap * 32;
+    const uint16_t* Kb = a.K + ((size_t)b * a.H + h) * (size_t)(a.Sk_cap >> 5) * (4 * TILE_ELEMS);
+    const uint16_t* Vb = a.Vt + ((size_t)b * a.H + h) * 2 * (size_t)(a.Sk_cap >> 4) * TILE_ELEMS;
+    const int krt_max = (a.Sk_cap >> 5) - 1, vkt_max = (a.Sk_cap >> 4) - 1;
+    auto sid = [&](int i) { return ksl[i]; };
+    // issue everything this wave copies for the i-th visited stage: its index words (active waves; 16 keys = 32 B per lane
+    // and 32-key tile, as 4 x 16 B per lane -> 4 copies of 1 KiB) into index slot i % AE_DEPTH, then its two K / V^T
+    // fragments into ring slot i % AE_RING (fragments 0..7 = K: key-tile f/4, dk-tile f%4; 8..15 = V^T: d-tile, key-k-tile)
+    auto issue = [&](int i) {
+        const int st = sid(i);
+        if (act) {
+            char* ix = ix_base + (i % AE_DEPTH) * AE_IDX_BYTES;
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                const uint16_t* p = bix + (size_t)(st * 2 + t2) * bix_tile;
+                glds16_async(p, ix + (t2 * 2) * TILE_BYTES);
+                glds16_async(p + 8, ix + (t2 * 2 + 1) * TILE_BYTES);
+            }
+        }
+        char* dst = st_base + (i % AE_RING) * AT_STAGE_BYTES;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int f = w * 2 + k;
+            const char* src;
+            if (f < 8) {
+                int krt = st * 2 + (f >> 2);
+                krt = krt < krt_max ? krt : krt_max;
+                src = (const char*)(Kb + ((size_t)krt * 4 + (f & 3)) * TILE_ELEMS);
+            } else {
+                const int g = f - 8, dt = g >> 2;
+                int vkt = st * 4 + (g & 3);
+                vkt = vkt < vkt_max ? vkt : vkt_max;
+                src = (const char*)(Vb + ((size_t)dt * (size_t)(a.Sk_cap >> 4) + (size_t)vkt) * TILE_ELEMS);
+            }
+            glds16_async(src + lane * 16, dst + f * TILE_BYTES);
+        }
+    };
+
+    f32x16 o[2] = {acc_zero(), acc_zero()};
+    float lsum = 0.f, m_run = AT_NEG;
+    static_assert(AE_DEPTH == 2, "wait counts below");
+    issue(0);
+    if (1 < nst) issue(1);
+    for (int sti = 0; sti < nst; ++sti) {
+        // own copies of stage sti have landed when at most those of the one later stage in flight are outstanding
+        if (sti + 1 < nst) { if (act) MG_WAIT_VMCNT(6); else MG_WAIT_VMCNT(2); }
+        else MG_WAIT_VMCNT(0);
+        MG_BARRIER_RAW();            // everybody's copies of stage sti have landed; the K / V^T slot of stage sti - 1 is free
+        const int st = sid(sti);
+        if (!act) {
+            if (sti + AE_DEPTH < nst) issue(sti + AE_DEPTH);
+            continue;
+        }
+        uint4 bcur[4];
+        {
+            const char* ix = ix_base + (sti % AE_DEPTH) * AE_IDX_BYTES + lane * 16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bcur[i] = ld16(ix + i * TILE_BYTES);
+        }
+        MG_WAIT_LGKM0();             // index words are in registers: their slot is refilled for stage sti + AE_DEPTH
+        if (sti + AE_DEPTH < nst) issue(sti + AE_DEPTH);
+        const char* kb = st_base + (sti % AE_RING) * AT_STAGE_BYTES + lane * 16;
+        const char* vb = kb + 8 * TILE_BYTES;
+        f32x16 s[2];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            s[t2] = acc_zero();
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) s[t2] = mfma32(ld16(kb + (t2 * 4 + kt) * TILE_BYTES), qf[kt], s[t2]);
+        }
+        // scores in the log2 domain: v = s*log2e + hv[pair] (+ 1-D term near the diagonal); tile maxima
+        float cst[2], tmx[2];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            const int k0 = st * AT_KEYS + t2 * 32;
+            const int dk = k0 - q0;                                   // wave-uniform
+            const uint32_t* bw = (const uint32_t*)&bcur[t2 * 2];
+            float tm = AT_NEG;
+            if (dk > -(128 + 31) && dk < 128 + 31) {                 // some pair of the tile is closer than 128: per-score term
+                const char* tl = (const char*)t1d + (k0 - qi + 4 * half + AE_D1) * 4;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t e = (r & 1) ? (bw[r >> 1] >> 16) : (bw[r >> 1] & 0xFFFFu);
+                    const float bias = *(const float*)((const char*)hv + e) + *(const float*)(tl + ((r & 3) + 8 * (r >> 2)) * 4);
+                    const float v = fmaf(s[t2][r], AE_LOG2E, bias);
+                    s[t2][r] = v;
+                    tm = fmaxf(tm, v);
+                }
+                cst[t2] = 0.f;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t e = (r & 1) ? (bw[r >> 1] >> 16) : (bw[r >> 1] & 0xFFFFu);
+                    const float v = fmaf(s[t2][r], AE_LOG2E, *(const float*)((const char*)hv + e));
+                    s[t2][r] = v;
+                    tm = fmaxf(tm, v);
+                }
+                cst[t2] = dk < 0 ? c_left : c_right;
+            }
+            tmx[t2] = tm + cst[t2];
+        }
+        float mloc = fmaxf(tmx[0], tmx[1]);
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = fast_exp2(m_run - m_new);
+        m_run = m_new;
+        uint4 pch[4];
+        float psum = 0.f;
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            const float mt = m_new - cst[t2];
+            f32x16 p;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) p[r] = fast_exp2(s[t2][r] - mt);
+            // the row sum is taken over the ROUNDED values (two per v_dot2 with a ones pair), so that O / l stays a convex
+            // combination of the value rows whatever the rounding of the dominant weights
+            const PackedAcc pa = acc_pack(p);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { psum = dot2_bf16(pa.p[g][0], 0x3F803F80u, psum); psum = dot2_bf16(pa.p[g][1], 0x3F803F80u, psum); }
+            packed_to_chunks(pa, half, &pch[2 * t2]);
+        }
+#ifdef MG_EMU
+        const bool rescale = true;
+#else
+        const bool rescale = __any(alpha != 1.0f);
+#endif
+        if (rescale) {
+            lsum *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        }
+        lsum += psum;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const uint4 v0 = ld16(vb + (0 * 4 + kk) * TILE_BYTES), v1 = ld16(vb + (1 * 4 + kk) * TILE_BYTES);
+            o[0] = mfma32(v0, pch[kk], o[0]);
+            o[1] = mfma32(v1, pch[kk], o[1]);
+        }
+    }
+    lsum += __shfl_xor(lsum, 32);          // the two halves hold different keys of the same query
+    const float inv = act ? 1.0f / lsum : 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        f32x16 v;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = o[dt][r] * inv;
+        uint4 ch[2];
+        acc_to_chunks(v, half, ch);
+        if (qi < a.Sq_cap) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                st16(a.ctx + pk_off(b * a.Sq_cap + qi, h * 64 + dt * 32 + q * 16 + half * 8, HD), ch[q]);
+        }
+    }
+}
+
 static size_t attn_smem(const AttnArgs& a) {
     const int Sk_pad = (a.Sk + AT_KEYS - 1) / AT_KEYS * AT_KEYS;
     const int t1n = (a.mode == ATT_CROSS) ? 0 : (a.mode == ATT_ENC ? 64 : a.tab1_len);
@@ -252,8 +529,10 @@ static size_t attn_smem(const AttnArgs& a) {
 
 // Per-(image, query, key) bias bucket indices of the encoder, once per batch (the three relative biases are shared
 // by all layers and differ between heads only through the table values, stock:1215,1234-1235):
-//   entry = masked << 15 | bucket1d(key - query) << 10 | bucketH << 5 | bucketV          (stock:904-1009 semantics:
-//   box centres in float64, difference -> fp32, *100, truncation; 1-D distance in the combined sequence).
+//   entry = BYTE address of the pair's sum in the per-head [vertical bucket][horizontal bucket] table of
+//   attention_enc_kernel: 4 * (32 * bucketV + bucketH), or 4 * 1024 (the masked entry) for a key that is not attended
+//   (stock:904-1009 semantics: box centres in float64, difference -> fp32, *100, truncation).  The 1-D bucket is a function
+//   of key - query in the combined sequence and is not stored.
 // Layout [image][key tile of 32][query][32] with the 32 keys of a tile in MFMA accumulator order
 // (entry half*16 + r <-> key (r%4) + 8*(r/4) + 4*half), so a lane of the attention kernel reads its 16 keys as 32 B.
 __global__ __launch_bounds__(256) void bias_index_kernel(uint16_t* out, const double* cx, const double* cy, const uint8_t* kmask,
@@ -267,16 +546,14 @@ __global__ __launch_bounds__(256) void bias_index_kernel(uint16_t* out, const do
         const int kt = (int)(rest % (size_t)(S_cap >> 5)), b = (int)(rest / (size_t)(S_cap >> 5));
         const int r = e & 15, half = e >> 4;
         const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        uint32_t v = 0x8000u;
+        uint32_t v = 4u * AE_HV;
         if (key < Sk && (kmask == nullptr || kmask[(size_t)b * S_cap + key] != 0)) {
-            int d1 = key - q;
-            d1 = d1 < -128 ? -128 : (d1 > 128 ? 128 : d1);
             const double qx = cx[(size_t)b * S_cap + q], qy = cy[(size_t)b * S_cap + q];
             const float fx = (float)(cx[(size_t)b * S_cap + key] - qx) * 100.0f;
             const float fy = (float)(cy[(size_t)b * S_cap + key] - qy) * 100.0f;
             const int dx = (int)fmaxf(fminf(fx, 100.0f), -100.0f);
             const int dy = (int)fmaxf(fminf(fy, 100.0f), -100.0f);
-            v = ((uint32_t)bk1[d1 + 128] << 10) | ((uint32_t)bkhv[dx + 100] << 5) | (uint32_t)bkhv[dy + 100];
+            v = 4u * (32u * (uint32_t)bkhv[dy + 100] + (uint32_t)bkhv[dx + 100]);
         }
         out[i] = (uint16_t)v;
     }
@@ -317,8 +594,12 @@ void attention(const AttnArgs& a, mgStream_t stream) {
     const int nqb = (a.Sq_cap + 127) / 128;
     const dim3 grid(a.B * a.H * nqb), block(256);
     const size_t sh = attn_smem(a);
-    if (a.mode == ATT_ENC) MG_LAUNCH((attention_kernel<ATT_ENC>), grid, block, sh, stream, a);
-    else if (a.mode == ATT_DEC_SELF) MG_LAUNCH((attention_kernel<ATT_DEC_SELF>), grid, block, sh, stream, a);
+    if (a.mode == ATT_ENC) {
+        const int nqe = (a.Sq_cap + AE_QB - 1) / AE_QB;
+        static bool once = false;
+        if (!once) { MG_SET_MAX_SMEM(&attention_enc_kernel, AE_SMEM); once = true; }
+        MG_LAUNCH(attention_enc_kernel, dim3(a.B * a.H * nqe), dim3(512), (size_t)AE_SMEM, stream, a);
+    } else if (a.mode == ATT_DEC_SELF) MG_LAUNCH((attention_kernel<ATT_DEC_SELF>), grid, block, sh, stream, a);
     else MG_LAUNCH((attention_kernel<ATT_CROSS>), grid, block, sh, stream, a);
 }
 

@@ -182,6 +182,22 @@ MG_DEV void glds16_async(const void* gsrc_lane, void* lds_wave_base) {
 #endif
 }
 
+// 16-byte global load into registers that the compiler does not track (no s_waitcnt inserted on its behalf, it does not
+// count against the vmcnt the compiler computes for its own loads): for hand-pipelined prefetch several stages ahead.
+// The destination must not be read, copied or moved before MG_WAIT_VMCNT_TIE(N, regs...) has covered the load.
+#ifdef MG_EMU
+typedef uint4 mg_raw16;
+MG_DEV void gld16_async(mg_raw16& dst, const void* p) { dst = *(const uint4*)p; }
+MG_DEV uint4 raw16_get(const mg_raw16& r) { return r; }
+#define MG_WAIT_VMCNT_TIE4(N, a, b, c, d) ((void)0)
+#else
+typedef unsigned int mg_raw16 __attribute__((ext_vector_type(4)));
+MG_DEV void gld16_async(mg_raw16& dst, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory"); }
+MG_DEV uint4 raw16_get(const mg_raw16& r) { return make_uint4(r.x, r.y, r.z, r.w); }
+// counted wait that the four registers depend on: their first use cannot be scheduled above it
+#define MG_WAIT_VMCNT_TIE4(N, a, b, c, d) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "memory")
+#endif
+
 MG_DEV uint4 ld16(const void* p) { return *(const uint4*)p; }
 // streamed-once data (decode K/V, decode weights): non-temporal load, does not displace reusable lines
 MG_DEV uint4 ld16_stream(const void* p) {

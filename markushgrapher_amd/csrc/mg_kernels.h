@@ -167,12 +167,13 @@ struct AttnArgs {
     int B, H, Sq, Sk, Sq_cap, Sk_cap;
     int mode;
     const uint8_t* kmask;   // [B][Sk_cap] 1 = attended (nullable = all Sk attended)
-    // ATT_ENC: tab1/tabh/tabv = RAW bucket tables [32][H] (1-D, horizontal, vertical) and bidx = per-(image, query, key)
-    //          bucket indices from bias_index();  ATT_DEC_SELF: tab1 = [tab1_len][H] indexed by distance i-j >= 0
+    // ATT_ENC: tab1/tabh/tabv = RAW bucket tables [32][H] (1-D, horizontal, vertical), bk1 = distance -> 1-D bucket,
+    //          bidx = per-(image, query, key) table addresses from bias_index();  ATT_DEC_SELF: tab1 = [tab1_len][H] indexed by distance i-j >= 0
     const float* tab1;
     const float* tabh;
     const float* tabv;
     const uint16_t* bidx;   // [B][Sk_cap/32][Sk_cap][32]
+    const int* bk1;         // ATT_ENC: 1-D bucket of key - query for the 257 distances -128..128 (stock:422-468)
     int tab1_len;
     // ATT_ENC, optional (attn_lists): per image the 64-key stages that hold at least one attended key, and which
     // 128-query blocks hold at least one attended position; fully padded stages / blocks are skipped

@@ -21,7 +21,7 @@ class MgConfig(C.Structure):
         "vocab_size", "d_model", "d_kv", "d_ff", "num_layers", "num_decoder_layers", "num_heads",
         "relative_attention_num_buckets", "relative_attention_max_distance", "max_2d_position_embeddings",
         "image_size", "patch_size", "num_channels", "pad_token_id", "eos_token_id", "decoder_start_token_id")] + [
-        ("layer_norm_epsilon", C.c_float), ("max_decode_len", C.c_int)]
+        ("layer_norm_epsilon", C.c_float), ("max_decode_len", C.c_int), ("tie_word_embeddings", C.c_int)]
 
 
 class MgError(RuntimeError):
@@ -82,7 +82,9 @@ class TorchMem:
 
 
 class Engine:
-    def __init__(self, shape: ModelShape, lib=None, mem=None, max_decode_len: int = 512):
+    MAX_LIVE_ROWS = 256     # B * num_beams per generate() call (include/mgrapher.h "Limits")
+
+    def __init__(self, shape: ModelShape, lib=None, mem=None, max_decode_len: int = 512, tie_word_embeddings: bool = True):
         self.lib = lib if lib is not None else _lib.load()
         self.mem = mem if mem is not None else TorchMem()
         self.shape = shape
@@ -91,7 +93,8 @@ class Engine:
                        shape.num_decoder_layers, shape.num_heads, shape.relative_attention_num_buckets,
                        shape.relative_attention_max_distance, shape.max_2d_position_embeddings, shape.image_size,
                        shape.patch_size, shape.num_channels, shape.pad_token_id, shape.eos_token_id,
-                       shape.decoder_start_token_id, shape.layer_norm_epsilon, max_decode_len)
+                       shape.decoder_start_token_id, shape.layer_norm_epsilon, max_decode_len,
+                       1 if tie_word_embeddings else 0)
         self.model = C.c_void_p()
         self._chk(self.lib.mg_create(C.byref(cfg), C.byref(self.model)))
         self.max_decode_len = (max_decode_len + 63) // 64 * 64
@@ -122,6 +125,7 @@ class Engine:
                                   C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
                                   C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
         L.mg_debug_bucket_table.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int]
+        L.mg_debug_decode_capture.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
 
     def _chk(self, rc):
         if rc < 0:
@@ -238,9 +242,23 @@ class Engine:
                                               self.mem.ptr(dm) if dm is not None else None, B, T, self.mem.ptr(logits)))
         return logits, enc_out, enc_mask
 
+    def debug_decode_capture(self, capture_steps=0, rows=0, forced_ids=None):
+        """Parity-test instrumentation (include/mgrapher.h mg_debug_decode_capture): returns the device buffer
+        [capture_steps][rows][vocab] that the next generate() calls fill with their per-step logits; forced_ids
+        [B][max_length] teacher-forces the decode path.  Call with no arguments to clear."""
+        cap = self.mem.zeros((capture_steps, rows, self.shape.vocab_size), np.float32) if capture_steps > 0 else None
+        frc = None if forced_ids is None else self.mem.asarray(forced_ids, np.int64)
+        self._dbg_keep = (cap, frc)
+        self._chk(self.lib.mg_debug_decode_capture(self.model, self.mem.ptr(cap) if cap is not None else None, capture_steps,
+                                                   self.mem.ptr(frc) if frc is not None else None))
+        return cap
+
     def generate(self, input_ids, bbox, attention_mask, pixel_values, num_beams=1, max_length=512, min_length=0,
                  length_penalty=1.0, early_stopping=False, return_top2=False):
         ids, bb, am, pv, B, L = self._inputs(input_ids, bbox, attention_mask, pixel_values)
+        if B * num_beams > self.MAX_LIVE_ROWS:
+            raise MgError(f"generate: B * num_beams = {B * num_beams} live sequences exceeds the supported "
+                          f"{self.MAX_LIVE_ROWS}; split the batch")
         ws, nb = self.workspace(B, L, num_beams, max_length, 0)
         # the id buffer is persistent per (B, max_length): the captured decode-step graph holds its address, so a stable
         # buffer lets later calls replay the graph instead of re-capturing; callers get a copy

@@ -103,6 +103,18 @@ class ModelShape:
         return asdict(self)
 
 
+# The benchmark configuration (bench.py, tests/golden/g4_bench.npz): input seed and the recipe of the random-init weights.
+# With the plain recipe (all gains 1) greedy decoding is degenerate: the tied head echoes the input token (one id repeated
+# with margin ~4).  Scaling every block linear (the survey's x6) does make it varied, but only by making
+# the softmax of 48 attention stacks near-argmax, i.e. the network chaotic: two fp32 implementations (stock UDOP and the
+# oracle) then disagree by O(1) on the encoder output (measured: 3.6e-6 at gain 1, 6e-4 at gain 2, 2.5 at gain 4), so
+# nothing could be pinned on it.  This recipe gets varied, image-dependent sequences from a numerically tame network
+# instead: small token embeddings (no echo through the tied head), strong FFNs (a smooth pseudo-random function of the
+# running state), moderately sharp cross-attention (image dependence); self-attention scores stay O(1).  bf16-emulated
+# and fp32 oracles agree on its logits to ~0.01 (|logit| ~ 1).  Kernel cost does not depend on the values.
+BENCH_SEED = 20260928
+BENCH_RECIPE = dict(gain=1.0, embed_gain=0.25, ffn_gain=6.0, xq_gain=3.0)
+
 SHAPES: Dict[str, ModelShape] = {
     # UDOP-large shape = MarkushGrapher-2's VTL encoder/decoder
     "large": ModelShape(),
@@ -181,7 +193,8 @@ def tied_aliases(s: ModelShape) -> Dict[str, str]:
 
 
 def recipe_state_dict(s: ModelShape, seed: int = 20260928, gain: float = 1.0,
-                      bf16_exact: bool = True) -> Dict[str, np.ndarray]:
+                      bf16_exact: bool = True, embed_gain: float = 1.0, ffn_gain: float = 1.0,
+                      xq_gain: float = 1.0) -> Dict[str, np.ndarray]:
     """Random-init weights of the given shape.  Uniform(-a, a) with a chosen per kind so activations
     stay O(1); ``gain`` scales the attention/FFN linears (default-scale random weights make
     greedy decoding collapse onto one token).  With ``bf16_exact`` every value is representable in bf16 so
@@ -191,7 +204,7 @@ def recipe_state_dict(s: ModelShape, seed: int = 20260928, gain: float = 1.0,
     inner = s.num_heads * dk
     r3 = math.sqrt(3.0)
     amp = {
-        "embed": 1.0 * r3,
+        "embed": embed_gain * r3,
         "conv": r3 / math.sqrt(s.num_channels * s.patch_size * s.patch_size),
         "bias": 0.1,
         "cell": 0.5 * r3,
@@ -199,8 +212,8 @@ def recipe_state_dict(s: ModelShape, seed: int = 20260928, gain: float = 1.0,
         "q": gain * r3 / math.sqrt(d) * (dk ** -0.25),
         "kv": gain * r3 / math.sqrt(d),
         "o": gain * r3 / math.sqrt(inner),
-        "wi": gain * r3 / math.sqrt(d),
-        "wo": gain * r3 / math.sqrt(dff),
+        "wi": gain * ffn_gain * r3 / math.sqrt(d),
+        "wo": gain * ffn_gain * r3 / math.sqrt(dff),
     }
     def make(item):
         key, shape, kind = item
@@ -208,7 +221,8 @@ def recipe_state_dict(s: ModelShape, seed: int = 20260928, gain: float = 1.0,
         if kind == "norm":
             w = (np.float32(1.0) + np.float32(0.25) * u).astype(np.float32)
         else:
-            w = (u * np.float32(amp[kind])).astype(np.float32)
+            a = amp[kind] * (xq_gain if key.endswith("EncDecAttention.q.weight") else 1.0)
+            w = (u * np.float32(a)).astype(np.float32)
         return key, (round_bf16(w) if bf16_exact else w)
 
     spec = state_dict_spec(s)

@@ -1,0 +1,164 @@
+"""Parity of the BENCHMARK configuration itself (BASELINE.json configs[1] greedy and configs[2] beam-5): UDOP-large
+shape, B = 32 on bench.py's own inputs (synthetic 1024 px pages -> device LANCZOS -> 512 px), recipe weights with the
+bench's gain, against tests/golden/g4_bench.npz minted from stock transformers UDOP (tools/make_golden.py g4; the
+reference's fork is unavailable: fork-only pieces stay parity-unpinned).  These are the tests that put the
+M = 32 production-dimension decode kernels (and the 160-row beam forms) under an oracle check.
+
+Tolerances (measured with tools/g4_probe.py on MI355X - profiles/r02_g4_probe.log - then set with >= 2x margin):
+  ENC_*      encoder output rows (unit-RMS after the final norm x gains in [0.75, 1.25]); measured max 0.025, mean 0.0038,
+             per-image |sum| within 8e-6
+  LOGIT_TOL  pre-argmax logits (max |logit| 1.28 with this recipe): bf16 operands / fp32 accumulation vs the fp32 reference;
+             measured max 0.0089 over 32 images x (16 decode steps + 32 teacher-forced positions) x top-8
+  ids        bit-exact wherever the reference's top-1/top-2 margin exceeds MARGIN_TOL = 2 x LOGIT_TOL (two logits each within
+             LOGIT_TOL cannot swap across a larger gap); measured: argmax equal in 100 % of the cases with margin > 0.02
+"""
+import numpy as np
+import pytest
+
+from markushgrapher_amd import synth
+from tests.backends import make_engine
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+ENC_MAX, ENC_MEAN, ENC_SUM_REL = 0.06, 0.01, 1e-3
+LOGIT_TOL = 0.02
+MARGIN_TOL = 2 * LOGIT_TOL
+
+_state = {}
+
+
+def _setup():
+    if not _state:
+        g = load_golden("g4_bench.npz")
+        shape = synth.SHAPES["large"]
+        rec = dict(zip(("gain", "embed_gain", "ffn_gain", "xq_gain"), [float(v) for v in g["recipe"]]))
+        assert rec == synth.BENCH_RECIPE and int(g["synth_seed"]) == synth.BENCH_SEED      # the fixture IS bench.py's configuration
+        sd = synth.recipe_state_dict(shape, **rec)
+        eng = make_engine("hip", shape, sd, max_decode_len=64)
+        inp = synth.synth_batch(shape, int(g["batch"]), seed=int(g["synth_seed"]), return_pages=True)
+        pix = eng.preprocess(inp["pages_u8"])              # the bench step's own first stage
+        _state.update(g=g, shape=shape, eng=eng, args=(inp["input_ids"], inp["bbox"], inp["attention_mask"], pix))
+    return _state["g"], _state["shape"], _state["eng"], _state["args"]
+
+
+def _check_top8(logits, vals, idx, live=None):
+    """logits [B, T, V] (ours) vs the reference's top-8 values / indices per position: every one of the 8 values within
+    LOGIT_TOL at the reference's index; the argmax equal wherever the reference margin exceeds MARGIN_TOL; our own top-8
+    set equals the reference's wherever the 8th/9th boundary is decided by more than the tolerance can move."""
+    at = np.take_along_axis(logits, idx, -1)
+    err = np.abs(at - vals)
+    if live is not None:
+        err = err[live]
+    assert err.max() < LOGIT_TOL, err.max()
+    am = logits.argmax(-1)
+    margin = vals[..., 0] - vals[..., 1]
+    sel = margin > MARGIN_TOL
+    if live is not None:
+        sel &= live
+    assert sel.sum() > 0.25 * sel.size
+    assert np.array_equal(am[sel], idx[..., 0][sel])
+    # rank-k index equal wherever both neighbouring gaps exceed the margin tolerance
+    ours = np.argsort(-logits, axis=-1, kind="stable")[..., :8]
+    gap_lo = np.concatenate([np.full(vals[..., :1].shape, np.inf), vals[..., :-1] - vals[..., 1:]], -1)
+    gap_hi = np.concatenate([vals[..., :-1] - vals[..., 1:], np.zeros(vals[..., :1].shape)], -1)
+    solid = (gap_lo > MARGIN_TOL) & (gap_hi > MARGIN_TOL)
+    if live is not None:
+        solid &= live[..., None]
+    assert np.array_equal(ours[solid], idx[solid])
+    return err
+
+
+def test_g4_encoder_all_32_images():
+    g, shape, eng, args = _setup()
+    enc, mask = eng.encode(*args)
+    enc, mask = eng.mem.numpy(enc), eng.mem.numpy(mask)
+    assert np.array_equal(mask, g["enc_mask"].astype(np.uint8))
+    for b in range(enc.shape[0]):
+        v = mask[b].astype(bool)
+        s_abs = np.abs(enc[b][v]).astype(np.float64).sum()
+        assert abs(s_abs - g["enc_abs_sum"][b]) / g["enc_abs_sum"][b] < ENC_SUM_REL, b
+        err = np.abs(enc[b][g["enc_rows"][b]] - g["enc_probe"][b])
+        assert err.max() < ENC_MAX and err.mean() < ENC_MEAN, (b, err.max(), err.mean())
+
+
+def test_g4_greedy_free_running_ids_under_margin_rule():
+    """generate() exactly as bench.py calls it (B = 32, EOS suppressed), first 16 steps: ids equal the reference's up to the
+    first step of each row whose reference margin is below MARGIN_TOL; per-step top-1 logit within LOGIT_TOL while equal."""
+    g, shape, eng, args = _setup()
+    new = int(g["new_tokens"])
+    ids, _, top2 = eng.generate(*args, max_length=new + 1, min_length=new + 1, return_top2=True)
+    ids, top2 = eng.mem.numpy(ids), eng.mem.numpy(top2)
+    ref, vals = g["greedy_ids"], g["step_top_vals"]
+    margin = vals[..., 0] - vals[..., 1]
+    compared = 0
+    for b in range(ref.shape[0]):
+        for t in range(1, new + 1):
+            if margin[b, t - 1] < MARGIN_TOL:
+                break
+            assert ids[b, t] == ref[b, t], (b, t)
+            assert abs(top2[t, b, 0] - vals[b, t - 1, 0]) < LOGIT_TOL
+            compared += 1
+    assert compared >= 30, compared          # the rule must leave a real sample (random-weight margins: median 0.04)
+    # non-degenerate: many different tokens, image-dependent sequences (the reference's ids: 0 repeats of one token)
+    assert len({tuple(r) for r in ref.tolist()}) >= 16 and len(set(ref[:, 1:].ravel().tolist())) > 50
+    same_rows = int((ids == ref).all(1).sum())
+    assert same_rows >= 16, same_rows         # measured 23 of 32 rows identical over all 16 steps; the others part at margins < 0.004
+
+
+def test_g4_decode_path_teacher_forced_top8():
+    """The KV-cached decode path with the reference's own greedy ids forced in (mg_debug_decode_capture): every one of the
+    16 steps of all 32 rows is comparable - logits at the reference's top-8 within LOGIT_TOL, ranks under the margin rule.
+    This is the check that covers gemm_rows_*<M=32>, attn_step_kernel<1,8,*> with 32 ragged cross lengths, lm_head."""
+    g, shape, eng, args = _setup()
+    new, B = int(g["new_tokens"]), int(g["batch"])
+    cap = eng.debug_decode_capture(new, B, g["greedy_ids"])
+    try:
+        ids, _, _ = eng.generate(*args, max_length=new + 1, min_length=new + 1)
+        logits = eng.mem.numpy(cap).transpose(1, 0, 2).copy()
+    finally:
+        eng.debug_decode_capture()
+    _check_top8(logits, g["step_top_vals"], g["step_top_idx"])
+    # and the forced run's own selections agree with the captured logits (EOS masked out)
+    lm = logits.copy()
+    lm[..., shape.eos_token_id] = -np.inf
+    assert np.array_equal(eng.mem.numpy(ids)[:, 1:], lm.argmax(-1))
+
+
+def test_g4_teacher_forced_forward_top8_t32():
+    """forward() surface at T = 32 decoder positions on the 32 bench images (labels with -100 tails on two rows)."""
+    from oracle.udop_oracle import Oracle
+    g, shape, eng, args = _setup()
+    labels = g["labels"]
+    dec_ids = Oracle.shift_right(labels, shape.decoder_start_token_id, shape.pad_token_id).numpy()
+    dam = (labels != -100).astype(np.uint8)
+    logits, _, _ = eng.forward_logits(*args, dec_ids, dam)
+    logits = eng.mem.numpy(logits)
+    live = labels != -100
+    _check_top8(logits, g["tf_top_vals"], g["tf_top_idx"], live)
+    # per-token negative log-likelihood of the labels (what the reference's loss averages, stock:1565-1570)
+    lse = np.log(np.exp(logits - logits.max(-1, keepdims=True)).sum(-1)) + logits.max(-1)
+    nll = lse - np.take_along_axis(logits, np.clip(labels, 0, None)[..., None], -1)[..., 0]
+    assert np.abs(nll - g["tf_nll"])[live].max() < 2 * LOGIT_TOL
+
+
+def test_g4_beam5_subset_and_full_batch():
+    """configs[2]: beam-5.  The 4-image subset against stock's ids / sequence scores; then all 32 images (160 live rows: the
+    5-row-tile forms of the decode kernels, whose K-split differs from the one-tile forms, so near-tied beams may part) against
+    the same reference scores, and deterministic."""
+    g, shape, eng, args = _setup()
+    new, nb = int(g["new_tokens"]), int(g["beam_rows"])
+    sub = tuple(a[:nb] for a in args)
+    bids, bsc, _ = eng.generate(*sub, num_beams=5, max_length=new + 1, min_length=new + 1)
+    bids, bsc = eng.mem.numpy(bids).copy(), eng.mem.numpy(bsc).copy()
+    assert bids.shape == g["beam_ids"].shape
+    # sum of 16 log-probabilities / 16: the tolerance of one logit (log-softmax is 1-Lipschitz in the max norm, x2)
+    np.testing.assert_allclose(bsc, g["beam_scores"], atol=2 * LOGIT_TOL)
+    assert sum(np.array_equal(bids[b], g["beam_ids"][b]) for b in range(nb)) >= nb // 2      # measured: 3 of 4 rows identical
+    ids32, sc32, _ = eng.generate(*args, num_beams=5, max_length=new + 1, min_length=new + 1)
+    ids32, sc32 = eng.mem.numpy(ids32).copy(), eng.mem.numpy(sc32).copy()
+    assert ids32.shape == (int(g["batch"]), new + 1) and np.all(ids32[:, 0] == 0) and ids32.min() >= 0 and ids32.max() < shape.vocab_size
+    np.testing.assert_allclose(sc32[:nb], g["beam_scores"], atol=2 * LOGIT_TOL)
+    assert sum(np.array_equal(ids32[b], g["beam_ids"][b]) for b in range(nb)) >= nb // 2
+    again, sc_again, _ = eng.generate(*args, num_beams=5, max_length=new + 1, min_length=new + 1)
+    assert np.array_equal(eng.mem.numpy(again), ids32) and np.array_equal(eng.mem.numpy(sc_again), sc32)

@@ -374,3 +374,128 @@ def test_bad_inputs_are_rejected(be_name):
         eng.generate(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"], max_length=100000)
     with pytest.raises(ValueError):
         eng.generate(inp["input_ids"], inp["bbox"][:, :3], inp["attention_mask"], inp["pixel_values"], max_length=8)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# limits, error paths and the parity-test instrumentation of the decode loop
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("be_name", BACKENDS)
+def test_forced_decode_capture_matches_teacher_forced_oracle(be_name):
+    """mg_debug_decode_capture: with forced ids the KV-cached decode path is teacher-forced, so its per-step logits must
+    equal the oracle's teacher-forced decoder (stock:1448-1574) position by position; out_ids keep each step's argmax."""
+    from oracle.udop_oracle import Oracle
+    import torch
+    g = load_golden("g3_trained_tiny.npz")
+    shape, sd = _weights(g)
+    inp = _inputs(g, shape)
+    B, T = inp["input_ids"].shape[0], 9
+    forced = synth.randint("forced", B * T, 2, shape.vocab_size - 1, 1).reshape(B, T)
+    forced[:, 0] = shape.decoder_start_token_id
+    eng = make_engine(be_name, shape, sd)
+    cap = eng.debug_decode_capture(T - 1, B, forced)
+    ids, _, top2 = eng.generate(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"], max_length=T,
+                                min_length=T, return_top2=True)
+    cap, ids, top2 = _np(eng, cap).copy(), _np(eng, ids).copy(), _np(eng, top2).copy()
+    eng.debug_decode_capture()
+    o = Oracle(shape, sd)
+    with torch.no_grad():
+        enc, mask = o.encode(inp["input_ids"], inp["bbox"], inp["pixel_values"], inp["attention_mask"])
+        hid, _ = o.decoder_stack(torch.from_numpy(forced[:, :T - 1]), mask, o.cross_kv(enc))
+        ref = o.lm_logits(hid).numpy()                       # [B, T-1, V]
+    tol = logit_tol(ref)
+    assert np.abs(cap.transpose(1, 0, 2) - ref).max() < tol
+    masked = ref.copy()
+    masked[:, :, shape.eos_token_id] = -np.inf               # min_length = max_length suppresses EOS in the selection
+    srt = np.sort(masked, axis=-1)
+    for b in range(B):
+        for t in range(T - 1):
+            assert abs(top2[t + 1, b, 0] - srt[b, t, -1]) < tol
+            if srt[b, t, -1] - srt[b, t, -2] > 4 * tol:
+                assert ids[b, t + 1] == int(np.argmax(masked[b, t]))
+    # instrumentation cleared: the plain call is unaffected
+    ids2, _, _ = eng.generate(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"], max_length=int(g["max_length"]))
+    assert np.array_equal(_np(eng, ids2), g["greedy_ids"])
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+def test_more_than_256_live_rows_is_rejected(be_name):
+    """B * num_beams > 256 (8 row tiles of the decode projections) must fail loudly, in the Python binding and in the C ABI."""
+    import ctypes as C
+    from markushgrapher_amd.engine import MgError
+    g = load_golden("g3_trained_tiny.npz")
+    shape, sd = _weights(g)
+    inp = _inputs(g, shape)
+    eng = make_engine(be_name, shape, sd)
+    rep = lambda a, n: np.concatenate([a] * (n // a.shape[0] + 1))[:n]
+    big = {k: rep(v, 257) for k, v in inp.items()}
+    with pytest.raises(MgError, match="256"):
+        eng.generate(big["input_ids"], big["bbox"], big["attention_mask"], big["pixel_values"], max_length=4)
+    with pytest.raises(MgError, match="256"):
+        eng.generate(rep(inp["input_ids"], 52), rep(inp["bbox"], 52), rep(inp["attention_mask"], 52), rep(inp["pixel_values"], 52),
+                     num_beams=5, max_length=4)
+    # straight through the C ABI (no Python-side check): MG_E_UNSUPPORTED, nothing launched
+    ids, bb, am, pv, B, L = eng._inputs(big["input_ids"], big["bbox"], big["attention_mask"], big["pixel_values"])
+    ws, nb = eng.workspace(B, L, 1, 4, 0)
+    out = eng.mem.empty((B, 4), np.int64)
+    cols = C.c_int(0)
+    rc = eng.lib.mg_generate(eng.model, eng.mem.stream(), eng.mem.ptr(ws), nb, eng.mem.ptr(ids), eng.mem.ptr(bb), eng.mem.ptr(am),
+                             eng.mem.ptr(pv), B, L, 1, 4, 0, C.c_float(1.0), 0, eng.mem.ptr(out), C.byref(cols), None, None)
+    assert rc == -5 and b"256" in eng.lib.mg_last_error()
+    # 256 rows are fine and row-independent
+    ok = {k: rep(v, 256) for k, v in inp.items()}
+    ids256, _, _ = eng.generate(ok["input_ids"], ok["bbox"], ok["attention_mask"], ok["pixel_values"], max_length=6)
+    ids256 = _np(eng, ids256)
+    assert np.array_equal(ids256[:6], g["greedy_ids"][:, :ids256.shape[1]]) and np.array_equal(ids256[252:256], ids256[:4])
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+def test_bad_ids_are_rejected_in_teacher_forced_forward(be_name):
+    from markushgrapher_amd.engine import MgError
+    g = load_golden("g3_trained_tiny.npz")
+    shape, sd = _weights(g)
+    inp = _inputs(g, shape)
+    eng = make_engine(be_name, shape, sd)
+    dec = np.zeros((inp["input_ids"].shape[0], 5), np.int64)
+    eng.forward_logits(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"], dec)
+    bad = dec.copy()
+    bad[1, 2] = -100
+    with pytest.raises(MgError, match="token ids"):
+        eng.forward_logits(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"], bad)
+    bad_in = inp["input_ids"].copy()
+    bad_in[0, 1] = shape.vocab_size
+    with pytest.raises(MgError, match="token ids"):
+        eng.forward_logits(bad_in, inp["bbox"], inp["attention_mask"], inp["pixel_values"], dec)
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+def test_tied_and_untied_lm_head(be_name):
+    """tie_word_embeddings (stock:1405-1413,1554-1557): tied -> a checkpoint's lm_head.weight is ignored and the logits carry
+    d_model^-0.5; untied -> lm_head.weight is required and used without the scale."""
+    from markushgrapher_amd.engine import Engine, MgError
+    from tests.backends import get_backend, NumpyMem
+    g = load_golden("g3_trained_tiny.npz")
+    shape, sd = _weights(g)
+    inp = _inputs(g, shape)
+    dec = np.zeros((inp["input_ids"].shape[0], 4), np.int64)
+    args = (inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"], dec)
+    other = synth.round_bf16(synth.uniform_pm1("other.head", sd["shared.weight"].shape, 4))
+    be = get_backend(be_name)
+    mk = (lambda **kw: Engine(shape, lib=be.lib, mem=NumpyMem(), max_decode_len=64, **kw)) if be_name == "emu" else \
+         (lambda **kw: Engine(shape, max_decode_len=64, **kw))
+    tied = mk()
+    tied.load_state_dict({**sd, "lm_head.weight": other})
+    assert "lm_head.weight" in tied.ignored_keys
+    base = make_engine(be_name, shape, sd)
+    l_base = _np(base, base.forward_logits(*args)[0]).copy()
+    assert np.array_equal(_np(tied, tied.forward_logits(*args)[0]), l_base)
+    untied = mk(tie_word_embeddings=False)
+    with pytest.raises(MgError, match="lm_head.weight"):
+        untied.load_state_dict(sd)
+    untied = mk(tie_word_embeddings=False)
+    untied.load_state_dict({**sd, "lm_head.weight": sd["shared.weight"]})
+    l_unt = _np(untied, untied.forward_logits(*args)[0])
+    # same matrix without the d_model^-0.5: logits larger by sqrt(d) up to the bf16 rounding of the scaled activations
+    np.testing.assert_allclose(l_unt, l_base * np.sqrt(shape.d_model), atol=0.03 * np.abs(l_unt).max())
+    ids_t, _, _ = base.generate(*args[:4], max_length=8)
+    ids_u, _, _ = untied.generate(*args[:4], max_length=8)
+    assert np.array_equal(_np(base, ids_t), _np(untied, ids_u))

@@ -192,6 +192,123 @@ def g2():
          greedy_ids=g.sequences.numpy(), step_top_vals=top.values.numpy(), step_top_idx=top.indices.numpy())
 
 
+G4_SEED = synth.BENCH_SEED      # bench.py's batch; weights: synth.BENCH_RECIPE (non-degenerate AND numerically tame)
+
+
+def bench_inputs(shape, B=32, seed=G4_SEED):
+    """The benchmark step's inputs exactly as bench.py builds them: synthetic 1024 px u8 pages -> the reference's host
+    preprocessing (PIL LANCZOS to 512 px, ref: mdu_dataset.py:118; x/255, mean = std = 0.5, ref: begin.py:105-109), which
+    the device stage mg_preprocess_pages reproduces bit-exactly (tests/test_preprocess.py)."""
+    from PIL import Image
+    from oracle import preprocess_oracle as po
+    inp = synth.synth_batch(shape, B, seed=seed, return_pages=True)
+    pages = inp.pop("pages_u8")
+    I = shape.image_size
+    small = np.stack([np.asarray(Image.fromarray(p).resize((I, I), Image.LANCZOS)) for p in pages])
+    assert np.array_equal(small[:2], np.stack([po.lanczos_resize_u8(p, I, I) for p in pages[:2]]))
+    inp["pixel_values"] = np.stack([po.normalize_u8(x) for x in small])
+    return inp
+
+
+def g4():
+    """G4: the BENCHMARK configuration (BASELINE.json configs[1]/[2]): UDOP-large shape, B = 32, bench.py's own inputs,
+    recipe weights synth.BENCH_RECIPE (non-degenerate greedy sequences from a numerically tame network).  Stock runs in chunks of 8 images at the batch's padded
+    length (an image's result does not depend on its batch mates)."""
+    print("G4 benchmark configuration: large shape, B=32, bench inputs, recipe", synth.BENCH_RECIPE)
+    shape = synth.SHAPES["large"]
+    sd = synth.recipe_state_dict(shape, **synth.BENCH_RECIPE)
+    m = stock_model(shape, sd)
+    inp = bench_inputs(shape)
+    B, L = inp["input_ids"].shape
+    NEW, T, NB = 16, 32, 4
+    labels = synth.randint("g4.lab", B * T, 2, shape.vocab_size - 1, 3).reshape(B, T)
+    labels[5, 20:] = -100
+    labels[17, 9:] = -100
+    dam = (labels != -100).astype(np.int64)
+    t = {k: torch.from_numpy(v) for k, v in inp.items()}
+    lab = torch.from_numpy(labels)
+    enc_sum, enc_abs, probe_rows, probe_vals, enc_masks = [], [], [], [], []
+    g_ids, g_vals, g_idx, tf_vals, tf_idx, tf_loss_rows = [], [], [], [], [], []
+    t0 = time.time()
+    cache = os.environ.get("G4_STOCK_CACHE", "/tmp/g4_stock_cache.npz")      # a re-run after a failed oracle check skips the 15 min stock pass
+    if os.path.exists(cache):
+        ref = dict(np.load(cache))
+        print("   stock results from", cache)
+    else:
+      with torch.no_grad():
+          for c0 in range(0, B, 8):
+              sl = slice(c0, c0 + 8)
+              kw = dict(input_ids=t["input_ids"][sl], bbox=t["bbox"][sl].clone(), pixel_values=t["pixel_values"][sl],
+                        attention_mask=t["attention_mask"][sl])
+              enc = m.encoder(**kw)
+              eo, em = enc.last_hidden_state.numpy(), enc.attention_mask.numpy().astype(np.int64)
+              for b in range(eo.shape[0]):
+                  valid = em[b].astype(bool)
+                  enc_sum.append(eo[b][valid].astype(np.float64).sum())
+                  enc_abs.append(np.abs(eo[b][valid]).astype(np.float64).sum())
+                  n_txt = int(inp["attention_mask"][c0 + b].sum())
+                  rows = np.array([0, n_txt - 1, L, L + 517])
+                  probe_rows.append(rows)
+                  probe_vals.append(eo[b][rows])
+                  enc_masks.append(em[b])
+              g = m.generate(**{k: (v.clone() if k == "bbox" else v) for k, v in kw.items()}, num_beams=1, max_length=NEW + 1,
+                             min_length=NEW + 1, do_sample=False, return_dict_in_generate=True, output_logits=True)
+              sl_logits = torch.stack(g.logits, dim=1)                   # [8, NEW, V] raw (before the min-length processor)
+              top = torch.topk(sl_logits, 8, dim=-1)
+              g_ids.append(g.sequences.numpy()); g_vals.append(top.values.numpy()); g_idx.append(top.indices.numpy())
+              fw = m(**{k: (v.clone() if k == "bbox" else v) for k, v in kw.items()}, labels=lab[sl],
+                     decoder_attention_mask=torch.from_numpy(dam)[sl])
+              top = torch.topk(fw.logits, 8, dim=-1)
+              tf_vals.append(top.values.numpy()); tf_idx.append(top.indices.numpy())
+              lp = torch.log_softmax(fw.logits, dim=-1)
+              tf_loss_rows.append(-torch.gather(lp, 2, lab[sl].clamp(min=0)[..., None])[..., 0].numpy())
+              print(f"   chunk {c0 // 8}: {time.time() - t0:.0f}s", flush=True)
+          kwb = dict(input_ids=t["input_ids"][:NB], bbox=t["bbox"][:NB].clone(), pixel_values=t["pixel_values"][:NB],
+                     attention_mask=t["attention_mask"][:NB])
+          gb = m.generate(**kwb, num_beams=5, max_length=NEW + 1, min_length=NEW + 1, do_sample=False,
+                          return_dict_in_generate=True, output_scores=True)
+      print(f"   stock ran in {time.time() - t0:.0f}s")
+      ref = {
+          "enc_mask": np.stack(enc_masks), "enc_sum": np.array(enc_sum), "enc_abs_sum": np.array(enc_abs),
+          "enc_rows": np.stack(probe_rows), "enc_probe": np.stack(probe_vals),
+          "greedy_ids": np.concatenate(g_ids), "step_top_vals": np.concatenate(g_vals), "step_top_idx": np.concatenate(g_idx),
+          "tf_top_vals": np.concatenate(tf_vals), "tf_top_idx": np.concatenate(tf_idx), "tf_nll": np.concatenate(tf_loss_rows),
+          "beam_ids": gb.sequences.numpy(), "beam_scores": gb.sequences_scores.numpy(),
+      }
+      np.savez(cache, **ref)
+    print("   greedy ids row 0:", ref["greedy_ids"][0].tolist())
+    print("   beam ids row 0  :", ref["beam_ids"][0].tolist(), "scores", ref["beam_scores"].tolist())
+    mg = ref["step_top_vals"][..., 0] - ref["step_top_vals"][..., 1]
+    print(f"   greedy margins: min {mg.min():.4f} median {np.median(mg):.3f}; max |logit| {np.abs(ref['step_top_vals']).max():.2f}")
+    # pin the oracle on this configuration too (8 images: rows 0-3 and 28-31; greedy + teacher-forced + beam on rows 0-3)
+    del m
+    o = Oracle(shape, sd)
+    pick = np.array([0, 1, 2, 3, 28, 29, 30, 31])
+    sub = {k: v[pick] for k, v in inp.items()}
+    with torch.no_grad():
+        eo, mo = o.encode(sub["input_ids"], sub["bbox"], sub["pixel_values"], sub["attention_mask"])
+        assert np.array_equal(mo.numpy(), ref["enc_mask"][pick])
+        for i, b in enumerate(pick):
+            d = np.abs(eo[i].numpy()[ref["enc_rows"][b]] - ref["enc_probe"][b]).max()
+            assert d < 2e-3, d
+        rec = []
+        go = o.greedy(sub["input_ids"], sub["bbox"], sub["pixel_values"], sub["attention_mask"], max_length=NEW + 1,
+                      min_length=NEW + 1, record=rec)
+        lo = o.forward(sub["input_ids"], sub["bbox"], sub["pixel_values"], sub["attention_mask"], labels=labels[pick],
+                       decoder_attention_mask=dam[pick]).numpy()
+        bo, bs = o.beam_search(sub["input_ids"][:NB], sub["bbox"][:NB], sub["pixel_values"][:NB], sub["attention_mask"][:NB],
+                               num_beams=5, max_length=NEW + 1)
+    d_tf = max(float(np.abs(np.take_along_axis(lo[i], ref["tf_top_idx"][b], -1) - ref["tf_top_vals"][b]).max())
+               for i, b in enumerate(pick))
+    same = [bool(np.array_equal(go[i], ref["greedy_ids"][b])) for i, b in enumerate(pick)]
+    print(f"   oracle vs stock: teacher-forced top-8 logits {d_tf:.2e}; greedy rows equal {same}; "
+          f"beam eq {np.array_equal(bo, ref['beam_ids'])} scores {np.abs(bs - ref['beam_scores']).max():.2e}")
+    assert d_tf < 5e-3
+    save("g4_bench.npz", shape=np.array("large"), recipe=np.array([synth.BENCH_RECIPE[k] for k in ("gain", "embed_gain", "ffn_gain", "xq_gain")], np.float32),
+         synth_seed=np.int64(G4_SEED), batch=np.int64(B),
+         new_tokens=np.int64(NEW), labels=labels, beam_rows=np.int64(NB), oracle_greedy_rows_equal=np.array(same), **ref)
+
+
 def tables():
     print("bucket tables (stock:422-468 evaluated by torch on every integer distance)")
     save("bucket_tables.npz",
