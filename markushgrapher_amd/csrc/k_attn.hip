@@ -423,12 +423,11 @@ __global__ __launch_bounds__(512) void attention_enc_kernel(AttnArgs a) {
         if (sti + AE_DEPTH < nst) issue(sti + AE_DEPTH);
         const char* kb = st_base + (sti % AE_RING) * AT_STAGE_BYTES + lane * 16;
         const char* vb = kb + 8 * TILE_BYTES;
-        f32x16 s[2];
+        f32x16 s[2] = {acc_zero(), acc_zero()};
 #pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2) {
-            s[t2] = acc_zero();
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) s[t2] = mfma32(ld16(kb + (t2 * 4 + kt) * TILE_BYTES), qf[kt], s[t2]);
+        for (int kt = 0; kt < 4; ++kt) {           // the two key tiles alternate: two independent accumulator chains
+            s[0] = mfma32(ld16(kb + (0 * 4 + kt) * TILE_BYTES), qf[kt], s[0]);
+            s[1] = mfma32(ld16(kb + (1 * 4 + kt) * TILE_BYTES), qf[kt], s[1]);
         }
         // scores in the log2 domain: v = s*log2e + hv[pair] (+ 1-D term near the diagonal); tile maxima
         float cst[2], tmx[2];
@@ -472,14 +471,29 @@ __global__ __launch_bounds__(512) void attention_enc_kernel(AttnArgs a) {
         for (int t2 = 0; t2 < 2; ++t2) {
             const float mt = m_new - cst[t2];
             f32x16 p;
+#ifdef MG_EMU
 #pragma unroll
             for (int r = 0; r < 16; ++r) p[r] = fast_exp2(s[t2][r] - mt);
-            // the row sum is taken over the ROUNDED values (two per v_dot2 with a ones pair), so that O / l stays a convex
-            // combination of the value rows whatever the rounding of the dominant weights
-            const PackedAcc pa = acc_pack(p);
+#else
+            typedef float mg_f32x2 __attribute__((ext_vector_type(2)));
+            const mg_f32x2 mt2 = {mt, mt};
 #pragma unroll
-            for (int g = 0; g < 4; ++g) { psum = dot2_bf16(pa.p[g][0], 0x3F803F80u, psum); psum = dot2_bf16(pa.p[g][1], 0x3F803F80u, psum); }
-            packed_to_chunks(pa, half, &pch[2 * t2]);
+            for (int r = 0; r < 16; r += 2) {                      // packed subtract: half an instruction per score
+                const mg_f32x2 sv = {s[t2][r], s[t2][r + 1]};
+                const mg_f32x2 d = sv - mt2;
+                p[r] = fast_exp2(d.x); p[r + 1] = fast_exp2(d.y);
+            }
+#endif
+            const PackedAcc pa = acc_pack(p);
+            packed_to_chunks_swap(pa, half, &pch[2 * t2]);
+        }
+        // the row sum is taken over the ROUNDED values (two per v_dot2 with a ones pair), so that O / l stays a convex
+        // combination of the value rows whatever the rounding of the dominant weights; summed after the half-wave exchange
+        // (which only permutes a query's weights between its two lanes), so the packed words die right there
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            psum = dot2_bf16(pch[c].x, 0x3F803F80u, psum); psum = dot2_bf16(pch[c].y, 0x3F803F80u, psum);
+            psum = dot2_bf16(pch[c].z, 0x3F803F80u, psum); psum = dot2_bf16(pch[c].w, 0x3F803F80u, psum);
         }
 #ifdef MG_EMU
         const bool rescale = true;

@@ -280,6 +280,29 @@ MG_DEV void packed_to_chunks(const PackedAcc& a, int half, uint4 chunk[2]) {
         else chunk[q] = make_uint4(r0, r1, a.p[2 * q + 1][0], a.p[2 * q + 1][1]);
     }
 }
+// The same exchange on v_permlane32_swap (gfx950): one instruction swaps a register of the upper half-wave with another
+// register of the lower half-wave, in place - no LDS crossbar (ds_bpermute), no selects.  With G0 = a.p[2q], G1 = a.p[2q+1]:
+// swap(vdst = G0[i], src0 = G1[i]) leaves G0 = {own G0 | lower's G1} and G1 = {upper's G0 | own G1} for the (lower | upper)
+// lanes, i.e. chunk q = [G0[0], G0[1], G1[0], G1[1]] = rows 16q + 8*half .. +7 in both halves.
+MG_DEV void packed_to_chunks_swap(const PackedAcc& a, int half, uint4 chunk[2]) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        uint32_t g0[2], g1[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#ifdef MG_EMU
+            const uint32_t got = __shfl_xor(half ? a.p[2 * q][i] : a.p[2 * q + 1][i], 32);
+            g0[i] = half ? got : a.p[2 * q][i];
+            g1[i] = half ? a.p[2 * q + 1][i] : got;
+#else
+            typedef unsigned int mg_u32x2 __attribute__((ext_vector_type(2)));
+            const mg_u32x2 r = __builtin_amdgcn_permlane32_swap(a.p[2 * q][i], a.p[2 * q + 1][i], false, false);
+            g0[i] = r.x; g1[i] = r.y;
+#endif
+        }
+        chunk[q] = make_uint4(g0[0], g0[1], g1[0], g1[1]);
+    }
+}
 MG_DEV void acc_to_chunks(const f32x16& v, int half, uint4 chunk[2]) {
     const PackedAcc a = acc_pack(v);
     packed_to_chunks(a, half, chunk);
