@@ -153,6 +153,12 @@ int mgk_rmsnorm_pack(void* stream, const float* h, const float* gain, void* x_pk
 int mgk_im2col_pack(void* stream, const float* pix, void* x_pk, int B, int C, int I, int ps);
 int mgk_gemm(void* stream, int mode, int epi, const void* X_pk, const void* W_pk, int M, int N, int K, float* out_f32,
              int ldo, const float* bias, void* out_pk);
+/* Deferred-RMSNorm pair of the encoder (tiled large-M kernels): epi 5 (EPI_RESID_NORM): h_tiled (fp32, tiles of
+ * [32 rows][4 features]: index ((m/32)*(N/4) + n/4)*128 + (m%32)*4 + n%4) += X W^T, out_pk = pack(bf16(h * gain)) un-normalised,
+ * part[M][part_ld] = per-64-column partial sums of h^2; epi 3 / 2 (packed / packed relu): rows scaled by
+ * rsqrt(sum(rs_part[m][0..rs_nparts)) * rs_inv_d + rs_eps) (rs_part NULL: no scale). */
+int mgk_gemm_norm(void* stream, int epi, const void* X_pk, const void* W_pk, int M, int N, int K, float* h_tiled, const float* gain,
+                  void* out_pk, float* part, int part_ld, const float* rs_part, int rs_nparts, float rs_inv_d, float rs_eps);
 int mgk_gemm_heads(void* stream, int mode, const void* X_pk, const void* W_pk, int M, int N, int K, void* p0, void* p1,
                    void* p2, int f0, int f1, int f2, int H, int S_in, int S_cap, const int* row_map, int pos);
 /* mode 0 (encoder): tab1/tabh/tabv are the RAW bucket tables [32][H]; bk1[257] / bkhv[201] the bucket ids of integer

@@ -37,6 +37,20 @@ int mgk_gemm(void* stream, int mode, int epi, const void* X_pk, const void* W_pk
     return MG_OK;
 }
 
+// Deferred-RMSNorm pair of the encoder (test entry):
+//   epi = EPI_RESID_NORM (5): h_tiled (fp32, layout ht_off) += X W^T, x_out_pk = pack(bf16(h * gain)), part[M][part_ld] partial sums
+//   epi = EPI_PK / EPI_PK_RELU (3 / 2): out_pk = pack(bf16(relu?(X W^T * r(m)))) with r from rs_part[M][rs_nparts] (null: r = 1)
+int mgk_gemm_norm(void* stream, int epi, const void* X_pk, const void* W_pk, int M, int N, int K, float* h_tiled, const float* gain,
+                  void* out_pk, float* part, int part_ld, const float* rs_part, int rs_nparts, float rs_inv_d, float rs_eps) {
+    if ((K & 63) || (N & 31) || (M & 31)) return MG_E_SHAPE;
+    GemmArgs a{};
+    a.X = (const uint16_t*)X_pk; a.W = (const uint16_t*)W_pk; a.M = M; a.N = N; a.K = K;
+    a.out_f32 = h_tiled; a.gain = gain; a.out_pk = (uint16_t*)out_pk; a.part = part; a.ldo = part_ld;
+    a.rs = RowScale{rs_part, rs_nparts, rs_inv_d, rs_eps};
+    gemm(a, epi, (mgStream_t)stream);
+    return MG_OK;
+}
+
 int mgk_gemm_heads(void* stream, int mode, const void* X_pk, const void* W_pk, int M, int N, int K, void* p0, void* p1,
                    void* p2, int f0, int f1, int f2, int H, int S_in, int S_cap, const int* row_map, int pos) {
     if ((K & 63) || (N % (H * 64))) return MG_E_SHAPE;

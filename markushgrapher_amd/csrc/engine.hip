@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void copy_bytes_rows_kernel(const uint8_t* src
 struct Ws {
     // encoder
     uint16_t *xim, *x_pk, *q_pk, *k_pk, *vt_pk, *ctx_pk, *y_pk, *enc_pk, *bidx;
-    float *patch_emb, *hidden, *enc_f32;
+    float *patch_emb, *hidden, *enc_f32, *enc_part_a, *enc_part_b;
     void* meta;
     double *cx, *cy;
     uint8_t* mask;
@@ -259,6 +259,11 @@ void carve(const mg_model* m, char* base, int B, int L, int K, int max_len, int 
     w->enc_pk = c.take<uint16_t>(M * d);
     w->enc_f32 = c.take<float>(M * d);
     w->bidx = c.take<uint16_t>(M * (size_t)S_cap);
+    {   // deferred-RMSNorm partial sums of the encoder: [rows][d/64 rounded up to 4] after the attention / FFN output
+        const size_t np4 = (size_t)round_up(d / 64 > 0 ? d / 64 : 1, 4);
+        w->enc_part_a = c.take<float>(M * np4);
+        w->enc_part_b = c.take<float>(M * np4);
+    }
     w->cx = c.take<double>(M);
     w->cy = c.take<double>(M);
     w->mask = c.take<uint8_t>(M);
@@ -655,18 +660,29 @@ int mg_encode(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_
         e.input_ids = input_ids; e.bbox = bbox; e.attn_mask = attention_mask; e.patch_emb = w.patch_emb;
         e.tok_emb = m->at<uint16_t>(m->tok_emb); e.x_emb = m->at<uint16_t>(m->x_emb); e.y_emb = m->at<uint16_t>(m->y_emb);
         e.B = B; e.L = L; e.P = P; e.d = d; e.n_side = m->n_side; e.M2 = m->M2; e.V = m->V; e.S_cap = S_cap;
-        e.hidden = w.hidden; e.cx = w.cx; e.cy = w.cy; e.mask = w.mask; e.xrow = w.xrow; e.xlen = w.xlen;
+        e.hidden = w.hidden; e.hidden_tiled = 1; e.cx = w.cx; e.cy = w.cy; e.mask = w.mask; e.xrow = w.xrow; e.xlen = w.xlen;
         e.err = w.counters + 3;
         embed_assemble(e, w.meta, st);
     }
     // bucket indices of the three relative biases: shared by all layers and heads, computed once per batch
     bias_index(w.bidx, w.cx, w.cy, w.mask, m->at<int>(m->bk1), m->at<int>(m->bkhv), B, S, S_cap, st);
     attn_lists(w.mask, B, S, S_cap, w.att_kst, w.att_qbv, st);
+    // Encoder stack (stock:1061-1246, 644-720).  The residual stream h is fp32 in the tiled layout (ht_off); RMSNorm is
+    // deferred as in the decode step: the residual projections (attention O, FFN wo) leave bf16(h * gain_next) and per-row
+    // partial sums of h^2, the consuming projections (QKV, FFN wi, cross-K/V) scale their output rows by rsqrt(mean h^2 + eps).
+    // Only the first norm (embedding output) and the final one (returned fp32 encoder states) are explicit launches.
+    const int np4 = round_up(d / 64 > 0 ? d / 64 : 1, 4);
+    mg_memset_async(w.enc_part_a, 0, (size_t)M * np4 * sizeof(float), st);
+    mg_memset_async(w.enc_part_b, 0, (size_t)M * np4 * sizeof(float), st);
+    const RowScale rs_a{w.enc_part_a, np4, 1.0f / (float)d, m->c.layer_norm_epsilon};     // after the FFN output
+    const RowScale rs_b{w.enc_part_b, np4, 1.0f / (float)d, m->c.layer_norm_epsilon};     // after the attention output
+    rmsnorm_pack_tiled(w.hidden, m->at<float>(m->enc[0].ln0), w.x_pk, nullptr, M, d, m->c.layer_norm_epsilon, st);
     for (size_t li = 0; li < m->enc.size(); ++li) {
         const EncLayer& l = m->enc[li];
-        rmsnorm_pack(w.hidden, m->at<float>(l.ln0), w.x_pk, nullptr, M, d, m->c.layer_norm_epsilon, 1.0f, st);
+        const bool last = li + 1 == m->enc.size();
         GemmArgs a = gemm_args(w.x_pk, m->at<uint16_t>(l.wqkv), M, 3 * inner, d);
         set_heads(a, H, S_cap, S_cap, w.q_pk, HF_PK_ROWS, w.k_pk, HF_PK_ROWS, w.vt_pk, HF_PK_T);
+        if (li > 0) a.rs = rs_a;                   // layer 0 reads the explicitly normalised embedding
         gemm(a, EPI_HEADS, st);
         AttnArgs t{};
         t.Q = w.q_pk; t.K = w.k_pk; t.Vt = w.vt_pk; t.ctx = w.ctx_pk; t.B = B; t.H = H; t.Sq = S; t.Sk = S;
@@ -674,12 +690,18 @@ int mg_encode(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_
         t.tab1 = m->at<float>(m->rb_raw[0]); t.tab1_len = 32; t.tabh = m->at<float>(m->rb_raw[1]); t.tabv = m->at<float>(m->rb_raw[2]);
         t.bidx = w.bidx; t.bk1 = m->at<int>(m->bk1); t.kst = w.att_kst; t.qbv = w.att_qbv;
         attention(t, st);
-        GemmArgs o = gemm_args(w.ctx_pk, m->at<uint16_t>(l.wo), M, d, inner);
-        o.out_f32 = w.hidden; o.ldo = d;
-        gemm(o, EPI_F32_RESID, st);
-        ffn_block(m, false, w.hidden, w.x_pk, w.y_pk, M, l.ln1, l.wi, l.wo2, st);
+        GemmArgs o = gemm_args(w.ctx_pk, m->at<uint16_t>(l.wo), M, d, inner);       // h += Wo ctx; x = bf16(h * ln1); partials -> b
+        o.out_f32 = w.hidden; o.gain = m->at<float>(l.ln1); o.out_pk = w.x_pk; o.part = w.enc_part_b; o.ldo = np4;
+        gemm(o, EPI_RESID_NORM, st);
+        GemmArgs f = gemm_args(w.x_pk, m->at<uint16_t>(l.wi), M, m->dff, d);
+        f.out_pk = w.y_pk; f.rs = rs_b;
+        gemm(f, EPI_PK_RELU, st);
+        GemmArgs g = gemm_args(w.y_pk, m->at<uint16_t>(l.wo2), M, d, m->dff);        // h += Wo2 y; x = bf16(h * next ln0); partials -> a
+        g.out_f32 = w.hidden; g.ldo = np4;
+        if (!last) { g.gain = m->at<float>(m->enc[li + 1].ln0); g.out_pk = w.x_pk; g.part = w.enc_part_a; }
+        gemm(g, EPI_RESID_NORM, st);
     }
-    rmsnorm_pack(w.hidden, m->at<float>(m->enc_ln), w.enc_pk, w.enc_f32, M, d, m->c.layer_norm_epsilon, 1.0f, st);
+    rmsnorm_pack_tiled(w.hidden, m->at<float>(m->enc_ln), w.enc_pk, w.enc_f32, M, d, m->c.layer_norm_epsilon, st);
     if (enc_out) MG_LAUNCH(copy_rows_kernel, dim3(1024), dim3(256), 0, st, (const float*)w.enc_f32, enc_out, B, S, S_cap, d);
     if (enc_mask) MG_LAUNCH(copy_bytes_rows_kernel, dim3(64), dim3(256), 0, st, (const uint8_t*)w.mask, enc_mask, B, S, S_cap);
     m->st_B = B; m->st_L = L; m->st_S = S; m->st_Scap = S_cap; m->st_ws = ws;

@@ -405,7 +405,7 @@ __global__ __launch_bounds__(512) void attention_enc_kernel(AttnArgs a) {
     if (1 < nst) issue(1);
     for (int sti = 0; sti < nst; ++sti) {
         // own copies of stage sti have landed when at most those of the one later stage in flight are outstanding
-        if (sti + 1 < nst) { if (act) MG_WAIT_VMCNT(6); else MG_WAIT_VMCNT(2); }
+        if (sti + 1 < nst && !(a.dbg & 1)) { if (act) MG_WAIT_VMCNT(6); else MG_WAIT_VMCNT(2); }
         else MG_WAIT_VMCNT(0);
         MG_BARRIER_RAW();            // everybody's copies of stage sti have landed; the K / V^T slot of stage sti - 1 is free
         const int st = sid(sti);
@@ -604,7 +604,11 @@ void attn_lists(const uint8_t* kmask, int B, int Sk, int S_cap, int* kst, uint8_
     MG_LAUNCH(attn_lists_kernel, dim3(B), dim3(64), (size_t)((S_cap >> 6) + 16), stream, kmask, Sk, S_cap, kst, qbv);
 }
 
-void attention(const AttnArgs& a, mgStream_t stream) {
+void attention(const AttnArgs& a_in, mgStream_t stream) {
+    AttnArgs a = a_in;
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("MG_ATT_DBG"); dbg = e ? atoi(e) : 0; }
+    a.dbg = dbg;
     const int nqb = (a.Sq_cap + 127) / 128;
     const dim3 grid(a.B * a.H * nqb), block(256);
     const size_t sh = attn_smem(a);

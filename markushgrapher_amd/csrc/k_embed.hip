@@ -136,7 +136,8 @@ __global__ __launch_bounds__(256) void embed_gather_kernel(EmbedArgs a, const Em
                 v[2] += ((bf16lo(e0.y) + bf16lo(e1.y)) + bf16lo(e2.y)) + bf16lo(e3.y);
                 v[3] += ((bf16hi(e0.y) + bf16hi(e1.y)) + bf16hi(e2.y)) + bf16hi(e3.y);
             }
-            *(float4*)(out + c) = make_float4(v[0], v[1], v[2], v[3]);
+            if (a.hidden_tiled) *(float4*)(a.hidden + ht_off(row, c, a.d)) = make_float4(v[0], v[1], v[2], v[3]);
+            else *(float4*)(out + c) = make_float4(v[0], v[1], v[2], v[3]);
         }
     }
 }

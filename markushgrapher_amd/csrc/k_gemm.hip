@@ -98,9 +98,59 @@ MG_DEV void heads_store(const HeadsOut& ho, int ri, int h, int m, int dim0, cons
 // Epilogue of one 32x32 accumulator tile.
 //  TOR (operands swapped, D = W·X^T): lane owns token m = m0 + lane%32, rows of D are output features n0 + i.
 //  !TOR (D = X·W^T):                  lane owns feature n = n0 + lane%32, rows of D are tokens m0 + i.
-template <int EPI, bool TOR>
-MG_DEV void tile_epilogue(const GemmArgs& a, const f32x16& acc, int m0, int n0, int lane, int qmask = 3) {
+// deferred RMSNorm scale of token row m from the partial sums of squares left by EPI_RESID_NORM (1 when rs.part is null)
+MG_DEV float row_scale_of(const RowScale& rs, int m, int M) {
+    if (!rs.part) return 1.0f;
+    const int mr = m < M ? m : M - 1;
+    const float* p = rs.part + (size_t)mr * rs.nparts;
+    float s = 0.f;
+    for (int i = 0; i < rs.nparts; i += 4) { const float4 v = *(const float4*)(p + i); s += (v.x + v.y) + (v.z + v.w); }
+    return rsqrtf(s * rs.inv_d + rs.eps);
+}
+
+// the scales of NT consecutive 32-token row tiles for this lane's token (m0 + 32 i + lane%32): all partial-sum loads are
+// unconditional and issued together (one L2 round trip at the start of the epilogue); nparts is a multiple of 4, at most 16
+// (groups past nparts re-read the last one with weight 0)
+template <int NT>
+MG_DEV void row_scales_tiles(const RowScale& rs, int m0, int M, int lane, float (&out)[NT]) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) out[i] = 1.0f;
+    if (!rs.part) return;
+    float4 v[NT][4];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        int m = m0 + 32 * i + (lane & 31);
+        m = m < M ? m : M - 1;
+        const float* p = rs.part + (size_t)m * rs.nparts;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[i][k] = *(const float4*)(p + (4 * k < rs.nparts ? 4 * k : rs.nparts - 4));
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s += (4 * k < rs.nparts) ? (v[i][k].x + v[i][k].y) + (v[i][k].z + v[i][k].w) : 0.f;
+        out[i] = rsqrtf(s * rs.inv_d + rs.eps);
+    }
+}
+
+// APPLY_RS (tiled large-M kernels only; the decode-step kernels scale their sums themselves): multiply the rows of the
+// packed / per-head outputs by the deferred RMSNorm scale a.rs of their token.
+template <int EPI, bool TOR, bool APPLY_RS = false>
+MG_DEV void tile_epilogue(const GemmArgs& a, const f32x16& acc_in, int m0, int n0, int lane, int qmask = 3, float rsl = 1.0f) {
     const int half = lane >> 5, l32 = lane & 31;
+    f32x16 acc = acc_in;
+    if constexpr (APPLY_RS && (EPI == EPI_PK || EPI == EPI_PK_RELU || EPI == EPI_HEADS)) {
+        if (a.rs.part) {                                              // rsl: the scale of token m0 + lane%32 (both half-waves)
+            if (TOR) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] *= rsl;
+            } else {                                                   // rows of D are tokens m0 + acc_row(r, half)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] *= __shfl(rsl, acc_row(r, half));
+            }
+        }
+    }
     if constexpr (EPI == EPI_F32_STORE || EPI == EPI_F32_RESID) {
         static_assert(!TOR, "fp32 epilogues use D = X·W^T");
         const int n = n0 + l32;
@@ -157,6 +207,44 @@ MG_DEV void tile_epilogue(const GemmArgs& a, const f32x16& acc, int m0, int n0, 
     }
 }
 
+// EPI_RESID_NORM for one 32-token row tile and a wave's two 32-feature column tiles (D = W·X^T: a lane owns token
+// m0 + lane%32 and, per accumulator group g, the 4 consecutive features n0 + 8g + 4*half ..: one float4 of the tiled h).
+MG_DEV void resid_norm_epilogue(const GemmArgs& a, const f32x16& acc0, const f32x16& acc1, int m0, int n0, int lane) {
+    const int half = lane >> 5, l32 = lane & 31, m = m0 + l32;
+    const bool row_ok = m < a.M;
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const f32x16& acc = j ? acc1 : acc0;
+        const int nj = n0 + 32 * j;
+        if (nj >= a.N) continue;                       // (N is a multiple of 32 here: whole tiles only)
+        f32x16 xg;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = nj + 8 * g + 4 * half;
+            float* p = a.out_f32 + ht_off(row_ok ? m : 0, n, a.N);
+            float4 hv = *(const float4*)p;
+            hv.x += acc[4 * g]; hv.y += acc[4 * g + 1]; hv.z += acc[4 * g + 2]; hv.w += acc[4 * g + 3];
+            if (row_ok) { *(float4*)p = hv; ss += (hv.x * hv.x + hv.y * hv.y) + (hv.z * hv.z + hv.w * hv.w); }
+            if (a.gain) {
+                const float4 gn = *(const float4*)(a.gain + n);
+                xg[4 * g] = hv.x * gn.x; xg[4 * g + 1] = hv.y * gn.y; xg[4 * g + 2] = hv.z * gn.z; xg[4 * g + 3] = hv.w * gn.w;
+            }
+        }
+        if (a.gain) {
+            uint4 ch[2];
+            acc_to_chunks(xg, half, ch);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (row_ok) st16(a.out_pk + pk_off(m, nj + 16 * q + 8 * half, a.N), ch[q]);
+        }
+    }
+    if (a.part) {
+        ss += __shfl_xor(ss, 32);
+        if (half == 0 && row_ok && n0 < a.N) a.part[(size_t)m * a.ldo + (n0 >> 6)] = ss;      // ldo = partial sums per row
+    }
+}
+
 MG_DEV bool heads_region_is_T(const HeadsOut& ho, int n) {
     const int ri = n / ho.inner;
     return ho.fmt[ri] == HF_PK_T;
@@ -205,7 +293,7 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs a) {
     bool tor;
     if (EPI == EPI_F32_STORE || EPI == EPI_F32_RESID) tor = false;
     else if (EPI == EPI_HEADS) tor = !heads_region_is_T(a.heads, n0w < a.N ? n0w : 0);
-    else tor = true;
+    else tor = true;                                   // packed epilogues and EPI_RESID_NORM: lane owns a token
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -243,6 +331,13 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs a) {
         __syncthreads();
     }
 
+    if constexpr (EPI == EPI_RESID_NORM) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) resid_norm_epilogue(a, acc[i][0], acc[i][1], m0w + 32 * i, n0w, lane);
+        return;
+    }
+    float rsv[2];
+    row_scales_tiles<2>(a.rs, m0w, a.M, lane, rsv);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -251,10 +346,10 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs a) {
             if constexpr (EPI == EPI_F32_STORE || EPI == EPI_F32_RESID) {
                 tile_epilogue<EPI, false>(a, acc[i][j], m0, n0, lane);
             } else if constexpr (EPI == EPI_HEADS) {
-                if (tor) tile_epilogue<EPI_HEADS, true>(a, acc[i][j], m0, n0, lane);
-                else tile_epilogue<EPI_HEADS, false>(a, acc[i][j], m0, n0, lane);
-            } else {
-                tile_epilogue<EPI, true>(a, acc[i][j], m0, n0, lane);
+                if (tor) tile_epilogue<EPI_HEADS, true, true>(a, acc[i][j], m0, n0, lane, 3, rsv[i]);
+                else tile_epilogue<EPI_HEADS, false, true>(a, acc[i][j], m0, n0, lane, 3, rsv[i]);
+            } else if constexpr (EPI != EPI_RESID_NORM) {
+                tile_epilogue<EPI, true, true>(a, acc[i][j], m0, n0, lane, 3, rsv[i]);
             }
         }
 }
@@ -306,7 +401,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmArgs a) {
     bool tor;
     if (EPI == EPI_F32_STORE || EPI == EPI_F32_RESID) tor = false;
     else if (EPI == EPI_HEADS) tor = !heads_region_is_T(a.heads, n0w < a.N ? n0w : 0);
-    else tor = true;
+    else tor = true;                                   // packed epilogues and EPI_RESID_NORM: lane owns a token
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -348,6 +443,13 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmArgs a) {
         cur = cur + 1 >= GW_STAGES ? 0 : cur + 1;
     }
 
+    if constexpr (EPI == EPI_RESID_NORM) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) resid_norm_epilogue(a, acc[i][0], acc[i][1], m0w + 32 * i, n0w, lane);
+        return;
+    }
+    float rsv[2];
+    row_scales_tiles<2>(a.rs, m0w, a.M, lane, rsv);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -356,10 +458,10 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmArgs a) {
             if constexpr (EPI == EPI_F32_STORE || EPI == EPI_F32_RESID) {
                 tile_epilogue<EPI, false>(a, acc[i][j], m0, n0, lane);
             } else if constexpr (EPI == EPI_HEADS) {
-                if (tor) tile_epilogue<EPI_HEADS, true>(a, acc[i][j], m0, n0, lane);
-                else tile_epilogue<EPI_HEADS, false>(a, acc[i][j], m0, n0, lane);
-            } else {
-                tile_epilogue<EPI, true>(a, acc[i][j], m0, n0, lane);
+                if (tor) tile_epilogue<EPI_HEADS, true, true>(a, acc[i][j], m0, n0, lane, 3, rsv[i]);
+                else tile_epilogue<EPI_HEADS, false, true>(a, acc[i][j], m0, n0, lane, 3, rsv[i]);
+            } else if constexpr (EPI != EPI_RESID_NORM) {
+                tile_epilogue<EPI, true, true>(a, acc[i][j], m0, n0, lane, 3, rsv[i]);
             }
         }
 }
@@ -418,7 +520,7 @@ __global__ __launch_bounds__(512) void gemm_xl_kernel(GemmArgs a) {
     bool tor;
     if (EPI == EPI_F32_STORE || EPI == EPI_F32_RESID) tor = false;
     else if (EPI == EPI_HEADS) tor = !heads_region_is_T(a.heads, n0w < a.N ? n0w : 0);
-    else tor = true;
+    else tor = true;                                   // packed epilogues and EPI_RESID_NORM: lane owns a token
 
     f32x16 acc[TI][2];
 #pragma unroll
@@ -455,6 +557,13 @@ __global__ __launch_bounds__(512) void gemm_xl_kernel(GemmArgs a) {
         }
     }
 
+    if constexpr (EPI == EPI_RESID_NORM) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i) resid_norm_epilogue(a, acc[i][0], acc[i][1], m0w + 32 * i, n0w, lane);
+        return;
+    }
+    float rsv[TI];
+    row_scales_tiles<TI>(a.rs, m0w, a.M, lane, rsv);
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -463,10 +572,10 @@ __global__ __launch_bounds__(512) void gemm_xl_kernel(GemmArgs a) {
             if constexpr (EPI == EPI_F32_STORE || EPI == EPI_F32_RESID) {
                 tile_epilogue<EPI, false>(a, acc[i][j], m0, n0, lane);
             } else if constexpr (EPI == EPI_HEADS) {
-                if (tor) tile_epilogue<EPI_HEADS, true>(a, acc[i][j], m0, n0, lane);
-                else tile_epilogue<EPI_HEADS, false>(a, acc[i][j], m0, n0, lane);
-            } else {
-                tile_epilogue<EPI, true>(a, acc[i][j], m0, n0, lane);
+                if (tor) tile_epilogue<EPI_HEADS, true, true>(a, acc[i][j], m0, n0, lane, 3, rsv[i]);
+                else tile_epilogue<EPI_HEADS, false, true>(a, acc[i][j], m0, n0, lane, 3, rsv[i]);
+            } else if constexpr (EPI != EPI_RESID_NORM) {
+                tile_epilogue<EPI, true, true>(a, acc[i][j], m0, n0, lane, 3, rsv[i]);
             }
         }
 }
@@ -508,6 +617,7 @@ void gemm(const GemmArgs& a, int epi, mgStream_t stream) {
                 case EPI_F32_RESID: launch_xl<EPI_F32_RESID, 5>(a, stream); break;
                 case EPI_PK_RELU: launch_xl<EPI_PK_RELU, 5>(a, stream); break;
                 case EPI_PK: launch_xl<EPI_PK, 5>(a, stream); break;
+                case EPI_RESID_NORM: launch_xl<EPI_RESID_NORM, 5>(a, stream); break;
                 default: launch_xl<EPI_HEADS, 5>(a, stream); break;
             }
             return;
@@ -518,6 +628,7 @@ void gemm(const GemmArgs& a, int epi, mgStream_t stream) {
                 case EPI_F32_RESID: launch_xl<EPI_F32_RESID, 4>(a, stream); break;
                 case EPI_PK_RELU: launch_xl<EPI_PK_RELU, 4>(a, stream); break;
                 case EPI_PK: launch_xl<EPI_PK, 4>(a, stream); break;
+                case EPI_RESID_NORM: launch_xl<EPI_RESID_NORM, 4>(a, stream); break;
                 default: launch_xl<EPI_HEADS, 4>(a, stream); break;
             }
             return;
@@ -529,6 +640,7 @@ void gemm(const GemmArgs& a, int epi, mgStream_t stream) {
             case EPI_F32_RESID: launch_wide<EPI_F32_RESID>(a, stream); break;
             case EPI_PK_RELU: launch_wide<EPI_PK_RELU>(a, stream); break;
             case EPI_PK: launch_wide<EPI_PK>(a, stream); break;
+            case EPI_RESID_NORM: launch_wide<EPI_RESID_NORM>(a, stream); break;
             default: launch_wide<EPI_HEADS>(a, stream); break;
         }
         return;
@@ -541,6 +653,7 @@ void gemm(const GemmArgs& a, int epi, mgStream_t stream) {
         case EPI_F32_RESID: MG_LAUNCH((gemm_big_kernel<EPI_F32_RESID>), grid, block, sh, stream, a); break;
         case EPI_PK_RELU: MG_LAUNCH((gemm_big_kernel<EPI_PK_RELU>), grid, block, sh, stream, a); break;
         case EPI_PK: MG_LAUNCH((gemm_big_kernel<EPI_PK>), grid, block, sh, stream, a); break;
+        case EPI_RESID_NORM: MG_LAUNCH((gemm_big_kernel<EPI_RESID_NORM>), grid, block, sh, stream, a); break;
         default: MG_LAUNCH((gemm_big_kernel<EPI_HEADS>), grid, block, sh, stream, a); break;
     }
 }

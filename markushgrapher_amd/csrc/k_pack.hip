@@ -123,6 +123,50 @@ void rmsnorm_pack(const float* h, const float* gain, uint16_t* x_pk, float* out_
     if (blocks < 1) blocks = 1;
     MG_LAUNCH(rmsnorm_pack_kernel, dim3(blocks), dim3(256), 0, stream, h, gain, x_pk, out_f32, (const int*)nullptr, M, d, eps, scale);
 }
+// RMSNorm + pack from the tiled fp32 layout: one workgroup per 32-row tile; thread = (row, one of 8 feature slices), so the
+// 32 lanes of a half-wave read 512 contiguous bytes per feature group and write 512 contiguous bytes of a packed tile.
+__global__ __launch_bounds__(256) void rmsnorm_pack_tiled_kernel(const float* h, const float* gain, uint16_t* x_pk, float* out_f32, int M, int d,
+                                                            float eps) {
+    MG_DYN_SMEM(smem);
+    float* red = (float*)smem;                       // [8][32]
+    const int tid = threadIdx.x, r = tid & 31, p = tid >> 5;
+    const int nch = d >> 3;                          // 8-feature chunks per row
+    for (int rt = blockIdx.x; rt < (M >> 5); rt += gridDim.x) {
+        const int m = rt * 32 + r;
+        float ss = 0.f;
+        for (int c = p; c < nch; c += 8) {
+            const float4 a = *(const float4*)(h + ht_off(m, c * 8, d)), b = *(const float4*)(h + ht_off(m, c * 8 + 4, d));
+            ss += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+        }
+        red[p * 32 + r] = ss;
+        __syncthreads();
+        float tot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tot += red[i * 32 + r];
+        const float rr = rsqrtf(tot / (float)d + eps);
+        for (int c = p; c < nch; c += 8) {
+            const float4 a = *(const float4*)(h + ht_off(m, c * 8, d)), b = *(const float4*)(h + ht_off(m, c * 8 + 4, d));
+            const float4 g0 = *(const float4*)(gain + c * 8), g1 = *(const float4*)(gain + c * 8 + 4);
+            const float v[8] = {g0.x * (a.x * rr), g0.y * (a.y * rr), g0.z * (a.z * rr), g0.w * (a.w * rr),
+                                g1.x * (b.x * rr), g1.y * (b.y * rr), g1.z * (b.z * rr), g1.w * (b.w * rr)};
+            if (out_f32) {
+                *(float4*)(out_f32 + (size_t)m * d + c * 8) = make_float4(v[0], v[1], v[2], v[3]);
+                *(float4*)(out_f32 + (size_t)m * d + c * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+            if (x_pk)
+                st16(x_pk + pk_off(m, c * 8, d),
+                     make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])));
+        }
+        __syncthreads();
+    }
+}
+void rmsnorm_pack_tiled(const float* h_tiled, const float* gain, uint16_t* x_pk, float* out_f32, int M, int d, float eps,
+                        mgStream_t stream) {
+    int blocks = M >> 5;
+    if (blocks > 65536) blocks = 65536;
+    if (blocks < 1) blocks = 1;
+    MG_LAUNCH(rmsnorm_pack_tiled_kernel, dim3(blocks), dim3(256), 8 * 32 * sizeof(float), stream, h_tiled, gain, x_pk, out_f32, M, d, eps);
+}
 void rmsnorm_pack_rows(const float* h, const float* gain, uint16_t* x_pk, const int* dst_row, int M, int d, float eps,
                        float scale, mgStream_t stream) {
     int blocks = (M + 3) / 4;

@@ -95,6 +95,13 @@ MG_HD size_t pk_off(int r, int k, int K) {
 }
 MG_HD size_t pk_elems(int R, int K) { return (size_t)((R + 31) / 32) * (size_t)(K / 16) * TILE_ELEMS; }
 
+// fp32 residual stream of the encoder, tiled so that a lane owning one token row touches whole 16-byte groups:
+// h[M][N] is stored as [M/32][N/4][32 rows][4 features]; the 32 lanes of a half-wave that own rows 32t..32t+31 read or
+// write 512 contiguous bytes per feature group.
+MG_HD size_t ht_off(int m, int n, int N) {
+    return ((size_t)(m >> 5) * (size_t)(N >> 2) + (size_t)(n >> 2)) * 128 + (size_t)((m & 31) * 4 + (n & 3));
+}
+
 MG_DEV float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 MG_DEV float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
 MG_DEV float bf16hi(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }

@@ -14,6 +14,11 @@ enum GemmEpi : int {
     EPI_PK_RELU = 2,     // out_pk packed [M][N] = bf16(relu(acc))                      (FFN wi)
     EPI_PK = 3,          // out_pk packed [M][N] = bf16(acc)
     EPI_HEADS = 4,       // per-head Q/K/V targets, see HeadsOut                        (QKV and cross-K/V projections)
+    // Encoder residual projection with the NEXT RMSNorm folded in (deferred norm, as in the decode step):
+    //   h (fp32, TILED layout ht_off) += acc;  out_pk = pack(bf16(h * gain)) un-normalised;  part[m][N/64] = sums of h^2 over
+    //   each wave's 64 columns.  Consumers (EPI_HEADS / EPI_PK_RELU with GemmArgs::rs set) multiply their output rows by
+    //   rsqrt(sum(part[m]) / N + eps): RMSNorm is a per-row scalar, so no norm launch sits between the GEMMs.
+    EPI_RESID_NORM = 5,
 };
 // Destination formats for per-head projections (head dim fixed at 64):
 enum HeadFmt : int {
@@ -52,7 +57,9 @@ struct GemmArgs {
     const float* bias;
     uint16_t* out_pk;
     HeadsOut heads;
-    RowScale rs;           // decode-step kernels only
+    RowScale rs;           // deferred RMSNorm scale of the rows of X (decode-step kernels; encoder: EPI_HEADS / EPI_PK_RELU)
+    const float* gain;     // EPI_RESID_NORM: gain of the next RMSNorm (null: no packed output / partial sums)
+    float* part;           // EPI_RESID_NORM: [M][N/64] partial sums of squares
     // decode-step kernels: X may be a column window of a wider packed buffer: x_kts = 16-wide k-tiles per row tile of
     // the buffer (0 = K/16), x_k0 = first k-tile of the window
     int x_kts, x_k0;
@@ -116,6 +123,9 @@ struct Slabs {
 // x_pk[M][d] (packed bf16) = RMSNorm(h[M][d] fp32) * gain * scale ; optionally also out_f32 row-major
 void rmsnorm_pack(const float* h, const float* gain, uint16_t* x_pk, float* out_f32, int M, int d, float eps,
                   float scale, mgStream_t stream);
+// the same from the TILED fp32 layout (ht_off) of the encoder's residual stream; M a multiple of 32
+void rmsnorm_pack_tiled(const float* h_tiled, const float* gain, uint16_t* x_pk, float* out_f32, int M, int d, float eps,
+                        mgStream_t stream);
 // same, but source row m is written to packed row dst_row[m] (skipped when negative)
 void rmsnorm_pack_rows(const float* h, const float* gain, uint16_t* x_pk, const int* dst_row, int M, int d, float eps,
                        float scale, mgStream_t stream);
@@ -144,7 +154,8 @@ struct EmbedArgs {
     const uint16_t* x_emb;      // [M2][d] bf16
     const uint16_t* y_emb;      // [M2][d] bf16
     int B, L, P, d, n_side, M2, V, S_cap;
-    float* hidden;              // [B][S_cap][d]
+    float* hidden;              // [B][S_cap][d] row-major, or the tiled layout ht_off when hidden_tiled != 0
+    int hidden_tiled;
     double* cx;                 // [B][S_cap]  box x-centre (float64 as in the reference)
     double* cy;
     uint8_t* mask;              // [B][S_cap]  1 = attended
@@ -179,6 +190,7 @@ struct AttnArgs {
     // 128-query blocks hold at least one attended position; fully padded stages / blocks are skipped
     const int* kst;         // [B][1 + Sk_cap/64]: count, stage ids
     const uint8_t* qbv;     // [B][Sq_cap/128 rounded up]
+    int dbg;                // diagnostics (MG_ATT_DBG): bit 0 = every stage waits for ALL outstanding copies
 };
 // bucket indices of the encoder's relative biases, once per batch (see k_attn.hip)
 void bias_index(uint16_t* out, const double* cx, const double* cy, const uint8_t* kmask, const int* bk1, const int* bkhv, int B,

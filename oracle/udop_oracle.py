@@ -212,15 +212,24 @@ class Oracle:
         keymask.masked_fill_(mask[:, None, None, :] == 0, torch.finfo(F32).min)
         bias, buckets = self.encoder_bias(bbox64, S)
         parts = {"embed": h.clone(), "patch_emb": img, "cell_idx": cell_idx, "buckets": buckets, "bbox64": bbox64}
+        def norm_in(hh, gain, deferred):
+            # emulate_bf16 only: where the HIP encoder stores bf16.  Layer 0 normalises explicitly, bf16(RMSNorm(h)*g);
+            # every later sub-layer input is the deferred form of DESIGN.md "Precision map": bf16(h*g) is what is stored
+            # and the consuming projection scales its fp32 output rows by r = rsqrt(mean h^2 + eps) - by linearity the
+            # same as feeding bf16(h*g)*r unrounded.  In fp32 mode both are the reference's RMSNorm (stock:293-306).
+            if not (self.bf and deferred):
+                return _bf(self.rmsnorm(hh, gain), self.bf)
+            r = torch.rsqrt(hh.pow(2).mean(-1, keepdim=True) + self.s.layer_norm_epsilon)
+            return _bf(hh * gain, True) * r
         for i in range(s.num_layers):
             p = f"encoder.block.{i}.layer"
-            x = _bf(self.rmsnorm(h, self.w[f"{p}.0.layer_norm.weight"]), self.bf)
+            x = norm_in(h, self.w[f"{p}.0.layer_norm.weight"], i > 0)
             q = _bf(self._heads(self.linear(x, f"{p}.0.SelfAttention.q.weight")), self.bf)
             k = _bf(self._heads(self.linear(x, f"{p}.0.SelfAttention.k.weight")), self.bf)
             v = _bf(self._heads(self.linear(x, f"{p}.0.SelfAttention.v.weight")), self.bf)
             ctx = _bf(self._merge(self.attention(q, k, v, bias, keymask)), self.bf)
             h = h + self.linear(ctx, f"{p}.0.SelfAttention.o.weight")
-            x = _bf(self.rmsnorm(h, self.w[f"{p}.1.layer_norm.weight"]), self.bf)
+            x = norm_in(h, self.w[f"{p}.1.layer_norm.weight"], True)
             y = _bf(torch.relu(self.linear(x, f"{p}.1.DenseReluDense.wi.weight")), self.bf)
             h = h + self.linear(y, f"{p}.1.DenseReluDense.wo.weight")
             if return_parts and i == 0:

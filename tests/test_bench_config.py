@@ -82,6 +82,19 @@ def test_g4_encoder_all_32_images():
         assert err.max() < ENC_MAX and err.mean() < ENC_MEAN, (b, err.max(), err.mean())
 
 
+def test_g4_encoder_is_bitwise_reproducible():
+    """Three passes over the same batch must agree bit for bit (fixed-order reductions, no races in the hand-pipelined
+    LDS-DMA loops: a missed wait shows up here as differing bits long before it shows up in a tolerance)."""
+    g, shape, eng, args = _setup()
+    ref = None
+    for _ in range(3):
+        enc, _ = eng.encode(*args)
+        cur = eng.mem.numpy(enc).copy()
+        if ref is None:
+            ref = cur
+        assert np.array_equal(ref, cur)
+
+
 def test_g4_greedy_free_running_ids_under_margin_rule():
     """generate() exactly as bench.py calls it (B = 32, EOS suppressed), first 16 steps: ids equal the reference's up to the
     first step of each row whose reference margin is below MARGIN_TOL; per-step top-1 logit within LOGIT_TOL while equal."""
