@@ -111,6 +111,9 @@ MG_DEV uint16_t f32_to_bf16(float f) {
     u += 0x7FFFu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
 }
+MG_DEV uint32_t pack_bf16(float lo, float hi);
+// one value, same rounding as pack_bf16 (v_cvt_pk_bf16_f32 on the device)
+MG_DEV uint16_t f32_to_bf16_rn(float f);
 MG_DEV uint32_t pack_bf16(float lo, float hi) {
 #ifdef MG_EMU
     return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
@@ -121,6 +124,8 @@ MG_DEV uint32_t pack_bf16(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, mg_bf16x2));
 #endif
 }
+
+MG_DEV uint16_t f32_to_bf16_rn(float f) { return (uint16_t)(pack_bf16(f, 0.f) & 0xFFFFu); }
 
 MG_DEV f32x16 acc_zero() {
     f32x16 c;
