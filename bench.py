@@ -1,25 +1,33 @@
 #!/usr/bin/env python
 """Headline benchmark (BASELINE.json): images/s, greedy CXSMILES decode, 1024 px crops, batch 32 per GPU.
 
-One "step" = one pass of the hot path over one batch of 32 synthetic pages per GPU: VTL encoder + cross-K/V
-projection + 256 greedy decode steps (EOS suppressed: min_length = max_length = 257) on the
-UDOP-large-shaped MarkushGrapher-2 model with recipe (random-init, bf16-exact) weights.  Inputs (the 1024x1024 u8 RGB
-crops, token ids, boxes, masks) are resident in HBM when the timed region starts; the step includes the device-side
-LANCZOS resize to the model's 512 px input + normalisation (mg_preprocess_pages).  With --gpus N, every rank runs its own 32-image shard (weak scaling) and the
-decoded token ids are all-gathered over RCCL inside the timed region.
+One "step" = one pass of the hot path over one batch of 32 synthetic pages per GPU: device LANCZOS resize of the
+1024 px u8 crops to the model's 512 px input (mg_preprocess_pages), VTL encoder, cross-K/V projection and 256 greedy
+decode steps (EOS suppressed: min_length = max_length = 257) on the UDOP-large-shaped
+MarkushGrapher-2 model with the recipe weights of tests/golden/g4_bench.npz (synth.BENCH_RECIPE: the configuration the
+parity tests pin on stock UDOP).  Inputs are resident in HBM when the timed region starts.  With --gpus N every rank
+runs its own 32-image shard (weak scaling) and the decoded ids are all-gathered over RCCL inside the timed region.
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel (single-query cross-attention over the
-per-image K/V stream: ~80 % of the decode step's HBM bytes), timed live with HIP events on the launch stream.
-`cpu_baseline` times the fp32 CPU oracle (oracle/udop_oracle.py) on a bounded sample on this box's host cores.
+Prints ONE JSON line on rank 0:
+  roofline       dominant kernel (single-query cross-attention over the per-image K/V stream), algorithmic bytes / average
+                 launch duration from HIP events on the launch stream; `traffic` = HBM bytes per launch from a FETCH_SIZE pass
+                 (rocprofv3 --pmc, run by this script as a child on a short copy of the workload when rocprofv3 is present)
+  phases         encoder (MFMA-bound) and decode step (HBM-bound) against their own rooflines: enc_mfma_frac, dec_hbm_frac,
+                 dec_mfma_frac (SURVEY.md §8d formulas), phase times from HIP events inside mg_generate
+  extra_runs     EOS-enabled greedy run (max_length 512) and beam-5 (BASELINE configs[2]) on the same inputs
+  cpu_baseline   the fp32 CPU oracle (oracle/udop_oracle.py, kind "port") on a bounded sample on this box's host cores
 """
 import argparse
 import ctypes as C
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 # before torch loads the HIP runtime: kernel arguments in device memory (see markushgrapher_amd/__init__.py)
@@ -31,34 +39,102 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 METRIC = "images/sec whole-node (greedy CXSMILES decode, 1024px crops, bs=32/GPU)"
-HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (same guide)
+EOS_ROW_SCALES = (2.5, 3.0, 3.5, 4.0, 5.0, 6.0)   # EOS-enabled run: ladder of scales of the EOS embedding row (see extra_runs)
 
 
-def cpu_baseline(shape, sd, new_tokens=16, B=2, L=128):
-    """fp32 CPU oracle (oracle/udop_oracle.py, kind "port") on a bounded sample, extrapolated to 256 new tokens."""
+def cpu_baseline(shape, sd, L=128, new_tokens=128, sample_steps=8, reps=3):
+    """fp32 CPU oracle (kind "port"), SURVEY.md §8d protocol bounded to ~30 s: B = 1 and B = 4, L_text = 128, greedy;
+    encoder + cross-K/V once per batch size, then 1 warm-up + `reps` timed repetitions of `sample_steps` decode steps,
+    per-step time extrapolated to 128 new tokens (a step's cost does not depend on the position: the cross-attention
+    over ~1150 encoder positions dominates the growing self-attention cache)."""
     import torch
     from markushgrapher_amd import synth
     from oracle.udop_oracle import Oracle
     # a small batch on a 100+-core host is slower with every core than with a few dozen threads (memory-bound GEMV)
     torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
     o = Oracle(shape, sd)
-    inp = synth.synth_batch(shape, B, seed=7, fixed_L=L)
-    with torch.no_grad():
-        t0 = time.time()
-        enc, mask = o.encode(inp["input_ids"], inp["bbox"], inp["pixel_values"], inp["attention_mask"])
-        xkv = o.cross_kv(enc)
-        t_enc = time.time() - t0
-        seq = torch.zeros((B, 1), dtype=torch.long)
-        kv, cur = None, seq
-        t0 = time.time()
-        for t in range(new_tokens):
-            hid, kv = o.decoder_stack(cur, mask, xkv, kv, t)
-            cur = torch.argmax(o.lm_logits(hid[:, -1:, :])[:, 0, :], dim=-1)[:, None]
-        t_step = (time.time() - t0) / new_tokens
-    ips = B / (t_enc + 256 * t_step)
-    return {"value": round(ips, 5), "unit": "images/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": f"oracle fp32 torch-CPU, UDOP-large shape, B={B}, L={L}: encoder+cross-KV {t_enc:.2f}s, "
-                      f"{new_tokens} decode steps at {t_step * 1e3:.1f} ms/step, extrapolated to 256 new tokens"}
+    out = {}
+    for B in (1, 4):
+        inp = synth.synth_batch(shape, B, seed=7, fixed_L=L)
+        with torch.no_grad():
+            t0 = time.time()
+            enc, mask = o.encode(inp["input_ids"], inp["bbox"], inp["pixel_values"], inp["attention_mask"])
+            xkv = o.cross_kv(enc)
+            t_enc = time.time() - t0
+
+            def run(n):
+                kv, cur = None, torch.zeros((B, 1), dtype=torch.long)
+                t1 = time.time()
+                for t in range(n):
+                    hid, kv = o.decoder_stack(cur, mask, xkv, kv, t)
+                    cur = torch.argmax(o.lm_logits(hid[:, -1:, :])[:, 0, :], dim=-1)[:, None]
+                return (time.time() - t1) / n
+            run(1)
+            t_step = min(run(sample_steps) for _ in range(reps))
+        out[B] = (B / (t_enc + new_tokens * t_step), t_enc, t_step)
+    return {"value": round(out[4][0], 5), "unit": "images/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "value_b1": round(out[1][0], 5),
+            "sample": f"oracle fp32 torch-CPU ({torch.__version__}), UDOP-large shape, L_text={L}, greedy, {new_tokens} new tokens: "
+                      f"B=1 encoder+cross-KV {out[1][1]:.2f}s + {out[1][2] * 1e3:.1f} ms/step; B=4 {out[4][1]:.2f}s + "
+                      f"{out[4][2] * 1e3:.1f} ms/step (1 warm-up + {reps} x {sample_steps} timed decode steps, best rep, "
+                      f"extrapolated to {new_tokens} steps); value = B=4"}
+
+
+def pmc_child(args):
+    """Child mode (run under rocprofv3 --pmc FETCH_SIZE by the parent): one short pass of the same workload."""
+    import torch
+    from markushgrapher_amd import synth
+    from markushgrapher_amd.engine import Engine
+    shape = synth.SHAPES[args.shape]
+    eng = Engine(shape, max_decode_len=64)
+    eng.load_state_dict(synth.recipe_state_dict(shape, **synth.BENCH_RECIPE))
+    inp = synth.synth_batch(shape, args.batch, seed=synth.BENCH_SEED, return_pages=True)
+    pix = eng.preprocess(inp["pages_u8"])
+    eng.generate(inp["input_ids"], inp["bbox"], inp["attention_mask"], pix, max_length=args.pmc_child + 1,
+                 min_length=args.pmc_child + 1)
+    torch.cuda.synchronize()
+
+
+def pmc_traffic(args):
+    """HBM bytes from the L2's memory-side read counters: FETCH_SIZE per dispatch (KiB; x2 on gfx950 for wide coalesced
+    streams, MI355X_MICROARCH.md 'HBM') of the cross-attention kernel and of a whole decode step, from a child run of
+    this script under `rocprofv3 --pmc FETCH_SIZE --kernel-trace` (counters in their own run).  None if unavailable."""
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None
+    tmp = tempfile.mkdtemp(prefix="mg_pmc_", dir="/tmp")
+    steps = 8
+    try:
+        env = dict(os.environ, TMPDIR="/tmp")
+        subprocess.run([exe, "--pmc", "FETCH_SIZE", "--kernel-trace", "-d", tmp, "-o", "pmc", "--", sys.executable,
+                        os.path.abspath(__file__), "--pmc-child", str(steps), "--shape", args.shape, "--batch", str(args.batch)],
+                       cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=420, check=False)
+        import sqlite3
+        db = None
+        for dp, _, fs in os.walk(tmp):
+            for f in fs:
+                if f.endswith(".db"):
+                    db = os.path.join(dp, f)
+        if db is None:
+            return None
+        rows = sqlite3.connect(db).execute(
+            "select kernel_name, value from counters_collection where counter_name = 'FETCH_SIZE'").fetchall()
+        xa = [v for n, v in rows if "attn_step_kernel<1, 8, true" in n]
+        dec = [v for n, v in rows if any(k in n for k in ("attn_step_kernel", "gemm_rows", "greedy_select", "embed_norm_rows",
+                                                          "qkv_attn_step"))]
+        if not xa or not dec:
+            return None
+        return {"cross_attention_bytes_per_launch": int(sum(xa) / len(xa) * 1024 * 2),
+                "decode_step_bytes": int(sum(dec) / steps * 1024 * 2),
+                "source": f"rocprofv3 --pmc FETCH_SIZE --kernel-trace on a child run of bench.py ({steps} decode steps, same batch): "
+                          "FETCH_SIZE KiB x 1024 x 2 (gfx950 reports half the bytes of wide coalesced reads; other access "
+                          "widths uncalibrated)"}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def main():
@@ -71,9 +147,14 @@ def main():
     ap.add_argument("--new-tokens", type=int, default=256)
     ap.add_argument("--beams", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-runs", action="store_true", help="skip the EOS-enabled and beam-5 side measurements")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 FETCH_SIZE child pass")
+    ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--profile-every", type=int, default=16)
     ap.add_argument("--decode-graph", type=int, default=1, help="1: replay the captured decode-step HIP graph; 0: eager launches")
     args = ap.parse_args()
+    if args.pmc_child:
+        return pmc_child(args)
 
     import torch
     from markushgrapher_amd import synth
@@ -97,7 +178,7 @@ def main():
     t0 = time.time()
     sd = synth.recipe_state_dict(shape, **synth.BENCH_RECIPE)
     t_weights = time.time() - t0
-    eng = Engine(shape, max_decode_len=max(512, max_length))
+    eng = Engine(shape, max_decode_len=512)
     eng.load_state_dict(sd)
     eng.set_decode_graph(args.decode_graph)
     # each rank gets its own shard of the global batch (independent images, no data-path exchange)
@@ -105,25 +186,37 @@ def main():
     dev = {k: eng.mem.asarray(v, {"input_ids": np.int64, "bbox": np.float32, "attention_mask": np.uint8,
                                   "pixel_values": np.float32, "pages_u8": np.uint8}[k]) for k, v in inp.items()}
     L = inp["input_ids"].shape[1]
-    gathered = torch.empty((world * B, max_length), dtype=torch.int64, device="cuda") if world > 1 else None
+    # the exchange: ids padded to the static shape [B, 512] int32 + one length per row, one all-gather each
+    gathered = torch.empty((world * B, 512), dtype=torch.int32, device="cuda") if world > 1 else None
+    gathered_len = torch.empty((world * B,), dtype=torch.int32, device="cuda") if world > 1 else None
+    send = torch.zeros((B, 512), dtype=torch.int32, device="cuda") if world > 1 else None
 
-    def step():
+    def step(beams=args.beams, max_len=max_length, min_len=max_length):
         # the 1024 px u8 crops are what is resident in HBM: LANCZOS resize to the 512 px model input + normalisation run
         # on the device inside the step (bit-exact with the reference's Pillow preprocessing)
         pix = eng.preprocess(dev["pages_u8"])
         ids, _, _ = eng.generate(dev["input_ids"], dev["bbox"], dev["attention_mask"], pix,
-                                 num_beams=args.beams, max_length=max_length, min_length=max_length)
+                                 num_beams=beams, max_length=max_len, min_length=min_len)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, ids.contiguous())
+            send.zero_()
+            send[:, :ids.shape[1]] = ids.to(torch.int32)
+            lens = torch.full((B,), ids.shape[1], dtype=torch.int32, device="cuda")
+            dist.all_gather_into_tensor(gathered, send)
+            dist.all_gather_into_tensor(gathered_len, lens)
         return ids
 
     for _ in range(args.warmup):
         step()
-    # live timing of the dominant kernel on the launch stream (HIP events), sampled every N-th decode step
-    eng.lib.mg_profile_cross_attention.argtypes = [C.c_void_p, C.c_int, C.c_int]
-    eng.lib.mg_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    # live timing of the dominant kernel on the launch stream (HIP events), sampled every N-th decode step; phase events
+    L_ = eng.lib
+    L_.mg_profile_cross_attention.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L_.mg_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L_.mg_profile_read_overhead.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    L_.mg_profile_phases.argtypes = [C.c_void_p, C.c_int]
+    L_.mg_profile_phases_read.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     nl = shape.num_decoder_layers
-    eng.lib.mg_profile_cross_attention(eng.model, args.profile_every, (new_tokens // max(args.profile_every, 1) + 1) * nl)
+    L_.mg_profile_cross_attention(eng.model, args.profile_every, (new_tokens // max(args.profile_every, 1) + 1) * nl)
+    L_.mg_profile_phases(eng.model, 1)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -138,51 +231,107 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    n_l, ms, keys = C.c_long(0), C.c_double(0), C.c_double(0)
-    eng.lib.mg_profile_read(eng.model, C.byref(n_l), C.byref(ms), C.byref(keys))
-    empty_ms = C.c_double(0)
-    eng.lib.mg_profile_read_overhead.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
-    eng.lib.mg_profile_read_overhead(eng.model, C.byref(empty_ms))
+    n_l, ms, keys, empty_ms = C.c_long(0), C.c_double(0), C.c_double(0), C.c_double(0)
+    L_.mg_profile_read(eng.model, C.byref(n_l), C.byref(ms), C.byref(keys))
+    L_.mg_profile_read_overhead(eng.model, C.byref(empty_ms))
+    n_ph, enc_ms, dec_ms = C.c_long(0), C.c_double(0), C.c_double(0)
+    L_.mg_profile_phases_read(eng.model, C.byref(n_ph), C.byref(enc_ms), C.byref(dec_ms))
+    L_.mg_profile_cross_attention(eng.model, 0, 0)
+    L_.mg_profile_phases(eng.model, 0)
     assert ids.shape == (B, max_length), ids.shape
 
     if rank == 0:
-        H = shape.num_heads
+        H, d, dff, V = shape.num_heads, shape.d_model, shape.d_ff, shape.vocab_size
+        n_enc, n_dec, P = shape.num_layers, shape.num_decoder_layers, shape.num_patches
+        # attended encoder positions per image (what the path computes on; padding excluded from the algorithmic work)
+        _, msk = eng.encode(dev["input_ids"], dev["bbox"], dev["attention_mask"], eng.preprocess(dev["pages_u8"]))
+        xlen = msk.sum(dim=1).cpu().numpy().astype(np.float64)
+        traffic = None if (args.no_pmc or world > 1 or args.beams != 1) else pmc_traffic(args)
         roof = None
         if n_l.value > 0:
             bytes_per_launch = keys.value / n_l.value * H * 64 * 2 * 2     # K and V rows of 64 bf16, all heads
             raw_s = ms.value / n_l.value * 1e-3            # e0 -> e1 around the launch
             empty_s = empty_ms.value / n_l.value * 1e-3    # e1 -> e2 with nothing in between: cost of the bracket itself
-            # The bracket over-reads the kernel by the dispatch latency behind the first record (rocprofv3 kernel trace:
-            # 24.2 us, profiles/r01_p_kernel_stats.md); the empty bracket (5.2 us) over-corrects, so the conservative raw
-            # bracket is what `achieved` uses and the empty one is reported for reference only.
-            dur_s = raw_s
-            ach = bytes_per_launch / dur_s / 1e9
-            traffic, traffic_src = None, None
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_cross_attention.json")
-            if os.path.exists(pmc) and args.shape == "large" and B == 32 and args.beams == 1:
-                with open(pmc) as f:
-                    pj = json.load(f)
-                traffic = int(pj["traffic_bytes_per_launch"])      # HBM bytes per launch from the separate --pmc pass
-                traffic_src = pj["source"]
+            # The bracket over-reads the kernel by the dispatch latency behind the first record (rocprofv3 kernel trace of
+            # the same command: profiles/); the empty bracket over-corrects, so the conservative raw bracket is `achieved`.
+            ach = bytes_per_launch / raw_s / 1e9
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
-                    "traffic_source": traffic_src,
+                    "frac": round(ach / HBM_PEAK_GBS, 4),
+                    "traffic": traffic["cross_attention_bytes_per_launch"] if traffic else None, "traffic_unit": "bytes/launch",
+                    "traffic_source": traffic["source"] if traffic else None,
                     "kernel": "attn_step_kernel<1, 8, true> (decoder cross-attention, single query per image/head)",
-                    "bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(dur_s * 1e6, 2),
+                    "bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(raw_s * 1e6, 2),
                     "empty_bracket_us": round(empty_s * 1e6, 2),
-                    "timing": "HIP events on the launch stream: (record, launch, record, record); avg_launch_us = first "
-                              "bracket, uncorrected; empty_bracket_us = second bracket (nothing in between)",
+                    "timing": "HIP events on the launch stream around the device-counter form of the launch the decode graph "
+                              "replays: (record, launch, record, record); avg_launch_us = first bracket, uncorrected; "
+                              "empty_bracket_us = second bracket (nothing in between)",
                     "launches_timed": int(n_l.value)}
+        phases = None
+        if n_ph.value > 0 and args.beams == 1:
+            t_enc = enc_ms.value / n_ph.value * 1e-3
+            t_step = dec_ms.value / n_ph.value * 1e-3 / new_tokens
+            # F_enc = N_enc*S*(8d^2 + 4*d*dff + 4*S*d) + 2*P*768*d;  F_xkv = N_dec*S_x*4d^2  (per image, S = attended positions)
+            f_enc = float(np.sum(n_enc * xlen * (8 * d * d + 4 * d * dff + 4 * xlen * d) + 2 * P * (shape.num_channels * shape.patch_size ** 2) * d))
+            f_xkv = float(np.sum(n_dec * xlen * 4 * d * d))
+            tbar = (new_tokens - 1) / 2.0
+            # Bytes_step = 2*(N_dec*16d^2 + d*V) + sum_b 2*N_dec*2*d*(S_x + t);  F_step = N_dec*(12d^2 + 4*d*dff) + N_dec*4*d*(S_x+t) + 2*d*V
+            bytes_step = 2.0 * (n_dec * 16 * d * d + d * V) + float(np.sum(2 * n_dec * 2 * d * (xlen + tbar)))
+            f_step = float(np.sum(n_dec * (12 * d * d + 4 * d * dff) + n_dec * 4 * d * (xlen + tbar) + 2 * d * V))
+            phases = {
+                "encoder_ms": round(t_enc * 1e3, 2), "decode_step_ms": round(t_step * 1e3, 4),
+                "enc_flops": f_enc + f_xkv, "enc_mfma_frac": round((f_enc + f_xkv) / t_enc / (MFMA_PEAK_TFLOPS * 1e12), 4),
+                "dec_bytes_step_algorithmic": int(bytes_step), "dec_hbm_frac": round(bytes_step / t_step / (HBM_PEAK_GBS * 1e9), 4),
+                "dec_bytes_step_fetched": traffic["decode_step_bytes"] if traffic else None,
+                "dec_mfma_frac": round(f_step / t_step / (MFMA_PEAK_TFLOPS * 1e12), 5),
+                "note": "phase times: HIP events in mg_generate [preprocess excluded | encoder + cross-K/V | decode loop]; formulas "
+                        "SURVEY.md §8d with S = attended positions per image (mean %.0f), t = mean decode position; the decode step "
+                        "is HBM-bound (dec_mfma_frac is reported because north_star asks for it); fetched bytes: child run of 8 steps "
+                        "(t < 8), they contain the product weights of the pair projections (+1.37x on weights, DESIGN.md) and not "
+                        "the cross-K/V projection weights the formula's 16d^2 counts" % float(xlen.mean())}
+        extra = None
+        if not args.no_extra_runs and world == 1 and args.beams == 1:
+            extra = {}
+            # beam-5, BASELINE configs[2]: 160 live sequences, 128 new tokens
+            step(beams=5, max_len=129, min_len=129)
+            torch.cuda.synchronize(); tb = time.time()
+            step(beams=5, max_len=129, min_len=129)
+            torch.cuda.synchronize(); tb = time.time() - tb
+            extra["beam5"] = {"images_per_s": round(B / tb, 2), "ms_per_batch": round(tb * 1e3, 1), "new_tokens": 128,
+                              "config": "configs[2]: batch 32, num_beams 5 (160 live rows), EOS suppressed"}
+            # EOS enabled (max_length 512): random-init weights never emit EOS on their own, so the EOS row of the tied embedding
+            # is scaled up until every row of the batch ends by itself (first scale of the ladder that does); rows then end at
+            # different steps, finished rows emit pad and the batch stops when all have ended (gen:2927-2937 bookkeeping)
+            emb = sd["shared.weight"].copy()
+            chosen = None
+            for scale in EOS_ROW_SCALES:
+                emb[shape.eos_token_id] = synth.round_bf16(sd["shared.weight"][shape.eos_token_id] * np.float32(scale))
+                eng.load_state_dict({"shared.weight": emb})
+                ids_e = step(max_len=512, min_len=0)
+                if ids_e.shape[1] < 512:
+                    chosen = scale
+                    break
+            torch.cuda.synchronize(); te = time.time()
+            ids_e = step(max_len=512, min_len=0)
+            torch.cuda.synchronize(); te = time.time() - te
+            ie = ids_e.cpu().numpy()
+            lens = np.array([int(np.argmax(r == shape.eos_token_id)) if (r == shape.eos_token_id).any() else ie.shape[1] - 1 for r in ie])
+            extra["eos_enabled"] = {"images_per_s": round(B / te, 2), "ms_per_batch": round(te * 1e3, 1), "max_length": 512,
+                                    "decode_steps_run": int(ie.shape[1] - 1), "mean_row_length": round(float(lens.mean()), 1),
+                                    "min_row_length": int(lens.min()), "max_row_length": int(lens.max()), "eos_row_scale": chosen,
+                                    "config": "greedy, EOS enabled (generate(max_length=512) as the reference calls it), same inputs; EOS "
+                                              "embedding row scaled so rows end at different steps"}
+            eng.load_state_dict({"shared.weight": sd["shared.weight"]})
         out = {
             "metric": METRIC, "value": round(world * B * args.steps / dt, 3), "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "configs[1]: batch 32/GPU synthetic 1024x1024 u8 crops -> device LANCZOS 512px model input, greedy "
                                    f"decode, {new_tokens} forced new tokens (EOS suppressed), UDOP-large-shaped "
-                                   "MarkushGrapher-2 VTL encoder + CXSMILES decoder, recipe weights",
+                                   "MarkushGrapher-2 VTL encoder + CXSMILES decoder, recipe weights = tests/golden/g4_bench.npz",
                        "shape": args.shape, "batch_per_gpu": B, "text_len_padded": int(L), "new_tokens": new_tokens,
-                       "num_beams": args.beams, "decode_graph": args.decode_graph, "parallelism": f"dp{world} (independent image shards, one RCCL all-gather of token ids)"},
-            "roofline": roof,
+                       "num_beams": args.beams, "decode_graph": args.decode_graph,
+                       "parallelism": f"dp{world} (independent image shards; one RCCL all-gather of [32,512] int32 ids + lengths per batch)"},
+            "roofline": roof, "phases": phases, "extra_runs": extra,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(shape, sd)
