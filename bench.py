@@ -186,10 +186,13 @@ def main():
     dev = {k: eng.mem.asarray(v, {"input_ids": np.int64, "bbox": np.float32, "attention_mask": np.uint8,
                                   "pixel_values": np.float32, "pages_u8": np.uint8}[k]) for k, v in inp.items()}
     L = inp["input_ids"].shape[1]
-    # the exchange: ids padded to the static shape [B, 512] int32 + one length per row, one all-gather each
-    gathered = torch.empty((world * B, 512), dtype=torch.int32, device="cuda") if world > 1 else None
-    gathered_len = torch.empty((world * B,), dtype=torch.int32, device="cuda") if world > 1 else None
-    send = torch.zeros((B, 512), dtype=torch.int32, device="cuda") if world > 1 else None
+    # the exchange: static [B, 512] int32 ids + [B] int32 lengths per rank, posted asynchronously and
+    # double-buffered (markushgrapher_amd/dist.py), so the gather of batch i overlaps the encoder of batch i+1
+    ex = None
+    if world > 1:
+        from markushgrapher_amd.dist import IdExchange
+        ex = IdExchange(B, torch.device("cuda", local_rank), pad_token_id=shape.pad_token_id)
+    handles = []
 
     def step(beams=args.beams, max_len=max_length, min_len=max_length):
         # the 1024 px u8 crops are what is resident in HBM: LANCZOS resize to the 512 px model input + normalisation run
@@ -197,16 +200,16 @@ def main():
         pix = eng.preprocess(dev["pages_u8"])
         ids, _, _ = eng.generate(dev["input_ids"], dev["bbox"], dev["attention_mask"], pix,
                                  num_beams=beams, max_length=max_len, min_length=min_len)
-        if world > 1:
-            send.zero_()
-            send[:, :ids.shape[1]] = ids.to(torch.int32)
-            lens = torch.full((B,), ids.shape[1], dtype=torch.int32, device="cuda")
-            dist.all_gather_into_tensor(gathered, send)
-            dist.all_gather_into_tensor(gathered_len, lens)
+        if ex is not None:
+            handles.append(ex.post(ids))
+            if len(handles) > 1:
+                ex.wait(handles.pop(0))      # the previous batch's gather has had this batch's whole step to complete
         return ids
 
     for _ in range(args.warmup):
         step()
+    while handles:
+        ex.wait(handles.pop(0))
     # live timing of the dominant kernel on the launch stream (HIP events), sampled every N-th decode step; phase events
     L_ = eng.lib
     L_.mg_profile_cross_attention.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -223,6 +226,8 @@ def main():
     t0 = time.time()
     for _ in range(args.steps):
         ids = step()
+    while handles:
+        all_ids, all_len = ex.wait(handles.pop(0))      # the last batch's exchange completes inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -64,17 +64,23 @@ int mg_load_tensor(mg_model* m, void* stream, const char* hf_key, const void* sr
                    int ndim);
 int mg_finalize(mg_model* m, void* stream);
 
-/* Workspace for a batch of B images with L text tokens, num_beams beams, decoder length max_length and (for
- * mg_decoder_forward) T teacher-forced positions (0 if unused). */
-int mg_workspace_bytes(const mg_model* m, int B, int L, int num_beams, int max_length, int T, size_t* out_bytes);
+/* Workspace for a batch of B images with L text tokens, num_beams beams, decoder length max_length, (for
+ * mg_decoder_forward) T teacher-forced positions (0 if unused) and M_e1 OCSR-branch tokens per image (0 if unused). */
+int mg_workspace_bytes(const mg_model* m, int B, int L, int num_beams, int max_length, int T, int M_e1, size_t* out_bytes);
 
 /* Encoder (stock modeling_udop.py:1102-1246 for the encoder stack).  attention_mask may be NULL (= everything
  * attended, incl. the zero-padded visual slots: stock:1183-1186).  Leaves the encoder state (final hidden states,
  * mask, compaction map) in the workspace for mg_decoder_forward / mg_generate_from_encoded.
- * enc_out [B][L+P][d_model] fp32 and enc_mask [B][L+P] u8 are optional outputs. */
+ * enc_out [B][L+P][d_model] fp32 and enc_mask [B][L+P] u8 are optional outputs (the VTL states e2 only).
+ * e1 (nullable, with M_e1 = 0): [B][M_e1][d_model] fp32, the projected embeddings of MarkushGrapher-2's OCSR vision branch
+ * (`encoder.molscribe_encoder` Swin-B + `encoder.molscribe_projector`, /root/reference/markushgrapher/utils/model/
+ * utils_model_loading.py:23,36), computed by the caller: that branch lives only in the reference's un-vendored fork and is
+ * NOT part of this library.  They are fused as the reference describes (README.md:212-215: "e1 is
+ * concatenated with the VTL embedding e2 and fed to the text decoder"): the decoder cross-attends over [e1 | e2], every e1
+ * token attended.  Parity of this fusion is UNPINNED (no fork source): order and normalisation are inferred. */
 int mg_encode(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* input_ids, const float* bbox,
-              const uint8_t* attention_mask, const float* pixel_values, int B, int L, float* enc_out,
-              uint8_t* enc_mask);
+              const uint8_t* attention_mask, const float* pixel_values, const float* e1, int M_e1, int B, int L,
+              float* enc_out, uint8_t* enc_mask);
 
 /* Teacher-forced decoder + lm_head over T positions (stock:1448-1574): logits [B][T][vocab] fp32.
  * decoder_attention_mask may be NULL.  Requires a preceding mg_encode on the same workspace. */
@@ -89,7 +95,8 @@ int mg_decoder_forward(mg_model* m, void* stream, void* ws, size_t ws_bytes, con
  * step_top2 [max_length][B*num_beams][2] fp32 top-1/top-2 logits per step (greedy only, nullable; parity tests).
  * SYNCHRONISES the stream before returning. */
 int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* input_ids, const float* bbox,
-                const uint8_t* attention_mask, const float* pixel_values, int B, int L, int num_beams, int max_length,
+                const uint8_t* attention_mask, const float* pixel_values, const float* e1 /* nullable, see mg_encode */,
+                int M_e1, int B, int L, int num_beams, int max_length,
                 int min_length, float length_penalty, int early_stopping, int64_t* out_ids, int* out_cols_host,
                 float* out_scores, float* step_top2);
 

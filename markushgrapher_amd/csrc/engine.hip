@@ -41,10 +41,10 @@ struct DecLayer { size_t wqkv, wo, ln0, xq, xkv, xo, ln1, wi, wo2, ln2, xq2, wi2
 struct StepGraph {
     struct Key {
         const void *ws, *out_ids, *top2, *stream;
-        int B, L, K, max_length, min_length, early_stopping;
+        int B, L, K, max_length, min_length, early_stopping, M_e1;
         float length_penalty;
         bool operator==(const Key& o) const {
-            return ws == o.ws && out_ids == o.out_ids && top2 == o.top2 && stream == o.stream && B == o.B && L == o.L && K == o.K &&
+            return ws == o.ws && out_ids == o.out_ids && top2 == o.top2 && stream == o.stream && B == o.B && L == o.L && K == o.K && M_e1 == o.M_e1 &&
                    max_length == o.max_length && min_length == o.min_length && early_stopping == o.early_stopping &&
                    length_penalty == o.length_penalty;
         }
@@ -72,7 +72,7 @@ struct mg_model {
     bool lm_head_loaded = false, finalized = false;
     std::vector<int> h_bk1, h_bkhv, h_bkdec;
     // encoder state left in the workspace by the last mg_encode
-    int st_B = 0, st_L = 0, st_S = 0, st_Scap = 0;
+    int st_B = 0, st_L = 0, st_S = 0, st_Scap = 0, st_M = 0;
     void* st_ws = nullptr;
     // optional live timing of the dominant decode kernel (cross-attention K/V stream), HIP events on the caller's stream
     int prof_every = 0;
@@ -215,6 +215,10 @@ struct Ws {
     uint8_t* mask;
     int *xrow, *xlen, *counters, *att_kst;
     uint8_t* att_qbv;
+    // OCSR-branch tokens e1, packed for the cross-K/V projections
+    uint16_t* e1_pk;
+    int* e1_map;
+    uint8_t* xmask;           // teacher-forced cross-attention key mask over [e1 | encoder] positions
     // decode (generate)
     uint16_t *xk, *xv, *sk, *sv, *dq, *dx_pk, *dy_pk;
     uint16_t *xa, *xb;        // packed [rows][d + inner] operand windows of the pair projections: [bf16(h) | attention context]
@@ -244,10 +248,11 @@ struct Carver {
     }
 };
 
-void carve(const mg_model* m, char* base, int B, int L, int K, int max_len, int T, Ws* w) {
+void carve(const mg_model* m, char* base, int B, int L, int K, int max_len, int T, int Me1, Ws* w) {
     Carver c{base};
     const int d = m->d, inner = m->inner, H = m->H;
     const int S_cap = round_up(L + m->P, 64);
+    const int M64 = Me1 > 0 ? round_up(Me1, 64) : 0, Sx_cap = S_cap + M64;      // cross-attention keys: [e1 | encoder]
     const size_t M = (size_t)B * S_cap;
     const size_t MP = (size_t)round_up(B * m->P, 32);
     w->xim = c.take<uint16_t>(MP * m->Kpatch);
@@ -276,11 +281,14 @@ void carve(const mg_model* m, char* base, int B, int L, int K, int max_len, int 
     w->counters = c.take<int>(16);
     w->att_kst = c.take<int>((size_t)B * (1 + (S_cap >> 6)));
     w->att_qbv = c.take<uint8_t>((size_t)B * ((S_cap + 127) / 128));
+    w->e1_pk = c.take<uint16_t>((size_t)B * M64 * d);
+    w->e1_map = c.take<int>((size_t)B * M64);
+    w->xmask = c.take<uint8_t>((size_t)B * Sx_cap);
     if (max_len > 0) {
         const int R = B * K, Rp = round_up(R, 32);
         const size_t nl = m->dec.size();
-        w->xk = c.take<uint16_t>(nl * B * H * S_cap * 64);
-        w->xv = c.take<uint16_t>(nl * B * H * S_cap * 64);
+        w->xk = c.take<uint16_t>(nl * B * H * Sx_cap * 64);
+        w->xv = c.take<uint16_t>(nl * B * H * Sx_cap * 64);
         w->sk = c.take<uint16_t>(nl * R * H * (size_t)m->T_cap * 64);
         w->sv = c.take<uint16_t>(nl * R * H * (size_t)m->T_cap * 64);
         w->dq = c.take<uint16_t>((size_t)Rp * inner);
@@ -320,8 +328,8 @@ void carve(const mg_model* m, char* base, int B, int L, int K, int max_len, int 
         w->tf_vt = c.take<uint16_t>(MT * inner);
         w->tf_ctx = c.take<uint16_t>(MT * inner);
         w->tf_y = c.take<uint16_t>(MT * m->dff);
-        w->tf_xk = c.take<uint16_t>(M * inner);
-        w->tf_xvt = c.take<uint16_t>(M * inner);
+        w->tf_xk = c.take<uint16_t>((size_t)B * Sx_cap * inner);
+        w->tf_xvt = c.take<uint16_t>((size_t)B * Sx_cap * inner);
         w->tf_xc = c.take<uint16_t>((size_t)round_up(B * T, 32) * d);
     }
     w->total = align_up(c.off, 256);
@@ -633,22 +641,24 @@ int mg_finalize(mg_model* m, void* stream) {
     return MG_OK;
 }
 
-int mg_workspace_bytes(const mg_model* m, int B, int L, int num_beams, int max_length, int T, size_t* out_bytes) {
-    if (!m || !out_bytes || B < 1 || L < 1 || num_beams < 1 || max_length < 0 || T < 0) return fail(MG_E_ARG, "mg_workspace_bytes: bad argument");
+int mg_workspace_bytes(const mg_model* m, int B, int L, int num_beams, int max_length, int T, int M_e1, size_t* out_bytes) {
+    if (!m || !out_bytes || B < 1 || L < 1 || num_beams < 1 || max_length < 0 || T < 0 || M_e1 < 0) return fail(MG_E_ARG, "mg_workspace_bytes: bad argument");
     Ws w;
-    carve(m, nullptr, B, L, num_beams, max_length, T, &w);
+    carve(m, nullptr, B, L, num_beams, max_length, T, M_e1, &w);
     *out_bytes = w.total;
     return MG_OK;
 }
 
 int mg_encode(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* input_ids, const float* bbox,
-              const uint8_t* attention_mask, const float* pixel_values, int B, int L, float* enc_out, uint8_t* enc_mask) {
+              const uint8_t* attention_mask, const float* pixel_values, const float* e1, int M_e1, int B, int L, float* enc_out,
+              uint8_t* enc_mask) {
     if (!m || !ws || !input_ids || !bbox || !pixel_values) return fail(MG_E_ARG, "mg_encode: null argument");
     if (!m->finalized) return fail(MG_E_STATE, "mg_encode: call mg_finalize first");
     if (B < 1 || L < 1) return fail(MG_E_SHAPE, "mg_encode: B and L must be >= 1");
+    if ((e1 == nullptr) != (M_e1 == 0) || M_e1 < 0) return fail(MG_E_ARG, "mg_encode: e1 and M_e1 must be given together");
     mgStream_t st = (mgStream_t)stream;
     Ws w;
-    carve(m, (char*)ws, B, L, 1, 0, 0, &w);
+    carve(m, (char*)ws, B, L, 1, 0, 0, M_e1, &w);
     if (w.total > ws_bytes) return fail(MG_E_WORKSPACE, "mg_encode: workspace too small (%zu < %zu)", ws_bytes, w.total);
     const int d = m->d, H = m->H, inner = m->inner, P = m->P;
     const int S = L + P, S_cap = round_up(S, 64), M = B * S_cap;
@@ -666,7 +676,7 @@ int mg_encode(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_
         e.tok_emb = m->at<uint16_t>(m->tok_emb); e.x_emb = m->at<uint16_t>(m->x_emb); e.y_emb = m->at<uint16_t>(m->y_emb);
         e.B = B; e.L = L; e.P = P; e.d = d; e.n_side = m->n_side; e.M2 = m->M2; e.V = m->V; e.S_cap = S_cap;
         e.hidden = w.hidden; e.hidden_tiled = 1; e.cx = w.cx; e.cy = w.cy; e.mask = w.mask; e.xrow = w.xrow; e.xlen = w.xlen;
-        e.err = w.counters + 3;
+        e.err = w.counters + 3; e.x_row0 = M_e1;
         embed_assemble(e, w.meta, st);
     }
     // bucket indices of the three relative biases: shared by all layers and heads, computed once per batch
@@ -709,7 +719,10 @@ int mg_encode(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_
     rmsnorm_pack_tiled(w.hidden, m->at<float>(m->enc_ln), w.enc_pk, w.enc_f32, M, d, m->c.layer_norm_epsilon, st);
     if (enc_out) MG_LAUNCH(copy_rows_kernel, dim3(1024), dim3(256), 0, st, (const float*)w.enc_f32, enc_out, B, S, S_cap, d);
     if (enc_mask) MG_LAUNCH(copy_bytes_rows_kernel, dim3(64), dim3(256), 0, st, (const uint8_t*)w.mask, enc_mask, B, S, S_cap);
-    m->st_B = B; m->st_L = L; m->st_S = S; m->st_Scap = S_cap; m->st_ws = ws;
+    // e1 tokens (OCSR vision branch, precomputed by the caller): fused with the VTL states by concatenation in front of the
+    // decoder (ref: README.md:212-215) - here: packed next to them for the cross-K/V projections, never normalised or mixed
+    if (e1) pack_e1(e1, B, M_e1, round_up(M_e1, 64), d, w.e1_pk, w.e1_map, w.mask, S_cap, w.xmask, st);
+    m->st_B = B; m->st_L = L; m->st_S = S; m->st_Scap = S_cap; m->st_M = M_e1; m->st_ws = ws;
     return check_launch("mg_encode");
 }
 
@@ -720,10 +733,11 @@ int mg_decoder_forward(mg_model* m, void* stream, void* ws, size_t ws_bytes, con
     if (T < 1 || T > m->T_cap) return fail(MG_E_SHAPE, "mg_decoder_forward: T must be in [1, %d]", m->T_cap);
     mgStream_t st = (mgStream_t)stream;
     Ws w;
-    carve(m, (char*)ws, B, m->st_L, 1, 0, T, &w);
+    carve(m, (char*)ws, B, m->st_L, 1, 0, T, m->st_M, &w);
     if (w.total > ws_bytes) return fail(MG_E_WORKSPACE, "mg_decoder_forward: workspace too small (%zu < %zu)", ws_bytes, w.total);
     const int d = m->d, H = m->H, inner = m->inner;
     const int T_cap = round_up(T, 64), MT = B * T_cap, S = m->st_S, S_cap = m->st_Scap, M = B * S_cap;
+    const int M64 = m->st_M > 0 ? round_up(m->st_M, 64) : 0, Sx_cap = S_cap + M64;
     MG_LAUNCH(pad_dec_inputs_kernel, dim3(64), dim3(256), 0, st, decoder_input_ids, decoder_attention_mask, w.tf_ids, w.tf_mask,
               w.tf_rowmap, B, T, T_cap);
     embed_rows(w.tf_ids, m->at<uint16_t>(m->tok_emb), w.tf_hidden, MT, d, m->V, w.counters + 3, st);
@@ -746,12 +760,19 @@ int mg_decoder_forward(mg_model* m, void* stream, void* ws, size_t ws_bytes, con
         GemmArgs q = gemm_args(w.tf_x, m->at<uint16_t>(l.xq), MT, inner, d);
         set_heads(q, H, T_cap, T_cap, w.tf_q, HF_PK_ROWS, nullptr, HF_NONE, nullptr, HF_NONE);
         gemm(q, EPI_HEADS, st);
+        // keys / values: [e1 tokens (M64 slots) | encoder positions] side by side per image
+        if (M64) {
+            GemmArgs ke = gemm_args(w.e1_pk, m->at<uint16_t>(l.xkv), B * M64, 2 * inner, d);
+            set_heads(ke, H, M64, Sx_cap, w.tf_xk, HF_PK_ROWS, w.tf_xvt, HF_PK_T, nullptr, HF_NONE);
+            gemm(ke, EPI_HEADS, st);
+        }
         GemmArgs kv = gemm_args(w.enc_pk, m->at<uint16_t>(l.xkv), M, 2 * inner, d);
-        set_heads(kv, H, S_cap, S_cap, w.tf_xk, HF_PK_ROWS, w.tf_xvt, HF_PK_T, nullptr, HF_NONE);
+        set_heads(kv, H, S_cap, Sx_cap, w.tf_xk, HF_PK_ROWS, w.tf_xvt, HF_PK_T, nullptr, HF_NONE);
+        kv.heads.s_off = M64;
         gemm(kv, EPI_HEADS, st);
         AttnArgs x{};
-        x.Q = w.tf_q; x.K = w.tf_xk; x.Vt = w.tf_xvt; x.ctx = w.tf_ctx; x.B = B; x.H = H; x.Sq = T; x.Sk = S;
-        x.Sq_cap = T_cap; x.Sk_cap = S_cap; x.mode = ATT_CROSS; x.kmask = w.mask;
+        x.Q = w.tf_q; x.K = w.tf_xk; x.Vt = w.tf_xvt; x.ctx = w.tf_ctx; x.B = B; x.H = H; x.Sq = T; x.Sk = M64 + S;
+        x.Sq_cap = T_cap; x.Sk_cap = Sx_cap; x.mode = ATT_CROSS; x.kmask = M64 ? w.xmask : w.mask;
         attention(x, st);
         GemmArgs xo = gemm_args(w.tf_ctx, m->at<uint16_t>(l.xo), MT, d, inner);
         xo.out_f32 = w.tf_hidden; xo.ldo = d;
@@ -776,7 +797,7 @@ int mg_decoder_forward(mg_model* m, void* stream, void* ws, size_t ws_bytes, con
 }
 
 int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* input_ids, const float* bbox,
-                const uint8_t* attention_mask, const float* pixel_values, int B, int L, int num_beams, int max_length,
+                const uint8_t* attention_mask, const float* pixel_values, const float* e1, int M_e1, int B, int L, int num_beams, int max_length,
                 int min_length, float length_penalty, int early_stopping, int64_t* out_ids, int* out_cols_host,
                 float* out_scores, float* step_top2) {
     if (!m || !out_ids || !out_cols_host) return fail(MG_E_ARG, "mg_generate: null argument");
@@ -789,19 +810,29 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
     mgStream_t st = (mgStream_t)stream;
     const int K = num_beams;
     Ws w;
-    carve(m, (char*)ws, B, L, K, max_length, 0, &w);
+    if ((e1 == nullptr) != (M_e1 == 0) || M_e1 < 0) return fail(MG_E_ARG, "mg_generate: e1 and M_e1 must be given together");
+    carve(m, (char*)ws, B, L, K, max_length, 0, M_e1, &w);
     if (w.total > ws_bytes) return fail(MG_E_WORKSPACE, "mg_generate: workspace too small (%zu < %zu)", ws_bytes, w.total);
     if (m->phase_on) mg_event_record(m->phase_ev[0], st);
-    int rc = mg_encode(m, stream, ws, ws_bytes, input_ids, bbox, attention_mask, pixel_values, B, L, nullptr, nullptr);
+    int rc = mg_encode(m, stream, ws, ws_bytes, input_ids, bbox, attention_mask, pixel_values, e1, M_e1, B, L, nullptr, nullptr);
     if (rc != MG_OK) return rc;
     const int d = m->d, H = m->H, inner = m->inner, S_cap = m->st_Scap, M = B * S_cap;
     const int R = B * K, T_cap = m->T_cap;
     const size_t nl = m->dec.size();
-    const size_t xkv_stride = (size_t)B * H * S_cap * 64, skv_stride = (size_t)R * H * T_cap * 64;
-    // cross-attention K/V of every decoder layer, once per image (stock:524-538), compacted to attended positions
+    const int M64 = M_e1 > 0 ? round_up(M_e1, 64) : 0, Sx_cap = S_cap + M64;
+    const size_t xkv_stride = (size_t)B * H * Sx_cap * 64, skv_stride = (size_t)R * H * T_cap * 64;
+    // cross-attention K/V of every decoder layer, once per image (stock:524-538), compacted to attended positions; the
+    // e1 tokens (if any) occupy rows [0, M_e1) of an image's stream, the attended encoder positions follow (xrow carries
+    // the offset) - cross-attention has no positional term, so the order of the keys is immaterial
     for (size_t li = 0; li < nl; ++li) {
+        if (M64) {
+            GemmArgs ke = gemm_args(w.e1_pk, m->at<uint16_t>(m->dec[li].xkv), B * M64, 2 * inner, d);
+            set_heads(ke, H, M64, Sx_cap, w.xk + li * xkv_stride, HF_NATURAL, w.xv + li * xkv_stride, HF_NATURAL, nullptr, HF_NONE);
+            ke.heads.row_map = w.e1_map;
+            gemm(ke, EPI_HEADS, st);
+        }
         GemmArgs kv = gemm_args(w.enc_pk, m->at<uint16_t>(m->dec[li].xkv), M, 2 * inner, d);
-        set_heads(kv, H, S_cap, S_cap, w.xk + li * xkv_stride, HF_NATURAL, w.xv + li * xkv_stride, HF_NATURAL, nullptr, HF_NONE);
+        set_heads(kv, H, S_cap, Sx_cap, w.xk + li * xkv_stride, HF_NATURAL, w.xv + li * xkv_stride, HF_NATURAL, nullptr, HF_NONE);
         kv.heads.row_map = w.xrow;
         gemm(kv, EPI_HEADS, st);
     }
@@ -883,7 +914,7 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
             // cross-attention over the image's compacted K/V stream (all beams of an image share one pass)
             AttnStepArgs x{};
             x.q = w.dq; x.qrs = rs1; x.Kc = w.xk + li * xkv_stride; x.Vc = w.xv + li * xkv_stride; x.ctx = w.xb; x.ctx_ld = K2;
-            x.ctx_col0 = d; x.rows = R; x.H = H; x.group = K; x.cap = S_cap; x.len = w.xlen;
+            x.ctx_col0 = d; x.rows = R; x.H = H; x.group = K; x.cap = Sx_cap; x.len = w.xlen;
             const bool timed = time_cross && m->prof_used + 3 <= m->prof_ev.size();
             if (timed) mg_event_record(m->prof_ev[m->prof_used], st);
             attention_step(x, st);
@@ -936,7 +967,7 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
     const bool instrumented = m->dbg_logits || m->dbg_forced;      // by-value eager launches of the same kernels
 #ifndef MG_EMU
     if (m->use_graph == 1 && !instrumented) {
-        const StepGraph::Key key{ws, out_ids, step_top2, (const void*)st, B, L, K, max_length, min_length, early_stopping, length_penalty};
+        const StepGraph::Key key{ws, out_ids, step_top2, (const void*)st, B, L, K, max_length, min_length, early_stopping, M_e1, length_penalty};
         StepGraph& sg = m->step_graph;
         if (!(sg.valid && sg.key == key)) {
             sg.reset();

@@ -105,8 +105,8 @@ __global__ __launch_bounds__(256) void embed_index_kernel(EmbedArgs a, EmbedMeta
     off = 0;
     for (int t = 0; t < tid; ++t) off += cnt[t];
     for (int s = tid * per2; s < a.S_cap && s < (tid + 1) * per2; ++s)
-        a.xrow[(size_t)b * a.S_cap + s] = a.mask[(size_t)b * a.S_cap + s] ? off++ : -1;
-    if (tid == 255) a.xlen[b] = off;
+        a.xrow[(size_t)b * a.S_cap + s] = a.mask[(size_t)b * a.S_cap + s] ? a.x_row0 + off++ : -1;
+    if (tid == 255) a.xlen[b] = a.x_row0 + off;
 }
 
 // one wave per output row: hidden = (tok + patch) + (((x[l] + y[u]) + x[r]) + y[lo])   (stock:206, 833-838, 1162)

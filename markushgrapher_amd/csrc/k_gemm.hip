@@ -72,12 +72,12 @@ MG_DEV void heads_store(const HeadsOut& ho, int ri, int h, int m, int dim0, cons
     const int fmt = ho.fmt[ri];
     uint16_t* base = ho.ptr[ri];
     if (fmt == HF_PK_ROWS) {
-        const int b = m / ho.S_in, s = m - b * ho.S_in;
+        const int b = m / ho.S_in, s = m - b * ho.S_in + ho.s_off;
         size_t off = (((size_t)b * ho.H + h) * (size_t)(ho.S_cap >> 5) + (size_t)(s >> 5)) * (4 * TILE_ELEMS) +
                      (size_t)(dim0 >> 4) * TILE_ELEMS + (size_t)(((dim0 >> 3) & 1) * 256 + (s & 31) * 8);
         st16(base + off, c);
     } else if (fmt == HF_PK_T) {
-        const int b = m / ho.S_in, s = m - b * ho.S_in;
+        const int b = m / ho.S_in, s = m - b * ho.S_in + ho.s_off;
         size_t off = ((((size_t)b * ho.H + h) * 2 + (size_t)(dim0 >> 5)) * (size_t)(ho.S_cap >> 4) + (size_t)(s >> 4)) *
                          TILE_ELEMS +
                      (size_t)(((s >> 3) & 1) * 256 + (dim0 & 31) * 8);

@@ -79,6 +79,37 @@ void im2col_pack(const float* pix, uint16_t* x_pk, int B, int C, int I, int ps, 
     MG_LAUNCH(im2col_pack_kernel, dim3(grid_for(nchunk)), dim3(256), 0, stream, pix, x_pk, B, C, I, ps);
 }
 
+__global__ __launch_bounds__(256) void pack_e1_kernel(const float* e1, int B, int M, int M_pad, int d, uint16_t* e1_pk, int* row_map,
+                                                 const uint8_t* enc_mask, int S_cap, uint8_t* xmask) {
+    const int nch = d >> 3;
+    const size_t total = (size_t)B * M_pad * nch;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % nch);
+        const size_t row = i / nch;
+        const int b = (int)(row / M_pad), j = (int)(row - (size_t)b * M_pad);
+        uint4 o = make_uint4(0, 0, 0, 0);
+        if (j < M) {
+            const float* p = e1 + ((size_t)b * M + j) * d + c * 8;
+            const float4 x = *(const float4*)p, y = *(const float4*)(p + 4);
+            o = make_uint4(pack_bf16(x.x, x.y), pack_bf16(x.z, x.w), pack_bf16(y.x, y.y), pack_bf16(y.z, y.w));
+        }
+        st16(e1_pk + pk_off((int)row, c * 8, d), o);
+        if (c == 0) row_map[row] = j < M ? j : -1;
+    }
+    if (xmask) {
+        const size_t nx = (size_t)B * (M_pad + S_cap);
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nx; i += (size_t)gridDim.x * blockDim.x) {
+            const int b = (int)(i / (M_pad + S_cap)), j = (int)(i - (size_t)b * (M_pad + S_cap));
+            xmask[i] = j < M ? 1 : (j < M_pad ? 0 : enc_mask[(size_t)b * S_cap + (j - M_pad)]);
+        }
+    }
+}
+void pack_e1(const float* e1, int B, int M, int M_pad, int d, uint16_t* e1_pk, int* row_map, const uint8_t* enc_mask, int S_cap,
+             uint8_t* xmask, mgStream_t stream) {
+    MG_LAUNCH(pack_e1_kernel, dim3(grid_for((size_t)B * (M_pad + S_cap) * (d >> 3))), dim3(256), 0, stream, e1, B, M, M_pad, d, e1_pk,
+              row_map, enc_mask, S_cap, xmask);
+}
+
 // Fused RMSNorm + bf16 pack (stock:293-306: fp32 variance, x*rsqrt(var+eps), then *gain; `scale` folds the
 // d_model^-0.5 of the tied lm_head, stock:1554-1555).  One wave per row, 8 consecutive features per lane
 // per step -> one 16-byte chunk of the packed operand.  Rows >= M of the last 32-row tile are zero-filled by

@@ -37,6 +37,7 @@ struct HeadsOut {
     int S_in;              // tokens per batch item in the GEMM's row space (m = b*S_in + s)
     int S_cap;             // token capacity of the destination per (b,h)
     const int* row_map;    // HF_NATURAL: destination row of token m, or -1 to drop (nullable)
+    int s_off;             // HF_PK_ROWS / HF_PK_T: destination token index = s + s_off (key blocks laid side by side)
     int pos;               // HF_STEP: cache position written
     const int* pos_dev;    // if non-null the position is read from device memory (graph replay)
 };
@@ -139,6 +140,11 @@ void relu_pack(const Slabs& in, uint16_t* y_pk, int M, int N, mgStream_t stream)
 void pack_weight(const void* src, int src_is_bf16, int N, int K, uint16_t* dst, int Npad, mgStream_t stream);
 void convert_to_f32(const void* src, int src_is_bf16, float* dst, size_t n, mgStream_t stream);
 void convert_to_bf16(const void* src, int src_is_bf16, uint16_t* dst, size_t n, mgStream_t stream);
+// OCSR-branch embeddings e1 [B][M][d] fp32 (precomputed by the caller) -> packed bf16 rows [B * M_pad][d]
+// (rows j >= M zero), row_map [B * M_pad] (j < M ? j : -1) for the compacted cross K/V stream, and - when xmask is
+// given - the key mask of the teacher-forced cross-attention [B][M_pad + S_cap] = [1 x M | 0 | enc_mask]
+void pack_e1(const float* e1, int B, int M, int M_pad, int d, uint16_t* e1_pk, int* row_map, const uint8_t* enc_mask, int S_cap,
+             uint8_t* xmask, mgStream_t stream);
 // pixel_values [B][C][I][I] fp32 -> packed bf16 im2col matrix [B*P][C*ps*ps]
 void im2col_pack(const float* pix, uint16_t* x_pk, int B, int C, int I, int ps, mgStream_t stream);
 
@@ -160,7 +166,8 @@ struct EmbedArgs {
     double* cy;
     uint8_t* mask;              // [B][S_cap]  1 = attended
     int* xrow;                  // [B][S_cap]  compacted cross-attention row of token s, -1 if masked
-    int* xlen;                  // [B]         number of attended tokens
+    int* xlen;                  // [B]         x_row0 + number of attended tokens
+    int x_row0;                 // first compacted row (rows [0, x_row0) of the cross K/V stream belong to the e1 tokens)
     int* err;                   // device error word (bit 0: token id out of range)
 };
 size_t embed_meta_bytes(int B, int S_cap);

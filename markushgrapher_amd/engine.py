@@ -116,13 +116,13 @@ class Engine:
         L.mg_load_tensor.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]
         L.mg_set_decode_graph.argtypes = [C.c_void_p, C.c_int]
         L.mg_decode_graph_active.argtypes = [C.c_void_p]
-        L.mg_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
+        L.mg_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
         L.mg_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
-                                C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+                                C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.mg_decoder_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                          C.c_int, C.c_int, C.c_void_p]
         L.mg_generate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
-                                  C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
+                                  C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
                                   C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
         L.mg_debug_bucket_table.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int]
         L.mg_debug_decode_capture.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
@@ -175,9 +175,9 @@ class Engine:
         k = self.lib.mg_debug_bucket_table(self.model, which, out, n)
         return np.array(out[:k], dtype=np.int32)
 
-    def workspace(self, B, L, num_beams, max_length, T):
+    def workspace(self, B, L, num_beams, max_length, T, M_e1=0):
         need = C.c_size_t()
-        self._chk(self.lib.mg_workspace_bytes(self.model, B, L, num_beams, max_length, T, C.byref(need)))
+        self._chk(self.lib.mg_workspace_bytes(self.model, B, L, num_beams, max_length, T, M_e1, C.byref(need)))
         if need.value > self._ws_bytes:
             self._ws = None
             self._ws = self.mem.empty((need.value,), np.uint8)
@@ -219,24 +219,35 @@ class Engine:
             raise ValueError(f"pixel_values must be [B,{s.num_channels},{s.image_size},{s.image_size}], got {tuple(pv.shape)}")
         return ids, bb, am, pv, B, L
 
-    def encode(self, input_ids, bbox, attention_mask, pixel_values, max_length=0, num_beams=1, T=0, want_out=True):
+    def _e1(self, e1, B):
+        """e1 [B, M, d_model] fp32: precomputed embeddings of the OCSR vision branch (include/mgrapher.h mg_encode), or None."""
+        if e1 is None:
+            return None, 0
+        t = self.mem.asarray(e1, np.float32)
+        if len(t.shape) != 3 or int(t.shape[0]) != B or int(t.shape[2]) != self.shape.d_model or int(t.shape[1]) < 1:
+            raise ValueError(f"e1 must be [B, M, {self.shape.d_model}], got {tuple(t.shape)}")
+        return t, int(t.shape[1])
+
+    def encode(self, input_ids, bbox, attention_mask, pixel_values, max_length=0, num_beams=1, T=0, want_out=True, e1=None):
         ids, bb, am, pv, B, L = self._inputs(input_ids, bbox, attention_mask, pixel_values)
-        ws, nb = self.workspace(B, L, num_beams, max_length, T)
+        e1t, M = self._e1(e1, B)
+        ws, nb = self.workspace(B, L, num_beams, max_length, T, M)
         S = L + self.shape.num_patches
         out = self.mem.empty((B, S, self.shape.d_model), np.float32) if want_out else None
         msk = self.mem.empty((B, S), np.uint8) if want_out else None
         self._chk(self.lib.mg_encode(self.model, self.mem.stream(), self.mem.ptr(ws), nb, self.mem.ptr(ids), self.mem.ptr(bb),
-                                     self.mem.ptr(am) if am is not None else None, self.mem.ptr(pv), B, L,
+                                     self.mem.ptr(am) if am is not None else None, self.mem.ptr(pv),
+                                     self.mem.ptr(e1t) if e1t is not None else None, M, B, L,
                                      self.mem.ptr(out) if want_out else None, self.mem.ptr(msk) if want_out else None))
-        self._keep = (ids, bb, am, pv)
+        self._keep = (ids, bb, am, pv, e1t)
         return out, msk
 
-    def forward_logits(self, input_ids, bbox, attention_mask, pixel_values, decoder_input_ids, decoder_attention_mask=None):
+    def forward_logits(self, input_ids, bbox, attention_mask, pixel_values, decoder_input_ids, decoder_attention_mask=None, e1=None):
         dec = self.mem.asarray(decoder_input_ids, np.int64)
         B, T = int(dec.shape[0]), int(dec.shape[1])
         dm = None if decoder_attention_mask is None else self.mem.asarray(decoder_attention_mask, np.uint8)
-        enc_out, enc_mask = self.encode(input_ids, bbox, attention_mask, pixel_values, T=T)
-        ws, nb = self.workspace(B, int(enc_out.shape[1]) - self.shape.num_patches, 1, 0, T)
+        enc_out, enc_mask = self.encode(input_ids, bbox, attention_mask, pixel_values, T=T, e1=e1)
+        ws, nb = self.workspace(B, int(enc_out.shape[1]) - self.shape.num_patches, 1, 0, T, 0 if e1 is None else int(e1.shape[1]))
         logits = self.mem.empty((B, T, self.shape.vocab_size), np.float32)
         self._chk(self.lib.mg_decoder_forward(self.model, self.mem.stream(), self.mem.ptr(ws), nb, self.mem.ptr(dec),
                                               self.mem.ptr(dm) if dm is not None else None, B, T, self.mem.ptr(logits)))
@@ -254,12 +265,13 @@ class Engine:
         return cap
 
     def generate(self, input_ids, bbox, attention_mask, pixel_values, num_beams=1, max_length=512, min_length=0,
-                 length_penalty=1.0, early_stopping=False, return_top2=False):
+                 length_penalty=1.0, early_stopping=False, return_top2=False, e1=None):
         ids, bb, am, pv, B, L = self._inputs(input_ids, bbox, attention_mask, pixel_values)
+        e1t, M = self._e1(e1, B)
         if B * num_beams > self.MAX_LIVE_ROWS:
             raise MgError(f"generate: B * num_beams = {B * num_beams} live sequences exceeds the supported "
                           f"{self.MAX_LIVE_ROWS}; split the batch")
-        ws, nb = self.workspace(B, L, num_beams, max_length, 0)
+        ws, nb = self.workspace(B, L, num_beams, max_length, 0, M)
         # the id buffer is persistent per (B, max_length): the captured decode-step graph holds its address, so a stable
         # buffer lets later calls replay the graph instead of re-capturing; callers get a copy
         okey = (B, max_length)
@@ -271,7 +283,8 @@ class Engine:
         top2 = self.mem.zeros((max_length, B * num_beams, 2), np.float32) if (return_top2 and num_beams == 1) else None
         cols = C.c_int(0)
         self._chk(self.lib.mg_generate(self.model, self.mem.stream(), self.mem.ptr(ws), nb, self.mem.ptr(ids), self.mem.ptr(bb),
-                                       self.mem.ptr(am) if am is not None else None, self.mem.ptr(pv), B, L, num_beams,
+                                       self.mem.ptr(am) if am is not None else None, self.mem.ptr(pv),
+                                       self.mem.ptr(e1t) if e1t is not None else None, M, B, L, num_beams,
                                        max_length, min_length, C.c_float(length_penalty), 1 if early_stopping is True else 0,
                                        self.mem.ptr(out), C.byref(cols), self.mem.ptr(scores),
                                        self.mem.ptr(top2) if top2 is not None else None))

@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import json
 import os
+import warnings
 from dataclasses import dataclass
 from typing import Dict, Optional
 
@@ -35,13 +36,17 @@ class MarkushgrapherConfig:
 
     def __init__(self, **kw):
         base = ModelShape()
+        ndl = kw.get("num_decoder_layers", None)                 # UdopConfig: defaults to num_layers when absent / None
         for k, v in base.to_dict().items():
             setattr(self, k, kw.pop(k, v))
-        self.num_decoder_layers = kw.pop("num_decoder_layers", None) or self.num_layers
-        self.architecture_variant = kw.pop("architecture_variant", "me-lf-stack-1")
+        self.num_decoder_layers = ndl if ndl is not None else self.num_layers
+        # "none" = the plain VTL encoder + decoder; "me-lf-stack-1" = MarkushGrapher-2's two-encoder late fusion, whose OCSR
+        # branch (e1) this package does not compute (ref default: core/common/arguments.py:258; set at begin.py:120)
+        self.architecture_variant = kw.pop("architecture_variant", "none")
+        self.allow_missing_e1 = bool(kw.pop("allow_missing_e1", False))
         self.output_attentions = kw.pop("output_attentions", False)
         self.max_length = kw.pop("max_length", 512)
-        self.tie_word_embeddings = True
+        self.tie_word_embeddings = bool(kw.pop("tie_word_embeddings", True))      # UDOP / T5 default
         self.is_encoder_decoder = True
         self.extra = kw
 
@@ -59,7 +64,8 @@ class MarkushgrapherConfig:
 
     def to_dict(self):
         d = self.to_shape().to_dict()
-        d.update(architecture_variant=self.architecture_variant, model_type=self.model_type)
+        d.update(architecture_variant=self.architecture_variant, model_type=self.model_type,
+                 tie_word_embeddings=self.tie_word_embeddings, max_length=self.max_length)
         return d
 
 
@@ -88,9 +94,20 @@ class _ParamTree(nn.Module):
         self._modules[head].add(rest, tensor)
 
 
-class _Placeholder(nn.Module):
-    """`encoder.molscribe_encoder` / `encoder.molscribe_projector` (OCSR e1 branch): the fork's
-    Swin-B branch is not part of this path; the attribute names exist so the reference's helpers do not fail."""
+class _E1Branch(_ParamTree):
+    """`encoder.molscribe_encoder` / `encoder.molscribe_projector` (OCSR e1 branch): the fork's Swin-B
+    encoder + MLP projector are NOT computed by this package (their source is not in the reference tree).  The modules exist
+    as tensor containers: whatever `encoder.molscribe_*` tensors a checkpoint holds are kept with their names and dtypes, so
+    `.state_dict()` / `.parameters()` / save_weights_separately (ref: utils/model/utils_model_loading.py:6-46) and
+    `model.safe_load(model.encoder.molscribe_projector, states)` (ref: begin.py:151) round-trip them unchanged; the tokens
+    they would produce have to be supplied as `e1=` to forward() / generate()."""
+
+    def load_state_dict(self, state_dict, strict=False):
+        self._modules.clear()
+        self._parameters.clear()
+        for k, v in state_dict.items():
+            self.add(k, torch.as_tensor(v).detach().clone())
+        return [], []
 
 
 class MarkushgrapherForConditionalGeneration(nn.Module):
@@ -111,10 +128,13 @@ class MarkushgrapherForConditionalGeneration(nn.Module):
         self.add_module("shared", self._tree._modules["shared"])
         self.add_module("patch_embed", self._tree._modules["patch_embed"])
         self.lm_head = _ParamTree()
-        self.lm_head.add("weight", self._tree._modules["shared"].weight.data)     # tied (stock:1412)
-        self.encoder.add_module("molscribe_encoder", _Placeholder())
-        self.encoder.add_module("molscribe_projector", _Placeholder())
+        shared_w = self._tree._modules["shared"].weight.data
+        self.lm_head.add("weight", shared_w if config.tie_word_embeddings else shared_w.clone())     # tied: stock:1412
+        self.encoder.add_module("molscribe_encoder", _E1Branch())
+        self.encoder.add_module("molscribe_projector", _E1Branch())
         del self._modules["_tree"]
+        self.ignored_keys = []                 # keys of the last load_state_dict that nothing on this path consumes
+        self._warned_e1 = False
 
     # ---- weights ------------------------------------------------------------------------------------------------
     def _canonical_items(self):
@@ -128,7 +148,13 @@ class MarkushgrapherForConditionalGeneration(nn.Module):
         own = {k: v for k, v in super().state_dict().items()}
         missing, unexpected = [], []
         seen = set()
+        self.ignored_keys = []
+        e1_parts = {"encoder.molscribe_encoder.": {}, "encoder.molscribe_projector.": {}}
         for k, v in state_dict.items():
+            pref = next((p for p in e1_parts if k.startswith(p)), None)
+            if pref is not None:                      # kept on the HF side (round trip), not consumed by the HIP engine
+                e1_parts[pref][k[len(pref):]] = v
+                continue
             ck = k if k == "lm_head.weight" else aliases.get(k, k)
             if ck in own and ck != "lm_head.weight":
                 if tuple(own[ck].shape) != tuple(v.shape):
@@ -136,15 +162,21 @@ class MarkushgrapherForConditionalGeneration(nn.Module):
                 own[ck].copy_(torch.as_tensor(v).to(own[ck].dtype))
                 seen.add(ck)
             elif k == "lm_head.weight":
-                t = torch.as_tensor(v).to(self._weight_dtype).to(self.lm_head.weight.device)
-                if torch.equal(t, self.shared.weight.data) or "shared.weight" not in state_dict:
-                    self.lm_head.weight.data = self.shared.weight.data        # tied
+                if self.config.tie_word_embeddings:
+                    # HF re-ties the head to shared.weight after loading (tie_weights): the checkpoint's tensor is dropped
+                    self.lm_head.weight.data = self.shared.weight.data
+                    self.ignored_keys.append(k)
                 else:
-                    self.lm_head.weight.data = t
+                    self.lm_head.weight.data = torch.as_tensor(v).to(self._weight_dtype).to(self.lm_head.weight.device)
                 seen.add(k)
-            elif not (k.startswith("decoder.embed_patches") or k.startswith("decoder.relative_bias")
-                      or k.startswith("encoder.molscribe_")):
+            elif k.startswith("decoder.embed_patches") or k.startswith("decoder.relative_bias"):
+                self.ignored_keys.append(k)           # present in UDOP state dicts, never used by the decoder (stock:1212-1213)
+            else:
                 unexpected.append(k)
+        if e1_parts["encoder.molscribe_encoder."]:
+            self.encoder.molscribe_encoder.load_state_dict(e1_parts["encoder.molscribe_encoder."])
+        if e1_parts["encoder.molscribe_projector."]:
+            self.encoder.molscribe_projector.load_state_dict(e1_parts["encoder.molscribe_projector."])
         for key, _, _ in state_dict_spec(self._shape):
             if key not in seen:
                 missing.append(key)
@@ -157,8 +189,30 @@ class MarkushgrapherForConditionalGeneration(nn.Module):
         module.load_state_dict(state_dict, strict=False)
         self._engine = None
 
-    def init_molscribe_weights(self):                        # ref: begin.py:137-138 — e1 branch is outside this path
-        return None
+    def init_molscribe_weights(self):
+        """ref: begin.py:137-138 loads the pretrained MolScribe Swin-B into the fork's e1 branch.  That branch is not part of
+        this package (source and weights unavailable): nothing to initialise; callers are told once."""
+        warnings.warn("markushgrapher_amd: init_molscribe_weights() is a no-op - the OCSR vision branch (e1) is not computed by "
+                      "this package; pass its projected embeddings as e1= to forward()/generate()", stacklevel=2)
+
+    def requires_e1(self) -> bool:
+        """True when the configured architecture fuses the OCSR branch: variant 'me-lf-stack-*' (ref: config/predict.yaml:12,
+        utils_model_loading.py:20) or a checkpoint that carries `encoder.molscribe_*` tensors."""
+        return str(self.config.architecture_variant).startswith("me-lf-stack") or \
+            len(self.encoder.molscribe_encoder.state_dict()) > 0 or len(self.encoder.molscribe_projector.state_dict()) > 0
+
+    def _check_e1(self, e1):
+        if e1 is not None or not self.requires_e1():
+            return
+        msg = (f"architecture_variant={self.config.architecture_variant!r} / encoder.molscribe_* tensors: this model fuses the "
+               "OCSR vision branch (e1), which markushgrapher_amd does not compute (SURVEY.md §8 a7/f-2). Pass the projected "
+               "embeddings as e1=[B, M, d_model]; running without them differs from the reference.")
+        if self.config.allow_missing_e1 or os.environ.get("MG_ALLOW_MISSING_E1") == "1":
+            if not self._warned_e1:
+                warnings.warn(msg + " (allow_missing_e1: continuing with the VTL branch only)", stacklevel=3)
+                self._warned_e1 = True
+            return
+        raise RuntimeError(msg + " Set config.allow_missing_e1 = True (or MG_ALLOW_MISSING_E1=1) to run the VTL branch alone.")
 
     @classmethod
     def from_pretrained(cls, path, config: Optional[MarkushgrapherConfig] = None, **kw):
@@ -179,7 +233,13 @@ class MarkushgrapherForConditionalGeneration(nn.Module):
         with open(os.path.join(path, "config.json"), "w") as f:
             json.dump(self.config.to_dict(), f, indent=1)
         from safetensors.torch import save_file
-        save_file({k: v.contiguous() for k, v in self._canonical_items()}, os.path.join(path, "model.safetensors"))
+        out = {k: v.contiguous() for k, v in self._canonical_items()}
+        if not self.config.tie_word_embeddings:
+            out["lm_head.weight"] = self.lm_head.weight.data.contiguous()
+        for name in ("molscribe_encoder", "molscribe_projector"):          # the e1 branch's tensors travel with the checkpoint
+            for k, v in getattr(self.encoder, name).state_dict().items():
+                out[f"encoder.{name}.{k}"] = v.contiguous()
+        save_file(out, os.path.join(path, "model.safetensors"))
 
     # ---- engine -------------------------------------------------------------------------------------------------
     @property
@@ -195,11 +255,12 @@ class MarkushgrapherForConditionalGeneration(nn.Module):
             raise RuntimeError("MarkushgrapherForConditionalGeneration runs on an MI355X only: call .to('cuda') first "
                                "(there is no CPU fallback)")
         if self._engine is None or self._engine_device != dev:
-            eng = Engine(self._shape, mem=TorchMem(dev), max_decode_len=max(512, int(self.config.max_length)))
+            tied = bool(self.config.tie_word_embeddings)
+            eng = Engine(self._shape, mem=TorchMem(dev), max_decode_len=max(512, int(self.config.max_length)),
+                         tie_word_embeddings=tied)
             sd = {k: v.data for k, v in self._canonical_items()}
-            lm = self.lm_head.weight.data
-            if lm.data_ptr() != self.shared.weight.data_ptr() and not torch.equal(lm.to(dev), self.shared.weight.data):
-                sd["lm_head.weight"] = lm       # untied head in the checkpoint (ref: utils_model_loading.py:41)
+            if not tied:                        # untied config: the checkpoint's head is used, without the d_model^-0.5 scale
+                sd["lm_head.weight"] = self.lm_head.weight.data
             eng.load_state_dict(sd)
             self._engine, self._engine_device = eng, dev
         return self._engine
@@ -213,15 +274,17 @@ class MarkushgrapherForConditionalGeneration(nn.Module):
 
     @torch.no_grad()
     def forward(self, input_ids=None, bbox=None, attention_mask=None, pixel_values=None, labels=None,
-                decoder_input_ids=None, decoder_attention_mask=None, **kw):
-        """stock:1448-1574.  Returns logits [B,T,V] fp32 (+ CE loss when labels are given)."""
+                decoder_input_ids=None, decoder_attention_mask=None, e1=None, **kw):
+        """stock:1448-1574.  Returns logits [B,T,V] fp32 (+ CE loss when labels are given).  e1: optional [B, M, d_model]
+        embeddings of the OCSR vision branch (see _E1Branch)."""
+        self._check_e1(e1)
         eng = self._eng()
         if decoder_input_ids is None:
             if labels is None:
                 raise ValueError("forward() needs labels or decoder_input_ids")
             decoder_input_ids = self._shift_right(labels)
         logits, enc, mask = eng.forward_logits(input_ids, bbox, attention_mask, pixel_values, decoder_input_ids,
-                                               decoder_attention_mask)
+                                               decoder_attention_mask, e1=e1)
         loss = None
         if labels is not None:
             loss = nn.functional.cross_entropy(logits.view(-1, logits.size(-1)), labels.to(logits.device).view(-1),
@@ -230,12 +293,13 @@ class MarkushgrapherForConditionalGeneration(nn.Module):
 
     @torch.no_grad()
     def generate(self, input_ids=None, bbox=None, pixel_values=None, attention_mask=None, labels=None, num_beams=1,
-                 max_length=None, min_length=0, length_penalty=1.0, early_stopping=False, do_sample=False, **kw):
+                 max_length=None, min_length=0, length_penalty=1.0, early_stopping=False, do_sample=False, e1=None, **kw):
         """ref call: utils_evaluation.py:269-285 (`labels` arrives as a stray kwarg and is ignored).  Without an
         attention_mask the fork's transformers 4.34 base infers one from pad tokens (all ones at the reference's batch
         size 1), which is what is reproduced here; pass a mask explicitly for padded batches."""
         if do_sample:
             raise NotImplementedError("sampling is not part of the reference's decode path")
+        self._check_e1(e1)
         eng = self._eng()
         max_length = int(max_length or self.config.max_length)
         if attention_mask is None:
@@ -246,5 +310,5 @@ class MarkushgrapherForConditionalGeneration(nn.Module):
                 attention_mask = torch.ones_like(input_ids)
         ids, _, _ = eng.generate(input_ids, bbox, attention_mask, pixel_values, num_beams=int(num_beams),
                                  max_length=max_length, min_length=int(min_length), length_penalty=float(length_penalty),
-                                 early_stopping=early_stopping)
+                                 early_stopping=early_stopping, e1=e1)
         return ids

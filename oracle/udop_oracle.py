@@ -324,10 +324,21 @@ class Oracle:
         out.masked_fill_(out == -100, pad_id)
         return out
 
+    @staticmethod
+    def fuse_e1(enc, mask, e1):
+        """MarkushGrapher-2 late fusion (ref: README.md:212-215 "the projected vision embedding (e1) is concatenated with the VTL
+        embedding (e2) and fed to a text decoder"): the decoder cross-attends over [e1 | e2], e1 tokens always attended.
+        INFERRED - the fork's source is unavailable: this is the build's own statement, parity unpinned."""
+        if e1 is None:
+            return enc, mask
+        e1 = _t(e1).to(F32)
+        return torch.cat([e1, enc], dim=1), torch.cat([torch.ones(e1.shape[:2], dtype=mask.dtype), mask], dim=1)
+
     def forward(self, input_ids, bbox, pixel_values, attention_mask=None, labels=None, decoder_input_ids=None,
-                decoder_attention_mask=None):
+                decoder_attention_mask=None, e1=None):
         """stock:1448-1574 UdopForConditionalGeneration.forward → logits [B,T,V]."""
         enc, mask = self.encode(input_ids, bbox, pixel_values, attention_mask)
+        enc, mask = self.fuse_e1(enc, mask, e1)
         if decoder_input_ids is None:
             decoder_input_ids = self.shift_right(labels, self.s.decoder_start_token_id, self.s.pad_token_id)
         dec_ids = _t(decoder_input_ids).long()
@@ -336,7 +347,7 @@ class Oracle:
 
     # ------------------------------------------------------------------------------------------
     def greedy(self, input_ids, bbox, pixel_values, attention_mask=None, max_length=512, min_length=0,
-               record=None):
+               record=None, e1=None):
         """gen:2783-2975 `_sample` with do_sample=False: argmax, EOS/pad bookkeeping, max_length counts the
         start token.  HF's generate() builds an all-ones text mask when none is given (gen:
         `_prepare_attention_mask_for_generation`).  `min_length` mirrors MinLengthLogitsProcessor
@@ -346,6 +357,7 @@ class Oracle:
         if attention_mask is None:
             attention_mask = self.default_generation_mask(input_ids)
         enc, mask = self.encode(input_ids, bbox, pixel_values, attention_mask)
+        enc, mask = self.fuse_e1(enc, mask, e1)
         xkv = self.cross_kv(enc)
         B = input_ids.shape[0]
         seq = torch.full((B, 1), s.decoder_start_token_id, dtype=torch.long)
@@ -370,13 +382,14 @@ class Oracle:
 
     # ------------------------------------------------------------------------------------------
     def beam_search(self, input_ids, bbox, pixel_values, attention_mask=None, num_beams=5, max_length=512,
-                    length_penalty=1.0, early_stopping=False):
+                    length_penalty=1.0, early_stopping=False, e1=None):
         """Beam search over this oracle's KV-cached decoder (see `beam_search_core`)."""
         s = self.s
         input_ids = _t(input_ids).long()
         if attention_mask is None:
             attention_mask = self.default_generation_mask(input_ids)
         enc, mask = self.encode(input_ids, bbox, pixel_values, attention_mask)
+        enc, mask = self.fuse_e1(enc, mask, e1)
         B = input_ids.shape[0]
         K = num_beams
         enc = enc.repeat_interleave(K, dim=0)

@@ -53,8 +53,10 @@ def test_create_validates_config_without_device_work():
     lib.mg_weights_bytes.argtypes = [C.c_void_p]
     assert lib.mg_weights_bytes(model) > 100000
     need = C.c_size_t()
-    lib.mg_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
-    assert lib.mg_workspace_bytes(model, 2, 8, 5, 16, 12, C.byref(need)) == 0 and need.value > 0
+    lib.mg_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
+    assert lib.mg_workspace_bytes(model, 2, 8, 5, 16, 12, 0, C.byref(need)) == 0 and need.value > 0
+    base = need.value
+    assert lib.mg_workspace_bytes(model, 2, 8, 5, 16, 12, 144, C.byref(need)) == 0 and need.value > base     # + e1 tokens
     # loading a tensor before binding an arena is a state error, an unknown key a key error (no device work)
     shp = (C.c_int64 * 1)(64)
     lib.mg_load_tensor.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]

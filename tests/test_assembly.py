@@ -117,3 +117,37 @@ def test_id_decoder_rules():
     assert d.batch_decode([[0, 6, 8, 7, 1, 0, 0], [0, 2, 3, 2, 3, 2, 1]]) == ["<cxsmi> C </cxsmi> ", "alkylgroup alkylgroup alkyl"]
     assert A.text_to_cxsmiles_opt("<markush><cxsmi> C C </cxsmi> <stable>x</stable>") == "CC"
     assert A.text_to_cxsmiles_opt("no tags") is None and A.text_to_cxsmiles_opt("<smi>C O</smi></s>", "ocsr") == "CO"
+
+
+def test_word_boxes_and_cell_text_match_the_reference_functions():
+    """f-3, pinned: split_bounding_box_for_words / prepare_cells_to_text (+ check_max_values, normalize_bbox_format,
+    estimate_word_width, normalText) against outputs of the REFERENCE's own functions
+    (ref: core/common/data_preprocessing.py:16-104, core/common/utils.py:204-222), executed unmodified by
+    tools/make_golden_wordboxes.py with the same stand-in tokenizer.  Box coordinates: bit-exact floats."""
+    import json
+    from markushgrapher_amd import assembly as A
+    from tools.make_golden_wordboxes import PieceTokenizer
+    with open(os.path.join(GOLDEN, "host_wordboxes.json")) as f:
+        g = json.load(f)
+    tok = PieceTokenizer()
+    for c in g["split_bounding_box_for_words"]:
+        words, boxes = A.split_bounding_box_for_words(c["sentence"], c["bbox"], tok)
+        assert words == c["words"]
+        assert [list(b) for b in boxes] == c["boxes"]
+    n_dropped = n_budget = 0
+    for c in g["prepare_cells_to_text"]:
+        words, boxes, tidx = A.prepare_cells_to_text(c["cells"], tok, **c["kwargs"])
+        assert words == c["words"] and tidx == c["token_idx"]
+        assert [list(b) for b in boxes] == c["boxes"]
+        n_budget += tidx >= c["kwargs"]["max_sequence_length"] - 15
+        total = sum(len([p for p in tok.tokenize(cell["text"]) if not p.isspace()]) for cell in c["cells"] if not cell["text"].isspace())
+        n_dropped += len(words) < total
+    assert n_dropped > 0 and n_budget > 0          # the >500 px drop and the token-budget stop are both exercised
+    for b, r in g["misc"]["check_max_values"]:
+        assert A.check_max_values(b) == r
+    for b, r in g["misc"]["normalize_bbox_format"]:
+        assert list(A.normalize_bbox_format(b, 512, 512)) == r
+    for w_, r in g["misc"]["estimate_word_width"]:
+        assert A.estimate_word_width(w_) == r
+    for t, r in g["misc"]["normalText"]:
+        assert A.normal_text(t) == r

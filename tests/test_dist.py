@@ -6,7 +6,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from markushgrapher_amd.dist import shard_bounds, sharded_generate
+from markushgrapher_amd.dist import ID_COLS, IdExchange, shard_bounds, sharded_generate
 
 
 def fake_generate(input_ids, bbox=None, pixel_values=None, attention_mask=None, max_length=8, **kw):
@@ -28,7 +28,16 @@ def _worker(rank, world, port, B, q):
     batch = {"input_ids": torch.randint(0, 50, (B, 6), generator=g), "bbox": torch.rand((B, 6, 4), generator=g),
              "pixel_values": torch.rand((B, 3, 4, 4), generator=g), "attention_mask": None}
     out = sharded_generate(fake_generate, batch, max_length=8)
-    q.put((rank, out.numpy()))
+    # the bench's own use of the exchange (bench.py step()): 32 rows per rank, [32, 512] int32 + lengths, posted asynchronously
+    # for two batches in a row (double buffering) before the first is waited for
+    ex = IdExchange(32, torch.device("cpu"))
+    mk = lambda step: (torch.arange(32 * (257 - step), dtype=torch.int64).reshape(32, 257 - step) % 33201) + 1000 * rank + step
+    h0, h1 = ex.post(mk(0)), ex.post(mk(1))
+    cp = lambda pair: (pair[0].numpy().copy(), pair[1].numpy().copy())     # the blocks are valid until their slot is posted again
+    r0 = cp(ex.wait(h0))
+    r1 = cp(ex.wait(h1))
+    r2 = cp(ex.wait(ex.post(mk(2))))      # reuses the first slot
+    q.put((rank, out.numpy(), [r0, r1, r2]))
     dist.destroy_process_group()
 
 
@@ -50,7 +59,9 @@ def test_sharded_generate_world2_gloo():
         procs = [ctx.Process(target=_worker, args=(r, 2, port, B, q)) for r in range(2)]
         for p in procs:
             p.start()
-        res = dict(q.get(timeout=120) for _ in range(2))
+        got = [q.get(timeout=120) for _ in range(2)]
+        res = {r: o for r, o, _ in got}
+        bench_payload = {r: p for r, _, p in got}
         for p in procs:
             p.join(timeout=60)
             assert p.exitcode == 0
@@ -63,3 +74,14 @@ def test_sharded_generate_world2_gloo():
             o = fake_generate(ids[lo:hi]).numpy()
             ref[lo:hi, :o.shape[1]] = o
         assert np.array_equal(res[0], ref) and np.array_equal(res[1], ref)
+        # bench payload: static [world * 32, 512] int32 + [world * 32] int32 on every rank, identical, rows in rank order
+        for step in range(3):
+            a, la = bench_payload[0][step]
+            b, lb = bench_payload[1][step]
+            assert a.dtype == np.int32 and a.shape == (64, ID_COLS) and la.shape == (64,) and la.dtype == np.int32
+            assert np.array_equal(a, b) and np.array_equal(la, lb)
+            t = 257 - step
+            assert np.all(la == t)
+            for r in range(2):
+                want = (np.arange(32 * t, dtype=np.int64).reshape(32, t) % 33201) + 1000 * r + step
+                assert np.array_equal(a[32 * r:32 * r + 32, :t], want) and np.all(a[32 * r:32 * r + 32, t:] == 0)

@@ -439,7 +439,7 @@ def test_more_than_256_live_rows_is_rejected(be_name):
     out = eng.mem.empty((B, 4), np.int64)
     cols = C.c_int(0)
     rc = eng.lib.mg_generate(eng.model, eng.mem.stream(), eng.mem.ptr(ws), nb, eng.mem.ptr(ids), eng.mem.ptr(bb), eng.mem.ptr(am),
-                             eng.mem.ptr(pv), B, L, 1, 4, 0, C.c_float(1.0), 0, eng.mem.ptr(out), C.byref(cols), None, None)
+                             eng.mem.ptr(pv), None, 0, B, L, 1, 4, 0, C.c_float(1.0), 0, eng.mem.ptr(out), C.byref(cols), None, None)
     assert rc == -5 and b"256" in eng.lib.mg_last_error()
     # 256 rows are fine and row-independent
     ok = {k: rep(v, 256) for k, v in inp.items()}
@@ -526,3 +526,51 @@ def test_fused_qkv_self_attention_form_is_equivalent(be_name, monkeypatch):
         for t in range(1, idn.shape[1]):
             if np.all(idn[b, 1:t] != shape.eos_token_id):
                 assert abs(t2[t, b, 0] - ref[b, t - 1].max()) < logit_tol(ref)
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+def test_e1_tokens_are_fused_into_the_cross_attention(be_name):
+    """optional precomputed OCSR-branch embeddings e1 [B, M, d].  The decoder cross-attends over
+    [e1 | VTL states]; teacher-forced logits and greedy / beam ids against the oracle's statement of the same fusion
+    (Oracle.fuse_e1).  PARITY UNPINNED: the fork that defines the fusion is unavailable; the oracle is the build's own."""
+    from oracle.udop_oracle import Oracle
+    g = load_golden("g3_trained_tiny.npz")
+    shape, sd = _weights(g)
+    inp = _inputs(g, shape)
+    B, M = inp["input_ids"].shape[0], 5
+    e1 = synth.round_bf16(synth.uniform_pm1("e1.tokens", (B, M, shape.d_model), 2) * np.float32(1.5))
+    eng = make_engine(be_name, shape, sd)
+    o = Oracle(shape, sd)
+    args = (inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"])
+    labels = g["labels"]
+    dec_ids = Oracle.shift_right(labels, shape.decoder_start_token_id, shape.pad_token_id).numpy()
+    dam = (labels != -100).astype(np.uint8)
+    logits, enc, mask = eng.forward_logits(*args, dec_ids, dam, e1=e1)
+    ref = o.forward(inp["input_ids"], inp["bbox"], inp["pixel_values"], inp["attention_mask"], labels=labels,
+                    decoder_attention_mask=dam.astype(np.int64), e1=e1).numpy()
+    plain = o.forward(inp["input_ids"], inp["bbox"], inp["pixel_values"], inp["attention_mask"], labels=labels,
+                      decoder_attention_mask=dam.astype(np.int64)).numpy()
+    assert np.abs(ref - plain).max() > 10 * logit_tol(ref)             # the tokens matter
+    assert np.abs(_np(eng, logits) - ref).max() < logit_tol(ref)
+    assert np.array_equal(_np(eng, mask), g["enc_mask"].astype(np.uint8))   # enc_out / enc_mask stay the VTL part
+    T = int(g["max_length"])
+    rec = []
+    ref_ids = o.greedy(inp["input_ids"], inp["bbox"], inp["pixel_values"], inp["attention_mask"], max_length=T, record=rec, e1=e1)
+    ids, _, top2 = eng.generate(*args, max_length=T, return_top2=True, e1=e1)
+    ids = _np(eng, ids)
+    tol = logit_tol(np.stack([r.numpy() for r in rec]))
+    for b in range(B):
+        for t in range(1, min(ids.shape[1], ref_ids.shape[1])):
+            srt = np.sort(rec[t - 1][b].numpy())
+            if srt[-1] - srt[-2] < 4 * tol:
+                break
+            assert ids[b, t] == ref_ids[b, t], (b, t)
+    bref, bsc_ref = o.beam_search(inp["input_ids"], inp["bbox"], inp["pixel_values"], inp["attention_mask"], num_beams=5,
+                                  max_length=T, e1=e1)
+    bids, bsc, _ = eng.generate(*args, num_beams=5, max_length=T, e1=e1)
+    np.testing.assert_allclose(_np(eng, bsc), bsc_ref, atol=5e-2)
+    # without e1 the same engine still reproduces the golden ids (state of a previous call does not leak)
+    ids0, _, _ = eng.generate(*args, max_length=T)
+    assert np.array_equal(_np(eng, ids0), g["greedy_ids"])
+    with pytest.raises(ValueError):
+        eng.generate(*args, max_length=T, e1=e1[:, :, :8])

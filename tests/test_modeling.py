@@ -89,3 +89,77 @@ def test_generate_and_forward_like_the_reference_calls_them():
     assert abs(float(out.loss) - float(g["loss"])) < 2e-2
     live = g["labels"] != -100
     assert np.array_equal(out.logits.argmax(-1).cpu().numpy()[live], g["logits"].argmax(-1)[live])
+
+
+def test_config_keeps_an_asymmetric_decoder_depth_and_tie_flag(tmp_path):
+    """UdopConfig semantics (stock configuration_udop.py:43-71): num_decoder_layers defaults to num_layers only when absent;
+    tie_word_embeddings is read from config.json (default True) and survives save / load."""
+    c = MarkushgrapherConfig(num_layers=4, num_decoder_layers=2)
+    assert c.num_layers == 4 and c.num_decoder_layers == 2 and c.to_shape().num_decoder_layers == 2
+    assert MarkushgrapherConfig(num_layers=3).num_decoder_layers == 3
+    assert MarkushgrapherConfig(num_layers=3, num_decoder_layers=None).num_decoder_layers == 3
+    assert MarkushgrapherConfig().tie_word_embeddings is True and MarkushgrapherConfig().architecture_variant == "none"
+    shape = synth.SHAPES["tiny"]
+    m = MarkushgrapherForConditionalGeneration(MarkushgrapherConfig(**{**shape.to_dict(), "num_decoder_layers": 1, "tie_word_embeddings": False}))
+    assert len(m.decoder.block._modules) == 1 and len(m.encoder.block._modules) == 2
+    m.save_pretrained(str(tmp_path))
+    c2 = MarkushgrapherConfig.from_pretrained(str(tmp_path))
+    assert c2.num_decoder_layers == 1 and c2.tie_word_embeddings is False
+
+
+def test_e1_branch_tensors_round_trip_and_missing_e1_is_loud(tmp_path):
+    """`encoder.molscribe_*` tensors (the OCSR branch this package does not compute) are kept, saved and reloaded with their
+    names, as the reference's helpers expect (ref: utils_model_loading.py:23,36; begin.py:151); a model that needs e1
+    refuses to run without it unless told otherwise."""
+    m, shape = tiny_model()
+    assert not m.requires_e1()
+    sd = {k: v for k, v in m.state_dict().items()}
+    sd["encoder.molscribe_encoder.layers.0.blocks.0.attn.qkv.weight"] = torch.arange(12, dtype=torch.float32).reshape(3, 4)
+    sd["encoder.molscribe_projector.0.weight"] = torch.ones(2, 3)
+    sd["encoder.molscribe_projector.0.bias"] = torch.zeros(2)
+    sd["decoder.relative_bias.biases.0.relative_attention_bias.weight"] = torch.zeros(32, 2)
+    missing, unexpected = m.load_state_dict(sd)
+    assert not missing and not unexpected
+    assert sorted(m.ignored_keys) == ["decoder.relative_bias.biases.0.relative_attention_bias.weight", "lm_head.weight"]
+    assert m.requires_e1()
+    assert sorted(m.encoder.molscribe_projector.state_dict().keys()) == ["0.bias", "0.weight"]
+    assert torch.equal(m.encoder.molscribe_encoder.state_dict()["layers.0.blocks.0.attn.qkv.weight"], sd["encoder.molscribe_encoder.layers.0.blocks.0.attn.qkv.weight"])
+    assert "encoder.molscribe_projector.0.weight" in m.state_dict()
+    # begin.py:151: model.safe_load(model.encoder.molscribe_projector, projector_states)
+    m.safe_load(m.encoder.molscribe_projector, {"0.weight": torch.full((2, 3), 2.0), "0.bias": torch.ones(2)})
+    assert float(m.encoder.molscribe_projector.state_dict()["0.weight"][0, 0]) == 2.0
+    m.save_pretrained(str(tmp_path))
+    m2 = MarkushgrapherForConditionalGeneration.from_pretrained(str(tmp_path))
+    assert torch.equal(m2.encoder.molscribe_projector.state_dict()["0.weight"], torch.full((2, 3), 2.0)) and m2.requires_e1()
+    g = load_golden("g3_trained_tiny.npz")
+    kw = dict(input_ids=torch.from_numpy(g["input_ids"]), bbox=torch.from_numpy(g["bbox"]), pixel_values=torch.from_numpy(g["pixel_values"]))
+    with pytest.raises(RuntimeError, match="e1"):
+        m.generate(**kw, max_length=8)
+    with pytest.raises(RuntimeError, match="e1"):
+        m(**kw, labels=torch.from_numpy(g["labels"]))
+    plain, _ = tiny_model()
+    plain.config.architecture_variant = "me-lf-stack-1"                 # ref: begin.py:120 with config/predict.yaml:12
+    with pytest.raises(RuntimeError, match="me-lf-stack-1"):
+        plain.generate(**kw, max_length=8)
+    with pytest.warns(UserWarning, match="no-op"):
+        plain.init_molscribe_weights()
+
+
+@pytest.mark.gpu
+def test_generate_with_e1_tokens_and_opt_out_on_gpu():
+    from oracle.udop_oracle import Oracle
+    m, shape = tiny_model()
+    m.config.architecture_variant = "me-lf-stack-1"
+    m = m.to("cuda")
+    g = load_golden("g3_trained_tiny.npz")
+    dev = m.device
+    kw = {k: torch.from_numpy(g[k]).to(dev) for k in ("input_ids", "bbox", "attention_mask", "pixel_values")}
+    e1 = synth.round_bf16(synth.uniform_pm1("e1.tokens", (g["input_ids"].shape[0], 5, shape.d_model), 2) * np.float32(1.5))
+    ids = m.generate(**kw, e1=torch.from_numpy(e1).to(dev), max_length=int(g["max_length"]))
+    sd = dict(np.load(os.path.join(GOLDEN, "g3_weights.npz")))
+    ref = Oracle(shape, sd).greedy(g["input_ids"], g["bbox"], g["pixel_values"], g["attention_mask"], max_length=int(g["max_length"]), e1=e1)
+    assert ids.shape[1] == ref.shape[1] and (ids.cpu().numpy() == ref).mean() > 0.9      # trained fixture: margins >> noise
+    m.config.allow_missing_e1 = True
+    with pytest.warns(UserWarning, match="allow_missing_e1"):
+        ids0 = m.generate(**kw, max_length=int(g["max_length"]))
+    assert np.array_equal(ids0.cpu().numpy(), g["greedy_ids"])
