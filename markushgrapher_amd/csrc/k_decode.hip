@@ -91,7 +91,9 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a, long
     }
 
     // software-pipelined stream: the loads of the next 8*U keys are issued before the current ones are consumed
-    auto issue = [&](int kb, uint4 (&kv)[U], uint4 (&vv)[U]) {
+    // (self-attention: the positional bias of a key travels with its K/V loads - a load issued where it is consumed
+    //  exposes a whole L2 round trip per round)
+    auto issue = [&](int kb, uint4 (&kv)[U], uint4 (&vv)[U], float (&bb)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             int kc = kb + u * 8 + ks;
@@ -100,10 +102,17 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a, long
             const size_t off = (((size_t)prow * a.H + h) * (size_t)a.cap + (size_t)kc) * 64 + sub * 8;
             kv[u] = (NW >= 8) ? ld16_stream(a.Kc + off) : ld16(a.Kc + off);
             vv[u] = (NW >= 8) ? ld16_stream(a.Vc + off) : ld16(a.Vc + off);
+            bb[u] = 0.f;
+            if (!XA && a.bias) {
+                int dist = tcur - kc;
+                dist = dist < 0 ? 0 : dist;
+                bb[u] = a.bias[(size_t)dist * a.H + h];
+            }
         }
     };
     uint4 kn[U], vn[U];
-    if (w * 8 * U < nkeys) issue(w * 8 * U, kn, vn);
+    float bn[U];
+    if (w * 8 * U < nkeys) issue(w * 8 * U, kn, vn, bn);
     stamp(1);
     // (after the first K/V round is in flight: the partial-sum round trip below overlaps it)
     // deferred RMSNorm of the query rows: q was projected from the un-normalised bf16(h), the row scale r(row) is applied
@@ -124,19 +133,15 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a, long
     }
     for (int kb = w * 8 * U; kb < nkeys; kb += NW * 8 * U) {
         uint4 kv[U], vv[U];
+        float bcur[U];
         int key[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) { kv[u] = kn[u]; vv[u] = vn[u]; key[u] = kb + u * 8 + ks; }
-        if (kb + NW * 8 * U < nkeys) issue(kb + NW * 8 * U, kn, vn);
+        for (int u = 0; u < U; ++u) { kv[u] = kn[u]; vv[u] = vn[u]; bcur[u] = bn[u]; key[u] = kb + u * 8 + ks; }
+        if (kb + NW * 8 * U < nkeys) issue(kb + NW * 8 * U, kn, vn, bn);
         float s[U][G];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            float bias = 0.f;
-            if (!XA && a.bias) {
-                int dist = tcur - key[u];
-                dist = dist < 0 ? 0 : dist;
-                bias = a.bias[(size_t)dist * a.H + h];
-            }
+            const float bias = bcur[u];
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 float p = dot2_bf16(q[g].x, kv[u].x, 0.f);
@@ -288,16 +293,27 @@ __global__ __launch_bounds__(GS_THREADS) void greedy_select_kernel(ArgmaxArgs a)
     float b1 = -3.0e38f, b2 = -3.0e38f;
     int i1 = 0x7fffffff;
     const int nq = (a.V + 3) >> 2;      // rows are padded to a multiple of 32 floats, so the last float4 is readable
-    for (int c = tid; c < nq; c += GS_THREADS) {
-        const float4 q = *(const float4*)(lg + c * 4);
-        const float vv[4] = {q.x, q.y, q.z, q.w};
+    // batches of 4 independent 16-byte loads per thread: one L2 round trip per batch instead of one per load (a row of
+    // 33 201 logits is 8.1 loads per thread; the kernel is latency-, not bandwidth-sized)
+    for (int c0 = tid; c0 < nq; c0 += 4 * GS_THREADS) {
+        float4 q[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i = c * 4 + j;
-            float v = vv[j];
-            if (i >= a.V || (no_eos && i == a.eos)) v = -3.0e38f;
-            if (v > b1 || (v == b1 && i < i1)) { b2 = b1; b1 = v; i1 = i; }
-            else if (v > b2) b2 = v;
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u * GS_THREADS;
+            q[u] = c < nq ? *(const float4*)(lg + c * 4) : make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u * GS_THREADS;
+            const float vv[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = c * 4 + j;
+                float v = vv[j];
+                if (i >= a.V || (no_eos && i == a.eos)) v = -3.0e38f;
+                if (v > b1 || (v == b1 && i < i1)) { b2 = b1; b1 = v; i1 = i; }
+                else if (v > b2) b2 = v;
+            }
         }
     }
 #pragma unroll

@@ -1,0 +1,23 @@
+"""GPU microbenchmark of the encoder attention at the benchmark shape (B=32, H=16, S_cap=1280) through mg_encode's own call:
+times `reps` launches with HIP events.  MG_ATT_DEPTH=1|2 selects the prefetch depth.  python tools/att_bench.py"""
+import ctypes as C, os, sys, time
+import numpy as np, torch
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+from markushgrapher_amd import synth
+from markushgrapher_amd.engine import Engine
+shape = synth.SHAPES["large"]
+eng = Engine(shape, max_decode_len=64)
+eng.load_state_dict(synth.recipe_state_dict(shape, **synth.BENCH_RECIPE))
+inp = synth.synth_batch(shape, 32, seed=synth.BENCH_SEED, return_pages=True)
+pix = eng.preprocess(inp["pages_u8"])
+for _ in range(2):
+    eng.encode(inp["input_ids"], inp["bbox"], inp["attention_mask"], pix, want_out=False)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(5):
+    eng.encode(inp["input_ids"], inp["bbox"], inp["attention_mask"], pix, want_out=False)
+e1.record(); torch.cuda.synchronize()
+print("MG_ATT_DEPTH", os.environ.get("MG_ATT_DEPTH", "default"), "encoder ms per batch: %.2f" % (e0.elapsed_time(e1) / 5))
