@@ -7,9 +7,13 @@ path and nothing here imports the oracle.
 Pinning status:
   * `DataCollator`            - pinned: fixtures minted by running the reference's own class, loaded by file path
                                 (`tools/make_golden_host.py`), `tests/golden/host_collator.json`.
-  * word boxes / cell text / id->text decoding - **parity unpinned**: their reference modules import torchvision,
-    matplotlib, rdkit and SmilesPE, none of which exist in this image, so they cannot be executed here; the tests
-    are known-answer cases written from the reference's documented behaviour.
+  * word boxes / cell text (f-3)  - pinned: `tests/golden/host_wordboxes.json` holds inputs and outputs of the reference's
+                                own `split_bounding_box_for_words` / `prepare_cells_to_text`, executed from
+                                /root/reference by `tools/make_golden_wordboxes.py` (a deterministic piece tokenizer stands
+                                in for the sentencepiece model, which is not available offline).
+  * id->text decoding (f-4)       - **parity unpinned**: `markush_tokenizer.py` / `utils_evaluation.py` import rdkit and
+                                SmilesPE, absent from this image; the tests are known-answer cases written from the
+                                reference's documented behaviour.
 
 Reference: markushgrapher/core/trainers/data_collator.py:11-108 (DataCollator, pad_sequence_native),
 markushgrapher/core/common/data_preprocessing.py:11-104 (word boxes, prepare_cells_to_text),
@@ -115,7 +119,7 @@ def collate_for_generate(features, pad_to=None):
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# f-3: OCR cells -> words + per-word boxes (data_preprocessing.py:11-104, task_collator.py:26-107)  [unpinned]
+# f-3: OCR cells -> words + per-word boxes (data_preprocessing.py:11-104, task_collator.py:26-107)  [pinned: host_wordboxes.json]
 # ---------------------------------------------------------------------------------------------------------------
 def estimate_word_width(piece):
     """12 px per character, the word-start marker not counted; a lone marker counts as one character."""
