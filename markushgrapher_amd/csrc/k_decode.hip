@@ -55,10 +55,7 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a, long
             }
         }
 #pragma unroll
-        for (int step = 8; step <= 32; step <<= 1) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] += __shfl_xor(v[j], step);
-        }
+        for (int j = 0; j < 8; ++j) v[j] = sum_slots(v[j], lane);
         return make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
     };
     uint4 q[G];
@@ -126,8 +123,7 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a, long
             row = row < a.rows ? row : a.rows - 1;
             float t = 0.f;
             for (int i = lane; i < a.qrs.nparts; i += 64) t += a.qrs.part[(size_t)row * a.qrs.nparts + i];
-#pragma unroll
-            for (int step = 1; step < 64; step <<= 1) t += __shfl_xor(t, step);
+            t = sum_slots(sum8(t), lane);
             qs[g] = rsqrtf(t * a.qrs.inv_d + a.qrs.eps);
         }
     }
@@ -194,53 +190,62 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a, long
         }
     }
     stamp(3);
-    // merge the 8 key slots of the wave
+    // merge the 8 key slots of the wave: a halving reduction over lane bits 5, 4, 3 (m and l travel whole, the accumulators
+    // half at a time: 4 + 2 + 1 exchanges instead of 3 x 8), after which lane (ks, sub) holds feature sub*8 + ks of the head
+    float o1[G];
 #pragma unroll
-    for (int step = 8; step <= 32; step <<= 1) {
+    for (int g = 0; g < G; ++g) {
+        float mo = lane_xor<32>(m[g], lane), lo = lane_xor<32>(l[g], lane);
+        float M = fmaxf(m[g], mo);
+        float f1 = fast_exp(m[g] - M), f2 = fast_exp(mo - M);
+        l[g] = l[g] * f1 + lo * f2;
+        m[g] = M;
+        float a4[4];
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const float mo = __shfl_xor(m[g], step), lo = __shfl_xor(l[g], step);
-            const float M = fmaxf(m[g], mo);
-            const float f1 = fast_exp(m[g] - M), f2 = fast_exp(mo - M);
-            l[g] = l[g] * f1 + lo * f2;
-#pragma unroll
-            for (int d = 0; d < 8; ++d) acc[g][d] = acc[g][d] * f1 + __shfl_xor(acc[g][d], step) * f2;
-            m[g] = M;
-        }
+        for (int d = 0; d < 4; ++d) a4[d] = lane_halve<32>(acc[g][d], acc[g][d + 4], f1, f2, lane);
+        mo = lane_xor<16>(m[g], lane); lo = lane_xor<16>(l[g], lane);
+        M = fmaxf(m[g], mo);
+        f1 = fast_exp(m[g] - M); f2 = fast_exp(mo - M);
+        l[g] = l[g] * f1 + lo * f2;
+        m[g] = M;
+        const float a20 = lane_halve<16>(a4[0], a4[2], f1, f2, lane), a21 = lane_halve<16>(a4[1], a4[3], f1, f2, lane);
+        mo = lane_xor<8>(m[g], lane); lo = lane_xor<8>(l[g], lane);
+        M = fmaxf(m[g], mo);
+        f1 = fast_exp(m[g] - M); f2 = fast_exp(mo - M);
+        l[g] = l[g] * f1 + lo * f2;
+        m[g] = M;
+        o1[g] = lane_halve<8>(a20, a21, f1, f2, lane);
     }
     stamp(4);
-    // merge the NW waves: red[w][g][sub][10]
+    // merge the NW waves through LDS: red[(w*G + g)*66 + feature], m at +64, l at +65 (fixed order: deterministic)
     float* red = (float*)smem;
-    if (ks == 0) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            float* r = red + (((size_t)w * G + g) * 8 + sub) * 10;
-            r[0] = m[g]; r[1] = l[g];
-#pragma unroll
-            for (int d = 0; d < 8; ++d) r[2 + d] = acc[g][d];
-        }
+    for (int g = 0; g < G; ++g) {
+        float* r = red + ((size_t)w * G + g) * 66;
+        r[sub * 8 + ks] = o1[g];
+        if (lane == 0) { r[64] = m[g]; r[65] = l[g]; }
     }
     __syncthreads();
     stamp(5);
-    if (w == 0 && ks == 0) {
+    if (w == 0) {          // lane = feature of the head
 #pragma unroll
         for (int g = 0; g < G; ++g) {
+            float mw[NW];
             float M = DC_NEG;
-            for (int ww = 0; ww < NW; ++ww) M = fmaxf(M, red[(((size_t)ww * G + g) * 8 + sub) * 10]);
-            float L = 0.f, o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            for (int ww = 0; ww < NW; ++ww) {
-                const float* r = red + (((size_t)ww * G + g) * 8 + sub) * 10;
-                const float f = fast_exp(r[0] - M);
-                L += r[1] * f;
 #pragma unroll
-                for (int d = 0; d < 8; ++d) o[d] += r[2 + d] * f;
+            for (int ww = 0; ww < NW; ++ww) { mw[ww] = red[((size_t)ww * G + g) * 66 + 64]; M = fmaxf(M, mw[ww]); }
+            float L = 0.f, o = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) {
+                const float* r = red + ((size_t)ww * G + g) * 66;
+                const float f = fast_exp(mw[ww] - M);
+                L += r[65] * f;
+                o += r[lane] * f;
             }
             const float inv = L > 0.f ? 1.0f / L : 0.f;
             const int row = owner * G + g;
             if (row < a.rows)
-                st16(a.ctx + pk_off(row, a.ctx_col0 + h * 64 + sub * 8, a.ctx_ld ? a.ctx_ld : a.H * 64),
-                     make_uint4(pack_bf16(o[0] * inv, o[1] * inv), pack_bf16(o[2] * inv, o[3] * inv),
-                                pack_bf16(o[4] * inv, o[5] * inv), pack_bf16(o[6] * inv, o[7] * inv)));
+                a.ctx[pk_off(row, a.ctx_col0 + h * 64 + lane, a.ctx_ld ? a.ctx_ld : a.H * 64)] = f32_to_bf16_rn(o * inv);
         }
     }
     stamp(6);

@@ -256,6 +256,64 @@ MG_DEV float sum8(float p) {
 #endif
 }
 
+// ---- lane exchanges without the LDS crossbar (ds_bpermute costs an address register and ~100 cycles of latency per value) ----
+// value of the lane whose index differs in bit STEP (8: DPP row_ror:8; 16 / 32: v_permlane16_swap / v_permlane32_swap, gfx950)
+// v_permlane16_swap / v_permlane32_swap exchange the upper rows (16 lanes) / upper half of `a` with the lower rows / lower half
+// of `b`, in place.  Inline asm, not the builtin: hipcc 7.2 folds the builtin's second result into the first when both are
+// consumed as floats (tools/lane_probe.hip shows it: the halving step came back as own + own).  The two wait states the
+// hardware wants between a VALU write of an operand and the swap are inside the string.
+template <int STEP>
+MG_DEV void lane_swap(unsigned& a, unsigned& b) {
+#ifndef MG_EMU
+    if constexpr (STEP == 16) asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    else asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+#endif
+}
+template <int STEP>
+MG_DEV float lane_xor(float v, int lane) {
+    static_assert(STEP == 8 || STEP == 16 || STEP == 32, "lane_xor: 8, 16 or 32");
+#ifdef MG_EMU
+    (void)lane;
+    return __shfl_xor(v, STEP);
+#else
+    if constexpr (STEP == 8) {
+        (void)lane;
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false));
+    } else {
+        unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+        lane_swap<STEP>(a, b);                    // a = {own | partner's}, b = {partner's | own} for the (clear | set) lanes
+        return __builtin_bit_cast(float, (lane & STEP) ? a : b);
+    }
+#endif
+}
+// One step of a halving reduction over lane bit STEP.  Lanes with the bit clear keep `lo`, lanes with it set keep `hi`; the
+// result is own_kept * f_own + partner's_same_part * f_oth.  The swap instructions move exactly the two halves that have to
+// travel, so a register pair costs ONE instruction and no select.
+template <int STEP>
+MG_DEV float lane_halve(float lo, float hi, float f_own, float f_oth, int lane) {
+    const bool up = (lane & STEP) != 0;
+#ifdef MG_EMU
+    const float recv = __shfl_xor(up ? lo : hi, STEP);
+    return (up ? hi : lo) * f_own + recv * f_oth;
+#else
+    if constexpr (STEP == 8) {
+        const float recv = lane_xor<8>(up ? lo : hi, lane);
+        return (up ? hi : lo) * f_own + recv * f_oth;
+    } else {
+        unsigned a = __builtin_bit_cast(unsigned, lo), b = __builtin_bit_cast(unsigned, hi);
+        lane_swap<STEP>(a, b);                    // a = {own lo | partner's hi}, b = {partner's lo | own hi}
+        return __builtin_bit_cast(float, a) * (up ? f_oth : f_own) + __builtin_bit_cast(float, b) * (up ? f_own : f_oth);
+    }
+#endif
+}
+// sum over the 8 key-slot groups (lane bits 3..5), result in all lanes
+MG_DEV float sum_slots(float v, int lane) {
+    v += lane_xor<8>(v, lane);
+    v += lane_xor<16>(v, lane);
+    v += lane_xor<32>(v, lane);
+    return v;
+}
+
 MG_DEV float wave_sum(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
