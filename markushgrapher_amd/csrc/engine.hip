@@ -870,6 +870,9 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
     const float eps = m->c.layer_norm_epsilon;
     const int ldl = round_up(m->V, 32);
     const int K2 = d + inner, kts2 = K2 >> 4, kt_ctx = d >> 4;
+    // greedy with EOS enabled: finished rows emit pad whatever they compute, their attention launches skip them
+    // (not under the parity instrumentation, which compares every row's logits at every captured step)
+    const int* live = (K == 1 && min_length < max_length && !m->dbg_logits && !m->dbg_forced) ? w.unfinished : nullptr;
     RowScale none{};
     RowScale rs0{w.rs_part, d / 8, 1.0f / (float)d, eps};     // after the FFN output (next layer's ln0 / final norm)
     RowScale rs1{w.rs_part1, d / 8, 1.0f / (float)d, eps};    // after the self-attention output (cross-attention norm)
@@ -901,6 +904,7 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
                 AttnStepArgs s{};
                 s.q = w.dq; s.Kc = sk; s.Vc = sv; s.ctx = w.xa; s.ctx_ld = K2; s.ctx_col0 = d; s.rows = R; s.H = H; s.group = 1;
                 s.cap = T_cap; s.n_keys = t + 1; s.bias = m->at<float>(m->dec_tab); s.anc = K > 1 ? w.anc : nullptr; s.t = t; s.t_dev = tdev;
+                s.live = live;
                 attention_step(s, st);
             }
             {   // h += Wo·ctx (partials of sum h^2 -> rs1, bf16(h) -> xb)   |   cross-attention q (un-normalised) -> dq
@@ -915,6 +919,7 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
             AttnStepArgs x{};
             x.q = w.dq; x.qrs = rs1; x.Kc = w.xk + li * xkv_stride; x.Vc = w.xv + li * xkv_stride; x.ctx = w.xb; x.ctx_ld = K2;
             x.ctx_col0 = d; x.rows = R; x.H = H; x.group = K; x.cap = Sx_cap; x.len = w.xlen;
+            x.live = live;
             const bool timed = time_cross && m->prof_used + 3 <= m->prof_ev.size();
             if (timed) mg_event_record(m->prof_ev[m->prof_used], st);
             attention_step(x, st);

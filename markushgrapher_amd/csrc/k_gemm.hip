@@ -6,6 +6,7 @@
 //   * swapping the two MFMA operands transposes the accumulator for free, which lets each epilogue store
 //     16-byte chunks in the layout its consumer wants (packed rows, packed transposed, or row-major fp32).
 #include "mg_kernels.h"
+#include <type_traits>
 
 namespace mg {
 
@@ -478,7 +479,10 @@ constexpr int GX_N = 256, GX_K = 64;
 // TI = row tiles (of 32) per wave: TI = 4 -> 256x256 block tile; TI = 5 -> 320x256 (0.7 LDS reads per MFMA, 160
 // accumulator registers, two 72 KiB stages), used where it makes the tile count a whole number of rounds over the 256 CUs
 // (M = 40960, N = 1024: 128 x 4 = 512 tiles instead of 640).
-template <int EPI, int TI>
+// XP != 0: timing experiments only (MG_GEMM_EXP, tools/kbench.py encgemm; WRONG results): 1 = the fragments of k-tile 0 are
+// reused for k-tiles 1..3 (LDS read traffic / 4), 2 = only the first two K-steps are staged (no global traffic afterwards), 4 = only one
+// of the wave's 2*TI output tiles is stored (epilogue / 10); sums combine
+template <int EPI, int TI, int XP = 0>
 __global__ __launch_bounds__(512) void gemm_xl_kernel(GemmArgs a) {
     MG_DYN_SMEM(smem);
     constexpr int BM = 64 * TI, XT = 2 * TI;                   // X row tiles per block (2 wave rows x TI)
@@ -508,11 +512,12 @@ __global__ __launch_bounds__(512) void gemm_xl_kernel(GemmArgs a) {
         trow = trow < tmax ? trow : tmax;
         src[i] = (const char*)((isW ? a.W : a.X) + pk_tile_off(trow, kt, a.K)) + lane * 16;
     }
+    const mg_lds_t sm0 = mg_lds_addr(smem);
     auto stage = [&](int buf, int ks) {
 #pragma unroll
         for (int i = 0; i < PER_WAVE; ++i)
             if (w * PER_WAVE + i < FRAGS)
-                glds16_async(src[i] + (size_t)ks * (4 * TILE_BYTES), smem + buf * STAGE_BYTES + (w * PER_WAVE + i) * TILE_BYTES);
+                glds16_async_lds(src[i] + (size_t)ks * (4 * TILE_BYTES), sm0 + buf * STAGE_BYTES + (w * PER_WAVE + i) * TILE_BYTES);
     };
 
     const int wr = w >> 2, wc = w & 3;
@@ -528,33 +533,87 @@ __global__ __launch_bounds__(512) void gemm_xl_kernel(GemmArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = acc_zero();
 
+    // Fragment registers are double-buffered: the reads of k-tile kt+1 are issued BEFORE the MFMAs of k-tile kt, and the step's
+    // barrier sits in front of the LAST k-tile's MFMAs, whose operands are in registers by then - so the next step's copies and
+    // first fragment reads are issued under 10 MFMAs per wave instead of in front of an idle matrix pipe.  (The schedule hipcc
+    // derives from a plain read-then-multiply loop overlapped one MFMA with the next k-tile's reads: measured 1.5 PFLOP/s with
+    // all memory traffic and the epilogue switched off.)
+    struct Frags { mg_raw16 x[TI], w[2]; };
+    // per-lane LDS addresses of the wave's first X / W fragment in stage 0 (stage 1: + STAGE_BYTES); the fragment and k-tile
+    // select an instruction immediate
+    const mg_lds_t lx0 = sm0 + lane * 16 + wr * (TI * 4 * TILE_BYTES);
+    const mg_lds_t lw0 = sm0 + lane * 16 + (4 * XT + wc * 8) * TILE_BYTES;
+    auto rd = [&](int buf, auto ktc, Frags& f) {
+        constexpr int kt = (XP & 1) ? 0 : decltype(ktc)::value;
+        const mg_lds_t lx = lx0 + buf * STAGE_BYTES, lw = lw0 + buf * STAGE_BYTES;
+        lds_rd16_async<(0 * 4 + kt) * TILE_BYTES>(f.w[0], lw);
+        lds_rd16_async<(1 * 4 + kt) * TILE_BYTES>(f.w[1], lw);
+        lds_rd16_async<(0 * 4 + kt) * TILE_BYTES>(f.x[0], lx);
+        lds_rd16_async<(1 * 4 + kt) * TILE_BYTES>(f.x[1], lx);
+        lds_rd16_async<(2 * 4 + kt) * TILE_BYTES>(f.x[2], lx);
+        lds_rd16_async<(3 * 4 + kt) * TILE_BYTES>(f.x[3], lx);
+        if constexpr (TI > 4) lds_rd16_async<(4 * 4 + kt) * TILE_BYTES>(f.x[TI - 1], lx);
+    };
+    // all outstanding fragment reads of the wave have landed; the MFMAs below cannot be moved above this point
+    auto landed = [&](Frags& f) {
+        MG_WAIT_LGKM_TIE(0, f.w[0]);
+        MG_TIE(f.w[1]);
+#pragma unroll
+        for (int i = 0; i < TI; ++i) MG_TIE(f.x[i]);
+    };
+    auto mm = [&](const Frags& f) {
+        uint4 xw[2], xx[TI];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) xw[j] = raw16_get(f.w[j]);
+#pragma unroll
+        for (int i = 0; i < TI; ++i) xx[i] = raw16_get(f.x[i]);
+        if (tor) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(xw[j], xx[i], acc[i][j]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(xx[i], xw[j], acc[i][j]);
+        }
+    };
+    Frags fa, fb;
+    using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
     stage(0, 0);
+    MG_WAIT_VMCNT(0);
+    MG_BARRIER_RAW();
+    if (nks > 1) stage(1, 1);
+    rd(0, K0{}, fa);
     for (int ks = 0; ks < nks; ++ks) {
         const int cur = ks & 1;
-        MG_WAIT_VMCNT(0);        // own copies of stage ks (issued one compute phase ago) have landed ...
-        MG_BARRIER_RAW();        // ... everybody's have, and everybody finished reading the other buffer
-        if (ks + 1 < nks) stage(cur ^ 1, ks + 1);
-        const char* xb = smem + cur * STAGE_BYTES + lane * 16;
-        const char* wb = xb + 4 * XT * TILE_BYTES;
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            uint4 xf[TI], wf[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) wf[j] = ld16(wb + ((wc * 2 + j) * 4 + kt) * TILE_BYTES);
-#pragma unroll
-            for (int i = 0; i < TI; ++i) xf[i] = ld16(xb + ((wr * TI + i) * 4 + kt) * TILE_BYTES);
-            if (tor) {
-#pragma unroll
-                for (int i = 0; i < TI; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(wf[j], xf[i], acc[i][j]);
-            } else {
-#pragma unroll
-                for (int i = 0; i < TI; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(xf[i], wf[j], acc[i][j]);
-            }
+        landed(fa);
+        rd(cur, K1{}, fb);
+        MG_SCHED_FENCE();            // (the reads stay in front of the MFMAs they are to be hidden under)
+        mm(fa);
+        MG_SCHED_FENCE();
+        landed(fb);
+        rd(cur, K2{}, fa);
+        MG_SCHED_FENCE();
+        mm(fb);
+        MG_SCHED_FENCE();
+        landed(fa);
+        rd(cur, K3{}, fb);
+        MG_SCHED_FENCE();
+        mm(fa);
+        MG_SCHED_FENCE();
+        landed(fb);                  // (also: own reads of this buffer are complete ...
+        if (ks + 1 < nks) {
+            MG_WAIT_VMCNT(0);        // ... own copies of the next step (issued one step ago) have landed ...
+            MG_BARRIER_RAW();        // ... and so have everybody's)
+            if (ks + 2 < nks && !(XP & 2)) stage(cur, ks + 2);
+            rd(cur ^ 1, K0{}, fa);
         }
+        MG_SCHED_FENCE();
+        mm(fb);
+        MG_SCHED_FENCE();
     }
 
     if constexpr (EPI == EPI_RESID_NORM) {
@@ -569,6 +628,7 @@ __global__ __launch_bounds__(512) void gemm_xl_kernel(GemmArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int m0 = m0w + 32 * i, n0 = n0w + 32 * j;
+            if constexpr ((XP & 4) != 0) { if ((i || j) && acc[i][j][0] != 123456.789f) continue; }
             if constexpr (EPI == EPI_F32_STORE || EPI == EPI_F32_RESID) {
                 tile_epilogue<EPI, false>(a, acc[i][j], m0, n0, lane);
             } else if constexpr (EPI == EPI_HEADS) {
@@ -586,6 +646,17 @@ static void launch_xl(const GemmArgs& a, mgStream_t stream) {
     const size_t sh = (size_t)2 * (2 * TI + 8) * 4 * TILE_BYTES;
     static bool once = false;
     if (!once) { MG_SET_MAX_SMEM((&gemm_xl_kernel<EPI, TI>), sh); once = true; }
+    if constexpr (EPI == EPI_PK && TI == 5) {          // timing experiments (see the kernel's XP parameter)
+        static int xp = -1;
+        if (xp < 0) { const char* e = getenv("MG_GEMM_EXP"); xp = e ? atoi(e) : 0; }
+        if (xp) {
+#define MG_XP(N) case N: { static bool o = false; if (!o) { MG_SET_MAX_SMEM((&gemm_xl_kernel<EPI, TI, N>), sh); o = true; } \
+                             MG_LAUNCH((gemm_xl_kernel<EPI, TI, N>), dim3(nblk), dim3(512), sh, stream, a); } break;
+            switch (xp) { MG_XP(1) MG_XP(2) MG_XP(3) MG_XP(4) MG_XP(5) MG_XP(6) default: MG_XP(7) }
+#undef MG_XP
+            return;
+        }
+    }
     MG_LAUNCH((gemm_xl_kernel<EPI, TI>), dim3(nblk), dim3(512), sh, stream, a);
 }
 

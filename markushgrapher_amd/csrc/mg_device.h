@@ -67,11 +67,14 @@ static inline void mg_event_destroy(mgEvent_t e) { (void)hipEventDestroy(e); }
 #define MG_BARRIER_RAW() __syncthreads()
 #define MG_WAIT_VMCNT(N) ((void)0)
 #define MG_WAIT_LGKM0() ((void)0)
+#define MG_SCHED_FENCE() ((void)0)
 #define MG_SET_MAX_SMEM(kern, bytes) ((void)0)
 #else
 #define MG_BARRIER_RAW() __builtin_amdgcn_s_barrier()
 #define MG_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 #define MG_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// the instruction scheduler moves nothing across this point (keeps a hand-written read / multiply interleave as written)
+#define MG_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define MG_SET_MAX_SMEM(kern, bytes) (void)hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))
 #endif
 
@@ -194,6 +197,29 @@ MG_DEV void glds16_async(const void* gsrc_lane, void* lds_wave_base) {
 #endif
 }
 
+// LDS reads the compiler does not schedule or count (hand-pipelined fragment read-ahead: hipcc's IR passes sink ordinary LDS
+// loads to their first use, which undoes "reads of k-tile kt+1 in front of the MFMAs of k-tile kt").  lds_rd16_async issues
+// ds_read_b128 from the LDS byte address `addr` (+ the immediate OFF <= 65535); the destination must not be touched before
+// MG_WAIT_LGKM_TIE(N, reg) / mg_tie(reg) covers it.  mg_lds_addr: the 32-bit LDS address of a __shared__ pointer.
+#ifdef MG_EMU
+MG_DEV const char* mg_lds_addr(const void* p) { return (const char*)p; }
+typedef const char* mg_lds_t;
+#else
+typedef unsigned mg_lds_t;
+MG_DEV mg_lds_t mg_lds_addr(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p; }
+#endif
+// the same copy with the destination given as an LDS address (mg_lds_addr): no generic-pointer conversion per copy
+MG_DEV void glds16_async_lds(const void* gsrc_lane, mg_lds_t lds_wave_base) {
+#ifdef MG_EMU
+    emu::glds16(gsrc_lane, (void*)lds_wave_base);
+#else
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_wave_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc_lane), "s"(dst) : "memory");
+#endif
+}
+
 // 16-byte global load into registers that the compiler does not track (no s_waitcnt inserted on its behalf, it does not
 // count against the vmcnt the compiler computes for its own loads): for hand-pipelined prefetch several stages ahead.
 // The destination must not be read, copied or moved before MG_WAIT_VMCNT_TIE(N, regs...) has covered the load.
@@ -201,11 +227,19 @@ MG_DEV void glds16_async(const void* gsrc_lane, void* lds_wave_base) {
 typedef uint4 mg_raw16;
 MG_DEV void gld16_async(mg_raw16& dst, const void* p) { dst = *(const uint4*)p; }
 MG_DEV uint4 raw16_get(const mg_raw16& r) { return r; }
+template <int OFF> MG_DEV void lds_rd16_async(mg_raw16& dst, mg_lds_t addr) { dst = *(const uint4*)(addr + OFF); }
+#define MG_WAIT_LGKM_TIE(N, r) ((void)0)
+#define MG_TIE(r) ((void)0)
 #define MG_WAIT_VMCNT_TIE4(N, a, b, c, d) ((void)0)
 #else
 typedef unsigned int mg_raw16 __attribute__((ext_vector_type(4)));
 MG_DEV void gld16_async(mg_raw16& dst, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory"); }
 MG_DEV uint4 raw16_get(const mg_raw16& r) { return make_uint4(r.x, r.y, r.z, r.w); }
+template <int OFF> MG_DEV void lds_rd16_async(mg_raw16& dst, mg_lds_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+#define MG_WAIT_LGKM_TIE(N, r) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(r) :: "memory")
+#define MG_TIE(r) asm volatile("" : "+v"(r))
 // counted wait that the four registers depend on: their first use cannot be scheduled above it
 #define MG_WAIT_VMCNT_TIE4(N, a, b, c, d) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) :: "memory")
 #endif

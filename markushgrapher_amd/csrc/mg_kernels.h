@@ -231,6 +231,8 @@ struct AttnStepArgs {
     int self_append;          // 1: slabs carry q,k,v and the new position is appended; 0: slabs carry q only
     uint16_t* Kc_w;           // writable cache pointers for the append
     uint16_t* Vc_w;
+    const int* live;          // group == 1 only, nullable: rows with live[row] == 0 (finished: they emit pad whatever their
+                              // logits are, gen:2927-2937) are skipped - their K/V streams are not read
 };
 void attention_step(const AttnStepArgs& a, mgStream_t stream);
 void attention_step_trace(const AttnStepArgs& a, long long* trace, mgStream_t stream);   // phase stamps, cross form, group 1
