@@ -220,6 +220,51 @@ int mgk_add_norm_pack(void* stream, float* h, const float* P, int KS, int ldp, s
                       void* x_pk, int M, int d, float eps, float scale);
 int mgk_relu_pack(void* stream, const float* P, int KS, int ldp, size_t slab_stride, void* y_pk, int M, int N);
 
+/* ------------------------------------------------------------------------------------------------------------------------------
+ * ChemicalOCR stage ("next" row f-1).  Replaces, for the OCR pass that produces the cells the main model
+ * reads, what /root/reference/markushgrapher/ocr/chemical_ocr.py does on one 512-px page at a time:
+ *     processor, model = AutoProcessor / AutoModelForVision2Seq.from_pretrained(model_path)            chemical_ocr.py:76-84
+ *     inputs = processor(text=prompt, images=[image], return_tensors="pt", size={"longest_edge": 512})  chemical_ocr.py:368-373
+ *     generated_ids = model.generate(**inputs, max_new_tokens=4096, do_sample=False)                    chemical_ocr.py:375-380
+ * i.e. stock Idefics3ForConditionalGeneration (SigLIP-style vision tower, pixel-shuffle connector, Llama-style text model),
+ * greedy.  Tokenisation / image resizing stay on the host (the stock processor); this library takes the processor's tensors.
+ * v1 limits: head dim 64 everywhere; every image is a full image_size x image_size frame (pixel_attention_mask all ones, as the
+ * processor produces for a 512-px page with a 512-px vision tower); every sequence of a call has the same prompt length (no
+ * padding) and exactly n_img * image_seq_len <image> tokens.  Same conventions as above (device pointers, caller-owned buffers).
+ * ------------------------------------------------------------------------------------------------------------------------------ */
+typedef struct mg_ocr_model mg_ocr_model;
+typedef struct mg_ocr_config {
+    /* Idefics3VisionConfig */
+    int v_hidden, v_inter, v_layers, v_heads, image_size, patch_size;
+    /* LlamaConfig of the text model */
+    int t_hidden, t_inter, t_layers, t_heads, t_kv_heads, vocab;
+    /* Idefics3Config */
+    int scale_factor, image_token_id, eos_token_id, pad_token_id, tie_word_embeddings;
+    float v_eps, rms_eps, rope_theta;
+} mg_ocr_config;
+
+int mg_ocr_create(const mg_ocr_config* cfg, mg_ocr_model** out);
+void mg_ocr_destroy(mg_ocr_model* m);
+size_t mg_ocr_weights_bytes(const mg_ocr_model* m);
+int mg_ocr_bind_weights(mg_ocr_model* m, void* arena);
+/* hf_key: a state-dict key of stock Idefics3ForConditionalGeneration ("model.vision_model....", "model.connector....",
+ * "model.text_model....", "lm_head.weight"); src: device tensor, fp32 (src_is_bf16 = 0) or bf16 bits. */
+int mg_ocr_load_tensor(mg_ocr_model* m, void* stream, const char* hf_key, const void* src, int src_is_bf16, const int64_t* shape, int ndim);
+int mg_ocr_finalize(mg_ocr_model* m, void* stream);
+int mg_ocr_workspace_bytes(const mg_ocr_model* m, int B, int n_img, int L, int max_new_tokens, int full_logits, size_t* out_bytes);
+/* get_image_features (modeling_idefics3.py:563-622): pixel_values [N][3][I][I] fp32 -> out [N][image_seq_len][t_hidden] fp32
+ * (workspace: mg_ocr_workspace_bytes(m, N, 1, 1, 0, 0)). */
+int mg_ocr_image_features(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, const float* pixel_values, int N, float* out);
+/* Teacher-forced forward (modeling_idefics3.py:750-840): input_ids [B][L] i64, pixel_values [B][n_img][3][I][I] fp32 (NULL with
+ * n_img = 0: text only) -> logits [B][L][vocab] fp32.  Workspace with full_logits = 1.  SYNCHRONISES (reports bad inputs). */
+int mg_ocr_forward(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* input_ids, const float* pixel_values, int B,
+                   int n_img, int L, float* logits);
+/* generate(max_new_tokens, do_sample=False) (generation/utils.py:2783-2975): out_ids [B][max_new_tokens] i64 = the NEW tokens
+ * (finished rows padded with pad_token_id), *out_cols_host = columns HF would have produced (steps until every row had emitted
+ * EOS).  step_logits (nullable, tests): [capture_steps][B][vocab] fp32 pre-argmax logits of the first steps.  SYNCHRONISES. */
+int mg_ocr_generate(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* input_ids, const float* pixel_values, int B,
+                    int n_img, int L, int max_new_tokens, int64_t* out_ids, int* out_cols_host, float* step_logits, int capture_steps);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
 SOURCES = ["k_gemm.hip", "k_pack.hip", "k_embed.hip", "k_attn.hip", "k_decode.hip", "k_fused.hip", "k_beam.hip", "k_prep.hip", "c_ops.hip",
-           "engine.hip"]
+           "engine.hip", "k_ocr.hip", "ocr.hip"]
 HIP_SO = os.path.join(ROOT, "markushgrapher_amd", "libmgrapher_hip.so")
 EMU_DIR = os.path.join(ROOT, "tools", "simt_emu")
 EMU_SO = os.path.join(EMU_DIR, "_build", "libmgrapher_emu.so")

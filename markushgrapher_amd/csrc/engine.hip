@@ -27,6 +27,11 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+}  // namespace
+namespace mg {
+int fail_msg(int code, const char* msg) { g_err = msg; return code; }      // ocr.hip
+}
+namespace {
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 int round_up(int x, int a) { return (x + a - 1) / a * a; }
 

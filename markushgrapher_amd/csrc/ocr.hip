@@ -1,0 +1,489 @@
+// ChemicalOCR stage: the C ABI `mg_ocr_*` of include/mgrapher.h.  What the reference does with
+//   processor, model = AutoProcessor / AutoModelForVision2Seq.from_pretrained(model_path)        (markushgrapher/ocr/chemical_ocr.py:76-84)
+//   generated_ids = model.generate(**inputs, max_new_tokens=4096, do_sample=False)               (chemical_ocr.py:366-392)
+// i.e. stock Idefics3ForConditionalGeneration: SigLIP-style vision tower -> pixel shuffle + projection -> the image tokens of the
+// prompt -> Llama-style text model, greedy search with a KV cache.  Host code only orchestrates launches; the contractions run on
+// the GEMM / attention kernels of the main path, the glue kernels are in k_ocr.hip.
+// Round-2 form: every operation its own launch, fp32 intermediates between GEMM and activation, eager decode steps.
+#include "mg_kernels.h"
+#include "mg_ocr.h"
+#include "../../include/mgrapher.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace mg;
+
+namespace {
+
+int failf(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    return fail_msg(code, buf);
+}
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+int round_up(int x, int a) { return (x + a - 1) / a * a; }
+int check(const char* what) {
+    const int e = mg_peek_error();
+    if (e != 0) return failf(MG_E_HIP, "%s: HIP error %d (%s)", what, e, mg_error_string(e));
+    return MG_OK;
+}
+GemmArgs ga(const uint16_t* X, const uint16_t* W, int M, int N, int K) {
+    GemmArgs a{};
+    a.X = X; a.W = W; a.M = M; a.N = N; a.K = K;
+    return a;
+}
+struct Raw { size_t off; std::vector<int64_t> shape; size_t n; bool loaded = false; };
+struct VLayer { size_t wqkv, wo, fc1, fc2; };
+struct TLayer { size_t wqkv, wo, wgu, wd; };
+struct Carver {
+    char* base;
+    size_t off = 0;
+    template <typename T> T* take(size_t n) {
+        off = align_up(off, 256);
+        T* p = base ? (T*)(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+}  // namespace
+
+struct mg_ocr_model {
+    mg_ocr_config c;
+    int P, g, P_cap, T_img, vka, kvd, qkvn;
+    char* arena = nullptr;
+    size_t arena_bytes = 0;
+    std::map<std::string, Raw> raw;          // HF key -> fp32 copy in the arena
+    std::vector<VLayer> vl;
+    std::vector<TLayer> tl;
+    size_t patch_w, pos_emb, conn, tok_emb, lm_head, zero_tab;
+    bool finalized = false;
+    template <typename T> T* at(size_t off) const { return (T*)(arena + off); }
+    const float* rawp(const std::string& k) const { return (const float*)(arena + raw.at(k).off); }
+};
+
+namespace {
+
+struct Ws {
+    // vision
+    uint16_t *xim, *vx, *vq, *vk, *vvt, *vctx, *vy, *xs;
+    float *patch, *vh, *vtmp, *vout, *feats;
+    // text
+    float *h, *qkv, *gu, *logits;
+    uint16_t *x, *q, *k, *vt, *ctx, *y, *xc, *dq, *Kc, *Vc;
+    uint8_t* kmask;
+    int *last_rows, *all_rows, *unfinished, *counters;
+    int64_t* next_ids;
+    size_t total, kv_layer;
+};
+
+void carve(const mg_ocr_model* m, char* base, int B, int n_img, int L, int max_new, bool full_logits, Ws* w) {
+    const mg_ocr_config& c = m->c;
+    Carver cv{base};
+    const size_t N = (size_t)B * n_img, MV = N * m->P_cap, vh = c.v_hidden, vi = c.v_inter, td = c.t_hidden, ti = c.t_inter;
+    const int T_cap = round_up(L, 64), H = c.t_heads;
+    const size_t MT = (size_t)B * T_cap;
+    const int cap = round_up(L + max_new, 64);
+    w->xim = cv.take<uint16_t>(pk_elems((int)(N * m->P), 3 * c.patch_size * c.patch_size));
+    w->patch = cv.take<float>(N * m->P * vh);
+    w->vh = cv.take<float>(MV * vh);
+    w->vx = cv.take<uint16_t>(pk_elems((int)MV, m->vka));
+    w->vq = cv.take<uint16_t>(MV * vh); w->vk = cv.take<uint16_t>(MV * vh); w->vvt = cv.take<uint16_t>(MV * vh);
+    w->vctx = cv.take<uint16_t>(pk_elems((int)MV, (int)vh));
+    w->vtmp = cv.take<float>(MV * vi);
+    w->vy = cv.take<uint16_t>(pk_elems((int)MV, (int)vi));
+    w->vout = cv.take<float>(MV * vh);
+    w->xs = cv.take<uint16_t>(pk_elems((int)(N * m->T_img), (int)(vh * c.scale_factor * c.scale_factor)));
+    w->feats = cv.take<float>(N * m->T_img * td);
+    w->h = cv.take<float>(MT * td);
+    w->x = cv.take<uint16_t>(pk_elems((int)MT, (int)td));
+    w->qkv = cv.take<float>(MT * m->qkvn);
+    w->q = cv.take<uint16_t>(MT * H * 64); w->k = cv.take<uint16_t>(MT * H * 64); w->vt = cv.take<uint16_t>(MT * H * 64);
+    w->ctx = cv.take<uint16_t>(pk_elems((int)MT, H * 64));
+    w->gu = cv.take<float>(MT * 2 * ti);
+    w->y = cv.take<uint16_t>(pk_elems((int)MT, (int)ti));
+    w->xc = cv.take<uint16_t>(pk_elems(full_logits ? (int)(B * L) : round_up(B, 32), (int)td));
+    w->logits = cv.take<float>((size_t)round_up(B, 32) * c.vocab);
+    w->dq = cv.take<uint16_t>((size_t)round_up(B, 32) * H * 64);
+    w->kv_layer = (size_t)B * H * cap * 64;
+    w->Kc = cv.take<uint16_t>(w->kv_layer * c.t_layers);
+    w->Vc = cv.take<uint16_t>(w->kv_layer * c.t_layers);
+    w->kmask = cv.take<uint8_t>(MT);
+    w->last_rows = cv.take<int>(MT); w->all_rows = cv.take<int>(MT);
+    w->unfinished = cv.take<int>(round_up(B, 32)); w->counters = cv.take<int>(16);
+    w->next_ids = cv.take<int64_t>(round_up(B, 32));
+    w->total = align_up(cv.off, 256);
+}
+
+int check_args(const mg_ocr_model* m, int B, int n_img, int L, const char* who) {
+    if (!m) return failf(MG_E_ARG, "%s: null model", who);
+    if (!m->finalized) return failf(MG_E_STATE, "%s: mg_ocr_finalize has not run", who);
+    if (B < 1 || B > 256 || n_img < 0 || L < 1 || L > 2048) return failf(MG_E_SHAPE, "%s: B=%d n_img=%d L=%d out of range", who, B, n_img, L);
+    return MG_OK;
+}
+
+// vision tower + connector: pixel_values [N][3][I][I] -> w.feats [N*T_img][t_hidden]
+void image_features(const mg_ocr_model* m, const Ws& w, const float* pix, int N, mgStream_t st) {
+    const mg_ocr_config& c = m->c;
+    const int vh = c.v_hidden, vi = c.v_inter, P = m->P, Pc = m->P_cap, MV = N * Pc, H = c.v_heads, kp = 3 * c.patch_size * c.patch_size;
+    const std::string v = "model.vision_model.";
+    im2col_pack(pix, w.xim, N, 3, c.image_size, c.patch_size, st);
+    GemmArgs pe = ga(w.xim, m->at<uint16_t>(m->patch_w), N * P, vh, kp);
+    pe.out_f32 = w.patch; pe.ldo = vh; pe.bias = m->rawp(v + "embeddings.patch_embedding.bias");
+    gemm(pe, EPI_F32_STORE, st);
+    ocr_add_pos(w.patch, m->at<uint16_t>(m->pos_emb), w.vh, N, P, Pc, vh, st);
+    for (int i = 0; i < c.v_layers; ++i) {
+        const std::string p = v + "encoder.layers." + std::to_string(i) + ".";
+        const VLayer& l = m->vl[i];
+        ocr_layernorm_pack(w.vh, m->rawp(p + "layer_norm1.weight"), m->rawp(p + "layer_norm1.bias"), m->rawp(p + "self_attn.out_proj.bias"),
+                           w.vx, nullptr, MV, vh, m->vka, c.v_eps, st);
+        GemmArgs a = ga(w.vx, m->at<uint16_t>(l.wqkv), MV, 3 * vh, m->vka);
+        a.heads.ptr[0] = w.vq; a.heads.ptr[1] = w.vk; a.heads.ptr[2] = w.vvt;
+        a.heads.fmt[0] = HF_PK_ROWS; a.heads.fmt[1] = HF_PK_ROWS; a.heads.fmt[2] = HF_PK_T;
+        a.heads.inner = vh; a.heads.H = H; a.heads.S_in = Pc; a.heads.S_cap = Pc;
+        gemm(a, EPI_HEADS, st);
+        AttnArgs t{};
+        t.Q = w.vq; t.K = w.vk; t.Vt = w.vvt; t.ctx = w.vctx; t.B = N; t.H = H; t.Sq = P; t.Sk = P; t.Sq_cap = Pc; t.Sk_cap = Pc;
+        t.mode = ATT_CROSS; t.kmask = nullptr;
+        attention(t, st);
+        GemmArgs o = ga(w.vctx, m->at<uint16_t>(l.wo), MV, vh, vh);
+        o.out_f32 = w.vh; o.ldo = vh;
+        gemm(o, EPI_F32_RESID, st);
+        ocr_layernorm_pack(w.vh, m->rawp(p + "layer_norm2.weight"), m->rawp(p + "layer_norm2.bias"), m->rawp(p + "mlp.fc2.bias"), w.vx,
+                           nullptr, MV, vh, m->vka, c.v_eps, st);
+        GemmArgs f1 = ga(w.vx, m->at<uint16_t>(l.fc1), MV, vi, m->vka);
+        f1.out_f32 = w.vtmp; f1.ldo = vi;
+        gemm(f1, EPI_F32_STORE, st);
+        ocr_gelu_pack(w.vtmp, w.vy, MV, vi, vi, st);
+        GemmArgs f2 = ga(w.vy, m->at<uint16_t>(l.fc2), MV, vh, vi);
+        f2.out_f32 = w.vh; f2.ldo = vh;
+        gemm(f2, EPI_F32_RESID, st);
+    }
+    ocr_layernorm_pack(w.vh, m->rawp(v + "post_layernorm.weight"), m->rawp(v + "post_layernorm.bias"), nullptr, nullptr, w.vout, MV, vh, vh,
+                       c.v_eps, st);
+    const int sf = c.scale_factor, F = vh * sf * sf;
+    ocr_pixel_shuffle_pack(w.vout, w.xs, N, m->g, Pc, vh, sf, st);
+    GemmArgs cn = ga(w.xs, m->at<uint16_t>(m->conn), N * m->T_img, c.t_hidden, F);
+    cn.out_f32 = w.feats; cn.ldo = c.t_hidden;
+    gemm(cn, EPI_F32_STORE, st);
+}
+
+// text model over the whole prompt (teacher-forced / prefill): leaves the final hidden states in w.h (before the last norm)
+// and the rotated keys / values of every layer in the decode caches
+void prefill(const mg_ocr_model* m, const Ws& w, const int64_t* ids, const float* feats, int B, int n_img, int L, int cap, mgStream_t st) {
+    const mg_ocr_config& c = m->c;
+    const int td = c.t_hidden, ti = c.t_inter, H = c.t_heads, KV = c.t_kv_heads, T_cap = round_up(L, 64), MT = B * T_cap;
+    ocr_row_maps(w.last_rows, w.all_rows, w.kmask, B, L, T_cap, st);
+    ocr_merge_embed(ids, m->at<uint16_t>(m->tok_emb), feats, w.h, B, L, T_cap, td, c.vocab, c.image_token_id, n_img * m->T_img, w.counters + 3, st);
+    for (int i = 0; i < c.t_layers; ++i) {
+        const std::string p = "model.text_model.layers." + std::to_string(i) + ".";
+        const TLayer& l = m->tl[i];
+        rmsnorm_pack(w.h, m->rawp(p + "input_layernorm.weight"), w.x, nullptr, MT, td, c.rms_eps, 1.0f, st);
+        GemmArgs a = ga(w.x, m->at<uint16_t>(l.wqkv), MT, m->qkvn, td);
+        a.out_f32 = w.qkv; a.ldo = m->qkvn;
+        gemm(a, EPI_F32_STORE, st);
+        ocr_rope_heads(w.qkv, B, L, T_cap, H, KV, c.rope_theta, w.q, w.k, w.vt, w.Kc + (size_t)i * w.kv_layer, w.Vc + (size_t)i * w.kv_layer, cap, st);
+        AttnArgs t{};
+        t.Q = w.q; t.K = w.k; t.Vt = w.vt; t.ctx = w.ctx; t.B = B; t.H = H; t.Sq = L; t.Sk = L; t.Sq_cap = T_cap; t.Sk_cap = T_cap;
+        t.mode = ATT_DEC_SELF; t.kmask = w.kmask; t.tab1 = m->at<float>(m->zero_tab); t.tab1_len = 1;
+        attention(t, st);
+        GemmArgs o = ga(w.ctx, m->at<uint16_t>(l.wo), MT, td, H * 64);
+        o.out_f32 = w.h; o.ldo = td;
+        gemm(o, EPI_F32_RESID, st);
+        rmsnorm_pack(w.h, m->rawp(p + "post_attention_layernorm.weight"), w.x, nullptr, MT, td, c.rms_eps, 1.0f, st);
+        GemmArgs gu = ga(w.x, m->at<uint16_t>(l.wgu), MT, 2 * ti, td);
+        gu.out_f32 = w.gu; gu.ldo = 2 * ti;
+        gemm(gu, EPI_F32_STORE, st);
+        ocr_silu_mul_pack(w.gu, w.y, MT, ti, st);
+        GemmArgs dn = ga(w.y, m->at<uint16_t>(l.wd), MT, td, ti);
+        dn.out_f32 = w.h; dn.ldo = td;
+        gemm(dn, EPI_F32_RESID, st);
+    }
+}
+
+// one decode step for B rows: token ids in w.next_ids, position `pos`; logits -> w.logits
+void decode_step(const mg_ocr_model* m, const Ws& w, int B, int pos, int cap, mgStream_t st) {
+    const mg_ocr_config& c = m->c;
+    const int td = c.t_hidden, ti = c.t_inter, H = c.t_heads, KV = c.t_kv_heads;
+    embed_rows(w.next_ids, m->at<uint16_t>(m->tok_emb), w.h, B, td, c.vocab, w.counters + 3, st);
+    for (int i = 0; i < c.t_layers; ++i) {
+        const std::string p = "model.text_model.layers." + std::to_string(i) + ".";
+        const TLayer& l = m->tl[i];
+        uint16_t* Kc = w.Kc + (size_t)i * w.kv_layer;
+        uint16_t* Vc = w.Vc + (size_t)i * w.kv_layer;
+        rmsnorm_pack(w.h, m->rawp(p + "input_layernorm.weight"), w.x, nullptr, B, td, c.rms_eps, 1.0f, st);
+        GemmArgs a = ga(w.x, m->at<uint16_t>(l.wqkv), B, m->qkvn, td);
+        a.out_f32 = w.qkv; a.ldo = m->qkvn;
+        gemm_rows(a, EPI_F32_STORE, st);
+        ocr_rope_step(w.qkv, B, H, KV, c.rope_theta, pos, nullptr, w.dq, Kc, Vc, cap, st);
+        AttnStepArgs s{};
+        s.q = w.dq; s.Kc = Kc; s.Vc = Vc; s.ctx = w.ctx; s.rows = B; s.H = H; s.group = 1; s.cap = cap; s.n_keys = pos + 1; s.t = pos;
+        attention_step(s, st);
+        GemmArgs o = ga(w.ctx, m->at<uint16_t>(l.wo), B, td, H * 64);
+        o.out_f32 = w.h; o.ldo = td;
+        gemm_rows(o, EPI_F32_RESID, st);
+        rmsnorm_pack(w.h, m->rawp(p + "post_attention_layernorm.weight"), w.x, nullptr, B, td, c.rms_eps, 1.0f, st);
+        GemmArgs gu = ga(w.x, m->at<uint16_t>(l.wgu), B, 2 * ti, td);
+        gu.out_f32 = w.gu; gu.ldo = 2 * ti;
+        gemm_rows(gu, EPI_F32_STORE, st);
+        ocr_silu_mul_pack(w.gu, w.y, B, ti, st);
+        GemmArgs dn = ga(w.y, m->at<uint16_t>(l.wd), B, td, ti);
+        dn.out_f32 = w.h; dn.ldo = td;
+        gemm_rows(dn, EPI_F32_RESID, st);
+    }
+    rmsnorm_pack(w.h, m->rawp("model.text_model.norm.weight"), w.xc, nullptr, B, td, c.rms_eps, 1.0f, st);
+    GemmArgs lg = ga(w.xc, m->at<uint16_t>(m->lm_head), B, c.vocab, td);
+    lg.out_f32 = w.logits; lg.ldo = c.vocab;
+    gemm_rows(lg, EPI_F32_STORE, st);
+}
+
+__global__ __launch_bounds__(256) void copy_f32_kernel(const float* src, float* dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+}  // namespace
+
+extern "C" {
+
+int mg_ocr_create(const mg_ocr_config* cfg, mg_ocr_model** out) {
+    if (!cfg || !out) return failf(MG_E_ARG, "mg_ocr_create: null argument");
+    const mg_ocr_config& c = *cfg;
+    if (c.v_hidden % 64 || c.v_hidden != c.v_heads * 64 || c.t_hidden != c.t_heads * 64 || c.t_heads % c.t_kv_heads || c.v_inter % 64 ||
+        c.t_inter % 64 || c.t_hidden % 64 || c.vocab % 32 || c.image_size % c.patch_size || (3 * c.patch_size * c.patch_size) % 64)
+        return failf(MG_E_SHAPE, "mg_ocr_create: unsupported geometry (head dim must be 64, widths multiples of 64, vocab of 32)");
+    const int g = c.image_size / c.patch_size;
+    if (g % c.scale_factor) return failf(MG_E_SHAPE, "mg_ocr_create: patch grid %d not divisible by scale_factor %d", g, c.scale_factor);
+    mg_ocr_model* m = new mg_ocr_model();
+    m->c = c; m->g = g; m->P = g * g; m->P_cap = round_up(m->P, 64); m->T_img = m->P / (c.scale_factor * c.scale_factor);
+    m->vka = c.v_hidden + 64; m->kvd = c.t_kv_heads * 64; m->qkvn = (c.t_heads + 2 * c.t_kv_heads) * 64;
+    // raw fp32 copies, keyed by the HF names of stock Idefics3ForConditionalGeneration
+    size_t off = 0;
+    auto add = [&](const std::string& k, std::vector<int64_t> shape) {
+        size_t n = 1;
+        for (int64_t s : shape) n *= (size_t)s;
+        off = align_up(off, 256);
+        m->raw[k] = Raw{off, shape, n};
+        off += n * sizeof(float);
+    };
+    const int64_t vh = c.v_hidden, vi = c.v_inter, td = c.t_hidden, ti = c.t_inter;
+    const std::string v = "model.vision_model.";
+    add(v + "embeddings.patch_embedding.weight", {vh, 3, c.patch_size, c.patch_size});
+    add(v + "embeddings.patch_embedding.bias", {vh});
+    add(v + "embeddings.position_embedding.weight", {m->P, vh});
+    for (int i = 0; i < c.v_layers; ++i) {
+        const std::string p = v + "encoder.layers." + std::to_string(i) + ".";
+        for (const char* n : {"k_proj", "v_proj", "q_proj", "out_proj"}) {
+            add(p + "self_attn." + n + ".weight", {vh, vh});
+            add(p + "self_attn." + n + ".bias", {vh});
+        }
+        add(p + "layer_norm1.weight", {vh}); add(p + "layer_norm1.bias", {vh});
+        add(p + "mlp.fc1.weight", {vi, vh}); add(p + "mlp.fc1.bias", {vi});
+        add(p + "mlp.fc2.weight", {vh, vi}); add(p + "mlp.fc2.bias", {vh});
+        add(p + "layer_norm2.weight", {vh}); add(p + "layer_norm2.bias", {vh});
+    }
+    add(v + "post_layernorm.weight", {vh}); add(v + "post_layernorm.bias", {vh});
+    add("model.connector.modality_projection.proj.weight", {td, vh * c.scale_factor * c.scale_factor});
+    add("model.text_model.embed_tokens.weight", {c.vocab, td});
+    for (int i = 0; i < c.t_layers; ++i) {
+        const std::string p = "model.text_model.layers." + std::to_string(i) + ".";
+        add(p + "self_attn.q_proj.weight", {td, td});
+        add(p + "self_attn.k_proj.weight", {m->kvd, td});
+        add(p + "self_attn.v_proj.weight", {m->kvd, td});
+        add(p + "self_attn.o_proj.weight", {td, td});
+        add(p + "mlp.gate_proj.weight", {ti, td});
+        add(p + "mlp.up_proj.weight", {ti, td});
+        add(p + "mlp.down_proj.weight", {td, ti});
+        add(p + "input_layernorm.weight", {td});
+        add(p + "post_attention_layernorm.weight", {td});
+    }
+    add("model.text_model.norm.weight", {td});
+    if (!c.tie_word_embeddings) add("lm_head.weight", {c.vocab, td});
+    // packed bf16 operands built by mg_ocr_finalize
+    auto pk = [&](int N, int K) { off = align_up(off, 256); const size_t o = off; off += pk_elems(round_up(N, 32), K) * 2; return o; };
+    m->patch_w = pk((int)vh, 3 * c.patch_size * c.patch_size);
+    off = align_up(off, 256); m->pos_emb = off; off += (size_t)m->P * vh * 2;
+    for (int i = 0; i < c.v_layers; ++i) m->vl.push_back(VLayer{pk(3 * (int)vh, m->vka), pk((int)vh, (int)vh), pk((int)vi, m->vka), pk((int)vh, (int)vi)});
+    m->conn = pk((int)td, (int)(vh * c.scale_factor * c.scale_factor));
+    off = align_up(off, 256); m->tok_emb = off; off += (size_t)c.vocab * td * 2;
+    for (int i = 0; i < c.t_layers; ++i) m->tl.push_back(TLayer{pk(m->qkvn, (int)td), pk((int)td, (int)td), pk(2 * (int)ti, (int)td), pk((int)td, (int)ti)});
+    m->lm_head = pk(c.vocab, (int)td);
+    off = align_up(off, 256); m->zero_tab = off; off += 64 * sizeof(float);
+    m->arena_bytes = align_up(off, 256);
+    *out = m;
+    return MG_OK;
+}
+
+void mg_ocr_destroy(mg_ocr_model* m) { delete m; }
+size_t mg_ocr_weights_bytes(const mg_ocr_model* m) { return m ? m->arena_bytes : 0; }
+int mg_ocr_bind_weights(mg_ocr_model* m, void* arena) {
+    if (!m || !arena) return failf(MG_E_ARG, "mg_ocr_bind_weights: null argument");
+    m->arena = (char*)arena;
+    m->finalized = false;
+    return MG_OK;
+}
+
+int mg_ocr_load_tensor(mg_ocr_model* m, void* stream, const char* hf_key, const void* src, int src_is_bf16, const int64_t* shape, int ndim) {
+    if (!m || !hf_key || !src) return failf(MG_E_ARG, "mg_ocr_load_tensor: null argument");
+    if (!m->arena) return failf(MG_E_STATE, "mg_ocr_load_tensor: no weights arena bound");
+    auto it = m->raw.find(hf_key);
+    if (it == m->raw.end()) return failf(MG_E_KEY, "mg_ocr_load_tensor: unknown key '%s'", hf_key);
+    Raw& r = it->second;
+    if ((size_t)ndim != r.shape.size()) return failf(MG_E_SHAPE, "mg_ocr_load_tensor: '%s' has %d dims, expected %zu", hf_key, ndim, r.shape.size());
+    for (int i = 0; i < ndim; ++i)
+        if (shape[i] != r.shape[i]) return failf(MG_E_SHAPE, "mg_ocr_load_tensor: '%s' dim %d is %lld, expected %lld", hf_key, i, (long long)shape[i], (long long)r.shape[i]);
+    convert_to_f32(src, src_is_bf16, (float*)(m->arena + r.off), r.n, (mgStream_t)stream);
+    r.loaded = true;
+    m->finalized = false;
+    return check(hf_key);
+}
+
+int mg_ocr_finalize(mg_ocr_model* m, void* stream) {
+    if (!m || !m->arena) return failf(MG_E_STATE, "mg_ocr_finalize: no model / arena");
+    for (auto& kv : m->raw)
+        if (!kv.second.loaded) return failf(MG_E_STATE, "mg_ocr_finalize: tensor '%s' was not loaded", kv.first.c_str());
+    mgStream_t st = (mgStream_t)stream;
+    const mg_ocr_config& c = m->c;
+    const int vh = c.v_hidden, vi = c.v_inter, td = c.t_hidden, ti = c.t_inter;
+    const std::string v = "model.vision_model.";
+    auto pack = [&](const std::string& k, size_t dst, int row0, int N, int K, int Kaug, const std::string& bias, float scale, int Nfill) {
+        ocr_pack_aug(m->rawp(k), bias.empty() ? nullptr : m->rawp(bias), scale, m->at<uint16_t>(dst), row0, N, K, Kaug, Nfill, st);
+    };
+    pack(v + "embeddings.patch_embedding.weight", m->patch_w, 0, vh, 3 * c.patch_size * c.patch_size, 3 * c.patch_size * c.patch_size, "", 1.f, round_up(vh, 32));
+    convert_to_bf16(m->rawp(v + "embeddings.position_embedding.weight"), 0, m->at<uint16_t>(m->pos_emb), (size_t)m->P * vh, st);
+    for (int i = 0; i < c.v_layers; ++i) {
+        const std::string p = v + "encoder.layers." + std::to_string(i) + ".";
+        const VLayer& l = m->vl[i];
+        // q | k | v with their biases in the constant-one column; the softmax scale 64^-0.5 = 2^-3 folded into q (exact in bf16)
+        pack(p + "self_attn.q_proj.weight", l.wqkv, 0, vh, vh, m->vka, p + "self_attn.q_proj.bias", 0.125f, vh);
+        pack(p + "self_attn.k_proj.weight", l.wqkv, vh, vh, vh, m->vka, p + "self_attn.k_proj.bias", 1.f, vh);
+        pack(p + "self_attn.v_proj.weight", l.wqkv, 2 * vh, vh, vh, m->vka, p + "self_attn.v_proj.bias", 1.f, round_up(3 * vh, 32) - 2 * vh);
+        pack(p + "self_attn.out_proj.weight", l.wo, 0, vh, vh, vh, "", 1.f, round_up(vh, 32));
+        pack(p + "mlp.fc1.weight", l.fc1, 0, vi, vh, m->vka, p + "mlp.fc1.bias", 1.f, round_up(vi, 32));
+        pack(p + "mlp.fc2.weight", l.fc2, 0, vh, vi, vi, "", 1.f, round_up(vh, 32));
+    }
+    const int F = vh * c.scale_factor * c.scale_factor;
+    pack("model.connector.modality_projection.proj.weight", m->conn, 0, td, F, F, "", 1.f, round_up(td, 32));
+    convert_to_bf16(m->rawp("model.text_model.embed_tokens.weight"), 0, m->at<uint16_t>(m->tok_emb), (size_t)c.vocab * td, st);
+    for (int i = 0; i < c.t_layers; ++i) {
+        const std::string p = "model.text_model.layers." + std::to_string(i) + ".";
+        const TLayer& l = m->tl[i];
+        pack(p + "self_attn.q_proj.weight", l.wqkv, 0, td, td, td, "", 1.f, td);
+        pack(p + "self_attn.k_proj.weight", l.wqkv, td, m->kvd, td, td, "", 1.f, m->kvd);
+        pack(p + "self_attn.v_proj.weight", l.wqkv, td + m->kvd, m->kvd, td, td, "", 1.f, round_up(m->qkvn, 32) - td - m->kvd);
+        pack(p + "self_attn.o_proj.weight", l.wo, 0, td, td, td, "", 1.f, round_up(td, 32));
+        pack(p + "mlp.gate_proj.weight", l.wgu, 0, ti, td, td, "", 1.f, ti);
+        pack(p + "mlp.up_proj.weight", l.wgu, ti, ti, td, td, "", 1.f, round_up(2 * ti, 32) - ti);
+        pack(p + "mlp.down_proj.weight", l.wd, 0, td, ti, ti, "", 1.f, round_up(td, 32));
+    }
+    pack(c.tie_word_embeddings ? "model.text_model.embed_tokens.weight" : "lm_head.weight", m->lm_head, 0, c.vocab, td, td, "", 1.f, round_up(c.vocab, 32));
+    mg_memset_async(m->at<float>(m->zero_tab), 0, 64 * sizeof(float), st);
+    const int rc = check("mg_ocr_finalize");
+    if (rc == MG_OK) m->finalized = true;
+    return rc;
+}
+
+int mg_ocr_workspace_bytes(const mg_ocr_model* m, int B, int n_img, int L, int max_new_tokens, int full_logits, size_t* out_bytes) {
+    if (!m || !out_bytes) return failf(MG_E_ARG, "mg_ocr_workspace_bytes: null argument");
+    Ws w;
+    carve(m, nullptr, B, n_img, L, max_new_tokens, full_logits != 0, &w);
+    *out_bytes = w.total;
+    return MG_OK;
+}
+
+int mg_ocr_image_features(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, const float* pixel_values, int N, float* out) {
+    int rc = check_args(m, N, 1, 1, "mg_ocr_image_features");
+    if (rc != MG_OK) return rc;
+    Ws w;
+    carve(m, (char*)ws, N, 1, 1, 0, false, &w);
+    if (!ws || ws_bytes < w.total) return failf(MG_E_WORKSPACE, "mg_ocr_image_features: workspace %zu < %zu bytes", ws_bytes, w.total);
+    mgStream_t st = (mgStream_t)stream;
+    image_features(m, w, pixel_values, N, st);
+    const size_t n = (size_t)N * m->T_img * m->c.t_hidden;
+    MG_LAUNCH(copy_f32_kernel, dim3(256), dim3(256), 0, st, (const float*)w.feats, out, n);
+    return check("mg_ocr_image_features");
+}
+
+int mg_ocr_forward(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* input_ids, const float* pixel_values, int B,
+                   int n_img, int L, float* logits) {
+    int rc = check_args(m, B, n_img, L, "mg_ocr_forward");
+    if (rc != MG_OK) return rc;
+    Ws w;
+    carve(m, (char*)ws, B, n_img, L, 0, true, &w);
+    if (!ws || ws_bytes < w.total) return failf(MG_E_WORKSPACE, "mg_ocr_forward: workspace %zu < %zu bytes", ws_bytes, w.total);
+    mgStream_t st = (mgStream_t)stream;
+    const mg_ocr_config& c = m->c;
+    mg_memset_async(w.counters, 0, 16 * sizeof(int), st);
+    if (pixel_values && n_img > 0) image_features(m, w, pixel_values, B * n_img, st);
+    prefill(m, w, input_ids, (pixel_values && n_img > 0) ? w.feats : nullptr, B, n_img, L, round_up(L, 64), st);
+    const int T_cap = round_up(L, 64);
+    rmsnorm_pack_rows(w.h, m->rawp("model.text_model.norm.weight"), w.xc, w.all_rows, B * T_cap, c.t_hidden, c.rms_eps, 1.0f, st);
+    GemmArgs lg = ga(w.xc, m->at<uint16_t>(m->lm_head), B * L, c.vocab, c.t_hidden);
+    lg.out_f32 = logits; lg.ldo = c.vocab;
+    gemm(lg, EPI_F32_STORE, st);
+    int bad = 0;
+    mg_memcpy_async(&bad, w.counters + 3, sizeof(int), st);
+    mg_stream_sync(st);
+    rc = check("mg_ocr_forward");
+    if (rc != MG_OK) return rc;
+    if (bad) return failf(MG_E_INPUT, "mg_ocr_forward: %d bad inputs (token id outside the vocabulary, or a sequence whose <image> count differs from n_img * %d)", bad, m->T_img);
+    return MG_OK;
+}
+
+int mg_ocr_generate(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* input_ids, const float* pixel_values, int B,
+                    int n_img, int L, int max_new_tokens, int64_t* out_ids, int* out_cols_host, float* step_logits, int capture_steps) {
+    int rc = check_args(m, B, n_img, L, "mg_ocr_generate");
+    if (rc != MG_OK) return rc;
+    if (max_new_tokens < 1 || !out_ids || !out_cols_host) return failf(MG_E_ARG, "mg_ocr_generate: bad output arguments");
+    Ws w;
+    carve(m, (char*)ws, B, n_img, L, max_new_tokens, false, &w);
+    if (!ws || ws_bytes < w.total) return failf(MG_E_WORKSPACE, "mg_ocr_generate: workspace %zu < %zu bytes", ws_bytes, w.total);
+    mgStream_t st = (mgStream_t)stream;
+    const mg_ocr_config& c = m->c;
+    const int cap = round_up(L + max_new_tokens, 64), T_cap = round_up(L, 64);
+    mg_memset_async(w.counters, 0, 16 * sizeof(int), st);
+    ocr_init(out_ids, w.unfinished, w.counters, B, max_new_tokens, c.pad_token_id, st);
+    if (pixel_values && n_img > 0) image_features(m, w, pixel_values, B * n_img, st);
+    prefill(m, w, input_ids, (pixel_values && n_img > 0) ? w.feats : nullptr, B, n_img, L, cap, st);
+    // logits of the last prompt position
+    rmsnorm_pack_rows(w.h, m->rawp("model.text_model.norm.weight"), w.xc, w.last_rows, B * T_cap, c.t_hidden, c.rms_eps, 1.0f, st);
+    GemmArgs lg = ga(w.xc, m->at<uint16_t>(m->lm_head), B, c.vocab, c.t_hidden);
+    lg.out_f32 = w.logits; lg.ldo = c.vocab;
+    gemm_rows(lg, EPI_F32_STORE, st);
+    int host_flag[4] = {0, 0, 0, 0};
+    int steps = 0;
+    for (int t = 0; t < max_new_tokens; ++t) {
+        if (step_logits && t < capture_steps)
+            MG_LAUNCH(copy_f32_kernel, dim3(256), dim3(256), 0, st, (const float*)w.logits, step_logits + (size_t)t * B * c.vocab, (size_t)B * c.vocab);
+        ArgmaxArgs g{};
+        g.logits = w.logits; g.rows = B; g.V = c.vocab; g.ldl = c.vocab; g.eos = c.eos_token_id; g.pad = c.pad_token_id;
+        g.next_ids = w.next_ids; g.out_ids = out_ids; g.max_len = max_new_tokens; g.pos = t; g.min_len = 0;
+        g.unfinished = w.unfinished; g.n_unfinished = w.counters + 5; g.step_ctr = w.counters;
+        greedy_select(g, st);
+        steps = t + 1;
+        if (t + 1 == max_new_tokens) break;
+        if ((t & 7) == 7) {     // termination is looked at every 8 steps: overrunning only appends pad columns (trimmed below)
+            mg_memcpy_async(host_flag, w.counters, sizeof host_flag, st);
+            mg_stream_sync(st);
+            if (host_flag[0] == 0) break;
+        }
+        decode_step(m, w, B, L + t, cap, st);
+    }
+    mg_memcpy_async(host_flag, w.counters, sizeof host_flag, st);
+    mg_stream_sync(st);
+    rc = check("mg_ocr_generate");
+    if (rc != MG_OK) return rc;
+    if (host_flag[3]) return failf(MG_E_INPUT, "mg_ocr_generate: %d bad inputs (token id outside the vocabulary, or a sequence whose <image> count differs from n_img * %d)", host_flag[3], m->T_img);
+    *out_cols_host = host_flag[1] >= 0 ? host_flag[1] + 1 : steps;
+    return MG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,166 @@
+"""ChemicalOCR stage on the MI355X engine: ctypes binding of the `mg_ocr_*` entries of
+include/mgrapher.h plus the small host surface the reference uses.
+
+Reference (markushgrapher/ocr/chemical_ocr.py:366-392):
+    inputs = self.processor(text=prompt, images=[image], return_tensors="pt", size={"longest_edge": 512}).to(device)
+    generated_ids = self.model.generate(**inputs, max_new_tokens=4096, do_sample=False)
+    output_text = self.processor.batch_decode(generated_ids[:, prompt_len:], skip_special_tokens=True)[0]
+`OcrModel.generate(input_ids=, pixel_values=, max_new_tokens=)` takes the processor's tensors and returns what
+`generated_ids` holds (prompt + new tokens), so the surrounding lines stay as they are.  Tokenising, chat template and image
+resizing remain the stock processor's job on the host.  There is no CPU fallback: without the HIP library this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict
+
+import numpy as np
+
+from . import _lib
+from .engine import MgError, TorchMem
+from .ocr_shapes import OcrShape, PRESETS, state_dict_spec
+
+
+class MgOcrConfig(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "v_hidden", "v_inter", "v_layers", "v_heads", "image_size", "patch_size", "t_hidden", "t_inter", "t_layers", "t_heads",
+        "t_kv_heads", "vocab", "scale_factor", "image_token_id", "eos_token_id", "pad_token_id", "tie_word_embeddings")] + [
+        ("v_eps", C.c_float), ("rms_eps", C.c_float), ("rope_theta", C.c_float)]
+
+
+class OcrEngine:
+    def __init__(self, shape: OcrShape, lib=None, mem=None):
+        self.lib = lib if lib is not None else _lib.load()
+        self.mem = mem if mem is not None else TorchMem()
+        self.shape = shape
+        L = self.lib
+        L.mg_last_error.restype = C.c_char_p
+        L.mg_ocr_weights_bytes.restype = C.c_size_t
+        L.mg_ocr_weights_bytes.argtypes = [C.c_void_p]
+        L.mg_ocr_destroy.argtypes = [C.c_void_p]
+        L.mg_ocr_bind_weights.argtypes = [C.c_void_p, C.c_void_p]
+        L.mg_ocr_finalize.argtypes = [C.c_void_p, C.c_void_p]
+        L.mg_ocr_load_tensor.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]
+        L.mg_ocr_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
+        L.mg_ocr_image_features.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]
+        L.mg_ocr_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                     C.c_void_p]
+        L.mg_ocr_generate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_int]
+        s = shape
+        cfg = MgOcrConfig(s.v_hidden, s.v_inter, s.v_layers, s.v_heads, s.image_size, s.patch_size, s.t_hidden, s.t_inter, s.t_layers,
+                          s.t_heads, s.t_kv_heads, s.vocab, s.scale_factor, s.image_token_id, s.eos_token_id, s.pad_token_id,
+                          1 if s.tie_word_embeddings else 0, s.v_eps, s.rms_eps, s.rope_theta)
+        self.model = C.c_void_p()
+        self._chk(L.mg_ocr_create(C.byref(cfg), C.byref(self.model)))
+        self.arena = self.mem.zeros((int(L.mg_ocr_weights_bytes(self.model)),), np.uint8)
+        self._chk(L.mg_ocr_bind_weights(self.model, self.mem.ptr(self.arena)))
+        self._ws = None
+        self._ws_bytes = 0
+
+    def __del__(self):
+        try:
+            if getattr(self, "model", None):
+                self.lib.mg_ocr_destroy(self.model)
+                self.model = None
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise MgError(f"libmgrapher error {rc}: {self.lib.mg_last_error().decode()}")
+        return rc
+
+    def load_state_dict(self, sd: Dict[str, "np.ndarray"]):
+        """HF state dict of stock Idefics3ForConditionalGeneration: numpy fp32 arrays or torch tensors (fp32 / bf16)."""
+        want = {k for k, _, _ in state_dict_spec(self.shape)}
+        missing = sorted(want - set(sd))
+        if missing:
+            raise MgError(f"state dict lacks {len(missing)} tensors, e.g. {missing[:3]}")
+        for k in sorted(want):
+            v = sd[k]
+            is_bf16 = (not isinstance(v, np.ndarray)) and str(v.dtype) == "torch.bfloat16"
+            h = self.mem.asarray(v, np.uint16 if is_bf16 else np.float32)
+            shape = tuple(int(x) for x in v.shape)
+            arr = (C.c_int64 * len(shape))(*shape)
+            self._chk(self.lib.mg_ocr_load_tensor(self.model, self.mem.stream(), k.encode(), self.mem.ptr(h), 1 if is_bf16 else 0, arr, len(shape)))
+        self.mem.sync()
+        self._chk(self.lib.mg_ocr_finalize(self.model, self.mem.stream()))
+        self.mem.sync()
+        return self
+
+    def _workspace(self, B, n_img, L, max_new, full_logits):
+        need = C.c_size_t()
+        self._chk(self.lib.mg_ocr_workspace_bytes(self.model, B, n_img, L, max_new, 1 if full_logits else 0, C.byref(need)))
+        if self._ws is None or self._ws_bytes < need.value:
+            self._ws = None
+            self._ws = self.mem.empty((int(need.value),), np.uint8)
+            self._ws_bytes = need.value
+        return self._ws, self._ws_bytes
+
+    def _inputs(self, input_ids, pixel_values):
+        ids = self.mem.asarray(input_ids, np.int64)
+        B, L = int(ids.shape[0]), int(ids.shape[1])
+        if pixel_values is None:
+            return ids, None, B, 0, L
+        pv = self.mem.asarray(pixel_values, np.float32)
+        s = self.shape
+        if pv.ndim != 5 or int(pv.shape[0]) != B or tuple(int(x) for x in pv.shape[2:]) != (3, s.image_size, s.image_size):
+            raise MgError(f"pixel_values must be [B={B}][n_img][3][{s.image_size}][{s.image_size}], got {tuple(pv.shape)}")
+        return ids, pv, B, int(pv.shape[1]), L
+
+    def image_features(self, pixel_values):
+        """[N][3][I][I] -> [N][image_seq_len][t_hidden] fp32 (get_image_features, modeling_idefics3.py:563-622)."""
+        pv = self.mem.asarray(pixel_values, np.float32)
+        N = int(pv.shape[0])
+        ws, nb = self._workspace(N, 1, 1, 0, False)
+        out = self.mem.empty((N, self.shape.image_seq_len, self.shape.t_hidden), np.float32)
+        self._chk(self.lib.mg_ocr_image_features(self.model, self.mem.stream(), self.mem.ptr(ws), nb, self.mem.ptr(pv), N, self.mem.ptr(out)))
+        return out
+
+    def forward_logits(self, input_ids, pixel_values=None):
+        ids, pv, B, n_img, L = self._inputs(input_ids, pixel_values)
+        ws, nb = self._workspace(B, n_img, L, 0, True)
+        out = self.mem.empty((B, L, self.shape.vocab), np.float32)
+        self._chk(self.lib.mg_ocr_forward(self.model, self.mem.stream(), self.mem.ptr(ws), nb, self.mem.ptr(ids),
+                                          self.mem.ptr(pv) if pv is not None else None, B, n_img, L, self.mem.ptr(out)))
+        return out
+
+    def generate(self, input_ids, pixel_values=None, max_new_tokens=4096, capture_steps=0):
+        """-> (new_ids [B][n], step_logits or None): the tokens after the prompt, as generated_ids[:, prompt_len:] of the reference."""
+        ids, pv, B, n_img, L = self._inputs(input_ids, pixel_values)
+        ws, nb = self._workspace(B, n_img, L, max_new_tokens, False)
+        out = self.mem.empty((B, max_new_tokens), np.int64)
+        cap = self.mem.empty((capture_steps, B, self.shape.vocab), np.float32) if capture_steps else None
+        cols = C.c_int()
+        self._chk(self.lib.mg_ocr_generate(self.model, self.mem.stream(), self.mem.ptr(ws), nb, self.mem.ptr(ids),
+                                           self.mem.ptr(pv) if pv is not None else None, B, n_img, L, max_new_tokens, self.mem.ptr(out),
+                                           C.byref(cols), self.mem.ptr(cap) if cap is not None else None, capture_steps))
+        return out[:, :cols.value], cap
+
+
+class OcrModel:
+    """The slice of the HF surface ChemicalOCR touches (`.generate(**inputs, max_new_tokens=, do_sample=False)`, `.eval()`, `.to()`)."""
+
+    def __init__(self, shape: OcrShape, state_dict, device=None):
+        self.engine = OcrEngine(shape, mem=TorchMem(device)).load_state_dict(state_dict)
+        self.shape = shape
+
+    def eval(self):
+        return self
+
+    def to(self, *_a, **_k):
+        return self
+
+    def generate(self, input_ids=None, pixel_values=None, attention_mask=None, pixel_attention_mask=None, max_new_tokens=4096,
+                 do_sample=False, **_unused):
+        import torch
+        if do_sample:
+            raise MgError("only greedy search (do_sample=False) is implemented, as the reference calls it")
+        if attention_mask is not None and not bool(torch.as_tensor(attention_mask).bool().all()):
+            raise MgError("padded prompts are not supported (v1): batch prompts of equal length, as one page per call produces")
+        if pixel_attention_mask is not None and not bool(torch.as_tensor(pixel_attention_mask).bool().all()):
+            raise MgError("partially masked images are not supported (v1): full image_size x image_size frames only")
+        new, _ = self.engine.generate(input_ids, pixel_values, max_new_tokens)
+        ids = torch.as_tensor(input_ids).to(new.device)
+        return torch.cat([ids, new], dim=1)

@@ -1,0 +1,152 @@
+"""Shapes, HF state-dict layout and deterministic recipe weights of the ChemicalOCR stage.
+
+The reference loads its OCR checkpoint with `AutoModelForVision2Seq.from_pretrained(model_path)` (an Idefics3 / SmolDocling-class
+vision-language model: SigLIP-style vision tower, pixel-shuffle connector, Llama-style text model) and calls
+`model.generate(**inputs, max_new_tokens=4096, do_sample=False)` on one 512-px page at a time
+(ref: markushgrapher/ocr/chemical_ocr.py:76-84, 366-392).  The checkpoint itself (`checkpoints/chemicalocr_v3`) is not in the
+reference tree: the "smoldocling" preset below is the published SmolDocling-256M geometry and is INFERRED, like SURVEY.md says;
+key names are those of stock `Idefics3ForConditionalGeneration` (transformers 5.15, models/idefics3/modeling_idefics3.py).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, asdict
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+from .synth import uniform_pm1, round_bf16
+
+
+@dataclass(frozen=True)
+class OcrShape:
+    # vision tower (Idefics3VisionConfig)
+    v_hidden: int = 768
+    v_inter: int = 3072
+    v_layers: int = 12
+    v_heads: int = 12
+    image_size: int = 512
+    patch_size: int = 16
+    v_eps: float = 1e-6
+    # text model (LlamaConfig)
+    t_hidden: int = 576
+    t_inter: int = 1536
+    t_layers: int = 30
+    t_heads: int = 9
+    t_kv_heads: int = 3
+    vocab: int = 49280
+    rms_eps: float = 1e-5
+    rope_theta: float = 100000.0
+    # glue (Idefics3Config)
+    scale_factor: int = 4
+    image_token_id: int = 49190
+    eos_token_id: int = 49279
+    pad_token_id: int = 2
+    tie_word_embeddings: bool = False
+
+    @property
+    def patches(self) -> int:
+        return (self.image_size // self.patch_size) ** 2
+
+    @property
+    def image_seq_len(self) -> int:
+        return self.patches // (self.scale_factor ** 2)
+
+    def as_dict(self):
+        return asdict(self)
+
+
+PRESETS = {
+    # SmolDocling-256M geometry (INFERRED for the reference's ChemicalOCR checkpoint)
+    "smoldocling": OcrShape(),
+    # parity fixture: every code path of the big one at a size the CPU oracle and the SIMT emulator finish in seconds
+    "tiny": OcrShape(v_hidden=64, v_inter=128, v_layers=2, v_heads=1, image_size=64, patch_size=16, t_hidden=128, t_inter=256,
+                     t_layers=2, t_heads=2, t_kv_heads=1, vocab=320, scale_factor=2, image_token_id=300, eos_token_id=1,
+                     pad_token_id=2),
+}
+
+
+def state_dict_spec(s: OcrShape) -> List[Tuple[str, Tuple[int, ...], str]]:
+    """(HF key, shape, kind) in stock order; kind in {linear, bias, norm_w, norm_b, embed, conv}."""
+    out = []
+    v = "model.vision_model."
+    out.append((v + "embeddings.patch_embedding.weight", (s.v_hidden, 3, s.patch_size, s.patch_size), "conv"))
+    out.append((v + "embeddings.patch_embedding.bias", (s.v_hidden,), "bias"))
+    out.append((v + "embeddings.position_embedding.weight", (s.patches, s.v_hidden), "embed"))
+    for i in range(s.v_layers):
+        p = f"{v}encoder.layers.{i}."
+        for n in ("k_proj", "v_proj", "q_proj", "out_proj"):
+            out.append((p + f"self_attn.{n}.weight", (s.v_hidden, s.v_hidden), "linear"))
+            out.append((p + f"self_attn.{n}.bias", (s.v_hidden,), "bias"))
+        out.append((p + "layer_norm1.weight", (s.v_hidden,), "norm_w"))
+        out.append((p + "layer_norm1.bias", (s.v_hidden,), "norm_b"))
+        out.append((p + "mlp.fc1.weight", (s.v_inter, s.v_hidden), "linear"))
+        out.append((p + "mlp.fc1.bias", (s.v_inter,), "bias"))
+        out.append((p + "mlp.fc2.weight", (s.v_hidden, s.v_inter), "linear"))
+        out.append((p + "mlp.fc2.bias", (s.v_hidden,), "bias"))
+        out.append((p + "layer_norm2.weight", (s.v_hidden,), "norm_w"))
+        out.append((p + "layer_norm2.bias", (s.v_hidden,), "norm_b"))
+    out.append((v + "post_layernorm.weight", (s.v_hidden,), "norm_w"))
+    out.append((v + "post_layernorm.bias", (s.v_hidden,), "norm_b"))
+    out.append(("model.connector.modality_projection.proj.weight", (s.t_hidden, s.v_hidden * s.scale_factor ** 2), "linear"))
+    t = "model.text_model."
+    out.append((t + "embed_tokens.weight", (s.vocab, s.t_hidden), "embed"))
+    kvd = s.t_kv_heads * 64
+    for i in range(s.t_layers):
+        p = f"{t}layers.{i}."
+        out.append((p + "self_attn.q_proj.weight", (s.t_hidden, s.t_hidden), "linear"))
+        out.append((p + "self_attn.k_proj.weight", (kvd, s.t_hidden), "linear"))
+        out.append((p + "self_attn.v_proj.weight", (kvd, s.t_hidden), "linear"))
+        out.append((p + "self_attn.o_proj.weight", (s.t_hidden, s.t_hidden), "linear"))
+        out.append((p + "mlp.gate_proj.weight", (s.t_inter, s.t_hidden), "linear"))
+        out.append((p + "mlp.up_proj.weight", (s.t_inter, s.t_hidden), "linear"))
+        out.append((p + "mlp.down_proj.weight", (s.t_hidden, s.t_inter), "linear"))
+        out.append((p + "input_layernorm.weight", (s.t_hidden,), "norm_w"))
+        out.append((p + "post_attention_layernorm.weight", (s.t_hidden,), "norm_w"))
+    out.append((t + "norm.weight", (s.t_hidden,), "norm_w"))
+    if not s.tie_word_embeddings:
+        out.append(("lm_head.weight", (s.vocab, s.t_hidden), "embed"))
+    return out
+
+
+def recipe_state_dict(s: OcrShape, seed: int = 20260929, gain: float = 1.0) -> Dict[str, np.ndarray]:
+    """Counter-based weights (bf16-exact fp32): linear ~ U(-1,1) * gain * sqrt(3 / fan_in), embeddings U(-1,1) * 0.5, norm weights
+    1 + 0.1 U, biases 0.1 U.  Regenerated identically on the GPU box; nothing is stored."""
+    sd = {}
+    for name, shape, kind in state_dict_spec(s):
+        u = uniform_pm1("ocr/" + name, shape, seed)
+        if kind in ("linear", "conv"):
+            fan_in = int(np.prod(shape[1:]))
+            w = u * np.float32(gain * np.sqrt(3.0 / fan_in))
+        elif kind == "embed":
+            w = u * np.float32(0.5)
+        elif kind == "norm_w":
+            w = np.float32(1.0) + np.float32(0.1) * u
+        else:
+            w = np.float32(0.1) * u
+        sd[name] = round_bf16(w.astype(np.float32))
+    return sd
+
+
+def synth_inputs(s: OcrShape, B: int, prompt_text_tokens: int = 12, seed: int = 20260929):
+    """The reference's input contract for one page per sample (chemical_ocr.py:366-373 with the Idefics3 processor): prompt ids
+    = [text..., <fake>, <image> x image_seq_len, <fake>, text...] and pixel_values [B][1][3][I][I] in [-1, 1] (full image, no
+    padding: pixel_attention_mask all ones).  Token ids avoid the image / eos / pad ids."""
+    from .synth import randint
+    n_img = s.image_seq_len
+    head = prompt_text_tokens // 2
+    tail = prompt_text_tokens - head
+    hi = min(s.vocab, s.image_token_id) - 2
+    ids = np.zeros((B, head + 1 + n_img + 1 + tail), np.int64)
+    fake = hi + 1 if hi + 1 != s.image_token_id else hi
+    for b in range(B):
+        t = randint(f"ocr/prompt/{b}", prompt_text_tokens, 3, hi - 1, seed)
+        ids[b, :head] = t[:head]
+        ids[b, head] = fake
+        ids[b, head + 1:head + 1 + n_img] = s.image_token_id
+        ids[b, head + 1 + n_img] = fake
+        ids[b, head + 2 + n_img:] = t[head:]
+    pix = uniform_pm1("ocr/pixels", (B, 1, 3, s.image_size, s.image_size), seed).astype(np.float32)
+    # page-like: mostly white with dark strokes (smooth-ish blocks), still fully deterministic
+    blocks = uniform_pm1("ocr/blocks", (B, 1, 1, s.image_size // 8, s.image_size // 8), seed)
+    pix = np.where(np.repeat(np.repeat(blocks, 8, -1), 8, -2) > 0.7, pix, np.float32(1.0) - np.float32(0.05) * np.abs(pix))
+    return ids, pix.astype(np.float32)

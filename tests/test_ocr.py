@@ -1,0 +1,143 @@
+"""ChemicalOCR stage: oracle vs the stock-Idefics3 golden vectors, and the C ABI `mg_ocr_*` against both.
+
+Fixtures (tools/make_golden_ocr.py, minted from stock transformers Idefics3ForConditionalGeneration on recipe weights):
+  ocr_tiny.npz        every code path at a size the emulator finishes in seconds; B = 3, rows end at different steps (EOS)
+  ocr_smoldocling.npz SmolDocling-256M geometry (INFERRED for the reference's checkpoint), B = 2, 8 greedy steps
+
+Tolerances: the HIP path keeps weights and GEMM / attention operands in bf16 with fp32 accumulation and an fp32 residual
+stream; the golden vectors are fp32.
+  * image features: max-abs error < 5 % of their mean magnitude (FEAT_TOL below)
+  * logits: max-abs error < 1.5 % of the fixture's max |logit| + 0.02 (the main path's rule)
+  * ids: equal wherever stock's top-1 / top-2 margin exceeds 4x the logit tolerance; after the first low-margin step of a
+    row the comparison of that row stops (its continuation legitimately differs)."""
+import numpy as np
+import pytest
+
+from markushgrapher_amd.ocr_shapes import PRESETS, recipe_state_dict, synth_inputs
+from tests.backends import get_backend, NumpyMem
+from tests.conftest import load_golden
+
+BACKENDS = [pytest.param("emu"), pytest.param("hip", marks=pytest.mark.gpu)]
+
+
+def logit_tol(absmax):
+    return 0.015 * float(absmax) + 0.02
+
+
+def _setup(name):
+    import dataclasses
+    g = load_golden(f"ocr_{name}.npz")
+    s = dataclasses.replace(PRESETS[name], eos_token_id=int(g["eos_token_id"]))
+    sd = recipe_state_dict(s, gain=float(g["gain"]))
+    ids, pix = synth_inputs(s, int(g["B"]))
+    assert np.array_equal(ids, g["input_ids"])
+    return g, s, sd, ids, pix
+
+
+def make_ocr(be_name, s, sd):
+    from markushgrapher_amd.ocr import OcrEngine
+    be = get_backend(be_name)
+    eng = OcrEngine(s, lib=be.lib, mem=NumpyMem()) if be_name == "emu" else OcrEngine(s)
+    return eng.load_state_dict(sd)
+
+
+def test_oracle_reproduces_stock_tiny():
+    """The CPU restatement against the stock outputs stored in the fixture (full logits, image features, ids with EOS)."""
+    import torch
+    from oracle.ocr_oracle import OcrOracle
+    g, s, sd, ids, pix = _setup("tiny")
+    orc = OcrOracle(s, sd)
+    with torch.no_grad():
+        feats = orc.image_features(pix).numpy()
+        logits = orc.forward(ids, pix).numpy()
+        new = orc.generate(ids, pix, int(g["new_tokens"])).numpy()
+    assert np.abs(feats - g["feats"]).max() < 2e-4
+    assert np.abs(logits - g["logits"]).max() < 2e-3
+    assert np.array_equal(new, g["new_ids"])
+    # rows end at different steps, finished rows are padded
+    assert (g["new_ids"][0] == s.pad_token_id).any() and not (g["new_ids"] == s.pad_token_id).all(axis=1).any()
+
+
+def test_recipe_and_spec_are_consistent():
+    from markushgrapher_amd.ocr_shapes import state_dict_spec
+    for name in ("tiny", "smoldocling"):
+        s = PRESETS[name]
+        spec = state_dict_spec(s)
+        assert len({k for k, _, _ in spec}) == len(spec)
+        n = sum(int(np.prod(shape)) for _, shape, _ in spec)
+        assert n > 0
+    assert 2.4e8 < sum(int(np.prod(shape)) for _, shape, _ in state_dict_spec(PRESETS["smoldocling"])) < 2.9e8   # "256M"
+
+
+def _check_generate(g, s, new, cap):
+    tol = logit_tol(g["logits_absmax"])
+    ref_ids, margin = g["new_ids"], g["step_margin"]
+    vals, idx = g["step_top8_val"], g["step_top8_idx"]
+    n = ref_ids.shape[1]
+    assert new.shape[1] <= int(g["new_tokens"])
+    checked = 0
+    for b in range(ref_ids.shape[0]):
+        alive = True
+        for t in range(n):
+            if not alive or ref_ids[b, t] == s.pad_token_id and t > 0 and (ref_ids[b, :t] == s.eos_token_id).any():
+                break
+            if t < cap.shape[0]:
+                got = cap[t, b, idx[b, t]]
+                assert np.abs(got - vals[b, t]).max() < tol, (b, t, got, vals[b, t])
+            if margin[b, t] > 4 * tol:
+                assert t < new.shape[1] and new[b, t] == ref_ids[b, t], (b, t, new[b].tolist(), ref_ids[b].tolist())
+                checked += 1
+            else:
+                alive = t < new.shape[1] and new[b, t] == ref_ids[b, t]
+    assert checked >= ref_ids.shape[0]
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+def test_ocr_tiny_matches_stock(be_name):
+    g, s, sd, ids, pix = _setup("tiny")
+    eng = make_ocr(be_name, s, sd)
+    feats = eng.mem.numpy(eng.image_features(pix[:, 0]))
+    FEAT_TOL = 0.05 * float(g["feats_abs_mean"])
+    assert np.abs(feats - g["feats"]).max() < FEAT_TOL, np.abs(feats - g["feats"]).max()
+    logits = eng.mem.numpy(eng.forward_logits(ids, pix))
+    tol = logit_tol(g["logits_absmax"])
+    assert np.abs(logits - g["logits"]).max() < tol, (np.abs(logits - g["logits"]).max(), tol)
+    new, cap = eng.generate(ids, pix, int(g["new_tokens"]), capture_steps=int(g["new_tokens"]))
+    new, cap = eng.mem.numpy(new), eng.mem.numpy(cap)
+    _check_generate(g, s, new, cap)
+    # the run stops when every row has ended: same number of columns as stock, finished rows padded
+    assert new.shape == g["new_ids"].shape
+    fin = g["new_ids"] == s.pad_token_id
+    assert np.array_equal(new[fin], g["new_ids"][fin])
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+def test_ocr_rejects_bad_inputs(be_name):
+    from markushgrapher_amd.engine import MgError
+    g, s, sd, ids, pix = _setup("tiny")
+    eng = make_ocr(be_name, s, sd)
+    bad = ids.copy()
+    bad[0, 0] = s.vocab + 5
+    with pytest.raises(MgError):
+        eng.forward_logits(bad, pix)
+    fewer = ids.copy()
+    fewer[1, np.argmax(ids[1] == s.image_token_id)] = 3          # one <image> token short
+    with pytest.raises(MgError):
+        eng.generate(fewer, pix, 2)
+
+
+@pytest.mark.gpu
+def test_ocr_smoldocling_shape_matches_stock():
+    g, s, sd, ids, pix = _setup("smoldocling")
+    eng = make_ocr("hip", s, sd)
+    feats = eng.mem.numpy(eng.image_features(pix[:, 0]))
+    step = max(1, feats.shape[1] // 4)
+    FEAT_TOL = 0.05 * float(g["feats_abs_mean"])
+    assert np.abs(feats[:, ::step] - g["feats_probe"]).max() < FEAT_TOL, np.abs(feats[:, ::step] - g["feats_probe"]).max()
+    assert np.abs(feats.astype(np.float64).sum(axis=(1, 2)) - g["feats_checksum"]).max() < FEAT_TOL * feats.shape[1] * feats.shape[2] * 0.02
+    logits = eng.mem.numpy(eng.forward_logits(ids, pix))
+    tol = logit_tol(g["logits_absmax"])
+    got = np.take_along_axis(logits, g["logits_top8_idx"], axis=-1)
+    assert np.abs(got - g["logits_top8_val"]).max() < tol, (np.abs(got - g["logits_top8_val"]).max(), tol)
+    new, cap = eng.generate(ids, pix, int(g["new_tokens"]), capture_steps=int(g["new_tokens"]))
+    _check_generate(g, s, eng.mem.numpy(new), eng.mem.numpy(cap))
