@@ -82,6 +82,38 @@ def cpu_baseline(shape, sd, L=128, new_tokens=128, sample_steps=8, reps=3):
                       f"extrapolated to {new_tokens} steps); value = B=4"}
 
 
+def ocr_stage_run(B=32, new_tokens=256):
+    """SURVEY.md §8 row f-1 (BASELINE configs[4] names the stage): ChemicalOCR = an Idefics3-class VLM, SmolDocling-256M geometry
+    (INFERRED), one 512-px page per sequence, greedy.  EOS cannot occur (eos id -1), so the work is fixed: vision tower +
+    prompt prefill + `new_tokens` KV-cached steps.  First form of the stage (eager launches, one kernel per operation)."""
+    import dataclasses
+    import torch
+    from markushgrapher_amd.ocr import OcrEngine
+    from markushgrapher_amd.ocr_shapes import PRESETS, recipe_state_dict, synth_inputs
+    s = dataclasses.replace(PRESETS["smoldocling"], eos_token_id=-1)
+    eng = OcrEngine(s).load_state_dict(recipe_state_dict(s))
+    ids, pix = synth_inputs(s, B)
+    ids, pix = torch.from_numpy(ids).cuda(), torch.from_numpy(pix).cuda()
+
+    def run(n):
+        torch.cuda.synchronize(); t0 = time.time()
+        eng.generate(ids, pix, n)
+        torch.cuda.synchronize()
+        return time.time() - t0
+    run(2)
+    t1 = min(run(1), run(1))                  # vision tower + prefill + first selection
+    tn = min(run(new_tokens), run(new_tokens))
+    step_ms = (tn - t1) / (new_tokens - 1) * 1e3
+    wbytes = 2 * (s.t_layers * ((s.t_heads + 2 * s.t_kv_heads) * 64 * s.t_hidden + s.t_hidden * s.t_hidden + 3 * s.t_inter * s.t_hidden) + s.vocab * s.t_hidden)
+    L = int(ids.shape[1])
+    kvbytes = B * s.t_layers * 2 * s.t_heads * 64 * 2 * (L + new_tokens / 2)      # caches hold the repeated key/value heads
+    return {"pages_per_s": round(B / tn, 2), "ms_per_batch": round(tn * 1e3, 1), "new_tokens": new_tokens, "batch": B, "prompt_len": L,
+            "vision_plus_prefill_ms": round(t1 * 1e3, 2), "decode_step_ms": round(step_ms, 4),
+            "dec_hbm_frac": round((wbytes + kvbytes) / (step_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
+            "config": "ChemicalOCR stage alone: SmolDocling-256M geometry (INFERRED), recipe weights, one 512-px page per sequence, "
+                      "greedy, EOS impossible; first form (eager launches, fp32 intermediates)"}
+
+
 def pmc_child(args):
     """Child mode (run under rocprofv3 --pmc FETCH_SIZE by the parent): one short pass of the same workload."""
     import torch
@@ -327,6 +359,7 @@ def main():
                                     "config": "greedy, EOS enabled (generate(max_length=512) as the reference calls it), same inputs; EOS "
                                               "embedding row scaled so rows end at different steps"}
             eng.load_state_dict({"shared.weight": sd["shared.weight"]})
+            extra["ocr_stage"] = ocr_stage_run()
         out = {
             "metric": METRIC, "value": round(world * B * args.steps / dt, 3), "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),

@@ -95,4 +95,4 @@ if __name__ == "__main__":
     if "tiny" in what:
         mint("tiny", B=3, new_tokens=12, gain=0.7, eos_from_step=5)
     if "smoldocling" in what:
-        mint("smoldocling", B=2, new_tokens=8, gain=1.5)
+        mint("smoldocling", B=2, new_tokens=8, gain=1.0)
