@@ -34,7 +34,7 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a, long
     const int sub = lane & 7, ks = lane >> 3;
     const int owner = blockIdx.x / a.H, h = blockIdx.x - owner * a.H;
     if constexpr (G == 1) { if (a.live && a.live[owner] == 0) return; }       // finished row (whole workgroup: uniform)
-    const int tcur = a.t_dev ? *a.t_dev : a.t;
+    const int tcur = a.t_dev ? *a.t_dev + a.t_off : a.t;
     const int nkeys_all = XA ? a.len[owner] : (a.t_dev ? tcur + 1 : a.n_keys);
     // with an in-kernel append the newest key (position t) comes from registers, the cache holds [0, t)
     const bool app0 = (G == 1) && a.qkv.P && a.self_append;

@@ -222,6 +222,7 @@ struct AttnStepArgs {
     const int* anc;           // self with beams: [T_cap][rows] physical row holding position j (nullable)
     int t;                    // current position (self)
     const int* t_dev;         // if non-null: t (and n_keys = t+1 for self-attention) are read from device memory
+    int t_off;                // added to *t_dev (the OCR stage's position = prompt length - 1 + step counter)
     RowScale qrs;             // deferred RMSNorm scale of the query rows (scores are multiplied by r(row)); part = null: none
     int ctx_ld, ctx_col0;     // ctx as a column window of a wider packed buffer (ctx_ld = 0: H*64 columns, offset 0)
     // split-K form of the projections feeding this step: q (and for self-attention k, v of the new position) are

@@ -11,6 +11,7 @@
 
 #include <math.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 #include <map>
@@ -67,6 +68,21 @@ struct mg_ocr_model {
     std::vector<TLayer> tl;
     size_t patch_w, pos_emb, conn, tok_emb, lm_head, zero_tab;
     bool finalized = false;
+    // one decode step (30 layers x 9 launches + lm_head + selection) captured as a HIP graph whose kernels read the position from the
+    // device step counter; replayed while the call's buffers and sizes match (MG_OCR_GRAPH=0: eager launches, same kernels)
+    int use_graph = 1;
+    bool graph_active = false;
+    struct Key { const void *ws, *out, *stream; int B, L, max_new; bool operator==(const Key& o) const { return ws == o.ws && out == o.out && stream == o.stream && B == o.B && L == o.L && max_new == o.max_new; } } gkey{};
+    bool gvalid = false;
+#ifndef MG_EMU
+    hipGraphExec_t gexec = nullptr;
+    hipStream_t own_stream = nullptr;
+    hipEvent_t fork_ev = nullptr;
+    void greset() { if (gexec) (void)hipGraphExecDestroy(gexec); gexec = nullptr; gvalid = false; }
+    ~mg_ocr_model() { greset(); if (own_stream) (void)hipStreamDestroy(own_stream); if (fork_ev) (void)hipEventDestroy(fork_ev); }
+#else
+    void greset() { gvalid = false; }
+#endif
     template <typename T> T* at(size_t off) const { return (T*)(arena + off); }
     const float* rawp(const std::string& k) const { return (const float*)(arena + raw.at(k).off); }
 };
@@ -211,7 +227,8 @@ void prefill(const mg_ocr_model* m, const Ws& w, const int64_t* ids, const float
 }
 
 // one decode step for B rows: token ids in w.next_ids, position `pos`; logits -> w.logits
-void decode_step(const mg_ocr_model* m, const Ws& w, int B, int pos, int cap, mgStream_t st) {
+// pos_dev != null: position = *pos_dev + pos (graph replay: pos_dev = the step counter, pos = prompt length - 1)
+void decode_step(const mg_ocr_model* m, const Ws& w, int B, int pos, const int* pos_dev, int cap, mgStream_t st) {
     const mg_ocr_config& c = m->c;
     const int td = c.t_hidden, ti = c.t_inter, H = c.t_heads, KV = c.t_kv_heads;
     embed_rows(w.next_ids, m->at<uint16_t>(m->tok_emb), w.h, B, td, c.vocab, w.counters + 3, st);
@@ -224,9 +241,10 @@ void decode_step(const mg_ocr_model* m, const Ws& w, int B, int pos, int cap, mg
         GemmArgs a = ga(w.x, m->at<uint16_t>(l.wqkv), B, m->qkvn, td);
         a.out_f32 = w.qkv; a.ldo = m->qkvn;
         gemm_rows(a, EPI_F32_STORE, st);
-        ocr_rope_step(w.qkv, B, H, KV, c.rope_theta, pos, nullptr, w.dq, Kc, Vc, cap, st);
+        ocr_rope_step(w.qkv, B, H, KV, c.rope_theta, pos, pos_dev, w.dq, Kc, Vc, cap, st);
         AttnStepArgs s{};
         s.q = w.dq; s.Kc = Kc; s.Vc = Vc; s.ctx = w.ctx; s.rows = B; s.H = H; s.group = 1; s.cap = cap; s.n_keys = pos + 1; s.t = pos;
+        s.t_dev = pos_dev; s.t_off = pos;
         attention_step(s, st);
         GemmArgs o = ga(w.ctx, m->at<uint16_t>(l.wo), B, td, H * 64);
         o.out_f32 = w.h; o.ldo = td;
@@ -318,6 +336,7 @@ int mg_ocr_create(const mg_ocr_config* cfg, mg_ocr_model** out) {
     m->lm_head = pk(c.vocab, (int)td);
     off = align_up(off, 256); m->zero_tab = off; off += 64 * sizeof(float);
     m->arena_bytes = align_up(off, 256);
+    { const char* e = getenv("MG_OCR_GRAPH"); if (e && e[0] == '0') m->use_graph = 0; }
     *out = m;
     return MG_OK;
 }
@@ -447,6 +466,16 @@ int mg_ocr_generate(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, co
     carve(m, (char*)ws, B, n_img, L, max_new_tokens, false, &w);
     if (!ws || ws_bytes < w.total) return failf(MG_E_WORKSPACE, "mg_ocr_generate: workspace %zu < %zu bytes", ws_bytes, w.total);
     mgStream_t st = (mgStream_t)stream;
+#ifndef MG_EMU
+    // the legacy null stream cannot be captured: the call then runs on a stream the model owns, ordered after the caller's stream
+    // by an event and host-synchronised before returning (as mg_generate does)
+    if (m->use_graph == 1 && st == nullptr && !step_logits) {
+        if (!m->own_stream && hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking) != hipSuccess) m->own_stream = nullptr;
+        if (!m->fork_ev && hipEventCreateWithFlags(&m->fork_ev, hipEventDisableTiming) != hipSuccess) m->fork_ev = nullptr;
+        if (m->own_stream && m->fork_ev && hipEventRecord(m->fork_ev, st) == hipSuccess && hipStreamWaitEvent(m->own_stream, m->fork_ev, 0) == hipSuccess)
+            st = m->own_stream;
+    }
+#endif
     const mg_ocr_config& c = m->c;
     const int cap = round_up(L + max_new_tokens, 64), T_cap = round_up(L, 64);
     mg_memset_async(w.counters, 0, 16 * sizeof(int), st);
@@ -460,22 +489,55 @@ int mg_ocr_generate(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, co
     gemm_rows(lg, EPI_F32_STORE, st);
     int host_flag[4] = {0, 0, 0, 0};
     int steps = 0;
-    for (int t = 0; t < max_new_tokens; ++t) {
-        if (step_logits && t < capture_steps)
-            MG_LAUNCH(copy_f32_kernel, dim3(256), dim3(256), 0, st, (const float*)w.logits, step_logits + (size_t)t * B * c.vocab, (size_t)B * c.vocab);
+    auto select = [&](int t, const int* pos_dev) {
         ArgmaxArgs g{};
         g.logits = w.logits; g.rows = B; g.V = c.vocab; g.ldl = c.vocab; g.eos = c.eos_token_id; g.pad = c.pad_token_id;
-        g.next_ids = w.next_ids; g.out_ids = out_ids; g.max_len = max_new_tokens; g.pos = t; g.min_len = 0;
+        g.next_ids = w.next_ids; g.out_ids = out_ids; g.max_len = max_new_tokens; g.pos = pos_dev ? 0 : t; g.pos_dev = pos_dev; g.min_len = 0;
         g.unfinished = w.unfinished; g.n_unfinished = w.counters + 5; g.step_ctr = w.counters;
         greedy_select(g, st);
-        steps = t + 1;
-        if (t + 1 == max_new_tokens) break;
-        if ((t & 7) == 7) {     // termination is looked at every 8 steps: overrunning only appends pad columns (trimmed below)
+    };
+    bool graphed = false;
+#ifndef MG_EMU
+    if (m->use_graph == 1 && !step_logits && max_new_tokens > 1) {
+        const mg_ocr_model::Key key{ws, out_ids, (const void*)st, B, L, max_new_tokens};
+        if (!(m->gvalid && m->gkey == key)) {
+            m->greset();
+            hipGraph_t graph = nullptr;
+            if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                decode_step(m, w, B, L - 1, w.counters + 2, cap, st);       // position = L - 1 + step counter (>= 1 here)
+                select(0, w.counters + 2);
+                if (hipStreamEndCapture(st, &graph) == hipSuccess && graph &&
+                    hipGraphInstantiate(&m->gexec, graph, nullptr, nullptr, 0) == hipSuccess) { m->gkey = key; m->gvalid = true; }
+                if (graph) (void)hipGraphDestroy(graph);
+            }
+            (void)hipGetLastError();
+        }
+        graphed = m->gvalid;
+    }
+#endif
+    m->graph_active = graphed;
+    if (step_logits && capture_steps > 0)
+        MG_LAUNCH(copy_f32_kernel, dim3(256), dim3(256), 0, st, (const float*)w.logits, step_logits, (size_t)B * c.vocab);
+    select(0, nullptr);
+    steps = 1;
+    for (int t = 1; t < max_new_tokens; ++t) {
+        if ((t & 7) == 0) {     // termination is looked at every 8 steps: overrunning only appends pad columns (trimmed below)
             mg_memcpy_async(host_flag, w.counters, sizeof host_flag, st);
             mg_stream_sync(st);
             if (host_flag[0] == 0) break;
         }
-        decode_step(m, w, B, L + t, cap, st);
+#ifndef MG_EMU
+        if (graphed) {
+            if (hipGraphLaunch(m->gexec, st) != hipSuccess) return failf(MG_E_HIP, "mg_ocr_generate: hipGraphLaunch failed");
+        } else
+#endif
+        {
+            decode_step(m, w, B, L + t - 1, nullptr, cap, st);
+            if (step_logits && t < capture_steps)
+                MG_LAUNCH(copy_f32_kernel, dim3(256), dim3(256), 0, st, (const float*)w.logits, step_logits + (size_t)t * B * c.vocab, (size_t)B * c.vocab);
+            select(t, nullptr);
+        }
+        steps = t + 1;
     }
     mg_memcpy_async(host_flag, w.counters, sizeof host_flag, st);
     mg_stream_sync(st);

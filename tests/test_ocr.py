@@ -141,3 +141,22 @@ def test_ocr_smoldocling_shape_matches_stock():
     assert np.abs(got - g["logits_top8_val"]).max() < tol, (np.abs(got - g["logits_top8_val"]).max(), tol)
     new, cap = eng.generate(ids, pix, int(g["new_tokens"]), capture_steps=int(g["new_tokens"]))
     _check_generate(g, s, eng.mem.numpy(new), eng.mem.numpy(cap))
+
+
+@pytest.mark.gpu
+def test_ocr_graph_replay_equals_eager():
+    """The captured decode step (positions read from the device step counter) produces the ids of the eager launches, bit for bit,
+    also when it is replayed by a second call and when rows end early."""
+    g, s, sd, ids, pix = _setup("tiny")
+    eng = make_ocr("hip", s, sd)
+    n = int(g["new_tokens"])
+    eager, _ = eng.generate(ids, pix, n, capture_steps=1)          # instrumented calls launch eagerly
+    eager = eng.mem.numpy(eager).copy()
+    for _ in range(2):
+        got, _ = eng.generate(ids, pix, n)
+        assert np.array_equal(eng.mem.numpy(got), eager)
+    g2, s2, sd2, ids2, pix2 = _setup("smoldocling")
+    eng2 = make_ocr("hip", s2, sd2)
+    a, _ = eng2.generate(ids2, pix2, 24, capture_steps=1)
+    b, _ = eng2.generate(ids2, pix2, 24)
+    assert np.array_equal(eng2.mem.numpy(a), eng2.mem.numpy(b))
