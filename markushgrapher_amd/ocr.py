@@ -139,6 +139,37 @@ class OcrEngine:
         return out[:, :cols.value], cap
 
 
+def shape_from_hf_config(cfg) -> OcrShape:
+    """OcrShape from an Idefics3 `config.json` (a dict, a path to the file, or a checkpoint directory)."""
+    import json
+    import os
+    if not isinstance(cfg, dict):
+        path = os.path.join(cfg, "config.json") if os.path.isdir(cfg) else cfg
+        with open(path) as f:
+            cfg = json.load(f)
+    v, t = cfg.get("vision_config", {}), cfg.get("text_config", {})
+    rope = t.get("rope_parameters") or {}
+    d = PRESETS["smoldocling"]
+    eos = cfg.get("eos_token_id", t.get("eos_token_id", d.eos_token_id))
+    if isinstance(eos, (list, tuple)):
+        eos = eos[0]
+    if v.get("hidden_act", "gelu_pytorch_tanh") != "gelu_pytorch_tanh" or t.get("hidden_act", "silu") != "silu":
+        raise MgError("unsupported activation (vision: gelu_pytorch_tanh, text: silu)")
+    if t.get("model_type", "llama") != "llama" or t.get("attention_bias", False) or t.get("mlp_bias", False):
+        raise MgError("unsupported text model (bias-free Llama blocks only)")
+    return OcrShape(
+        v_hidden=v.get("hidden_size", 1152), v_inter=v.get("intermediate_size", 3072), v_layers=v.get("num_hidden_layers", 12),
+        v_heads=v.get("num_attention_heads", 16), image_size=v.get("image_size", 224), patch_size=v.get("patch_size", 32),
+        v_eps=float(v.get("layer_norm_eps", 1e-6)),
+        t_hidden=t.get("hidden_size", 4096), t_inter=t.get("intermediate_size", 11008), t_layers=t.get("num_hidden_layers", 32),
+        t_heads=t.get("num_attention_heads", 32), t_kv_heads=t.get("num_key_value_heads", t.get("num_attention_heads", 32)),
+        vocab=t.get("vocab_size", cfg.get("vocab_size", d.vocab)), rms_eps=float(t.get("rms_norm_eps", 1e-6)),
+        rope_theta=float(rope.get("rope_theta", t.get("rope_theta", 10000.0))),
+        scale_factor=cfg.get("scale_factor", 2), image_token_id=cfg.get("image_token_id", d.image_token_id), eos_token_id=int(eos),
+        pad_token_id=int(cfg.get("pad_token_id", t.get("pad_token_id", 0)) or 0),
+        tie_word_embeddings=bool(cfg.get("tie_word_embeddings", t.get("tie_word_embeddings", False))))
+
+
 class OcrModel:
     """The slice of the HF surface ChemicalOCR touches (`.generate(**inputs, max_new_tokens=, do_sample=False)`, `.eval()`, `.to()`)."""
 
@@ -146,6 +177,28 @@ class OcrModel:
         self.engine = OcrEngine(shape, mem=TorchMem(device)).load_state_dict(state_dict)
         self.shape = shape
 
+    @classmethod
+    def from_pretrained(cls, path, device=None, **_unused):
+        """Checkpoint directory of an Idefics3-class model (config.json + *.safetensors), as `AutoModelForVision2Seq.from_pretrained`
+        takes it (chemical_ocr.py:76-84)."""
+        import glob
+        import os
+        from safetensors import safe_open
+        shape = shape_from_hf_config(path)
+        sd = {}
+        files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
+        if not files:
+            raise MgError(f"no *.safetensors under {path}")
+        for fn in files:
+            with safe_open(fn, framework="pt") as f:
+                for k in f.keys():
+                    sd[k] = f.get_tensor(k)
+        if shape.tie_word_embeddings and "lm_head.weight" in sd:
+            del sd["lm_head.weight"]
+        return cls(shape, sd, device=device)
+
+    def eval(self):
+        return self
     def eval(self):
         return self
 

@@ -151,3 +151,17 @@ def test_word_boxes_and_cell_text_match_the_reference_functions():
         assert A.estimate_word_width(w_) == r
     for t, r in g["misc"]["normalText"]:
         assert A.normal_text(t) == r
+
+
+def test_ocr_text_parser_matches_reference_outputs():
+    """ocr_text.parse_ocr_string / clean_ocr_text against outputs of the reference's own functions (tools/make_golden_ocrtext.py)."""
+    import json
+    import os
+    from markushgrapher_amd import ocr_text
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "host_ocrtext.json")))
+    for c in g["parse"]:
+        w, b = ocr_text.parse_ocr_string(c["in"])
+        assert w == c["words"] and b == c["boxes"], (c["in"], w, b, c["words"], c["boxes"])
+    for c in g["clean"]:
+        assert ocr_text.clean_ocr_text(c["in"]) == c["out"], c["in"]
+        assert ocr_text.clean_ocr_text(c["in"], end_tag=None) == c["out_no_end"], c["in"]

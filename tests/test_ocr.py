@@ -160,3 +160,47 @@ def test_ocr_graph_replay_equals_eager():
     a, _ = eng2.generate(ids2, pix2, 24, capture_steps=1)
     b, _ = eng2.generate(ids2, pix2, 24)
     assert np.array_equal(eng2.mem.numpy(a), eng2.mem.numpy(b))
+
+
+def _stock_tiny(tmp_path, s, sd):
+    import torch
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    from make_golden_ocr import stock_model
+    m = stock_model(s, sd)
+    m.save_pretrained(str(tmp_path), safe_serialization=True)
+    return m
+
+
+def test_shape_from_hf_config_roundtrip(tmp_path):
+    """config.json written by the stock class -> OcrShape: what from_pretrained builds the engine from."""
+    import dataclasses
+    from markushgrapher_amd.ocr import shape_from_hf_config
+    g, s, sd, ids, pix = _setup("tiny")
+    _stock_tiny(tmp_path, s, sd)
+    got = shape_from_hf_config(str(tmp_path))
+    assert dataclasses.asdict(got) == dataclasses.asdict(s)
+
+
+@pytest.mark.gpu
+def test_ocr_model_from_pretrained_generates_like_stock(tmp_path):
+    """The reference-facing surface: OcrModel.from_pretrained(dir).generate(**inputs, max_new_tokens=, do_sample=False) returns
+    [prompt | new tokens] as the stock model does (chemical_ocr.py:375-386)."""
+    import torch
+    from markushgrapher_amd.ocr import OcrModel
+    g, s, sd, ids, pix = _setup("tiny")
+    _stock_tiny(tmp_path, s, sd)
+    model = OcrModel.from_pretrained(str(tmp_path)).eval()
+    tid, tpix = torch.from_numpy(ids), torch.from_numpy(pix)
+    out = model.generate(input_ids=tid, attention_mask=torch.ones_like(tid), pixel_values=tpix,
+                         pixel_attention_mask=torch.ones(ids.shape[0], 1, s.image_size, s.image_size, dtype=torch.bool),
+                         max_new_tokens=int(g["new_tokens"]), do_sample=False).cpu().numpy()
+    assert np.array_equal(out[:, :ids.shape[1]], ids)
+    new = out[:, ids.shape[1]:]
+    ref, margin = g["new_ids"], g["step_margin"]
+    tol = logit_tol(g["logits_absmax"])
+    for b in range(ref.shape[0]):
+        for t in range(min(new.shape[1], ref.shape[1])):
+            if margin[b, t] <= 4 * tol:
+                break
+            assert new[b, t] == ref[b, t]
