@@ -183,19 +183,39 @@ __global__ __launch_bounds__(256) void rope_heads_kernel(const float* qkv, int B
         }
     }
 }
+// r(row) = rsqrt(sum(part[row][0..nparts)) * inv_d + eps) of the deferred RMSNorm (RowScale), by the whole workgroup; 1 if part is null
+MG_DEV float block_row_scale(const RowScale& rs, int row, float* red, int tid, int nthreads) {
+    if (!rs.part) return 1.0f;
+    float t = 0.f;
+    for (int i = tid; i < rs.nparts; i += nthreads) t += rs.part[(size_t)row * rs.nparts + i];
+    return rsqrtf(block_sum(t, red, tid, nthreads) * rs.inv_d + rs.eps);
+}
+// y_pk[m][0..I) = bf16(silu(r g) * (r u)), r = the deferred RMSNorm scale of row m (gate | up were projected from the un-normalised
+// bf16(h * gain)); one workgroup per row
+__global__ __launch_bounds__(256) void silu_mul_rows_kernel(const float* in, RowScale rs, uint16_t* y_pk, int M, int I) {
+    MG_DYN_SMEM(smem);
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const float r = block_row_scale(rs, m, (float*)smem, tid, 256);
+    for (int c = tid; c < I; c += 256) {
+        const float g = in[(size_t)m * 2 * I + c] * r, u = in[(size_t)m * 2 * I + I + c] * r;
+        y_pk[pk_off(m, c, I)] = f32_to_bf16_rn(g / (1.0f + fast_exp(-g)) * u);
+    }
+}
 // Decode step: one new position `pos` per sequence: q -> [B][H][64] bf16 (scaled), k / v appended to the caches
-__global__ __launch_bounds__(256) void rope_step_kernel(const float* qkv, int B, int H, int KV, float theta_log2, int pos, const int* pos_dev,
-                                                        uint16_t* q_out, uint16_t* Kc, uint16_t* Vc, int cap) {
+__global__ __launch_bounds__(256) void rope_step_kernel(const float* qkv, RowScale rs, int B, int H, int KV, float theta_log2, int pos,
+                                                        const int* pos_dev, uint16_t* q_out, uint16_t* Kc, uint16_t* Vc, int cap) {
+    MG_DYN_SMEM(smem);
     const int rep = H / KV, ld = (H + 2 * KV) * 64;
     const int p = pos_dev ? *pos_dev + pos : pos;
-    const int n = B * H * 32;
-    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n; idx += gridDim.x * 256) {
-        const int i = idx & 31, hh = (idx >> 5) % H, b = (idx >> 5) / H;
-        const float* row = qkv + (size_t)b * ld;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float r = block_row_scale(rs, b, (float*)smem, tid, 256);        // deferred RMSNorm scale of the row (1 without partials)
+    const float* row = qkv + (size_t)b * ld;
+    for (int idx = tid; idx < H * 32; idx += 256) {
+        const int i = idx & 31, hh = idx >> 5;
         const int g = hh / rep;
-        float q0 = row[hh * 64 + i], q1 = row[hh * 64 + 32 + i];
-        float k0 = row[(H + g) * 64 + i], k1 = row[(H + g) * 64 + 32 + i];
-        const float v0 = row[(H + KV + g) * 64 + i], v1 = row[(H + KV + g) * 64 + 32 + i];
+        float q0 = row[hh * 64 + i] * r, q1 = row[hh * 64 + 32 + i] * r;
+        float k0 = row[(H + g) * 64 + i] * r, k1 = row[(H + g) * 64 + 32 + i] * r;
+        const float v0 = row[(H + KV + g) * 64 + i] * r, v1 = row[(H + KV + g) * 64 + 32 + i] * r;
         rope_pair(q0, q1, i, (float)p, theta_log2);
         rope_pair(k0, k1, i, (float)p, theta_log2);
         const size_t qo = ((size_t)b * H + hh) * 64;
@@ -271,9 +291,12 @@ void ocr_rope_heads(const float* qkv, int B, int T, int T_cap, int H, int KV, fl
                     uint16_t* Kc, uint16_t* Vc, int cap, mgStream_t st) {
     MG_LAUNCH(rope_heads_kernel, dim3(grid_for((size_t)B * T_cap * H * 32)), dim3(256), 0, st, qkv, B, T, T_cap, H, KV, log2f(theta), Q, K, Vt, Kc, Vc, cap);
 }
-void ocr_rope_step(const float* qkv, int B, int H, int KV, float theta, int pos, const int* pos_dev, uint16_t* q_out, uint16_t* Kc,
-                   uint16_t* Vc, int cap, mgStream_t st) {
-    MG_LAUNCH(rope_step_kernel, dim3(grid_for((size_t)B * H * 32)), dim3(256), 0, st, qkv, B, H, KV, log2f(theta), pos, pos_dev, q_out, Kc, Vc, cap);
+void ocr_rope_step(const float* qkv, const RowScale& rs, int B, int H, int KV, float theta, int pos, const int* pos_dev, uint16_t* q_out,
+                   uint16_t* Kc, uint16_t* Vc, int cap, mgStream_t st) {
+    MG_LAUNCH(rope_step_kernel, dim3(B), dim3(256), 64, st, qkv, rs, B, H, KV, log2f(theta), pos, pos_dev, q_out, Kc, Vc, cap);
+}
+void ocr_silu_mul_rows(const float* in, const RowScale& rs, uint16_t* y_pk, int M, int I, mgStream_t st) {
+    MG_LAUNCH(silu_mul_rows_kernel, dim3(M), dim3(256), 64, st, in, rs, y_pk, M, I);
 }
 void ocr_pack_aug(const float* W, const float* bias, float scale, uint16_t* dst, int row0, int N, int K, int Kaug, int Nfill, mgStream_t st) {
     MG_LAUNCH(pack_aug_kernel, dim3(grid_for((size_t)Nfill * Kaug)), dim3(256), 0, st, W, bias, scale, dst, row0, N, K, Kaug, Nfill);

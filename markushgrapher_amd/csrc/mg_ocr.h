@@ -1,6 +1,6 @@
 // Launchers of k_ocr.hip (ChemicalOCR stage).
 #pragma once
-#include "mg_device.h"
+#include "mg_kernels.h"
 
 namespace mg {
 void ocr_layernorm_pack(float* h, const float* w, const float* b, const float* add_bias, uint16_t* x_pk, float* out_f32, int M, int d,
@@ -13,8 +13,9 @@ void ocr_merge_embed(const int64_t* ids, const uint16_t* tok_emb, const float* f
                      int image_token, int per_seq, int* err, mgStream_t st);
 void ocr_rope_heads(const float* qkv, int B, int T, int T_cap, int H, int KV, float theta, uint16_t* Q, uint16_t* K, uint16_t* Vt,
                     uint16_t* Kc, uint16_t* Vc, int cap, mgStream_t st);
-void ocr_rope_step(const float* qkv, int B, int H, int KV, float theta, int pos, const int* pos_dev, uint16_t* q_out, uint16_t* Kc,
-                   uint16_t* Vc, int cap, mgStream_t st);
+void ocr_rope_step(const float* qkv, const RowScale& rs, int B, int H, int KV, float theta, int pos, const int* pos_dev, uint16_t* q_out,
+                   uint16_t* Kc, uint16_t* Vc, int cap, mgStream_t st);
+void ocr_silu_mul_rows(const float* in, const RowScale& rs, uint16_t* y_pk, int M, int I, mgStream_t st);
 void ocr_pack_aug(const float* W, const float* bias, float scale, uint16_t* dst, int row0, int N, int K, int Kaug, int Nfill, mgStream_t st);
 void ocr_init(int64_t* out_ids, int* unfinished, int* counters, int rows, int max_new, int64_t pad, mgStream_t st);
 void ocr_row_maps(int* last_rows, int* all_rows, uint8_t* key_mask, int B, int T, int T_cap, mgStream_t st);

@@ -71,6 +71,7 @@ struct mg_ocr_model {
     // one decode step (30 layers x 9 launches + lm_head + selection) captured as a HIP graph whose kernels read the position from the
     // device step counter; replayed while the call's buffers and sizes match (MG_OCR_GRAPH=0: eager launches, same kernels)
     int use_graph = 1;
+    int fused = 1;            // decode step on the deferred-norm kernels (MG_OCR_FUSED=0: one kernel per operation, same arithmetic points)
     bool graph_active = false;
     struct Key { const void *ws, *out, *stream; int B, L, max_new; bool operator==(const Key& o) const { return ws == o.ws && out == o.out && stream == o.stream && B == o.B && L == o.L && max_new == o.max_new; } } gkey{};
     bool gvalid = false;
@@ -94,7 +95,7 @@ struct Ws {
     uint16_t *xim, *vx, *vq, *vk, *vvt, *vctx, *vy, *xs;
     float *patch, *vh, *vtmp, *vout, *feats;
     // text
-    float *h, *qkv, *gu, *logits;
+    float *h, *qkv, *gu, *logits, *rs_a, *rs_b;
     uint16_t *x, *q, *k, *vt, *ctx, *y, *xc, *dq, *Kc, *Vc;
     uint8_t* kmask;
     int *last_rows, *all_rows, *unfinished, *counters;
@@ -130,6 +131,7 @@ void carve(const mg_ocr_model* m, char* base, int B, int n_img, int L, int max_n
     w->xc = cv.take<uint16_t>(pk_elems(full_logits ? (int)(B * L) : round_up(B, 32), (int)td));
     w->logits = cv.take<float>((size_t)round_up(B, 32) * c.vocab);
     w->dq = cv.take<uint16_t>((size_t)round_up(B, 32) * H * 64);
+    w->rs_a = cv.take<float>((size_t)round_up(B, 32) * (td / 8)); w->rs_b = cv.take<float>((size_t)round_up(B, 32) * (td / 8));
     w->kv_layer = (size_t)B * H * cap * 64;
     w->Kc = cv.take<uint16_t>(w->kv_layer * c.t_layers);
     w->Vc = cv.take<uint16_t>(w->kv_layer * c.t_layers);
@@ -241,7 +243,7 @@ void decode_step(const mg_ocr_model* m, const Ws& w, int B, int pos, const int* 
         GemmArgs a = ga(w.x, m->at<uint16_t>(l.wqkv), B, m->qkvn, td);
         a.out_f32 = w.qkv; a.ldo = m->qkvn;
         gemm_rows(a, EPI_F32_STORE, st);
-        ocr_rope_step(w.qkv, B, H, KV, c.rope_theta, pos, pos_dev, w.dq, Kc, Vc, cap, st);
+        ocr_rope_step(w.qkv, RowScale{}, B, H, KV, c.rope_theta, pos, pos_dev, w.dq, Kc, Vc, cap, st);
         AttnStepArgs s{};
         s.q = w.dq; s.Kc = Kc; s.Vc = Vc; s.ctx = w.ctx; s.rows = B; s.H = H; s.group = 1; s.cap = cap; s.n_keys = pos + 1; s.t = pos;
         s.t_dev = pos_dev; s.t_off = pos;
@@ -262,6 +264,47 @@ void decode_step(const mg_ocr_model* m, const Ws& w, int B, int pos, const int* 
     GemmArgs lg = ga(w.xc, m->at<uint16_t>(m->lm_head), B, c.vocab, td);
     lg.out_f32 = w.logits; lg.ldo = c.vocab;
     gemm_rows(lg, EPI_F32_STORE, st);
+}
+
+// The same step on the decode path's deferred-RMSNorm kernels (7 launches per layer instead of 9): the residual projections
+// (o_proj, down_proj) leave bf16(h * gain_next) un-normalised plus per-row partial sums of h^2, and the consumers of the
+// projections that read it (rotary / cache kernel, SiLU kernel, lm_head) apply r(row) = rsqrt(mean h^2 + eps) themselves.
+void decode_step_fused(const mg_ocr_model* m, const Ws& w, int B, int pos, const int* pos_dev, int cap, mgStream_t st) {
+    const mg_ocr_config& c = m->c;
+    const int td = c.t_hidden, ti = c.t_inter, H = c.t_heads, KV = c.t_kv_heads;
+    const RowScale none{};
+    const RowScale rs_a{w.rs_a, td / 8, 1.0f / (float)td, c.rms_eps};      // after a layer's MLP (next input_layernorm / final norm)
+    const RowScale rs_b{w.rs_b, td / 8, 1.0f / (float)td, c.rms_eps};      // after the attention (post_attention_layernorm)
+    embed_norm_rows(w.next_ids, m->at<uint16_t>(m->tok_emb), w.h, m->rawp("model.text_model.layers.0.input_layernorm.weight"), w.x, nullptr, 0, 0,
+                    B, td, c.vocab, w.counters + 3, c.rms_eps, st);
+    for (int i = 0; i < c.t_layers; ++i) {
+        const std::string p = "model.text_model.layers." + std::to_string(i) + ".";
+        const TLayer& l = m->tl[i];
+        uint16_t* Kc = w.Kc + (size_t)i * w.kv_layer;
+        uint16_t* Vc = w.Vc + (size_t)i * w.kv_layer;
+        GemmArgs a = ga(w.x, m->at<uint16_t>(l.wqkv), B, m->qkvn, td);
+        a.out_f32 = w.qkv; a.ldo = m->qkvn;
+        gemm_rows(a, EPI_F32_STORE, st);
+        ocr_rope_step(w.qkv, i == 0 ? none : rs_a, B, H, KV, c.rope_theta, pos, pos_dev, w.dq, Kc, Vc, cap, st);
+        AttnStepArgs s{};
+        s.q = w.dq; s.Kc = Kc; s.Vc = Vc; s.ctx = w.ctx; s.rows = B; s.H = H; s.group = 1; s.cap = cap; s.n_keys = pos + 1; s.t = pos;
+        s.t_dev = pos_dev; s.t_off = pos;
+        attention_step(s, st);
+        ResidArgs o{};
+        o.X = w.ctx; o.W = m->at<uint16_t>(l.wo); o.h = w.h; o.gain = m->rawp(p + "post_attention_layernorm.weight"); o.gscale = 1.0f;
+        o.x_pk = w.x; o.part = w.rs_b; o.M = B; o.N = td; o.K = H * 64;
+        gemm_rows_resid(o, st);
+        GemmArgs gu = ga(w.x, m->at<uint16_t>(l.wgu), B, 2 * ti, td);
+        gu.out_f32 = w.gu; gu.ldo = 2 * ti;
+        gemm_rows(gu, EPI_F32_STORE, st);
+        ocr_silu_mul_rows(w.gu, rs_b, w.y, B, ti, st);
+        ResidArgs d{};
+        d.X = w.y; d.W = m->at<uint16_t>(l.wd); d.h = w.h; d.gscale = 1.0f;
+        d.gain = m->rawp(i + 1 < c.t_layers ? "model.text_model.layers." + std::to_string(i + 1) + ".input_layernorm.weight" : std::string("model.text_model.norm.weight"));
+        d.x_pk = w.x; d.part = w.rs_a; d.M = B; d.N = td; d.K = ti;
+        gemm_rows_resid(d, st);
+    }
+    gemm_rows_splitk(w.x, m->at<uint16_t>(m->lm_head), w.logits, B, c.vocab, td, c.vocab, 0, 1, rs_a, st);
 }
 
 __global__ __launch_bounds__(256) void copy_f32_kernel(const float* src, float* dst, size_t n) {
@@ -337,6 +380,7 @@ int mg_ocr_create(const mg_ocr_config* cfg, mg_ocr_model** out) {
     off = align_up(off, 256); m->zero_tab = off; off += 64 * sizeof(float);
     m->arena_bytes = align_up(off, 256);
     { const char* e = getenv("MG_OCR_GRAPH"); if (e && e[0] == '0') m->use_graph = 0; }
+    { const char* e = getenv("MG_OCR_FUSED"); if (e && e[0] == '0') m->fused = 0; }
     *out = m;
     return MG_OK;
 }
@@ -504,7 +548,7 @@ int mg_ocr_generate(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, co
             m->greset();
             hipGraph_t graph = nullptr;
             if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                decode_step(m, w, B, L - 1, w.counters + 2, cap, st);       // position = L - 1 + step counter (>= 1 here)
+                (m->fused ? decode_step_fused : decode_step)(m, w, B, L - 1, w.counters + 2, cap, st);   // position = L - 1 + step counter (>= 1 here)
                 select(0, w.counters + 2);
                 if (hipStreamEndCapture(st, &graph) == hipSuccess && graph &&
                     hipGraphInstantiate(&m->gexec, graph, nullptr, nullptr, 0) == hipSuccess) { m->gkey = key; m->gvalid = true; }
@@ -532,7 +576,7 @@ int mg_ocr_generate(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, co
         } else
 #endif
         {
-            decode_step(m, w, B, L + t - 1, nullptr, cap, st);
+            (m->fused ? decode_step_fused : decode_step)(m, w, B, L + t - 1, nullptr, cap, st);
             if (step_logits && t < capture_steps)
                 MG_LAUNCH(copy_f32_kernel, dim3(256), dim3(256), 0, st, (const float*)w.logits, step_logits + (size_t)t * B * c.vocab, (size_t)B * c.vocab);
             select(t, nullptr);
