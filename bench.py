@@ -85,7 +85,8 @@ def cpu_baseline(shape, sd, L=128, new_tokens=128, sample_steps=8, reps=3):
 def ocr_stage_run(B=32, new_tokens=256):
     """SURVEY.md §8 row f-1 (BASELINE configs[4] names the stage): ChemicalOCR = an Idefics3-class VLM, SmolDocling-256M geometry
     (INFERRED), one 512-px page per sequence, greedy.  EOS cannot occur (eos id -1), so the work is fixed: vision tower +
-    prompt prefill + `new_tokens` KV-cached steps.  First form of the stage (one kernel per operation; the decode step is replayed as a HIP graph)."""
+    prompt prefill + `new_tokens` KV-cached steps.  Vision tower and prefill are in their first form (one kernel per operation); the decode step runs on the main path's
+    deferred-RMSNorm kernels, 5 launches per layer, replayed as a HIP graph."""
     import dataclasses
     import torch
     from markushgrapher_amd.ocr import OcrEngine
@@ -111,7 +112,7 @@ def ocr_stage_run(B=32, new_tokens=256):
             "vision_plus_prefill_ms": round(t1 * 1e3, 2), "decode_step_ms": round(step_ms, 4),
             "dec_hbm_frac": round((wbytes + kvbytes) / (step_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
             "config": "ChemicalOCR stage alone: SmolDocling-256M geometry (INFERRED), recipe weights, one 512-px page per sequence, "
-                      "greedy, EOS impossible; first form (one kernel per operation, fp32 intermediates, decode step replayed as a HIP graph)"}
+                      "greedy, EOS impossible; vision tower / prefill: one kernel per operation with fp32 intermediates; decode step: 5 launches per layer (QKV, rotary attention + cache append, o_proj + norm, gate/up + SwiGLU, down_proj + norm), replayed as a HIP graph"}
 
 
 def pmc_child(args):

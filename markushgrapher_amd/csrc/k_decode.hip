@@ -16,7 +16,7 @@ constexpr float DC_NEG = -1.0e30f;
 // shuffles and across the 4 waves through LDS in a fixed order (deterministic).
 // XA = cross-attention form (per-image key counts from `len`, no positional bias, no beam ancestor table): a distinct
 // symbol, so that kernel traces keep the bandwidth-sized cross-attention apart from the short self-attention launches
-template <int G, int NW, bool XA, bool TRACE = false>
+template <int G, int NW, bool XA, bool TRACE = false, bool ROPE = false>
 __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a, long long* trace = nullptr) {
     MG_DYN_SMEM(smem);
     // TRACE (tools/trace_attn.py only): shader-clock stamps of wave phases -> trace[(workgroup*NW + wave)*8 + k]
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a, long
     const int tcur = a.t_dev ? *a.t_dev + a.t_off : a.t;
     const int nkeys_all = XA ? a.len[owner] : (a.t_dev ? tcur + 1 : a.n_keys);
     // with an in-kernel append the newest key (position t) comes from registers, the cache holds [0, t)
-    const bool app0 = (G == 1) && a.qkv.P && a.self_append;
+    const bool app0 = ROPE || ((G == 1) && a.qkv.P && a.self_append);
     const int nkeys = app0 ? nkeys_all - 1 : nkeys_all;
 
     const int inner = a.H * 64;
@@ -60,17 +60,54 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a, long
         return make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
     };
     uint4 q[G];
+    uint4 knew = make_uint4(0, 0, 0, 0), vnew = make_uint4(0, 0, 0, 0);
+    if constexpr (ROPE) {
+        static_assert(G == 1 && !XA, "rotary form: one query row per workgroup, self-attention");
+        const float* row = a.rope.qkv + (size_t)owner * a.rope.ld;
+        const int gkv = h / (a.H / a.rope.kv_heads);
+        float r = 1.0f;
+        if (a.rope.rs.part) {        // deferred RMSNorm scale of the row (every wave sums the partials itself, fixed order)
+            float t = 0.f;
+            for (int i = lane; i < a.rope.rs.nparts; i += 64) t += a.rope.rs.part[(size_t)owner * a.rope.rs.nparts + i];
+            t = sum_slots(sum8(t), lane);
+            r = rsqrtf(t * a.rope.rs.inv_d + a.rope.rs.eps);
+        }
+        // this lane's 8 dims d = sub*8 + j pair with d +- 32 (rotate_half); both use the angles (sub & 3)*8 + j
+        const float* cs = a.rope.cs + (size_t)tcur * 64 + (sub & 3) * 8;
+        const float4 c0 = *(const float4*)cs, c1 = *(const float4*)(cs + 4), s0 = *(const float4*)(cs + 32), s1 = *(const float4*)(cs + 36);
+        const float cv[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        const float sgn = sub < 4 ? -1.0f : 1.0f;
+        auto rot8 = [&](const float* base, float scale) {
+            const float4 a0 = *(const float4*)(base + sub * 8), a1 = *(const float4*)(base + sub * 8 + 4);
+            const float4 b0 = *(const float4*)(base + (sub ^ 4) * 8), b1 = *(const float4*)(base + (sub ^ 4) * 8 + 4);
+            const float x[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, y[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            float o[8];
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        int row = owner * G + g;
-        row = row < a.rows ? row : a.rows - 1;
-        q[g] = a.qkv.P ? slab_chunk(row, h * 64 + sub * 8) : ld16(a.q + ((size_t)row * a.H + h) * 64 + sub * 8);
+            for (int j = 0; j < 8; ++j) o[j] = ((x[j] * r) * cv[j] + sgn * (y[j] * r) * sv[j]) * scale;
+            return make_uint4(pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7]));
+        };
+        q[0] = rot8(row + h * 64, a.rope.qscale);
+        knew = rot8(row + (a.H + gkv) * 64, 1.0f);
+        const float* vb = row + (a.H + a.rope.kv_heads + gkv) * 64 + sub * 8;
+        const float4 v0 = *(const float4*)vb, v1 = *(const float4*)(vb + 4);
+        vnew = make_uint4(pack_bf16(v0.x * r, v0.y * r), pack_bf16(v0.z * r, v0.w * r), pack_bf16(v1.x * r, v1.y * r), pack_bf16(v1.z * r, v1.w * r));
+        if (w == 0 && ks == 0) {
+            const size_t off = (((size_t)owner * a.H + h) * (size_t)a.cap + (size_t)tcur) * 64 + sub * 8;
+            st16(a.Kc_w + off, knew);
+            st16(a.Vc_w + off, vnew);
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            int row = owner * G + g;
+            row = row < a.rows ? row : a.rows - 1;
+            q[g] = a.qkv.P ? slab_chunk(row, h * 64 + sub * 8) : ld16(a.q + ((size_t)row * a.H + h) * 64 + sub * 8);
+        }
     }
     // self-attention with split-K projections: this workgroup also owns the new position's k, v (kept in registers
     // for its own use and appended to the cache for later steps)
-    uint4 knew = make_uint4(0, 0, 0, 0), vnew = make_uint4(0, 0, 0, 0);
-    const bool append = (G == 1) && a.qkv.P && a.self_append;
-    if (append) {
+    const bool append = ROPE || ((G == 1) && a.qkv.P && a.self_append);
+    if (!ROPE && append) {
         knew = slab_chunk(owner, inner + h * 64 + sub * 8);
         vnew = slab_chunk(owner, 2 * inner + h * 64 + sub * 8);
         if (w == 0 && ks == 0) {
@@ -266,6 +303,10 @@ void attention_step(const AttnStepArgs& a, mgStream_t stream) {
     // the chip with the short self-attention streams (beam search: rows x heads >= 1024 workgroups), where 4 waves
     // win.  Measured end to end: greedy B=32 (512 workgroups) 8 waves +1.2 % over 4, 16 waves -3 %; beam-5 (2560
     // workgroups) 4 waves +4 % over 8.
+    if (a.rope.qkv) {            // rotary self-attention step (group 1)
+        MG_LAUNCH((attn_step_kernel<1, 8, false, false, true>), grid, dim3(8 * 64), (size_t)8 * 8 * 10 * sizeof(float), stream, a, (long long*)nullptr);
+        return;
+    }
     const bool eight = a.len != nullptr || grid.x < 1024;
     const int NW = eight ? 8 : 4;
     const dim3 block(NW * 64);

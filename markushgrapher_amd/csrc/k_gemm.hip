@@ -832,7 +832,7 @@ MG_DEV void rows_block(const GemmArgs& a, int bid, char* smem) {
 // 16-byte chunk.  Operand addressing as in resid_block16.
 template <int EPI, int MT, int NW, int U>
 MG_DEV void rows_block16(const GemmArgs& a, int bid, char* smem) {
-    static_assert(EPI == EPI_PK || EPI == EPI_PK_RELU || EPI == EPI_HEADS, "half-tile form has packed / per-head epilogues only");
+    static_assert(EPI == EPI_PK || EPI == EPI_PK_RELU || EPI == EPI_HEADS || EPI == EPI_PK_SWIGLU, "half-tile form has packed / per-head epilogues only");
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r16 = lane & 15, kg = lane >> 4;
     const int nt = bid >> 1, sub = bid & 1;
@@ -914,6 +914,14 @@ MG_DEV void rows_block16(const GemmArgs& a, int bid, char* smem) {
                     for (int ww = 0; ww < NW; ++ww) t += slab[(ww * 8 + g * 4 + j) * 64 + lane];
                     t *= rsl[32 * i + 16 * g + r16];
                     v[j] = (EPI == EPI_PK_RELU) ? fmaxf(t, 0.f) : t;
+                }
+                if constexpr (EPI == EPI_PK_SWIGLU) {
+                    // (gate, up, gate, up) of two MLP features here, the partner lane holds the next two: 8 bytes of the output row
+                    const uint32_t mine = pack_bf16(v[0] / (1.0f + fast_exp(-v[0])) * v[1], v[2] / (1.0f + fast_exp(-v[2])) * v[3]);
+                    const uint32_t other = __shfl_xor(mine, 16);
+                    const int n = nt * 32 + 16 * sub + 4 * kg;
+                    if ((kg & 1) == 0 && m < a.M && n < a.N) *(uint2*)(a.out_pk + pk_off(m, n >> 1, a.N >> 1)) = make_uint2(mine, other);
+                    continue;
                 }
                 // features 4*kg .. 4*kg+3 of token m here; lanes with even kg collect the partner's four (kg + 1)
                 const uint32_t lo = pack_bf16(v[0], v[1]), hi = pack_bf16(v[2], v[3]);
@@ -1005,7 +1013,7 @@ MG_DEV void rows_split_block(const GemmArgs& a, int ht, int g, char* smem) {
 template <int EPI, int MT, bool HALF, int NW = 4>
 __global__ __launch_bounds__(NW * 64) void gemm_rows_kernel(GemmArgs a) {
     MG_DYN_SMEM(smem);
-    if constexpr (HALF && (EPI == EPI_PK || EPI == EPI_PK_RELU || EPI == EPI_HEADS)) rows_block16<EPI, MT, NW, 4>(a, blockIdx.x, smem);
+    if constexpr (HALF && (EPI == EPI_PK || EPI == EPI_PK_RELU || EPI == EPI_HEADS || EPI == EPI_PK_SWIGLU)) rows_block16<EPI, MT, NW, 4>(a, blockIdx.x, smem);
     else rows_block<EPI, MT, HALF, NW, 8>(a, blockIdx.x, smem);
 }
 
@@ -1020,6 +1028,19 @@ static void gemm_rows_mt(const GemmArgs& a, int mt, bool half, mgStream_t stream
         if (half) MG_LAUNCH((gemm_rows_kernel<EPI, MTV, true, 8>), grid, block, sh, stream, a);      \
         else MG_LAUNCH((gemm_rows_kernel<EPI, MTV, false, 4>), grid, block, sh, stream, a);          \
         break;
+    switch (mt) {
+        MG_GR(1) MG_GR(2) MG_GR(3) MG_GR(4) MG_GR(5) MG_GR(6) MG_GR(7) MG_GR(8)
+        default: break;
+    }
+#undef MG_GR
+}
+
+// half-tile form only (epilogues that exist there alone)
+template <int EPI>
+static void gemm_rows_mt_half(const GemmArgs& a, int mt, mgStream_t stream) {
+    const dim3 grid(((a.N + 31) / 32) * 2), block(8 * 64);
+    const size_t sh = (size_t)8 * 16 * 64 * sizeof(float) + (size_t)32 * mt * sizeof(float);
+#define MG_GR(MTV) case MTV: MG_LAUNCH((gemm_rows_kernel<EPI, MTV, true, 8>), grid, block, sh, stream, a); break;
     switch (mt) {
         MG_GR(1) MG_GR(2) MG_GR(3) MG_GR(4) MG_GR(5) MG_GR(6) MG_GR(7) MG_GR(8)
         default: break;
@@ -1637,6 +1658,7 @@ void gemm_rows(const GemmArgs& a, int epi, mgStream_t stream) {
         case EPI_F32_RESID: gemm_rows_mt<EPI_F32_RESID>(a, mt, false, stream); break;
         case EPI_PK_RELU: gemm_rows_mt<EPI_PK_RELU>(a, mt, half, stream); break;
         case EPI_PK: gemm_rows_mt<EPI_PK>(a, mt, half, stream); break;
+        case EPI_PK_SWIGLU: gemm_rows_mt_half<EPI_PK_SWIGLU>(a, mt, stream); break;      // N % 16 == 0
         default: gemm_rows_mt<EPI_HEADS>(a, mt, half, stream); break;
     }
 }

@@ -62,12 +62,13 @@ __global__ __launch_bounds__(256) void gelu_pack_kernel(const float* in, uint16_
         y_pk[pk_off(m, c, Kaug)] = f32_to_bf16_rn(y);
     }
 }
-// y_pk[m][0..I) = bf16(silu(in[m][c]) * in[m][I + c])      (in = [gate | up], modeling_llama.py LlamaMLP)
+// y_pk[m][0..I) = bf16(silu(in[m][2c]) * in[m][2c + 1])      (in = gate / up interleaved: the packed weight has gate_j in row 2j and
+// up_j in row 2j + 1, so that the decode-step GEMM's SwiGLU epilogue finds a pair in one lane; modeling_llama.py LlamaMLP)
 __global__ __launch_bounds__(256) void silu_mul_pack_kernel(const float* in, uint16_t* y_pk, int M, int I) {
     const size_t n = (size_t)M * I;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const int m = (int)(i / I), c = (int)(i - (size_t)m * I);
-        const float g = in[(size_t)m * 2 * I + c], u = in[(size_t)m * 2 * I + I + c];
+        const float g = in[(size_t)m * 2 * I + 2 * c], u = in[(size_t)m * 2 * I + 2 * c + 1];
         y_pk[pk_off(m, c, I)] = f32_to_bf16_rn(g / (1.0f + fast_exp(-g)) * u);
     }
 }
@@ -141,6 +142,18 @@ MG_DEV void rope_pair(float& a, float& b, int i, float pos, float theta_log2) { 
     b = y * cs + x * sn;
 }
 
+// cs[pos][0..32) = cos(pos * theta^(-2i/64)), cs[pos][32..64) = sin(...): the rotation table of the rotary attention step
+__global__ __launch_bounds__(256) void rope_table_kernel(float* cs, int positions, float theta_log2) {
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < positions * 32; idx += gridDim.x * 256) {
+        const int i = idx & 31, p = idx >> 5;
+        const float inv = exp2f(-(float)(2 * i) / 64.0f * theta_log2);
+        float sn, c;
+        sincosf((float)p * inv, &sn, &c);
+        cs[(size_t)p * 64 + i] = c;
+        cs[(size_t)p * 64 + 32 + i] = sn;
+    }
+}
+
 // Prefill: qkv fp32 [B*T_cap][(H + 2*KV)*64] -> rotary embedding (LlamaRotaryEmbedding "default", rotate_half), q * 64^-0.5,
 // bf16; written as the attention kernel's operands (Q, K: HF_PK_ROWS; V^T: HF_PK_T, key/value heads repeated H/KV times =
 // repeat_kv) and into the decode caches [B][H][cap][64].  One thread per (row, head, pair i).
@@ -197,7 +210,7 @@ __global__ __launch_bounds__(256) void silu_mul_rows_kernel(const float* in, Row
     const int m = blockIdx.x, tid = threadIdx.x;
     const float r = block_row_scale(rs, m, (float*)smem, tid, 256);
     for (int c = tid; c < I; c += 256) {
-        const float g = in[(size_t)m * 2 * I + c] * r, u = in[(size_t)m * 2 * I + I + c] * r;
+        const float g = in[(size_t)m * 2 * I + 2 * c] * r, u = in[(size_t)m * 2 * I + 2 * c + 1] * r;
         y_pk[pk_off(m, c, I)] = f32_to_bf16_rn(g / (1.0f + fast_exp(-g)) * u);
     }
 }
@@ -229,13 +242,13 @@ __global__ __launch_bounds__(256) void rope_step_kernel(const float* qkv, RowSca
 // packed [Npad][K + aug] rows [row0, row0 + N) <- W[N][K] * scale | bias * scale at column K | 0   (rows beyond N up to the next
 // multiple of 32 are zeroed when `zero_tail`)
 __global__ __launch_bounds__(256) void pack_aug_kernel(const float* W, const float* bias, float scale, uint16_t* dst, int row0, int N, int K,
-                                                       int Kaug, int Nfill) {
+                                                       int Kaug, int Nfill, int rstride) {
     const size_t n = (size_t)Nfill * Kaug;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const int r = (int)(i / Kaug), c = (int)(i - (size_t)r * Kaug);
         float v = 0.f;
         if (r < N) v = c < K ? W[(size_t)r * K + c] * scale : ((c == K && bias) ? bias[r] * scale : 0.f);
-        dst[pk_off(row0 + r, c, Kaug)] = f32_to_bf16_rn(v);
+        dst[pk_off(row0 + r * rstride, c, Kaug)] = f32_to_bf16_rn(v);
     }
 }
 
@@ -295,11 +308,14 @@ void ocr_rope_step(const float* qkv, const RowScale& rs, int B, int H, int KV, f
                    uint16_t* Kc, uint16_t* Vc, int cap, mgStream_t st) {
     MG_LAUNCH(rope_step_kernel, dim3(B), dim3(256), 64, st, qkv, rs, B, H, KV, log2f(theta), pos, pos_dev, q_out, Kc, Vc, cap);
 }
+void ocr_rope_table(float* cs, int positions, float theta, mgStream_t st) {
+    MG_LAUNCH(rope_table_kernel, dim3(grid_for((size_t)positions * 32)), dim3(256), 0, st, cs, positions, log2f(theta));
+}
 void ocr_silu_mul_rows(const float* in, const RowScale& rs, uint16_t* y_pk, int M, int I, mgStream_t st) {
     MG_LAUNCH(silu_mul_rows_kernel, dim3(M), dim3(256), 64, st, in, rs, y_pk, M, I);
 }
-void ocr_pack_aug(const float* W, const float* bias, float scale, uint16_t* dst, int row0, int N, int K, int Kaug, int Nfill, mgStream_t st) {
-    MG_LAUNCH(pack_aug_kernel, dim3(grid_for((size_t)Nfill * Kaug)), dim3(256), 0, st, W, bias, scale, dst, row0, N, K, Kaug, Nfill);
+void ocr_pack_aug(const float* W, const float* bias, float scale, uint16_t* dst, int row0, int N, int K, int Kaug, int Nfill, int rstride, mgStream_t st) {
+    MG_LAUNCH(pack_aug_kernel, dim3(grid_for((size_t)Nfill * Kaug)), dim3(256), 0, st, W, bias, scale, dst, row0, N, K, Kaug, Nfill, rstride);
 }
 void ocr_init(int64_t* out_ids, int* unfinished, int* counters, int rows, int max_new, int64_t pad, mgStream_t st) {
     MG_LAUNCH(ocr_init_kernel, dim3(rows), dim3(256), 0, st, out_ids, unfinished, counters, rows, max_new, pad);

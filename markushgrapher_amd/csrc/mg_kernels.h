@@ -19,6 +19,9 @@ enum GemmEpi : int {
     //   each wave's 64 columns.  Consumers (EPI_HEADS / EPI_PK_RELU with GemmArgs::rs set) multiply their output rows by
     //   rsqrt(sum(part[m]) / N + eps): RMSNorm is a per-row scalar, so no norm launch sits between the GEMMs.
     EPI_RESID_NORM = 5,
+    // decode-step kernels only (gemm_rows): W rows interleaved gate_0, up_0, gate_1, up_1, ...; out_pk packed [M][N/2] =
+    // bf16(silu(r g_j) * (r u_j)) with r the deferred RMSNorm scale of the row (Llama MLP, modeling_llama.py LlamaMLP)
+    EPI_PK_SWIGLU = 6,
 };
 // Destination formats for per-head projections (head dim fixed at 64):
 enum HeadFmt : int {
@@ -232,6 +235,11 @@ struct AttnStepArgs {
     int self_append;          // 1: slabs carry q,k,v and the new position is appended; 0: slabs carry q only
     uint16_t* Kc_w;           // writable cache pointers for the append
     uint16_t* Vc_w;
+    // Rotary form of the self-attention step (ChemicalOCR text model, modeling_llama.py): q, k, v of the new position come as one fp32
+    // row [rows][ld] = [H q heads | kv_heads k heads | kv_heads v heads] x 64, un-normalised; the kernel applies the deferred RMSNorm
+    // scale `rs`, the rotation of position t (cs: [positions][64] = cos[32] | sin[32]), q * qscale, rounds to bf16, appends k, v of
+    // key/value head h / (H / kv_heads) to the cache row of (row, h) and attends over [0, t].  qkv == null: not used.
+    struct Rope { const float* qkv; int ld, kv_heads; const float* cs; RowScale rs; float qscale; } rope;
     const int* live;          // group == 1 only, nullable: rows with live[row] == 0 (finished: they emit pad whatever their
                               // logits are, gen:2927-2937) are skipped - their K/V streams are not read
 };

@@ -15,8 +15,9 @@ void ocr_rope_heads(const float* qkv, int B, int T, int T_cap, int H, int KV, fl
                     uint16_t* Kc, uint16_t* Vc, int cap, mgStream_t st);
 void ocr_rope_step(const float* qkv, const RowScale& rs, int B, int H, int KV, float theta, int pos, const int* pos_dev, uint16_t* q_out,
                    uint16_t* Kc, uint16_t* Vc, int cap, mgStream_t st);
+void ocr_rope_table(float* cs, int positions, float theta, mgStream_t st);
 void ocr_silu_mul_rows(const float* in, const RowScale& rs, uint16_t* y_pk, int M, int I, mgStream_t st);
-void ocr_pack_aug(const float* W, const float* bias, float scale, uint16_t* dst, int row0, int N, int K, int Kaug, int Nfill, mgStream_t st);
+void ocr_pack_aug(const float* W, const float* bias, float scale, uint16_t* dst, int row0, int N, int K, int Kaug, int Nfill, int rstride, mgStream_t st);
 void ocr_init(int64_t* out_ids, int* unfinished, int* counters, int rows, int max_new, int64_t pad, mgStream_t st);
 void ocr_row_maps(int* last_rows, int* all_rows, uint8_t* key_mask, int B, int T, int T_cap, mgStream_t st);
 // engine.hip: sets the thread-local message mg_last_error() returns

@@ -66,7 +66,8 @@ struct mg_ocr_model {
     std::map<std::string, Raw> raw;          // HF key -> fp32 copy in the arena
     std::vector<VLayer> vl;
     std::vector<TLayer> tl;
-    size_t patch_w, pos_emb, conn, tok_emb, lm_head, zero_tab;
+    size_t patch_w, pos_emb, conn, tok_emb, lm_head, zero_tab, rope_cs;
+    static constexpr int MAX_POS = 8192;     // positions of the rotation table (prompt + new tokens)
     bool finalized = false;
     // one decode step (30 layers x 9 launches + lm_head + selection) captured as a HIP graph whose kernels read the position from the
     // device step counter; replayed while the call's buffers and sizes match (MG_OCR_GRAPH=0: eager launches, same kernels)
@@ -285,19 +286,19 @@ void decode_step_fused(const mg_ocr_model* m, const Ws& w, int B, int pos, const
         GemmArgs a = ga(w.x, m->at<uint16_t>(l.wqkv), B, m->qkvn, td);
         a.out_f32 = w.qkv; a.ldo = m->qkvn;
         gemm_rows(a, EPI_F32_STORE, st);
-        ocr_rope_step(w.qkv, i == 0 ? none : rs_a, B, H, KV, c.rope_theta, pos, pos_dev, w.dq, Kc, Vc, cap, st);
-        AttnStepArgs s{};
-        s.q = w.dq; s.Kc = Kc; s.Vc = Vc; s.ctx = w.ctx; s.rows = B; s.H = H; s.group = 1; s.cap = cap; s.n_keys = pos + 1; s.t = pos;
+        AttnStepArgs s{};         // rotary embedding, cache append and attention over [0, pos] in one launch
+        s.Kc = Kc; s.Vc = Vc; s.Kc_w = Kc; s.Vc_w = Vc; s.ctx = w.ctx; s.rows = B; s.H = H; s.group = 1; s.cap = cap; s.n_keys = pos + 1; s.t = pos;
         s.t_dev = pos_dev; s.t_off = pos;
+        s.rope.qkv = w.qkv; s.rope.ld = m->qkvn; s.rope.kv_heads = KV; s.rope.cs = m->at<float>(m->rope_cs); s.rope.rs = i == 0 ? none : rs_a;
+        s.rope.qscale = 0.125f;
         attention_step(s, st);
         ResidArgs o{};
         o.X = w.ctx; o.W = m->at<uint16_t>(l.wo); o.h = w.h; o.gain = m->rawp(p + "post_attention_layernorm.weight"); o.gscale = 1.0f;
         o.x_pk = w.x; o.part = w.rs_b; o.M = B; o.N = td; o.K = H * 64;
         gemm_rows_resid(o, st);
         GemmArgs gu = ga(w.x, m->at<uint16_t>(l.wgu), B, 2 * ti, td);
-        gu.out_f32 = w.gu; gu.ldo = 2 * ti;
-        gemm_rows(gu, EPI_F32_STORE, st);
-        ocr_silu_mul_rows(w.gu, rs_b, w.y, B, ti, st);
+        gu.out_pk = w.y; gu.rs = rs_b;
+        gemm_rows(gu, EPI_PK_SWIGLU, st);           // y = silu(r gate) * (r up), packed
         ResidArgs d{};
         d.X = w.y; d.W = m->at<uint16_t>(l.wd); d.h = w.h; d.gscale = 1.0f;
         d.gain = m->rawp(i + 1 < c.t_layers ? "model.text_model.layers." + std::to_string(i + 1) + ".input_layernorm.weight" : std::string("model.text_model.norm.weight"));
@@ -378,6 +379,7 @@ int mg_ocr_create(const mg_ocr_config* cfg, mg_ocr_model** out) {
     for (int i = 0; i < c.t_layers; ++i) m->tl.push_back(TLayer{pk(m->qkvn, (int)td), pk((int)td, (int)td), pk(2 * (int)ti, (int)td), pk((int)td, (int)ti)});
     m->lm_head = pk(c.vocab, (int)td);
     off = align_up(off, 256); m->zero_tab = off; off += 64 * sizeof(float);
+    off = align_up(off, 256); m->rope_cs = off; off += (size_t)mg_ocr_model::MAX_POS * 64 * sizeof(float);
     m->arena_bytes = align_up(off, 256);
     { const char* e = getenv("MG_OCR_GRAPH"); if (e && e[0] == '0') m->use_graph = 0; }
     { const char* e = getenv("MG_OCR_FUSED"); if (e && e[0] == '0') m->fused = 0; }
@@ -417,8 +419,8 @@ int mg_ocr_finalize(mg_ocr_model* m, void* stream) {
     const mg_ocr_config& c = m->c;
     const int vh = c.v_hidden, vi = c.v_inter, td = c.t_hidden, ti = c.t_inter;
     const std::string v = "model.vision_model.";
-    auto pack = [&](const std::string& k, size_t dst, int row0, int N, int K, int Kaug, const std::string& bias, float scale, int Nfill) {
-        ocr_pack_aug(m->rawp(k), bias.empty() ? nullptr : m->rawp(bias), scale, m->at<uint16_t>(dst), row0, N, K, Kaug, Nfill, st);
+    auto pack = [&](const std::string& k, size_t dst, int row0, int N, int K, int Kaug, const std::string& bias, float scale, int Nfill, int rstride = 1) {
+        ocr_pack_aug(m->rawp(k), bias.empty() ? nullptr : m->rawp(bias), scale, m->at<uint16_t>(dst), row0, N, K, Kaug, Nfill, rstride, st);
     };
     pack(v + "embeddings.patch_embedding.weight", m->patch_w, 0, vh, 3 * c.patch_size * c.patch_size, 3 * c.patch_size * c.patch_size, "", 1.f, round_up(vh, 32));
     convert_to_bf16(m->rawp(v + "embeddings.position_embedding.weight"), 0, m->at<uint16_t>(m->pos_emb), (size_t)m->P * vh, st);
@@ -443,12 +445,13 @@ int mg_ocr_finalize(mg_ocr_model* m, void* stream) {
         pack(p + "self_attn.k_proj.weight", l.wqkv, td, m->kvd, td, td, "", 1.f, m->kvd);
         pack(p + "self_attn.v_proj.weight", l.wqkv, td + m->kvd, m->kvd, td, td, "", 1.f, round_up(m->qkvn, 32) - td - m->kvd);
         pack(p + "self_attn.o_proj.weight", l.wo, 0, td, td, td, "", 1.f, round_up(td, 32));
-        pack(p + "mlp.gate_proj.weight", l.wgu, 0, ti, td, td, "", 1.f, ti);
-        pack(p + "mlp.up_proj.weight", l.wgu, ti, ti, td, td, "", 1.f, round_up(2 * ti, 32) - ti);
+        pack(p + "mlp.gate_proj.weight", l.wgu, 0, ti, td, td, "", 1.f, ti, 2);       // gate_j -> row 2j, up_j -> row 2j + 1 (EPI_PK_SWIGLU)
+        pack(p + "mlp.up_proj.weight", l.wgu, 1, ti, td, td, "", 1.f, ti, 2);
         pack(p + "mlp.down_proj.weight", l.wd, 0, td, ti, ti, "", 1.f, round_up(td, 32));
     }
     pack(c.tie_word_embeddings ? "model.text_model.embed_tokens.weight" : "lm_head.weight", m->lm_head, 0, c.vocab, td, td, "", 1.f, round_up(c.vocab, 32));
     mg_memset_async(m->at<float>(m->zero_tab), 0, 64 * sizeof(float), st);
+    ocr_rope_table(m->at<float>(m->rope_cs), mg_ocr_model::MAX_POS, c.rope_theta, st);
     const int rc = check("mg_ocr_finalize");
     if (rc == MG_OK) m->finalized = true;
     return rc;
@@ -506,6 +509,7 @@ int mg_ocr_generate(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, co
     int rc = check_args(m, B, n_img, L, "mg_ocr_generate");
     if (rc != MG_OK) return rc;
     if (max_new_tokens < 1 || !out_ids || !out_cols_host) return failf(MG_E_ARG, "mg_ocr_generate: bad output arguments");
+    if (L + max_new_tokens > mg_ocr_model::MAX_POS) return failf(MG_E_SHAPE, "mg_ocr_generate: %d + %d positions exceed %d", L, max_new_tokens, mg_ocr_model::MAX_POS);
     Ws w;
     carve(m, (char*)ws, B, n_img, L, max_new_tokens, false, &w);
     if (!ws || ws_bytes < w.total) return failf(MG_E_WORKSPACE, "mg_ocr_generate: workspace %zu < %zu bytes", ws_bytes, w.total);
