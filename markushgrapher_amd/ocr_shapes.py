@@ -127,12 +127,13 @@ def recipe_state_dict(s: OcrShape, seed: int = 20260929, gain: float = 1.0) -> D
     return sd
 
 
-def synth_inputs(s: OcrShape, B: int, prompt_text_tokens: int = 12, seed: int = 20260929):
+def synth_inputs(s: OcrShape, B: int, prompt_text_tokens: int = 12, seed: int = 20260929, n_img: int = 1):
     """The reference's input contract for one page per sample (chemical_ocr.py:366-373 with the Idefics3 processor): prompt ids
     = [text..., <fake>, <image> x image_seq_len, <fake>, text...] and pixel_values [B][1][3][I][I] in [-1, 1] (full image, no
     padding: pixel_attention_mask all ones).  Token ids avoid the image / eos / pad ids."""
     from .synth import randint
-    n_img = s.image_seq_len
+    n_frames = n_img
+    n_img = s.image_seq_len * n_frames            # <image> tokens per sequence (frames back to back inside one wrapper pair)
     head = prompt_text_tokens // 2
     tail = prompt_text_tokens - head
     hi = min(s.vocab, s.image_token_id) - 2
@@ -145,8 +146,8 @@ def synth_inputs(s: OcrShape, B: int, prompt_text_tokens: int = 12, seed: int = 
         ids[b, head + 1:head + 1 + n_img] = s.image_token_id
         ids[b, head + 1 + n_img] = fake
         ids[b, head + 2 + n_img:] = t[head:]
-    pix = uniform_pm1("ocr/pixels", (B, 1, 3, s.image_size, s.image_size), seed).astype(np.float32)
+    pix = uniform_pm1("ocr/pixels", (B, n_frames, 3, s.image_size, s.image_size), seed).astype(np.float32)
     # page-like: mostly white with dark strokes (smooth-ish blocks), still fully deterministic
-    blocks = uniform_pm1("ocr/blocks", (B, 1, 1, s.image_size // 8, s.image_size // 8), seed)
+    blocks = uniform_pm1("ocr/blocks", (B, n_frames, 1, s.image_size // 8, s.image_size // 8), seed)
     pix = np.where(np.repeat(np.repeat(blocks, 8, -1), 8, -2) > 0.7, pix, np.float32(1.0) - np.float32(0.05) * np.abs(pix))
     return ids, pix.astype(np.float32)

@@ -27,9 +27,9 @@ def logit_tol(absmax):
 def _setup(name):
     import dataclasses
     g = load_golden(f"ocr_{name}.npz")
-    s = dataclasses.replace(PRESETS[name], eos_token_id=int(g["eos_token_id"]))
+    s = dataclasses.replace(PRESETS[str(g["shape"])], eos_token_id=int(g["eos_token_id"]))
     sd = recipe_state_dict(s, gain=float(g["gain"]))
-    ids, pix = synth_inputs(s, int(g["B"]))
+    ids, pix = synth_inputs(s, int(g["B"]), n_img=int(g["n_img"]) if "n_img" in g else 1)
     assert np.array_equal(ids, g["input_ids"])
     return g, s, sd, ids, pix
 
@@ -213,6 +213,21 @@ def test_ocr_unfused_decode_step_agrees(be_name, monkeypatch):
     monkeypatch.setenv("MG_OCR_FUSED", "0")
     g, s, sd, ids, pix = _setup("tiny")
     eng = make_ocr(be_name, s, sd)
+    n = int(g["new_tokens"])
+    new, cap = eng.generate(ids, pix, n, capture_steps=n)
+    _check_generate(g, s, eng.mem.numpy(new), eng.mem.numpy(cap))
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+def test_ocr_two_frames_per_page(be_name):
+    """pixel_values [B][2][3][I][I]: a page the processor split into two frames - 2 x image_seq_len <image> tokens per sequence,
+    features scattered in frame order (inputs_merger's masked_scatter)."""
+    g, s, sd, ids, pix = _setup("tiny2")
+    assert pix.shape[1] == 2 and (ids == s.image_token_id).sum(axis=1).tolist() == [2 * s.image_seq_len] * ids.shape[0]
+    eng = make_ocr(be_name, s, sd)
+    logits = eng.mem.numpy(eng.forward_logits(ids, pix))
+    tol = logit_tol(g["logits_absmax"])
+    assert np.abs(logits - g["logits"]).max() < tol
     n = int(g["new_tokens"])
     new, cap = eng.generate(ids, pix, n, capture_steps=n)
     _check_generate(g, s, eng.mem.numpy(new), eng.mem.numpy(cap))

@@ -35,16 +35,16 @@ def stock_model(s, sd):
     return m
 
 
-def mint(name, B, new_tokens, gain, eos_from_step=None):
+def mint(name, B, new_tokens, gain, eos_from_step=None, n_img=1, tag=None):
     import dataclasses
     s = PRESETS[name]
     sd = recipe_state_dict(s, gain=gain)
-    ids, pix = synth_inputs(s, B)
+    ids, pix = synth_inputs(s, B, n_img=n_img)
     t0 = time.time()
     m = stock_model(s, sd)
     tid, tpix = torch.from_numpy(ids), torch.from_numpy(pix)
     kw = dict(input_ids=tid, attention_mask=torch.ones_like(tid), pixel_values=tpix,
-              pixel_attention_mask=torch.ones(B, 1, s.image_size, s.image_size, dtype=torch.bool))
+              pixel_attention_mask=torch.ones(B, n_img, s.image_size, s.image_size, dtype=torch.bool))
     with torch.no_grad():
         feats = m.model.get_image_features(tpix, kw["pixel_attention_mask"], return_dict=True).pooler_output
         logits = m(**kw).logits
@@ -76,7 +76,7 @@ def mint(name, B, new_tokens, gain, eos_from_step=None):
     top = torch.topk(scores, 8, dim=-1)
     ltop = torch.topk(logits, 8, dim=-1)
     srt = torch.sort(scores, dim=-1, descending=True).values
-    out = dict(shape=np.array(name), B=B, new_tokens=new_tokens, gain=np.float32(gain), eos_token_id=s.eos_token_id,
+    out = dict(shape=np.array(name), n_img=n_img, B=B, new_tokens=new_tokens, gain=np.float32(gain), eos_token_id=s.eos_token_id,
                input_ids=ids, new_ids=new.numpy(), step_top8_val=top.values.numpy(), step_top8_idx=top.indices.numpy(),
                step_margin=(srt[..., 0] - srt[..., 1]).numpy(), logits_top8_val=ltop.values.numpy(), logits_top8_idx=ltop.indices.numpy(),
                logits_absmax=np.float32(logits.abs().max()), feats_probe=feats[:, ::max(1, feats.shape[1] // 4)].numpy(),
@@ -85,7 +85,7 @@ def mint(name, B, new_tokens, gain, eos_from_step=None):
     if name == "tiny":
         out["logits"] = logits.numpy()
         out["feats"] = feats.numpy()
-    path = os.path.join(ROOT, "tests", "golden", f"ocr_{name}.npz")
+    path = os.path.join(ROOT, "tests", "golden", f"ocr_{tag or name}.npz")
     np.savez_compressed(path, **out)
     print(f"[{name}] wrote {path} {os.path.getsize(path)} bytes; margins min {float(out['step_margin'].min()):.4f} median {float(np.median(out['step_margin'])):.4f}")
 
@@ -94,5 +94,7 @@ if __name__ == "__main__":
     what = sys.argv[1:] or ["tiny", "smoldocling"]
     if "tiny" in what:
         mint("tiny", B=3, new_tokens=12, gain=0.7, eos_from_step=5)
+    if "tiny2" in what or not sys.argv[1:]:
+        mint("tiny", B=2, new_tokens=6, gain=0.7, n_img=2, tag="tiny2")      # two frames per page (a page split by the processor)
     if "smoldocling" in what:
         mint("smoldocling", B=2, new_tokens=8, gain=1.0)
