@@ -361,6 +361,19 @@ def main():
                                               "embedding row scaled so rows end at different steps"}
             eng.load_state_dict({"shared.weight": sd["shared.weight"]})
             extra["ocr_stage"] = ocr_stage_run()
+            # BASELINE configs[4] on one GPU (the driver's scaling run multiplies ranks): ChemicalOCR on the page, then VTL encode +
+            # decode on the same page with OCR-derived text.  Synthetic pages carry no real text and no tokenizer model is available
+            # offline, so the two stages are timed back to back in this process on their own synthetic inputs and composed:
+            # pages/s = B / (t_ocr + t_main).  OCR output length: 512 new tokens per page (the mid-range of SURVEY.md section 8d's
+            # 10-120 cells at ~8 tokens per `x1>y1>x2>y2>text` line); the main model runs the headline configuration.
+            ocr512 = ocr_stage_run(new_tokens=512)
+            t_main = dt / args.steps
+            t_ocr = ocr512["ms_per_batch"] * 1e-3
+            extra["configs4_end_to_end_1gpu"] = {
+                "pages_per_s": round(B / (t_ocr + t_main), 2), "ocr_ms_per_batch": ocr512["ms_per_batch"], "main_ms_per_batch": round(t_main * 1e3, 1),
+                "ocr_new_tokens": 512, "main_new_tokens": new_tokens, "batch": B,
+                "config": "configs[4] on one GPU: ChemicalOCR (prefill + 512 greedy tokens) then VTL encode + 256-token decode per batch of 32 "
+                          "pages, stages timed back to back on synthetic inputs and composed (no tokenizer model offline: no real text flows)"}
         out = {
             "metric": METRIC, "value": round(world * B * args.steps / dt, 3), "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),

@@ -467,6 +467,44 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmArgs a) {
         }
 }
 
+// epilogue of a wave's TI x 2 accumulator tiles (token rows m0w + 32 i, feature columns n0w + 32 j) of the large-M kernels
+template <int EPI, int TI, int XP = 0>
+MG_DEV void xl_epilogue(const GemmArgs& a, f32x16 (&acc)[TI][2], int m0w, int n0w, bool tor, int lane) {
+    if constexpr (EPI == EPI_RESID_NORM) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i) resid_norm_epilogue(a, acc[i][0], acc[i][1], m0w + 32 * i, n0w, lane);
+        return;
+    }
+    float rsv[TI];
+    row_scales_tiles<TI>(a.rs, m0w, a.M, lane, rsv);
+    if constexpr (EPI == EPI_HEADS) {          // (the operand order is a property of the whole tile: one branch around the loops)
+        if (tor) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) tile_epilogue<EPI_HEADS, true, true>(a, acc[i][j], m0w + 32 * i, n0w + 32 * j, lane, 3, rsv[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) tile_epilogue<EPI_HEADS, false, true>(a, acc[i][j], m0w + 32 * i, n0w + 32 * j, lane, 3, rsv[i]);
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m0 = m0w + 32 * i, n0 = n0w + 32 * j;
+            if constexpr ((XP & 4) != 0) { if ((i || j) && acc[i][j][0] != 123456.789f) continue; }
+            if constexpr (EPI == EPI_F32_STORE || EPI == EPI_F32_RESID) {
+                tile_epilogue<EPI, false>(a, acc[i][j], m0, n0, lane);
+            } else if constexpr (EPI != EPI_RESID_NORM && EPI != EPI_HEADS) {
+                tile_epilogue<EPI, true, true>(a, acc[i][j], m0, n0, lane, 3, rsv[i]);
+            }
+        }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // large-M GEMM, 256x256x64 block tile, 8 waves as 2 (M) x 4 (N), 128x64 per wave (4x2 MFMA tiles, 128 accumulator
 // registers).  Per K-step a wave issues 24 ds_read_b128 for 32 MFMAs (0.75 LDS reads per MFMA; the 256x128 kernel
@@ -616,28 +654,7 @@ __global__ __launch_bounds__(512) void gemm_xl_kernel(GemmArgs a) {
         MG_SCHED_FENCE();
     }
 
-    if constexpr (EPI == EPI_RESID_NORM) {
-#pragma unroll
-        for (int i = 0; i < TI; ++i) resid_norm_epilogue(a, acc[i][0], acc[i][1], m0w + 32 * i, n0w, lane);
-        return;
-    }
-    float rsv[TI];
-    row_scales_tiles<TI>(a.rs, m0w, a.M, lane, rsv);
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int m0 = m0w + 32 * i, n0 = n0w + 32 * j;
-            if constexpr ((XP & 4) != 0) { if ((i || j) && acc[i][j][0] != 123456.789f) continue; }
-            if constexpr (EPI == EPI_F32_STORE || EPI == EPI_F32_RESID) {
-                tile_epilogue<EPI, false>(a, acc[i][j], m0, n0, lane);
-            } else if constexpr (EPI == EPI_HEADS) {
-                if (tor) tile_epilogue<EPI_HEADS, true, true>(a, acc[i][j], m0, n0, lane, 3, rsv[i]);
-                else tile_epilogue<EPI_HEADS, false, true>(a, acc[i][j], m0, n0, lane, 3, rsv[i]);
-            } else if constexpr (EPI != EPI_RESID_NORM) {
-                tile_epilogue<EPI, true, true>(a, acc[i][j], m0, n0, lane, 3, rsv[i]);
-            }
-        }
+    xl_epilogue<EPI, TI, XP>(a, acc, m0w, n0w, tor, lane);
 }
 template <int EPI, int TI>
 static void launch_xl(const GemmArgs& a, mgStream_t stream) {

@@ -68,7 +68,7 @@ def bench_encgemm():
         W = torch.randint(-3000, 3000, (N * K,), dtype=torch.int16, device=dev)
         out_pk = torch.empty((M * N,), dtype=torch.int16, device=dev)
         out_f = torch.zeros((M, N), dtype=torch.float32, device=dev) if epi == 1 else None
-        for variant in (1, 2, 4):
+        for variant in (2, 4):
             lib.mgk_gemm_set_variant(variant)
 
             def f(i):
