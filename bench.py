@@ -107,12 +107,12 @@ def ocr_stage_run(B=32, new_tokens=256):
     step_ms = (tn - t1) / (new_tokens - 1) * 1e3
     wbytes = 2 * (s.t_layers * ((s.t_heads + 2 * s.t_kv_heads) * 64 * s.t_hidden + s.t_hidden * s.t_hidden + 3 * s.t_inter * s.t_hidden) + s.vocab * s.t_hidden)
     L = int(ids.shape[1])
-    kvbytes = B * s.t_layers * 2 * s.t_heads * 64 * 2 * (L + new_tokens / 2)      # caches hold the repeated key/value heads
+    kvbytes = B * s.t_layers * 2 * s.t_kv_heads * 64 * 2 * (L + new_tokens / 2)   # caches hold the key/value heads once (grouped-query attention)
     return {"pages_per_s": round(B / tn, 2), "ms_per_batch": round(tn * 1e3, 1), "new_tokens": new_tokens, "batch": B, "prompt_len": L,
             "vision_plus_prefill_ms": round(t1 * 1e3, 2), "decode_step_ms": round(step_ms, 4),
             "dec_hbm_frac": round((wbytes + kvbytes) / (step_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
             "config": "ChemicalOCR stage alone: SmolDocling-256M geometry (INFERRED), recipe weights, one 512-px page per sequence, "
-                      "greedy, EOS impossible; vision tower / prefill: one kernel per operation with fp32 intermediates; decode step: 5 launches per layer (QKV, rotary attention + cache append, o_proj + norm, gate/up + SwiGLU, down_proj + norm), replayed as a HIP graph"}
+                      "greedy, EOS impossible; vision tower / prefill: one kernel per operation with fp32 intermediates; decode step: 5 launches per layer (QKV, rotary grouped-query attention + cache append, o_proj + norm, gate/up + SwiGLU, down_proj + norm), replayed as a HIP graph"}
 
 
 def pmc_child(args):

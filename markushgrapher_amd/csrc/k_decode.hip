@@ -62,9 +62,11 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a, long
     uint4 q[G];
     uint4 knew = make_uint4(0, 0, 0, 0), vnew = make_uint4(0, 0, 0, 0);
     if constexpr (ROPE) {
-        static_assert(G == 1 && !XA, "rotary form: one query row per workgroup, self-attention");
+        // rotary form: the workgroup owns (sequence `owner`, key/value head h) and its G = H_q / H_kv query heads h*G .. h*G + G-1
+        // (grouped-query attention: repeat_kv is never materialised, the cache holds H_kv heads and is streamed once per group)
+        static_assert(!XA, "rotary form is self-attention");
         const float* row = a.rope.qkv + (size_t)owner * a.rope.ld;
-        const int gkv = h / (a.H / a.rope.kv_heads);
+        const int Hq = a.H * G;
         float r = 1.0f;
         if (a.rope.rs.part) {        // deferred RMSNorm scale of the row (every wave sums the partials itself, fixed order)
             float t = 0.f;
@@ -86,9 +88,10 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a, long
             for (int j = 0; j < 8; ++j) o[j] = ((x[j] * r) * cv[j] + sgn * (y[j] * r) * sv[j]) * scale;
             return make_uint4(pack_bf16(o[0], o[1]), pack_bf16(o[2], o[3]), pack_bf16(o[4], o[5]), pack_bf16(o[6], o[7]));
         };
-        q[0] = rot8(row + h * 64, a.rope.qscale);
-        knew = rot8(row + (a.H + gkv) * 64, 1.0f);
-        const float* vb = row + (a.H + a.rope.kv_heads + gkv) * 64 + sub * 8;
+#pragma unroll
+        for (int g = 0; g < G; ++g) q[g] = rot8(row + (h * G + g) * 64, a.rope.qscale);
+        knew = rot8(row + (Hq + h) * 64, 1.0f);
+        const float* vb = row + (Hq + a.H + h) * 64 + sub * 8;
         const float4 v0 = *(const float4*)vb, v1 = *(const float4*)(vb + 4);
         vnew = make_uint4(pack_bf16(v0.x * r, v0.y * r), pack_bf16(v0.z * r, v0.w * r), pack_bf16(v1.x * r, v1.y * r), pack_bf16(v1.z * r, v1.w * r));
         if (w == 0 && ks == 0) {
@@ -210,21 +213,24 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a, long
         if constexpr (TRACE) { if (kb == w * 8 * U) stamp(2); }
     }
     if (append && w == 0) {   // the new position (distance 0), handled by key slot 0 of wave 0; whole wave runs the shuffles
-        float p = dot2_bf16(q[0].x, knew.x, 0.f);
-        p = dot2_bf16(q[0].y, knew.y, p);
-        p = dot2_bf16(q[0].z, knew.z, p);
-        p = dot2_bf16(q[0].w, knew.w, p);
-        p = sum8(p);
-        if (ks == 0) {
-            const float sc = p * qs[0] + (a.bias ? a.bias[h] : 0.f);
-            const float mn = fmaxf(m[0], sc);
-            const float al = fast_exp(m[0] - mn), pe = fast_exp(sc - mn);
-            m[0] = mn;
-            l[0] = l[0] * al + pe;
-            acc[0][0] = acc[0][0] * al + pe * bf16lo(vnew.x); acc[0][1] = acc[0][1] * al + pe * bf16hi(vnew.x);
-            acc[0][2] = acc[0][2] * al + pe * bf16lo(vnew.y); acc[0][3] = acc[0][3] * al + pe * bf16hi(vnew.y);
-            acc[0][4] = acc[0][4] * al + pe * bf16lo(vnew.z); acc[0][5] = acc[0][5] * al + pe * bf16hi(vnew.z);
-            acc[0][6] = acc[0][6] * al + pe * bf16lo(vnew.w); acc[0][7] = acc[0][7] * al + pe * bf16hi(vnew.w);
+#pragma unroll
+        for (int g = 0; g < (ROPE ? G : 1); ++g) {
+            float p = dot2_bf16(q[g].x, knew.x, 0.f);
+            p = dot2_bf16(q[g].y, knew.y, p);
+            p = dot2_bf16(q[g].z, knew.z, p);
+            p = dot2_bf16(q[g].w, knew.w, p);
+            p = sum8(p);
+            if (ks == 0) {
+                const float sc = p * qs[g] + (a.bias ? a.bias[h] : 0.f);
+                const float mn = fmaxf(m[g], sc);
+                const float al = fast_exp(m[g] - mn), pe = fast_exp(sc - mn);
+                m[g] = mn;
+                l[g] = l[g] * al + pe;
+                acc[g][0] = acc[g][0] * al + pe * bf16lo(vnew.x); acc[g][1] = acc[g][1] * al + pe * bf16hi(vnew.x);
+                acc[g][2] = acc[g][2] * al + pe * bf16lo(vnew.y); acc[g][3] = acc[g][3] * al + pe * bf16hi(vnew.y);
+                acc[g][4] = acc[g][4] * al + pe * bf16lo(vnew.z); acc[g][5] = acc[g][5] * al + pe * bf16hi(vnew.z);
+                acc[g][6] = acc[g][6] * al + pe * bf16lo(vnew.w); acc[g][7] = acc[g][7] * al + pe * bf16hi(vnew.w);
+            }
         }
     }
     stamp(3);
@@ -281,9 +287,13 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a, long
                 o += r[lane] * f;
             }
             const float inv = L > 0.f ? 1.0f / L : 0.f;
-            const int row = owner * G + g;
-            if (row < a.rows)
-                a.ctx[pk_off(row, a.ctx_col0 + h * 64 + lane, a.ctx_ld ? a.ctx_ld : a.H * 64)] = f32_to_bf16_rn(o * inv);
+            if constexpr (ROPE) {      // query head h*G + g of sequence `owner`
+                a.ctx[pk_off(owner, a.ctx_col0 + (h * G + g) * 64 + lane, a.ctx_ld ? a.ctx_ld : a.H * G * 64)] = f32_to_bf16_rn(o * inv);
+            } else {
+                const int row = owner * G + g;
+                if (row < a.rows)
+                    a.ctx[pk_off(row, a.ctx_col0 + h * 64 + lane, a.ctx_ld ? a.ctx_ld : a.H * 64)] = f32_to_bf16_rn(o * inv);
+            }
         }
     }
     stamp(6);
@@ -297,16 +307,20 @@ void attention_step_trace(const AttnStepArgs& a, long long* trace, mgStream_t st
 
 void attention_step(const AttnStepArgs& a, mgStream_t stream) {
     const int G = a.group;
+    if (a.rope.qkv) {            // rotary self-attention step: H = key/value heads, group = query heads per key/value head
+        const dim3 rgrid(a.rows * a.H);
+        const size_t rsh = (size_t)8 * G * 8 * 10 * sizeof(float);
+#define MG_AR(GG) case GG: MG_LAUNCH((attn_step_kernel<GG, 8, false, false, true>), rgrid, dim3(8 * 64), rsh, stream, a, (long long*)nullptr); break;
+        switch (G) { MG_AR(1) MG_AR(2) MG_AR(3) MG_AR(4) MG_AR(6) MG_AR(8) default: break; }
+#undef MG_AR
+        return;
+    }
     const int owners = (a.rows + G - 1) / G;
     const dim3 grid(owners * a.H);
     // 8 waves per (row or image, head) - 128 keys per round, more loads in flight per CU - unless the grid alone fills
     // the chip with the short self-attention streams (beam search: rows x heads >= 1024 workgroups), where 4 waves
     // win.  Measured end to end: greedy B=32 (512 workgroups) 8 waves +1.2 % over 4, 16 waves -3 %; beam-5 (2560
     // workgroups) 4 waves +4 % over 8.
-    if (a.rope.qkv) {            // rotary self-attention step (group 1)
-        MG_LAUNCH((attn_step_kernel<1, 8, false, false, true>), grid, dim3(8 * 64), (size_t)8 * 8 * 10 * sizeof(float), stream, a, (long long*)nullptr);
-        return;
-    }
     const bool eight = a.len != nullptr || grid.x < 1024;
     const int NW = eight ? 8 : 4;
     const dim3 block(NW * 64);

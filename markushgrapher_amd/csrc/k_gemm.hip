@@ -849,7 +849,8 @@ MG_DEV void rows_block(const GemmArgs& a, int bid, char* smem) {
 // 16-byte chunk.  Operand addressing as in resid_block16.
 template <int EPI, int MT, int NW, int U>
 MG_DEV void rows_block16(const GemmArgs& a, int bid, char* smem) {
-    static_assert(EPI == EPI_PK || EPI == EPI_PK_RELU || EPI == EPI_HEADS || EPI == EPI_PK_SWIGLU, "half-tile form has packed / per-head epilogues only");
+    static_assert(EPI == EPI_PK || EPI == EPI_PK_RELU || EPI == EPI_HEADS || EPI == EPI_PK_SWIGLU || EPI == EPI_F32_STORE,
+                  "half-tile form: packed, per-head, SwiGLU and plain fp32 epilogues");
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r16 = lane & 15, kg = lane >> 4;
     const int nt = bid >> 1, sub = bid & 1;
@@ -931,6 +932,12 @@ MG_DEV void rows_block16(const GemmArgs& a, int bid, char* smem) {
                     for (int ww = 0; ww < NW; ++ww) t += slab[(ww * 8 + g * 4 + j) * 64 + lane];
                     t *= rsl[32 * i + 16 * g + r16];
                     v[j] = (EPI == EPI_PK_RELU) ? fmaxf(t, 0.f) : t;
+                }
+                if constexpr (EPI == EPI_F32_STORE) {
+                    // 4 consecutive features of token m: one 16-byte store (the row scale was applied above; no bias slot here)
+                    const int n = nt * 32 + 16 * sub + 4 * kg;
+                    if (m < a.M && n < a.N) *(float4*)(a.out_f32 + (size_t)m * a.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+                    continue;
                 }
                 if constexpr (EPI == EPI_PK_SWIGLU) {
                     // (gate, up, gate, up) of two MLP features here, the partner lane holds the next two: 8 bytes of the output row
@@ -1030,7 +1037,7 @@ MG_DEV void rows_split_block(const GemmArgs& a, int ht, int g, char* smem) {
 template <int EPI, int MT, bool HALF, int NW = 4>
 __global__ __launch_bounds__(NW * 64) void gemm_rows_kernel(GemmArgs a) {
     MG_DYN_SMEM(smem);
-    if constexpr (HALF && (EPI == EPI_PK || EPI == EPI_PK_RELU || EPI == EPI_HEADS || EPI == EPI_PK_SWIGLU)) rows_block16<EPI, MT, NW, 4>(a, blockIdx.x, smem);
+    if constexpr (HALF && (EPI == EPI_PK || EPI == EPI_PK_RELU || EPI == EPI_HEADS || EPI == EPI_PK_SWIGLU || EPI == EPI_F32_STORE)) rows_block16<EPI, MT, NW, 4>(a, blockIdx.x, smem);
     else rows_block<EPI, MT, HALF, NW, 8>(a, blockIdx.x, smem);
 }
 
@@ -1671,7 +1678,8 @@ void gemm_rows(const GemmArgs& a, int epi, mgStream_t stream) {
     // projections with few feature tiles get one workgroup per 16 features (packed / per-head epilogues only)
     const bool half = (epi == EPI_PK_RELU || epi == EPI_PK || epi == EPI_HEADS) && ((a.N + 31) / 32) < 256 && (a.N % 16) == 0;
     switch (epi) {
-        case EPI_F32_STORE: gemm_rows_mt<EPI_F32_STORE>(a, mt, false, stream); break;
+        case EPI_F32_STORE:      // few feature tiles, no bias, 16-byte aligned rows: the half-tile form (twice the workgroups, 8 waves splitting K)
+            gemm_rows_mt<EPI_F32_STORE>(a, mt, !a.bias && ((a.N + 31) / 32) < 128 && (a.N % 16) == 0 && (a.ldo % 4) == 0, stream); break;
         case EPI_F32_RESID: gemm_rows_mt<EPI_F32_RESID>(a, mt, false, stream); break;
         case EPI_PK_RELU: gemm_rows_mt<EPI_PK_RELU>(a, mt, half, stream); break;
         case EPI_PK: gemm_rows_mt<EPI_PK>(a, mt, half, stream); break;

@@ -156,7 +156,8 @@ __global__ __launch_bounds__(256) void rope_table_kernel(float* cs, int position
 
 // Prefill: qkv fp32 [B*T_cap][(H + 2*KV)*64] -> rotary embedding (LlamaRotaryEmbedding "default", rotate_half), q * 64^-0.5,
 // bf16; written as the attention kernel's operands (Q, K: HF_PK_ROWS; V^T: HF_PK_T, key/value heads repeated H/KV times =
-// repeat_kv) and into the decode caches [B][H][cap][64].  One thread per (row, head, pair i).
+// repeat_kv, which the prefill attention kernel wants materialised) and into the decode caches [B][KV][cap][64] (key/value heads
+// once: the decode step's rotary attention shares them among the query heads of a group).  One thread per (row, head, pair i).
 __global__ __launch_bounds__(256) void rope_heads_kernel(const float* qkv, int B, int T, int T_cap, int H, int KV, float theta_log2,
                                                          uint16_t* Q, uint16_t* K, uint16_t* Vt, uint16_t* Kc, uint16_t* Vc, int cap) {
     const int rep = H / KV, ld = (H + 2 * KV) * 64;
@@ -190,8 +191,8 @@ __global__ __launch_bounds__(256) void rope_heads_kernel(const float* qkv, int B
                    (size_t)(((t >> 3) & 1) * 256 + (dim & 31) * 8 + (t & 7));
         };
         Vt[t_off(i)] = bv0; Vt[t_off(i + 32)] = bv1;
-        if (t < T) {
-            const size_t c = (((size_t)b * H + hh) * (size_t)cap + (size_t)t) * 64;
+        if (t < T && hh % rep == 0) {         // decode caches hold the KV heads once: [B][KV][cap][64]
+            const size_t c = (((size_t)b * KV + g) * (size_t)cap + (size_t)t) * 64;
             Kc[c + i] = bk0; Kc[c + 32 + i] = bk1; Vc[c + i] = bv0; Vc[c + 32 + i] = bv1;
         }
     }
@@ -214,31 +215,6 @@ __global__ __launch_bounds__(256) void silu_mul_rows_kernel(const float* in, Row
         y_pk[pk_off(m, c, I)] = f32_to_bf16_rn(g / (1.0f + fast_exp(-g)) * u);
     }
 }
-// Decode step: one new position `pos` per sequence: q -> [B][H][64] bf16 (scaled), k / v appended to the caches
-__global__ __launch_bounds__(256) void rope_step_kernel(const float* qkv, RowScale rs, int B, int H, int KV, float theta_log2, int pos,
-                                                        const int* pos_dev, uint16_t* q_out, uint16_t* Kc, uint16_t* Vc, int cap) {
-    MG_DYN_SMEM(smem);
-    const int rep = H / KV, ld = (H + 2 * KV) * 64;
-    const int p = pos_dev ? *pos_dev + pos : pos;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const float r = block_row_scale(rs, b, (float*)smem, tid, 256);        // deferred RMSNorm scale of the row (1 without partials)
-    const float* row = qkv + (size_t)b * ld;
-    for (int idx = tid; idx < H * 32; idx += 256) {
-        const int i = idx & 31, hh = idx >> 5;
-        const int g = hh / rep;
-        float q0 = row[hh * 64 + i] * r, q1 = row[hh * 64 + 32 + i] * r;
-        float k0 = row[(H + g) * 64 + i] * r, k1 = row[(H + g) * 64 + 32 + i] * r;
-        const float v0 = row[(H + KV + g) * 64 + i] * r, v1 = row[(H + KV + g) * 64 + 32 + i] * r;
-        rope_pair(q0, q1, i, (float)p, theta_log2);
-        rope_pair(k0, k1, i, (float)p, theta_log2);
-        const size_t qo = ((size_t)b * H + hh) * 64;
-        q_out[qo + i] = f32_to_bf16_rn(q0 * 0.125f); q_out[qo + 32 + i] = f32_to_bf16_rn(q1 * 0.125f);
-        const size_t c = (((size_t)b * H + hh) * (size_t)cap + (size_t)p) * 64;
-        Kc[c + i] = f32_to_bf16_rn(k0); Kc[c + 32 + i] = f32_to_bf16_rn(k1);
-        Vc[c + i] = f32_to_bf16_rn(v0); Vc[c + 32 + i] = f32_to_bf16_rn(v1);
-    }
-}
-
 // packed [Npad][K + aug] rows [row0, row0 + N) <- W[N][K] * scale | bias * scale at column K | 0   (rows beyond N up to the next
 // multiple of 32 are zeroed when `zero_tail`)
 __global__ __launch_bounds__(256) void pack_aug_kernel(const float* W, const float* bias, float scale, uint16_t* dst, int row0, int N, int K,
@@ -303,10 +279,6 @@ void ocr_merge_embed(const int64_t* ids, const uint16_t* tok_emb, const float* f
 void ocr_rope_heads(const float* qkv, int B, int T, int T_cap, int H, int KV, float theta, uint16_t* Q, uint16_t* K, uint16_t* Vt,
                     uint16_t* Kc, uint16_t* Vc, int cap, mgStream_t st) {
     MG_LAUNCH(rope_heads_kernel, dim3(grid_for((size_t)B * T_cap * H * 32)), dim3(256), 0, st, qkv, B, T, T_cap, H, KV, log2f(theta), Q, K, Vt, Kc, Vc, cap);
-}
-void ocr_rope_step(const float* qkv, const RowScale& rs, int B, int H, int KV, float theta, int pos, const int* pos_dev, uint16_t* q_out,
-                   uint16_t* Kc, uint16_t* Vc, int cap, mgStream_t st) {
-    MG_LAUNCH(rope_step_kernel, dim3(B), dim3(256), 64, st, qkv, rs, B, H, KV, log2f(theta), pos, pos_dev, q_out, Kc, Vc, cap);
 }
 void ocr_rope_table(float* cs, int positions, float theta, mgStream_t st) {
     MG_LAUNCH(rope_table_kernel, dim3(grid_for((size_t)positions * 32)), dim3(256), 0, st, cs, positions, log2f(theta));

@@ -235,11 +235,12 @@ struct AttnStepArgs {
     int self_append;          // 1: slabs carry q,k,v and the new position is appended; 0: slabs carry q only
     uint16_t* Kc_w;           // writable cache pointers for the append
     uint16_t* Vc_w;
-    // Rotary form of the self-attention step (ChemicalOCR text model, modeling_llama.py): q, k, v of the new position come as one fp32
-    // row [rows][ld] = [H q heads | kv_heads k heads | kv_heads v heads] x 64, un-normalised; the kernel applies the deferred RMSNorm
-    // scale `rs`, the rotation of position t (cs: [positions][64] = cos[32] | sin[32]), q * qscale, rounds to bf16, appends k, v of
-    // key/value head h / (H / kv_heads) to the cache row of (row, h) and attends over [0, t].  qkv == null: not used.
-    struct Rope { const float* qkv; int ld, kv_heads; const float* cs; RowScale rs; float qscale; } rope;
+    // Rotary form of the self-attention step (ChemicalOCR text model, modeling_llama.py): here H = KEY/VALUE heads and group = query
+    // heads per key/value head (grouped-query attention), rows = sequences.  q, k, v of the new position come as one fp32 row
+    // [rows][ld] = [H*group q heads | H k heads | H v heads] x 64, un-normalised; the kernel applies the deferred RMSNorm scale `rs`,
+    // the rotation of position t (cs: [positions][64] = cos[32] | sin[32]), q * qscale, rounds to bf16, appends k, v to the cache
+    // [rows][H][cap][64] and attends over [0, t] for the group's query heads in one pass over the cache.  qkv == null: not used.
+    struct Rope { const float* qkv; int ld; const float* cs; RowScale rs; float qscale; } rope;
     const int* live;          // group == 1 only, nullable: rows with live[row] == 0 (finished: they emit pad whatever their
                               // logits are, gen:2927-2937) are skipped - their K/V streams are not read
 };

@@ -13,8 +13,6 @@ void ocr_merge_embed(const int64_t* ids, const uint16_t* tok_emb, const float* f
                      int image_token, int per_seq, int* err, mgStream_t st);
 void ocr_rope_heads(const float* qkv, int B, int T, int T_cap, int H, int KV, float theta, uint16_t* Q, uint16_t* K, uint16_t* Vt,
                     uint16_t* Kc, uint16_t* Vc, int cap, mgStream_t st);
-void ocr_rope_step(const float* qkv, const RowScale& rs, int B, int H, int KV, float theta, int pos, const int* pos_dev, uint16_t* q_out,
-                   uint16_t* Kc, uint16_t* Vc, int cap, mgStream_t st);
 void ocr_rope_table(float* cs, int positions, float theta, mgStream_t st);
 void ocr_silu_mul_rows(const float* in, const RowScale& rs, uint16_t* y_pk, int M, int I, mgStream_t st);
 void ocr_pack_aug(const float* W, const float* bias, float scale, uint16_t* dst, int row0, int N, int K, int Kaug, int Nfill, int rstride, mgStream_t st);

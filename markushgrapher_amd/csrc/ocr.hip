@@ -97,7 +97,7 @@ struct Ws {
     float *patch, *vh, *vtmp, *vout, *feats;
     // text
     float *h, *qkv, *gu, *logits, *rs_a, *rs_b;
-    uint16_t *x, *q, *k, *vt, *ctx, *y, *xc, *dq, *Kc, *Vc;
+    uint16_t *x, *q, *k, *vt, *ctx, *y, *xc, *Kc, *Vc;
     uint8_t* kmask;
     int *last_rows, *all_rows, *unfinished, *counters;
     int64_t* next_ids;
@@ -131,9 +131,8 @@ void carve(const mg_ocr_model* m, char* base, int B, int n_img, int L, int max_n
     w->y = cv.take<uint16_t>(pk_elems((int)MT, (int)ti));
     w->xc = cv.take<uint16_t>(pk_elems(full_logits ? (int)(B * L) : round_up(B, 32), (int)td));
     w->logits = cv.take<float>((size_t)round_up(B, 32) * c.vocab);
-    w->dq = cv.take<uint16_t>((size_t)round_up(B, 32) * H * 64);
     w->rs_a = cv.take<float>((size_t)round_up(B, 32) * (td / 8)); w->rs_b = cv.take<float>((size_t)round_up(B, 32) * (td / 8));
-    w->kv_layer = (size_t)B * H * cap * 64;
+    w->kv_layer = (size_t)B * c.t_kv_heads * cap * 64;      // decode caches hold the key/value heads once (grouped-query attention)
     w->Kc = cv.take<uint16_t>(w->kv_layer * c.t_layers);
     w->Vc = cv.take<uint16_t>(w->kv_layer * c.t_layers);
     w->kmask = cv.take<uint8_t>(MT);
@@ -244,10 +243,10 @@ void decode_step(const mg_ocr_model* m, const Ws& w, int B, int pos, const int* 
         GemmArgs a = ga(w.x, m->at<uint16_t>(l.wqkv), B, m->qkvn, td);
         a.out_f32 = w.qkv; a.ldo = m->qkvn;
         gemm_rows(a, EPI_F32_STORE, st);
-        ocr_rope_step(w.qkv, RowScale{}, B, H, KV, c.rope_theta, pos, pos_dev, w.dq, Kc, Vc, cap, st);
-        AttnStepArgs s{};
-        s.q = w.dq; s.Kc = Kc; s.Vc = Vc; s.ctx = w.ctx; s.rows = B; s.H = H; s.group = 1; s.cap = cap; s.n_keys = pos + 1; s.t = pos;
+        AttnStepArgs s{};         // rotary embedding, cache append and grouped-query attention over [0, pos]
+        s.Kc = Kc; s.Vc = Vc; s.Kc_w = Kc; s.Vc_w = Vc; s.ctx = w.ctx; s.rows = B; s.H = KV; s.group = H / KV; s.cap = cap; s.n_keys = pos + 1; s.t = pos;
         s.t_dev = pos_dev; s.t_off = pos;
+        s.rope.qkv = w.qkv; s.rope.ld = m->qkvn; s.rope.cs = m->at<float>(m->rope_cs); s.rope.qscale = 0.125f;
         attention_step(s, st);
         GemmArgs o = ga(w.ctx, m->at<uint16_t>(l.wo), B, td, H * 64);
         o.out_f32 = w.h; o.ldo = td;
@@ -287,9 +286,9 @@ void decode_step_fused(const mg_ocr_model* m, const Ws& w, int B, int pos, const
         a.out_f32 = w.qkv; a.ldo = m->qkvn;
         gemm_rows(a, EPI_F32_STORE, st);
         AttnStepArgs s{};         // rotary embedding, cache append and attention over [0, pos] in one launch
-        s.Kc = Kc; s.Vc = Vc; s.Kc_w = Kc; s.Vc_w = Vc; s.ctx = w.ctx; s.rows = B; s.H = H; s.group = 1; s.cap = cap; s.n_keys = pos + 1; s.t = pos;
+        s.Kc = Kc; s.Vc = Vc; s.Kc_w = Kc; s.Vc_w = Vc; s.ctx = w.ctx; s.rows = B; s.H = KV; s.group = H / KV; s.cap = cap; s.n_keys = pos + 1; s.t = pos;
         s.t_dev = pos_dev; s.t_off = pos;
-        s.rope.qkv = w.qkv; s.rope.ld = m->qkvn; s.rope.kv_heads = KV; s.rope.cs = m->at<float>(m->rope_cs); s.rope.rs = i == 0 ? none : rs_a;
+        s.rope.qkv = w.qkv; s.rope.ld = m->qkvn; s.rope.cs = m->at<float>(m->rope_cs); s.rope.rs = i == 0 ? none : rs_a;
         s.rope.qscale = 0.125f;
         attention_step(s, st);
         ResidArgs o{};
@@ -322,6 +321,9 @@ int mg_ocr_create(const mg_ocr_config* cfg, mg_ocr_model** out) {
     if (c.v_hidden % 64 || c.v_hidden != c.v_heads * 64 || c.t_hidden != c.t_heads * 64 || c.t_heads % c.t_kv_heads || c.v_inter % 64 ||
         c.t_inter % 64 || c.t_hidden % 64 || c.vocab % 32 || c.image_size % c.patch_size || (3 * c.patch_size * c.patch_size) % 64)
         return failf(MG_E_SHAPE, "mg_ocr_create: unsupported geometry (head dim must be 64, widths multiples of 64, vocab of 32)");
+    { const int rep = c.t_heads / c.t_kv_heads;
+      if (!(rep == 1 || rep == 2 || rep == 3 || rep == 4 || rep == 6 || rep == 8))
+          return failf(MG_E_SHAPE, "mg_ocr_create: %d query heads per key/value head (supported: 1, 2, 3, 4, 6, 8)", rep); }
     const int g = c.image_size / c.patch_size;
     if (g % c.scale_factor) return failf(MG_E_SHAPE, "mg_ocr_create: patch grid %d not divisible by scale_factor %d", g, c.scale_factor);
     mg_ocr_model* m = new mg_ocr_model();
