@@ -747,6 +747,53 @@ void gemm(const GemmArgs& a, int epi, mgStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Row-tile split of the decode-step projections.  With more than one 32-row tile of live sequences (beam search: 160 rows,
+// the OCR stage at 128 pages) a workgroup used to walk all MT tiles itself - the kernels are latency-sized, so their time grew
+// with MT (FFN-wo 6.1 us at 32 rows, 24.9 us at 160).  Instead the grid gets a second dimension: blockIdx.y = row tile, every
+// workgroup runs the one-tile form on a shifted view of the arguments (the weight slice is re-read from L2 by the other tiles'
+// workgroups, its first touch comes from HBM once).  Same arithmetic per row, same summation order: results are bit-identical.
+// ---------------------------------------------------------------------------------------------------------
+// Only where the weights are small enough to stay in the XCDs' L2 while the row tiles' workgroups come and go (<= 4 MiB: the OCR text
+// model's projections).  Measured (profiles/r02_rows_split_ab.txt): OCR stage at 128 pages 141 -> 163 pages/s; the main decoder's
+// 6-18 MB projections at 160 beam rows got SLOWER when split (61.7 -> 51.2 images/s: every row tile's workgroups pull the weight
+// slice from HBM again), so they keep walking their tiles with the weights in registers.
+static bool rows_split_enabled(size_t weight_elems) {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MG_ROWS_SPLIT"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v != 0 && weight_elems * sizeof(uint16_t) <= ((size_t)4 << 20);
+}
+template <int EPI>
+MG_DEV void shift_rows(GemmArgs& a, int rt) {
+    if (rt == 0) return;
+    const int xkts = a.x_kts ? a.x_kts : (a.K >> 4);
+    a.X += (size_t)rt * xkts * TILE_ELEMS;
+    if (a.out_f32) a.out_f32 += (size_t)rt * 32 * a.ldo;
+    if (a.out_pk) a.out_pk += (size_t)rt * ((EPI == EPI_PK_SWIGLU ? a.N >> 1 : a.N) >> 4) * TILE_ELEMS;
+    if constexpr (EPI == EPI_HEADS) {
+#pragma unroll
+        for (int ri = 0; ri < 3; ++ri) {
+            if (!a.heads.ptr[ri]) continue;
+            if (a.heads.fmt[ri] == HF_STEP_Q) a.heads.ptr[ri] += (size_t)rt * 32 * a.heads.H * 64;
+            else if (a.heads.fmt[ri] == HF_STEP_KV && !a.heads.row_map) a.heads.ptr[ri] += (size_t)rt * 32 * a.heads.H * (size_t)a.heads.S_cap * 64;
+        }
+        if (a.heads.row_map) a.heads.row_map += 32 * rt;
+    }
+    if (a.rs.part) a.rs.part += (size_t)rt * 32 * a.rs.nparts;
+    a.M -= 32 * rt;
+}
+MG_DEV void shift_rows(ResidArgs& a, int rt) {
+    if (rt == 0) return;
+    const int xkts = a.x_kts ? a.x_kts : (a.K >> 4);
+    a.X += (size_t)rt * xkts * TILE_ELEMS;
+    a.h += (size_t)rt * 32 * a.N;
+    if (a.x_pk) a.x_pk += (size_t)rt * ((a.x_ld ? a.x_ld : a.N) >> 4) * TILE_ELEMS;
+    if (a.x2_pk) a.x2_pk += (size_t)rt * ((a.x2_ld ? a.x2_ld : a.N) >> 4) * TILE_ELEMS;
+    if (a.part) a.part += (size_t)rt * 32 * (a.N >> 3);
+    if (a.rs.part) a.rs.part += (size_t)rt * 32 * a.rs.nparts;
+    a.M -= 32 * rt;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // decode-step GEMM (M <= 32*MT live sequences): HBM-bound weight streaming.  One workgroup per 32 output
 // features; its 4 waves split K, each streaming its weight fragments straight to registers (one contiguous
 // 1 KiB wave-load per fragment, no LDS round trip for a stream that is read once), the activation fragments
@@ -1041,12 +1088,29 @@ __global__ __launch_bounds__(NW * 64) void gemm_rows_kernel(GemmArgs a) {
     else rows_block<EPI, MT, HALF, NW, 8>(a, blockIdx.x, smem);
 }
 
+// row-tile split forms (grid.y = row tile, one tile per workgroup): separate kernels, so that the argument structs of the
+// ordinary forms stay read-only (modifying the by-value arguments in place cost the per-head QKV projection 5.2 -> 10.5 us)
+template <int EPI, bool HALF, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_rows_split_kernel(GemmArgs a) {
+    MG_DYN_SMEM(smem);
+    shift_rows<EPI>(a, blockIdx.y);
+    if constexpr (HALF && (EPI == EPI_PK || EPI == EPI_PK_RELU || EPI == EPI_HEADS || EPI == EPI_PK_SWIGLU || EPI == EPI_F32_STORE)) rows_block16<EPI, 1, NW, 4>(a, blockIdx.x, smem);
+    else rows_block<EPI, 1, HALF, NW, 8>(a, blockIdx.x, smem);
+}
+
 template <int EPI>
 static void gemm_rows_mt(const GemmArgs& a, int mt, bool half, mgStream_t stream) {
     // half-tile projections (few workgroups, latency-bound): 8 waves split K so each wave's share is one load round
     const int NW = half ? 8 : 4;
-    const dim3 grid(((a.N + 31) / 32) * (half ? 2 : 1)), block(NW * 64);
+    const bool split = mt > 1 && rows_split_enabled((size_t)a.N * a.K);
+    const dim3 grid(((a.N + 31) / 32) * (half ? 2 : 1), split ? mt : 1), block(NW * 64);
+    if (split) mt = 1;
     const size_t sh = (size_t)NW * 16 * 64 * sizeof(float) + (size_t)32 * mt * sizeof(float);
+    if (split) {
+        if (half) MG_LAUNCH((gemm_rows_split_kernel<EPI, true, 8>), grid, block, sh, stream, a);
+        else MG_LAUNCH((gemm_rows_split_kernel<EPI, false, 4>), grid, block, sh, stream, a);
+        return;
+    }
 #define MG_GR(MTV)                                                                                   \
     case MTV:                                                                                        \
         if (half) MG_LAUNCH((gemm_rows_kernel<EPI, MTV, true, 8>), grid, block, sh, stream, a);      \
@@ -1062,8 +1126,11 @@ static void gemm_rows_mt(const GemmArgs& a, int mt, bool half, mgStream_t stream
 // half-tile form only (epilogues that exist there alone)
 template <int EPI>
 static void gemm_rows_mt_half(const GemmArgs& a, int mt, mgStream_t stream) {
-    const dim3 grid(((a.N + 31) / 32) * 2), block(8 * 64);
+    const bool split = mt > 1 && rows_split_enabled((size_t)a.N * a.K);
+    const dim3 grid(((a.N + 31) / 32) * 2, split ? mt : 1), block(8 * 64);
+    if (split) mt = 1;
     const size_t sh = (size_t)8 * 16 * 64 * sizeof(float) + (size_t)32 * mt * sizeof(float);
+    if (split) { MG_LAUNCH((gemm_rows_split_kernel<EPI, true, 8>), grid, block, sh, stream, a); return; }
 #define MG_GR(MTV) case MTV: MG_LAUNCH((gemm_rows_kernel<EPI, MTV, true, 8>), grid, block, sh, stream, a); break;
     switch (mt) {
         MG_GR(1) MG_GR(2) MG_GR(3) MG_GR(4) MG_GR(5) MG_GR(6) MG_GR(7) MG_GR(8)
@@ -1407,6 +1474,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_rows_resid_kernel(ResidArgs a) {
     resid_block16<MT, NW, (NW >= 16 ? 8 : 4)>(a, blockIdx.x, smem);
 }
 
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_rows_resid_rowsplit_kernel(ResidArgs a) {     // grid.y = row tile (shift_rows)
+    MG_DYN_SMEM(smem);
+    shift_rows(a, blockIdx.y);
+    resid_block16<1, NW, (NW >= 16 ? 8 : 4)>(a, blockIdx.x, smem);
+}
+
 // FFN-wo form (K = d_ff) for ONE row tile, split by token group: a workgroup owns 8 output features and 16 of the 32
 // rows, so that 2*N/8 workgroups cover all 256 CUs and each pulls 64 KB of weights + 128 KB of activations through its
 // CU's L1 instead of 64 + 256 KB (the per-CU ingest at 64 B/clk is what bounds this projection).  The
@@ -1502,12 +1576,14 @@ void gemm_rows_resid_trace(const ResidArgs& r, long long* trace, mgStream_t stre
 }
 
 void gemm_rows_resid(const ResidArgs& r, mgStream_t stream) {
-    const int mt = (r.M + 31) / 32;
-    const dim3 grid(r.N / 8);
+    int mt = (r.M + 31) / 32;
+    const bool split = mt > 1 && rows_split_enabled((size_t)r.N * r.K);      // one row tile per workgroup, grid.y = row tiles (shift_rows)
+    const dim3 grid(r.N / 8, split ? mt : 1);
+    if (split) mt = 1;
     // 16 waves for the long K = d_ff stream, unless 3+ live m-tiles need the registers (1024 threads: 128 per lane,
     // 80 of them accumulators at 5 m-tiles -> measured 52 us with scratch spills)
     const bool wide = r.K > 2048 && mt <= 2;
-    if (wide && mt == 1 && r.M > 16 && ((r.N >> 3) & 7) == 0 && r.x_kts == 0) {      // one row tile: split by token group
+    if (wide && mt == 1 && !split && r.M > 16 && ((r.N >> 3) & 7) == 0 && r.x_kts == 0) {      // one row tile: split by token group
         const size_t shs = (size_t)16 * 4 * 64 * sizeof(float) + 32 * sizeof(float);
         MG_LAUNCH((gemm_rows_resid_split_kernel<16, 8>), dim3(2 * (r.N >> 3)), dim3(1024), shs, stream, r);
         return;
@@ -1515,6 +1591,11 @@ void gemm_rows_resid(const ResidArgs& r, mgStream_t stream) {
     const int NW = wide ? 16 : 8;
     const dim3 block(NW * 64);
     const size_t sh = (size_t)NW * 8 * 64 * sizeof(float) + (size_t)32 * mt * sizeof(float);
+    if (split) {
+        if (wide) MG_LAUNCH((gemm_rows_resid_rowsplit_kernel<16>), grid, block, sh, stream, r);
+        else MG_LAUNCH((gemm_rows_resid_rowsplit_kernel<8>), grid, block, sh, stream, r);
+        return;
+    }
 #define MG_RR(MTV)                                                                                 \
     case MTV:                                                                                      \
         if (wide) MG_LAUNCH((gemm_rows_resid_kernel<MTV, 16>), grid, block, sh, stream, r);        \
@@ -1553,13 +1634,15 @@ __global__ __launch_bounds__(512) void gemm_rows_pair_kernel(ResidArgs r, GemmAr
     else rows_block<EPI, MT, false, 8, 16>(g, (int)blockIdx.x - nres, smem);
 }
 void gemm_rows_pair(const ResidArgs& r, const GemmArgs& g, int epi, mgStream_t stream) {
-    const int mt = (r.M + 31) / 32;
+    const int mt = (r.M + 31) / 32;       // (no row-tile split form: the pair projections exist for the main decoder's large weights only)
+    const bool split = false;
+    const int ny = 1;
     // every workgroup of the second projection reads ALL of its activation window (rows x K) from L2: with many output
     // features (FFN wi: 128 tiles) whole 32-feature tiles halve that traffic (+0.8 % end to end), with few (cross-Q:
     // 32 tiles) half tiles give the workgroups that keep the weight stream wide
     const bool full = g.N >= 2048;
     const int nhalf = (g.N + 15) / 16;
-    if (!full && mt == 1 && r.M > 16 && (nhalf & 7) == 0 && (r.N & 63) == 0 && epi == EPI_HEADS) {
+    if (!full && mt == 1 && !split && r.M > 16 && (nhalf & 7) == 0 && (r.N & 63) == 0 && epi == EPI_HEADS) {
         // one row tile, few output features (cross-Q): the second projection split by token group, 2*nhalf units; with
         // nres a multiple of 8 the two units of a slice keep the same XCD
         const int nres_s = r.N / 8;
@@ -1568,7 +1651,7 @@ void gemm_rows_pair(const ResidArgs& r, const GemmArgs& g, int epi, mgStream_t s
         return;
     }
     const int nres = r.N / 8, nrows = ((g.N + 31) / 32) * (full ? 1 : 2);
-    const dim3 grid(nres + nrows), block(512);
+    const dim3 grid(nres + nrows, ny), block(512);
     const size_t sh = (size_t)8 * 16 * 64 * sizeof(float) + (size_t)32 * mt * sizeof(float);
 #define MG_RP(MTV)                                                                                                   \
     case MTV:                                                                                                        \
