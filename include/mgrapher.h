@@ -158,6 +158,9 @@ int mgk_pack_weight(void* stream, const void* src, int src_is_bf16, int N, int K
 int mgk_rmsnorm_pack(void* stream, const float* h, const float* gain, void* x_pk, float* out_f32, int M, int d,
                      float eps, float scale);
 int mgk_im2col_pack(void* stream, const float* pix, void* x_pk, int B, int C, int I, int ps);
+/* row-tile split policy of the decode-step projections with more than 32 live rows: -1 default (by weight size), 0 never,
+ * 1 always one row tile per workgroup (test / A-B hook; results are identical in every mode) */
+int mgk_set_rows_split(int mode);
 int mgk_gemm(void* stream, int mode, int epi, const void* X_pk, const void* W_pk, int M, int N, int K, float* out_f32,
              int ldo, const float* bias, void* out_pk);
 /* Deferred-RMSNorm pair of the encoder (tiled large-M kernels): epi 5 (EPI_RESID_NORM): h_tiled (fp32, tiles of

@@ -753,14 +753,21 @@ void gemm(const GemmArgs& a, int epi, mgStream_t stream) {
 // workgroup runs the one-tile form on a shifted view of the arguments (the weight slice is re-read from L2 by the other tiles'
 // workgroups, its first touch comes from HBM once).  Same arithmetic per row, same summation order: results are bit-identical.
 // ---------------------------------------------------------------------------------------------------------
-// Only where the weights are small enough to stay in the XCDs' L2 while the row tiles' workgroups come and go (<= 4 MiB: the OCR text
+// One tile per workgroup only where the weights are small enough to stay in the XCDs' L2 while the row tiles' workgroups come and go (<= 4 MiB: the OCR text
 // model's projections).  Measured (profiles/r02_rows_split_ab.txt): OCR stage at 128 pages 141 -> 163 pages/s; the main decoder's
 // 6-18 MB projections at 160 beam rows got SLOWER when split (61.7 -> 51.2 images/s: every row tile's workgroups pull the weight
 // slice from HBM again), so they keep walking their tiles with the weights in registers.
-static bool rows_split_enabled(size_t weight_elems) {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("MG_ROWS_SPLIT"); v = (e && e[0] == '0') ? 0 : 1; }
-    return v != 0 && weight_elems * sizeof(uint16_t) <= ((size_t)4 << 20);
+// Larger weights (the main decoder at beam search, 160 rows = 5 tiles, 6-18 MB per projection) do NOT split: one tile per workgroup
+// measured 61.7 -> 51.2 images/s and two groups of tiles 67.4 -> 60.5 (profiles/r02_rows_split_ab.txt) - the other groups' workgroups
+// pull the weight slice from HBM again instead of finding it in L2.
+static int g_rows_split_mode = -1;      // -1: by weight size (default); 0: never; 1: always one tile per workgroup  (tests, A/B runs)
+void gemm_rows_set_split(int mode) { g_rows_split_mode = mode; }
+static int rows_split_tiles(int mt, size_t weight_elems) {          // row tiles per workgroup; mt = no split
+    static bool env_read = false;
+    if (!env_read) { env_read = true; if (const char* e = getenv("MG_ROWS_SPLIT")) g_rows_split_mode = atoi(e); }
+    if (mt <= 1 || g_rows_split_mode == 0) return mt;
+    const bool small = weight_elems * sizeof(uint16_t) <= ((size_t)4 << 20);
+    return (g_rows_split_mode == 1 || (g_rows_split_mode < 0 && small)) ? 1 : mt;
 }
 template <int EPI>
 MG_DEV void shift_rows(GemmArgs& a, int rt) {
@@ -1102,9 +1109,10 @@ template <int EPI>
 static void gemm_rows_mt(const GemmArgs& a, int mt, bool half, mgStream_t stream) {
     // half-tile projections (few workgroups, latency-bound): 8 waves split K so each wave's share is one load round
     const int NW = half ? 8 : 4;
-    const bool split = mt > 1 && rows_split_enabled((size_t)a.N * a.K);
-    const dim3 grid(((a.N + 31) / 32) * (half ? 2 : 1), split ? mt : 1), block(NW * 64);
-    if (split) mt = 1;
+    const int mts = rows_split_tiles(mt, (size_t)a.N * a.K);
+    const bool split = mts < mt;
+    const dim3 grid(((a.N + 31) / 32) * (half ? 2 : 1), split ? (mt + mts - 1) / mts : 1), block(NW * 64);
+    if (split) mt = mts;
     const size_t sh = (size_t)NW * 16 * 64 * sizeof(float) + (size_t)32 * mt * sizeof(float);
     if (split) {
         if (half) MG_LAUNCH((gemm_rows_split_kernel<EPI, true, 8>), grid, block, sh, stream, a);
@@ -1126,9 +1134,10 @@ static void gemm_rows_mt(const GemmArgs& a, int mt, bool half, mgStream_t stream
 // half-tile form only (epilogues that exist there alone)
 template <int EPI>
 static void gemm_rows_mt_half(const GemmArgs& a, int mt, mgStream_t stream) {
-    const bool split = mt > 1 && rows_split_enabled((size_t)a.N * a.K);
-    const dim3 grid(((a.N + 31) / 32) * 2, split ? mt : 1), block(8 * 64);
-    if (split) mt = 1;
+    const int mts = rows_split_tiles(mt, (size_t)a.N * a.K);
+    const bool split = mts < mt;
+    const dim3 grid(((a.N + 31) / 32) * 2, split ? (mt + mts - 1) / mts : 1), block(8 * 64);
+    if (split) mt = mts;
     const size_t sh = (size_t)8 * 16 * 64 * sizeof(float) + (size_t)32 * mt * sizeof(float);
     if (split) { MG_LAUNCH((gemm_rows_split_kernel<EPI, true, 8>), grid, block, sh, stream, a); return; }
 #define MG_GR(MTV) case MTV: MG_LAUNCH((gemm_rows_kernel<EPI, MTV, true, 8>), grid, block, sh, stream, a); break;
@@ -1577,9 +1586,10 @@ void gemm_rows_resid_trace(const ResidArgs& r, long long* trace, mgStream_t stre
 
 void gemm_rows_resid(const ResidArgs& r, mgStream_t stream) {
     int mt = (r.M + 31) / 32;
-    const bool split = mt > 1 && rows_split_enabled((size_t)r.N * r.K);      // one row tile per workgroup, grid.y = row tiles (shift_rows)
-    const dim3 grid(r.N / 8, split ? mt : 1);
-    if (split) mt = 1;
+    const int mts = rows_split_tiles(mt, (size_t)r.N * r.K);                  // row tiles per workgroup, grid.y = groups (shift_rows)
+    const bool split = mts < mt;
+    const dim3 grid(r.N / 8, split ? (mt + mts - 1) / mts : 1);
+    if (split) mt = mts;
     // 16 waves for the long K = d_ff stream, unless 3+ live m-tiles need the registers (1024 threads: 128 per lane,
     // 80 of them accumulators at 5 m-tiles -> measured 52 us with scratch spills)
     const bool wide = r.K > 2048 && mt <= 2;
@@ -1635,14 +1645,12 @@ __global__ __launch_bounds__(512) void gemm_rows_pair_kernel(ResidArgs r, GemmAr
 }
 void gemm_rows_pair(const ResidArgs& r, const GemmArgs& g, int epi, mgStream_t stream) {
     const int mt = (r.M + 31) / 32;       // (no row-tile split form: the pair projections exist for the main decoder's large weights only)
-    const bool split = false;
-    const int ny = 1;
     // every workgroup of the second projection reads ALL of its activation window (rows x K) from L2: with many output
     // features (FFN wi: 128 tiles) whole 32-feature tiles halve that traffic (+0.8 % end to end), with few (cross-Q:
     // 32 tiles) half tiles give the workgroups that keep the weight stream wide
     const bool full = g.N >= 2048;
     const int nhalf = (g.N + 15) / 16;
-    if (!full && mt == 1 && !split && r.M > 16 && (nhalf & 7) == 0 && (r.N & 63) == 0 && epi == EPI_HEADS) {
+    if (!full && mt == 1 && r.M > 16 && (nhalf & 7) == 0 && (r.N & 63) == 0 && epi == EPI_HEADS) {
         // one row tile, few output features (cross-Q): the second projection split by token group, 2*nhalf units; with
         // nres a multiple of 8 the two units of a slice keep the same XCD
         const int nres_s = r.N / 8;
@@ -1651,7 +1659,7 @@ void gemm_rows_pair(const ResidArgs& r, const GemmArgs& g, int epi, mgStream_t s
         return;
     }
     const int nres = r.N / 8, nrows = ((g.N + 31) / 32) * (full ? 1 : 2);
-    const dim3 grid(nres + nrows, ny), block(512);
+    const dim3 grid(nres + nrows), block(512);
     const size_t sh = (size_t)8 * 16 * 64 * sizeof(float) + (size_t)32 * mt * sizeof(float);
 #define MG_RP(MTV)                                                                                                   \
     case MTV:                                                                                                        \

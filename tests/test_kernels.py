@@ -608,3 +608,40 @@ def test_attention_encoder_skips_padded_stages(be_name):
         np.testing.assert_allclose(got[b][:, rows], ref[b][:, rows], rtol=0, atol=2e-2)
     assert np.all(got[1][:, 128:256] == 0)            # the skipped query block was cleared
     assert np.all(np.isfinite(got[:, :, :S]))
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+def test_decode_projections_row_tile_split_modes_are_bit_identical(be_name):
+    """More than one 32-row tile of live sequences (beam search, the OCR stage at large batch): the decode projections either walk
+    their row tiles in one workgroup (mode 0) or run one tile per workgroup (mode 1: grid.y and shifted argument views, the default
+    for small weights).  Both must give the SAME BITS (same arithmetic per row, same summation order)."""
+    be = get_backend(be_name)
+    be.lib.mgk_gemm_resid.argtypes = [C.c_void_p] * 5 + [C.c_float] + [C.c_void_p] * 2 + [C.c_int] * 3 + [C.c_void_p, C.c_int, C.c_float, C.c_float]
+    M, N, K = 150, 64, 256                      # 5 row tiles, the last one partial
+    x, w = rnd((M, K), 300), rnd((N, K), 301, 0.1)
+    h0, g = rnd((M, N), 302), 1 + 0.2 * rnd((N,), 303)
+    Mp = (M + 31) // 32 * 32
+    Xp, Wp, G = be.buf(pk.pack_tiles(x)), be.buf(pk.pack_tiles(w)), be.buf(g)
+    w3 = rnd((96, K), 304, 0.1)
+    W3 = be.buf(pk.pack_tiles(w3))
+    results = {}
+    try:
+        for mode in (0, 1):
+            assert be.lib.mgk_set_rows_split(mode) == 0
+            h = be.buf(h0)
+            xp = be.zeros((Mp * N,), np.uint16)
+            part = be.zeros((Mp, N // 8), np.float32)
+            assert be.lib.mgk_gemm_resid(be.stream, be.p(Xp), be.p(Wp), be.p(h), be.p(G), 0.5, be.p(xp), be.p(part), M, N, K, None, 0, 0.0, 0.0) == 0
+            out_f = be.zeros((M, 96), np.float32)
+            out_pk = be.zeros((Mp * 96,), np.uint16)
+            assert be.lib.mgk_gemm(be.stream, 1, 0, be.p(Xp), be.p(W3), M, 96, K, be.p(out_f), 96, None, None) == 0      # fp32 store
+            assert be.lib.mgk_gemm(be.stream, 1, 2, be.p(Xp), be.p(W3), M, 96, K, None, 96, None, be.p(out_pk)) == 0    # packed relu
+            results[mode] = [np.array(a.numpy(), copy=True) for a in (h, xp, part, out_f, out_pk)]
+    finally:
+        be.lib.mgk_set_rows_split(-1)
+    ref_h = h0 + pk.bf16_round(x) @ pk.bf16_round(w).T
+    np.testing.assert_allclose(results[0][0], ref_h, rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(results[0][3], pk.bf16_round(x) @ pk.bf16_round(w3).T, rtol=1e-4, atol=2e-4)
+    for mode in (1,):
+        for a, b in zip(results[0], results[mode]):
+            assert np.array_equal(a, b), mode
