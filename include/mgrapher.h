@@ -70,7 +70,7 @@ int mg_workspace_bytes(const mg_model* m, int B, int L, int num_beams, int max_l
 
 /* Encoder (stock modeling_udop.py:1102-1246 for the encoder stack).  attention_mask may be NULL (= everything
  * attended, incl. the zero-padded visual slots: stock:1183-1186).  Leaves the encoder state (final hidden states,
- * mask, compaction map) in the workspace for mg_decoder_forward / mg_generate_from_encoded.
+ * mask, compaction map) in the workspace for mg_decoder_forward.
  * enc_out [B][L+P][d_model] fp32 and enc_mask [B][L+P] u8 are optional outputs (the VTL states e2 only).
  * e1 (nullable, with M_e1 = 0): [B][M_e1][d_model] fp32, the projected embeddings of MarkushGrapher-2's OCSR vision branch
  * (`encoder.molscribe_encoder` Swin-B + `encoder.molscribe_projector`, /root/reference/markushgrapher/utils/model/
