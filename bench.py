@@ -115,6 +115,27 @@ def ocr_stage_run(B=32, new_tokens=256):
                       "greedy, EOS impossible; vision tower / prefill: one kernel per operation with fp32 intermediates; decode step: 5 launches per layer (QKV, rotary grouped-query attention + cache append, o_proj + norm, gate/up + SwiGLU, down_proj + norm), replayed as a HIP graph"}
 
 
+def ocr_cpu_baseline(B=1, new_tokens=256, sample_steps=16):
+    """The reference's own CPU path for this stage is stock transformers on the host (chemical_ocr.py:366-392); what travels to the GPU
+    box is its restatement oracle/ocr_oracle.py (fp32 torch-CPU, pinned on stock).  One page, SmolDocling-256M geometry: vision tower
+    + prefill once, `sample_steps` decode steps timed and extrapolated to `new_tokens`."""
+    import dataclasses
+    import torch
+    from markushgrapher_amd.ocr_shapes import PRESETS, recipe_state_dict, synth_inputs
+    from oracle.ocr_oracle import OcrOracle
+    s = dataclasses.replace(PRESETS["smoldocling"], eos_token_id=-1)
+    orc = OcrOracle(s, recipe_state_dict(s))
+    ids, pix = synth_inputs(s, B)
+    with torch.no_grad():
+        orc.generate(ids, pix, 2)                                   # warm-up
+        t0 = time.time(); orc.generate(ids, pix, 1); t1 = time.time() - t0
+        t0 = time.time(); orc.generate(ids, pix, 1 + sample_steps); tn = time.time() - t0
+    step = max(tn - t1, 1e-6) / sample_steps
+    total = t1 + step * (new_tokens - 1)
+    return {"pages_per_s": round(B / total, 4), "unit": "pages/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle fp32 torch-CPU, B={B}: vision + prefill {t1:.2f}s + {step * 1e3:.0f} ms/step ({sample_steps} timed steps, extrapolated to {new_tokens} new tokens)"}
+
+
 def pmc_child(args):
     """Child mode (run under rocprofv3 --pmc FETCH_SIZE by the parent): one short pass of the same workload."""
     import torch
@@ -361,6 +382,8 @@ def main():
                                               "embedding row scaled so rows end at different steps"}
             eng.load_state_dict({"shared.weight": sd["shared.weight"]})
             extra["ocr_stage"] = ocr_stage_run()
+            if not args.no_cpu_baseline:
+                extra["ocr_stage"]["cpu_baseline"] = ocr_cpu_baseline()
             # BASELINE configs[4] on one GPU (the driver's scaling run multiplies ranks): ChemicalOCR on the page, then VTL encode +
             # decode on the same page with OCR-derived text.  Synthetic pages carry no real text and no tokenizer model is available
             # offline, so the two stages are timed back to back in this process on their own synthetic inputs and composed:

@@ -162,12 +162,14 @@ def test_ocr_graph_replay_equals_eager():
     assert np.array_equal(eng2.mem.numpy(a), eng2.mem.numpy(b))
 
 
-def _stock_tiny(tmp_path, s, sd):
+def _stock_tiny(tmp_path, s, sd, bf16=False):
     import torch
     import sys, os
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
     from make_golden_ocr import stock_model
     m = stock_model(s, sd)
+    if bf16:
+        m = m.to(torch.bfloat16)          # the recipe weights are bf16-exact: the checkpoint holds the same values in half the bytes
     m.save_pretrained(str(tmp_path), safe_serialization=True)
     return m
 
@@ -183,13 +185,14 @@ def test_shape_from_hf_config_roundtrip(tmp_path):
 
 
 @pytest.mark.gpu
-def test_ocr_model_from_pretrained_generates_like_stock(tmp_path):
+@pytest.mark.parametrize("bf16", [False, True])
+def test_ocr_model_from_pretrained_generates_like_stock(tmp_path, bf16):
     """The reference-facing surface: OcrModel.from_pretrained(dir).generate(**inputs, max_new_tokens=, do_sample=False) returns
     [prompt | new tokens] as the stock model does (chemical_ocr.py:375-386)."""
     import torch
     from markushgrapher_amd.ocr import OcrModel
     g, s, sd, ids, pix = _setup("tiny")
-    _stock_tiny(tmp_path, s, sd)
+    _stock_tiny(tmp_path, s, sd, bf16=bf16)
     model = OcrModel.from_pretrained(str(tmp_path)).eval()
     tid, tpix = torch.from_numpy(ids), torch.from_numpy(pix)
     out = model.generate(input_ids=tid, attention_mask=torch.ones_like(tid), pixel_values=tpix,
