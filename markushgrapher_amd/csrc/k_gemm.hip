@@ -775,7 +775,7 @@ MG_DEV void shift_rows(GemmArgs& a, int rt) {
     const int xkts = a.x_kts ? a.x_kts : (a.K >> 4);
     a.X += (size_t)rt * xkts * TILE_ELEMS;
     if (a.out_f32) a.out_f32 += (size_t)rt * 32 * a.ldo;
-    if (a.out_pk) a.out_pk += (size_t)rt * ((EPI == EPI_PK_SWIGLU ? a.N >> 1 : a.N) >> 4) * TILE_ELEMS;
+    if (a.out_pk) a.out_pk += (size_t)rt * ((EPI == EPI_PK_SWIGLU ? (a.out_ld ? a.out_ld : a.N >> 1) : a.N) >> 4) * TILE_ELEMS;
     if constexpr (EPI == EPI_HEADS) {
 #pragma unroll
         for (int ri = 0; ri < 3; ++ri) {
@@ -998,7 +998,8 @@ MG_DEV void rows_block16(const GemmArgs& a, int bid, char* smem) {
                     const uint32_t mine = pack_bf16(v[0] / (1.0f + fast_exp(-v[0])) * v[1], v[2] / (1.0f + fast_exp(-v[2])) * v[3]);
                     const uint32_t other = __shfl_xor(mine, 16);
                     const int n = nt * 32 + 16 * sub + 4 * kg;
-                    if ((kg & 1) == 0 && m < a.M && n < a.N) *(uint2*)(a.out_pk + pk_off(m, n >> 1, a.N >> 1)) = make_uint2(mine, other);
+                    if ((kg & 1) == 0 && m < a.M && n < a.N)
+                        *(uint2*)(a.out_pk + pk_off(m, a.out_col0 + (n >> 1), a.out_ld ? a.out_ld : a.N >> 1)) = make_uint2(mine, other);
                     continue;
                 }
                 // features 4*kg .. 4*kg+3 of token m here; lanes with even kg collect the partner's four (kg + 1)
@@ -1648,7 +1649,7 @@ void gemm_rows_pair(const ResidArgs& r, const GemmArgs& g, int epi, mgStream_t s
     // every workgroup of the second projection reads ALL of its activation window (rows x K) from L2: with many output
     // features (FFN wi: 128 tiles) whole 32-feature tiles halve that traffic (+0.8 % end to end), with few (cross-Q:
     // 32 tiles) half tiles give the workgroups that keep the weight stream wide
-    const bool full = g.N >= 2048;
+    const bool full = g.N >= 2048 && epi != EPI_F32_STORE;      // (the fp32 epilogue exists in the half-tile form)
     const int nhalf = (g.N + 15) / 16;
     if (!full && mt == 1 && r.M > 16 && (nhalf & 7) == 0 && (r.N & 63) == 0 && epi == EPI_HEADS) {
         // one row tile, few output features (cross-Q): the second projection split by token group, 2*nhalf units; with
@@ -1665,6 +1666,7 @@ void gemm_rows_pair(const ResidArgs& r, const GemmArgs& g, int epi, mgStream_t s
     case MTV:                                                                                                        \
         if (epi == EPI_PK_RELU && full) MG_LAUNCH((gemm_rows_pair_kernel<EPI_PK_RELU, MTV, false>), grid, block, sh, stream, r, g, nres); \
         else if (epi == EPI_PK_RELU) MG_LAUNCH((gemm_rows_pair_kernel<EPI_PK_RELU, MTV, true>), grid, block, sh, stream, r, g, nres); \
+        else if (epi == EPI_F32_STORE) MG_LAUNCH((gemm_rows_pair_kernel<EPI_F32_STORE, MTV, true>), grid, block, sh, stream, r, g, nres); \
         else MG_LAUNCH((gemm_rows_pair_kernel<EPI_HEADS, MTV, true>), grid, block, sh, stream, r, g, nres);          \
         break;
     switch (mt) {

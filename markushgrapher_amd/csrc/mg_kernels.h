@@ -67,6 +67,8 @@ struct GemmArgs {
     // decode-step kernels: X may be a column window of a wider packed buffer: x_kts = 16-wide k-tiles per row tile of
     // the buffer (0 = K/16), x_k0 = first k-tile of the window
     int x_kts, x_k0;
+    // EPI_PK_SWIGLU: the packed output as a column window of a wider buffer (out_ld columns, first column out_col0); out_ld = 0: N/2, 0
+    int out_ld, out_col0;
 };
 void gemm(const GemmArgs& a, int epi, mgStream_t stream);
 void gemm_set_variant(int v);   // 0: 128x128 kernel only; 1: + 256x128 three-stage; 2: + 256x256; 4: + 320x256 wherever it fits; 3 (default): by shape

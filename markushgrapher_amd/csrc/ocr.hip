@@ -66,6 +66,11 @@ struct mg_ocr_model {
     std::map<std::string, Raw> raw;          // HF key -> fp32 copy in the arena
     std::vector<VLayer> vl;
     std::vector<TLayer> tl;
+    // decode step: [down_proj of layer l-1 | QKV of layer l] in one launch - the QKV part reads [bf16(h) | y] against the product weight
+    // [Wqkv G | Wqkv G Wd] (G = the input_layernorm gain), so it does not wait for the residual update next to it (as the main path's
+    // pair projections, engine.hip)
+    std::vector<size_t> wqkv2;     // per layer l >= 1; [0] unused
+    size_t fin_a = 0, fin_c = 0;
     size_t patch_w, pos_emb, conn, tok_emb, lm_head, zero_tab, rope_cs;
     static constexpr int MAX_POS = 8192;     // positions of the rotation table (prompt + new tokens)
     bool finalized = false;
@@ -97,6 +102,7 @@ struct Ws {
     float *patch, *vh, *vtmp, *vout, *feats;
     // text
     float *h, *qkv, *gu, *logits, *rs_a, *rs_b;
+    uint16_t* xw;            // decode step: packed [rows][t_hidden + t_inter] = [bf16(h) | SwiGLU output]
     uint16_t *x, *q, *k, *vt, *ctx, *y, *xc, *Kc, *Vc;
     uint8_t* kmask;
     int *last_rows, *all_rows, *unfinished, *counters;
@@ -131,6 +137,7 @@ void carve(const mg_ocr_model* m, char* base, int B, int n_img, int L, int max_n
     w->y = cv.take<uint16_t>(pk_elems((int)MT, (int)ti));
     w->xc = cv.take<uint16_t>(pk_elems(full_logits ? (int)(B * L) : round_up(B, 32), (int)td));
     w->logits = cv.take<float>((size_t)round_up(B, 32) * c.vocab);
+    w->xw = cv.take<uint16_t>(pk_elems(round_up(B, 32), (int)(td + ti)));
     w->rs_a = cv.take<float>((size_t)round_up(B, 32) * (td / 8)); w->rs_b = cv.take<float>((size_t)round_up(B, 32) * (td / 8));
     w->kv_layer = (size_t)B * c.t_kv_heads * cap * 64;      // decode caches hold the key/value heads once (grouped-query attention)
     w->Kc = cv.take<uint16_t>(w->kv_layer * c.t_layers);
@@ -271,38 +278,51 @@ void decode_step(const mg_ocr_model* m, const Ws& w, int B, int pos, const int* 
 // projections that read it (rotary / cache kernel, SiLU kernel, lm_head) apply r(row) = rsqrt(mean h^2 + eps) themselves.
 void decode_step_fused(const mg_ocr_model* m, const Ws& w, int B, int pos, const int* pos_dev, int cap, mgStream_t st) {
     const mg_ocr_config& c = m->c;
-    const int td = c.t_hidden, ti = c.t_inter, H = c.t_heads, KV = c.t_kv_heads;
+    const int td = c.t_hidden, ti = c.t_inter, H = c.t_heads, KV = c.t_kv_heads, K2 = td + ti;
     const RowScale none{};
     const RowScale rs_a{w.rs_a, td / 8, 1.0f / (float)td, c.rms_eps};      // after a layer's MLP (next input_layernorm / final norm)
     const RowScale rs_b{w.rs_b, td / 8, 1.0f / (float)td, c.rms_eps};      // after the attention (post_attention_layernorm)
     embed_norm_rows(w.next_ids, m->at<uint16_t>(m->tok_emb), w.h, m->rawp("model.text_model.layers.0.input_layernorm.weight"), w.x, nullptr, 0, 0,
                     B, td, c.vocab, w.counters + 3, c.rms_eps, st);
+    // One row tile of sequences: the next layer's QKV rides in the down_proj launch (product weights).  More rows: the pair kernel has
+    // no row-tile split form, the separate launches (which split) are faster (measured at 128 pages: 1.40 vs 1.34 ms per step).
+    const bool pair = B <= 32;
     for (int i = 0; i < c.t_layers; ++i) {
         const std::string p = "model.text_model.layers." + std::to_string(i) + ".";
         const TLayer& l = m->tl[i];
+        if (i == 0 || !pair) {   // QKV from x: the explicitly normalised embedding (layer 0) or bf16(h gain) un-normalised (rs_a applied by the attention)
+            GemmArgs a = ga(w.x, m->at<uint16_t>(l.wqkv), B, m->qkvn, td);
+            a.out_f32 = w.qkv; a.ldo = m->qkvn;
+            gemm_rows(a, EPI_F32_STORE, st);
+        }
         uint16_t* Kc = w.Kc + (size_t)i * w.kv_layer;
         uint16_t* Vc = w.Vc + (size_t)i * w.kv_layer;
-        GemmArgs a = ga(w.x, m->at<uint16_t>(l.wqkv), B, m->qkvn, td);
-        a.out_f32 = w.qkv; a.ldo = m->qkvn;
-        gemm_rows(a, EPI_F32_STORE, st);
-        AttnStepArgs s{};         // rotary embedding, cache append and attention over [0, pos] in one launch
+        AttnStepArgs s{};         // rotary embedding, cache append and grouped-query attention over [0, pos] in one launch
         s.Kc = Kc; s.Vc = Vc; s.Kc_w = Kc; s.Vc_w = Vc; s.ctx = w.ctx; s.rows = B; s.H = KV; s.group = H / KV; s.cap = cap; s.n_keys = pos + 1; s.t = pos;
         s.t_dev = pos_dev; s.t_off = pos;
         s.rope.qkv = w.qkv; s.rope.ld = m->qkvn; s.rope.cs = m->at<float>(m->rope_cs); s.rope.rs = i == 0 ? none : rs_a;
         s.rope.qscale = 0.125f;
         attention_step(s, st);
-        ResidArgs o{};
+        ResidArgs o{};            // h += Wo ctx;  x = bf16(h gain_post) un-normalised;  window[:, :td] = bf16(h);  partials -> rs_b
         o.X = w.ctx; o.W = m->at<uint16_t>(l.wo); o.h = w.h; o.gain = m->rawp(p + "post_attention_layernorm.weight"); o.gscale = 1.0f;
-        o.x_pk = w.x; o.part = w.rs_b; o.M = B; o.N = td; o.K = H * 64;
+        o.x_pk = w.x; o.x2_pk = w.xw; o.x2_ld = K2; o.x2_col0 = 0; o.part = w.rs_b; o.M = B; o.N = td; o.K = H * 64;
         gemm_rows_resid(o, st);
         GemmArgs gu = ga(w.x, m->at<uint16_t>(l.wgu), B, 2 * ti, td);
-        gu.out_pk = w.y; gu.rs = rs_b;
-        gemm_rows(gu, EPI_PK_SWIGLU, st);           // y = silu(r gate) * (r up), packed
-        ResidArgs d{};
-        d.X = w.y; d.W = m->at<uint16_t>(l.wd); d.h = w.h; d.gscale = 1.0f;
-        d.gain = m->rawp(i + 1 < c.t_layers ? "model.text_model.layers." + std::to_string(i + 1) + ".input_layernorm.weight" : std::string("model.text_model.norm.weight"));
-        d.x_pk = w.x; d.part = w.rs_a; d.M = B; d.N = td; d.K = ti;
-        gemm_rows_resid(d, st);
+        gu.out_pk = w.xw; gu.out_ld = K2; gu.out_col0 = td; gu.rs = rs_b;
+        gemm_rows(gu, EPI_PK_SWIGLU, st);           // window[:, td:] = silu(r gate) * (r up)
+        ResidArgs d{};            // h += Wd y;  partials -> rs_a
+        d.X = w.xw; d.x_kts = K2 >> 4; d.x_k0 = td >> 4; d.W = m->at<uint16_t>(l.wd); d.h = w.h; d.gscale = 1.0f;
+        d.part = w.rs_a; d.M = B; d.N = td; d.K = ti;
+        if (pair && i + 1 < c.t_layers) {
+            // ... side by side with the next layer's QKV = [Wqkv G | Wqkv G Wd] [bf16(h) ; y]  (un-normalised: the attention applies rs_a)
+            GemmArgs q = ga(w.xw, m->at<uint16_t>(m->wqkv2[i + 1]), B, m->qkvn, K2);
+            q.out_f32 = w.qkv; q.ldo = m->qkvn;
+            gemm_rows_pair(d, q, EPI_F32_STORE, st);
+        } else {
+            d.gain = m->rawp(i + 1 < c.t_layers ? "model.text_model.layers." + std::to_string(i + 1) + ".input_layernorm.weight" : std::string("model.text_model.norm.weight"));
+            d.x_pk = w.x;
+            gemm_rows_resid(d, st);
+        }
     }
     gemm_rows_splitk(w.x, m->at<uint16_t>(m->lm_head), w.logits, B, c.vocab, td, c.vocab, 0, 1, rs_a, st);
 }
@@ -380,6 +400,10 @@ int mg_ocr_create(const mg_ocr_config* cfg, mg_ocr_model** out) {
     off = align_up(off, 256); m->tok_emb = off; off += (size_t)c.vocab * td * 2;
     for (int i = 0; i < c.t_layers; ++i) m->tl.push_back(TLayer{pk(m->qkvn, (int)td), pk((int)td, (int)td), pk(2 * (int)ti, (int)td), pk((int)td, (int)ti)});
     m->lm_head = pk(c.vocab, (int)td);
+    m->wqkv2.assign(c.t_layers, 0);
+    for (int i = 1; i < c.t_layers; ++i) m->wqkv2[i] = pk(m->qkvn, (int)(td + ti));
+    off = align_up(off, 256); m->fin_a = off; off += (size_t)m->qkvn * td * sizeof(float);
+    off = align_up(off, 256); m->fin_c = off; off += (size_t)m->qkvn * (td + ti) * sizeof(float);
     off = align_up(off, 256); m->zero_tab = off; off += 64 * sizeof(float);
     off = align_up(off, 256); m->rope_cs = off; off += (size_t)mg_ocr_model::MAX_POS * 64 * sizeof(float);
     m->arena_bytes = align_up(off, 256);
@@ -452,6 +476,21 @@ int mg_ocr_finalize(mg_ocr_model* m, void* stream) {
         pack(p + "mlp.down_proj.weight", l.wd, 0, td, ti, ti, "", 1.f, round_up(td, 32));
     }
     pack(c.tie_word_embeddings ? "model.text_model.embed_tokens.weight" : "lm_head.weight", m->lm_head, 0, c.vocab, td, td, "", 1.f, round_up(c.vocab, 32));
+    {   // product weights of the decode step's [down_proj | next QKV] launches, fp32 then one rounding to bf16
+        float* A = m->at<float>(m->fin_a);
+        float* C = m->at<float>(m->fin_c);
+        const int K2 = td + ti;
+        for (int i = 1; i < c.t_layers; ++i) {
+            const std::string p = "model.text_model.layers." + std::to_string(i) + ".", q = "model.text_model.layers." + std::to_string(i - 1) + ".";
+            mg_memcpy_async(A, m->rawp(p + "self_attn.q_proj.weight"), (size_t)td * td * sizeof(float), st);
+            mg_memcpy_async(A + (size_t)td * td, m->rawp(p + "self_attn.k_proj.weight"), (size_t)m->kvd * td * sizeof(float), st);
+            mg_memcpy_async(A + (size_t)(td + m->kvd) * td, m->rawp(p + "self_attn.v_proj.weight"), (size_t)m->kvd * td * sizeof(float), st);
+            const float* gain = m->rawp(p + "input_layernorm.weight");
+            scale_cols_f32(A, gain, C, m->qkvn, td, K2, st);
+            gemm_f32_scaled(A, gain, m->rawp(q + "mlp.down_proj.weight"), C + td, m->qkvn, td, ti, K2, st);
+            pack_weight(C, 0, m->qkvn, K2, m->at<uint16_t>(m->wqkv2[i]), round_up(m->qkvn, 32), st);
+        }
+    }
     mg_memset_async(m->at<float>(m->zero_tab), 0, 64 * sizeof(float), st);
     ocr_rope_table(m->at<float>(m->rope_cs), mg_ocr_model::MAX_POS, c.rope_theta, st);
     const int rc = check("mg_ocr_finalize");
