@@ -86,7 +86,7 @@ def ocr_stage_run(B=32, new_tokens=256):
     """SURVEY.md §8 row f-1 (BASELINE configs[4] names the stage): ChemicalOCR = an Idefics3-class VLM, SmolDocling-256M geometry
     (INFERRED), one 512-px page per sequence, greedy.  EOS cannot occur (eos id -1), so the work is fixed: vision tower +
     prompt prefill + `new_tokens` KV-cached steps.  Vision tower and prefill are in their first form (one kernel per operation); the decode step runs on the main path's
-    deferred-RMSNorm kernels, 5 launches per layer, replayed as a HIP graph."""
+    deferred-RMSNorm kernels, 4 launches per layer, replayed as a HIP graph."""
     import dataclasses
     import torch
     from markushgrapher_amd.ocr import OcrEngine
@@ -112,7 +112,7 @@ def ocr_stage_run(B=32, new_tokens=256):
             "vision_plus_prefill_ms": round(t1 * 1e3, 2), "decode_step_ms": round(step_ms, 4),
             "dec_hbm_frac": round((wbytes + kvbytes) / (step_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
             "config": "ChemicalOCR stage alone: SmolDocling-256M geometry (INFERRED), recipe weights, one 512-px page per sequence, "
-                      "greedy, EOS impossible; vision tower / prefill: one kernel per operation with fp32 intermediates; decode step: 5 launches per layer (QKV, rotary grouped-query attention + cache append, o_proj + norm, gate/up + SwiGLU, down_proj + norm), replayed as a HIP graph"}
+                      "greedy, EOS impossible; vision tower / prefill: one kernel per operation with fp32 intermediates; decode step: 4 launches per layer at one row tile (rotary grouped-query attention + cache append, o_proj + norm, gate/up + SwiGLU, [down_proj + norm | next QKV]), replayed as a HIP graph"}
 
 
 def ocr_cpu_baseline(B=1, new_tokens=256, sample_steps=16):
@@ -123,6 +123,8 @@ def ocr_cpu_baseline(B=1, new_tokens=256, sample_steps=16):
     import torch
     from markushgrapher_amd.ocr_shapes import PRESETS, recipe_state_dict, synth_inputs
     from oracle.ocr_oracle import OcrOracle
+    prev = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))      # B = 1 on a 135 M-parameter text model: more threads only add overhead
     s = dataclasses.replace(PRESETS["smoldocling"], eos_token_id=-1)
     orc = OcrOracle(s, recipe_state_dict(s))
     ids, pix = synth_inputs(s, B)
@@ -132,7 +134,9 @@ def ocr_cpu_baseline(B=1, new_tokens=256, sample_steps=16):
         t0 = time.time(); orc.generate(ids, pix, 1 + sample_steps); tn = time.time() - t0
     step = max(tn - t1, 1e-6) / sample_steps
     total = t1 + step * (new_tokens - 1)
-    return {"pages_per_s": round(B / total, 4), "unit": "pages/s", "cores": torch.get_num_threads(), "kind": "port",
+    used = torch.get_num_threads()
+    torch.set_num_threads(prev)
+    return {"pages_per_s": round(B / total, 4), "unit": "pages/s", "cores": used, "kind": "port",
             "sample": f"oracle fp32 torch-CPU, B={B}: vision + prefill {t1:.2f}s + {step * 1e3:.0f} ms/step ({sample_steps} timed steps, extrapolated to {new_tokens} new tokens)"}
 
 
