@@ -231,9 +231,11 @@ int mgk_relu_pack(void* stream, const float* P, int KS, int ldp, size_t slab_str
  *     generated_ids = model.generate(**inputs, max_new_tokens=4096, do_sample=False)                    chemical_ocr.py:375-380
  * i.e. stock Idefics3ForConditionalGeneration (SigLIP-style vision tower, pixel-shuffle connector, Llama-style text model),
  * greedy.  Tokenisation / image resizing stay on the host (the stock processor); this library takes the processor's tensors.
- * v1 limits: head dim 64 everywhere; every image is a full image_size x image_size frame (pixel_attention_mask all ones, as the
- * processor produces for a 512-px page with a 512-px vision tower); every sequence of a call has the same prompt length (no
- * padding) and exactly n_img * image_seq_len <image> tokens.  Same conventions as above (device pointers, caller-owned buffers).
+ * Padded frames (non-square pages: pixel_attention_mask not all ones) are given as the patch grid the stock model derives from the
+ * mask: patch_mask [N][P] u8 (a patch is valid if any of its pixels is) and patch_pos [N][P] i32 (the bucketed fractional coordinates
+ * of Idefics3VisionEmbeddings, modeling_idefics3.py:128-172, computed by the host wrapper with the same torch ops); both NULL = full
+ * frames.  v1 limits: head dim 64 everywhere; every sequence of a call has the same prompt length (no padding), the same number of
+ * frames and exactly n_img * image_seq_len <image> tokens.  Same conventions as above (device pointers, caller-owned buffers).
  * ------------------------------------------------------------------------------------------------------------------------------ */
 typedef struct mg_ocr_model mg_ocr_model;
 typedef struct mg_ocr_config {
@@ -257,16 +259,18 @@ int mg_ocr_finalize(mg_ocr_model* m, void* stream);
 int mg_ocr_workspace_bytes(const mg_ocr_model* m, int B, int n_img, int L, int max_new_tokens, int full_logits, size_t* out_bytes);
 /* get_image_features (modeling_idefics3.py:563-622): pixel_values [N][3][I][I] fp32 -> out [N][image_seq_len][t_hidden] fp32
  * (workspace: mg_ocr_workspace_bytes(m, N, 1, 1, 0, 0)). */
-int mg_ocr_image_features(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, const float* pixel_values, int N, float* out);
+int mg_ocr_image_features(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, const float* pixel_values, const int32_t* patch_pos,
+                          const uint8_t* patch_mask, int N, float* out);
 /* Teacher-forced forward (modeling_idefics3.py:750-840): input_ids [B][L] i64, pixel_values [B][n_img][3][I][I] fp32 (NULL with
  * n_img = 0: text only) -> logits [B][L][vocab] fp32.  Workspace with full_logits = 1.  SYNCHRONISES (reports bad inputs). */
-int mg_ocr_forward(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* input_ids, const float* pixel_values, int B,
-                   int n_img, int L, float* logits);
+int mg_ocr_forward(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* input_ids, const float* pixel_values,
+                   const int32_t* patch_pos, const uint8_t* patch_mask, int B, int n_img, int L, float* logits);
 /* generate(max_new_tokens, do_sample=False) (generation/utils.py:2783-2975): out_ids [B][max_new_tokens] i64 = the NEW tokens
  * (finished rows padded with pad_token_id), *out_cols_host = columns HF would have produced (steps until every row had emitted
  * EOS).  step_logits (nullable, tests): [capture_steps][B][vocab] fp32 pre-argmax logits of the first steps.  SYNCHRONISES. */
-int mg_ocr_generate(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* input_ids, const float* pixel_values, int B,
-                    int n_img, int L, int max_new_tokens, int64_t* out_ids, int* out_cols_host, float* step_logits, int capture_steps);
+int mg_ocr_generate(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* input_ids, const float* pixel_values,
+                    const int32_t* patch_pos, const uint8_t* patch_mask, int B, int n_img, int L, int max_new_tokens, int64_t* out_ids,
+                    int* out_cols_host, float* step_logits, int capture_steps);
 
 #ifdef __cplusplus
 }

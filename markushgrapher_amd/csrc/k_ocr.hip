@@ -73,15 +73,23 @@ __global__ __launch_bounds__(256) void silu_mul_pack_kernel(const float* in, uin
     }
 }
 
-// hidden[n][p] = patch_emb[n*P + p] + pos_emb[p]   (full image: position ids = arange, modeling_idefics3.py:128-172); rows
-// p >= P of an image (P_cap > P) are zero
-__global__ __launch_bounds__(256) void add_pos_kernel(const float* patch, const uint16_t* pos, float* hidden, int N, int P, int P_cap, int d) {
+// hidden[n][p] = patch_emb[n*P + p] + pos_emb[pos_ids[n][p]]   (pos_ids null = full image: position ids = arange,
+// modeling_idefics3.py:128-172; otherwise the bucketed fractional coordinates computed by the host wrapper); rows p >= P of an
+// image (P_cap > P) are zero.  vmask (nullable): [N][P_cap] key mask of the tower's attention <- patch_mask [N][P] (null = all ones)
+__global__ __launch_bounds__(256) void add_pos_kernel(const float* patch, const uint16_t* pos, const int* pos_ids, const uint8_t* patch_mask,
+                                                      uint8_t* vmask, float* hidden, int N, int P, int P_cap, int d) {
+    if (vmask)
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)N * P_cap; i += (size_t)gridDim.x * 256) {
+            const int p = (int)(i % P_cap), im = (int)(i / P_cap);
+            vmask[i] = p < P ? (patch_mask ? patch_mask[(size_t)im * P + p] != 0 : 1) : 0;
+        }
     const size_t n = (size_t)N * P_cap * d;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const int c = (int)(i % d);
         const size_t r = i / d;
         const int p = (int)(r % P_cap), im = (int)(r / P_cap);
-        hidden[i] = p < P ? patch[((size_t)im * P + p) * d + c] + bf16_to_f32(pos[(size_t)p * d + c]) : 0.f;
+        const int pi = (p < P && pos_ids) ? pos_ids[(size_t)im * P + p] : p;
+        hidden[i] = p < P ? patch[((size_t)im * P + p) * d + c] + bf16_to_f32(pos[(size_t)pi * d + c]) : 0.f;
     }
 }
 
@@ -266,8 +274,9 @@ void ocr_gelu_pack(const float* in, uint16_t* y_pk, int M, int N, int Kaug, mgSt
 void ocr_silu_mul_pack(const float* in, uint16_t* y_pk, int M, int I, mgStream_t st) {
     MG_LAUNCH(silu_mul_pack_kernel, dim3(grid_for((size_t)M * I)), dim3(256), 0, st, in, y_pk, M, I);
 }
-void ocr_add_pos(const float* patch, const uint16_t* pos, float* hidden, int N, int P, int P_cap, int d, mgStream_t st) {
-    MG_LAUNCH(add_pos_kernel, dim3(grid_for((size_t)N * P_cap * d)), dim3(256), 0, st, patch, pos, hidden, N, P, P_cap, d);
+void ocr_add_pos(const float* patch, const uint16_t* pos, const int* pos_ids, const uint8_t* patch_mask, uint8_t* vmask, float* hidden, int N, int P,
+                 int P_cap, int d, mgStream_t st) {
+    MG_LAUNCH(add_pos_kernel, dim3(grid_for((size_t)N * P_cap * d)), dim3(256), 0, st, patch, pos, pos_ids, patch_mask, vmask, hidden, N, P, P_cap, d);
 }
 void ocr_pixel_shuffle_pack(const float* vis, uint16_t* x_pk, int N, int g, int P_cap, int e, int sf, mgStream_t st) {
     MG_LAUNCH(pixel_shuffle_pack_kernel, dim3(grid_for((size_t)N * (g / sf) * (g / sf) * e * sf * sf)), dim3(256), 0, st, vis, x_pk, N, g, P_cap, e, sf);

@@ -7,7 +7,8 @@ void ocr_layernorm_pack(float* h, const float* w, const float* b, const float* a
                         int Kaug, float eps, mgStream_t st);
 void ocr_gelu_pack(const float* in, uint16_t* y_pk, int M, int N, int Kaug, mgStream_t st);
 void ocr_silu_mul_pack(const float* in, uint16_t* y_pk, int M, int I, mgStream_t st);
-void ocr_add_pos(const float* patch, const uint16_t* pos, float* hidden, int N, int P, int P_cap, int d, mgStream_t st);
+void ocr_add_pos(const float* patch, const uint16_t* pos, const int* pos_ids, const uint8_t* patch_mask, uint8_t* vmask, float* hidden, int N, int P,
+                 int P_cap, int d, mgStream_t st);
 void ocr_pixel_shuffle_pack(const float* vis, uint16_t* x_pk, int N, int g, int P_cap, int e, int sf, mgStream_t st);
 void ocr_merge_embed(const int64_t* ids, const uint16_t* tok_emb, const float* feats, float* h, int B, int L, int T_cap, int d, int V,
                      int image_token, int per_seq, int* err, mgStream_t st);

@@ -104,7 +104,7 @@ struct Ws {
     float *h, *qkv, *gu, *logits, *rs_a, *rs_b;
     uint16_t* xw;            // decode step: packed [rows][t_hidden + t_inter] = [bf16(h) | SwiGLU output]
     uint16_t *x, *q, *k, *vt, *ctx, *y, *xc, *Kc, *Vc;
-    uint8_t* kmask;
+    uint8_t *kmask, *vmask;
     int *last_rows, *all_rows, *unfinished, *counters;
     int64_t* next_ids;
     size_t total, kv_layer;
@@ -143,6 +143,7 @@ void carve(const mg_ocr_model* m, char* base, int B, int n_img, int L, int max_n
     w->Kc = cv.take<uint16_t>(w->kv_layer * c.t_layers);
     w->Vc = cv.take<uint16_t>(w->kv_layer * c.t_layers);
     w->kmask = cv.take<uint8_t>(MT);
+    w->vmask = cv.take<uint8_t>(MV);
     w->last_rows = cv.take<int>(MT); w->all_rows = cv.take<int>(MT);
     w->unfinished = cv.take<int>(round_up(B, 32)); w->counters = cv.take<int>(16);
     w->next_ids = cv.take<int64_t>(round_up(B, 32));
@@ -157,7 +158,7 @@ int check_args(const mg_ocr_model* m, int B, int n_img, int L, const char* who) 
 }
 
 // vision tower + connector: pixel_values [N][3][I][I] -> w.feats [N*T_img][t_hidden]
-void image_features(const mg_ocr_model* m, const Ws& w, const float* pix, int N, mgStream_t st) {
+void image_features(const mg_ocr_model* m, const Ws& w, const float* pix, const int* patch_pos, const uint8_t* patch_mask, int N, mgStream_t st) {
     const mg_ocr_config& c = m->c;
     const int vh = c.v_hidden, vi = c.v_inter, P = m->P, Pc = m->P_cap, MV = N * Pc, H = c.v_heads, kp = 3 * c.patch_size * c.patch_size;
     const std::string v = "model.vision_model.";
@@ -165,7 +166,8 @@ void image_features(const mg_ocr_model* m, const Ws& w, const float* pix, int N,
     GemmArgs pe = ga(w.xim, m->at<uint16_t>(m->patch_w), N * P, vh, kp);
     pe.out_f32 = w.patch; pe.ldo = vh; pe.bias = m->rawp(v + "embeddings.patch_embedding.bias");
     gemm(pe, EPI_F32_STORE, st);
-    ocr_add_pos(w.patch, m->at<uint16_t>(m->pos_emb), w.vh, N, P, Pc, vh, st);
+    const bool masked = patch_mask != nullptr || P != Pc;
+    ocr_add_pos(w.patch, m->at<uint16_t>(m->pos_emb), patch_pos, patch_mask, masked ? w.vmask : nullptr, w.vh, N, P, Pc, vh, st);
     for (int i = 0; i < c.v_layers; ++i) {
         const std::string p = v + "encoder.layers." + std::to_string(i) + ".";
         const VLayer& l = m->vl[i];
@@ -178,7 +180,7 @@ void image_features(const mg_ocr_model* m, const Ws& w, const float* pix, int N,
         gemm(a, EPI_HEADS, st);
         AttnArgs t{};
         t.Q = w.vq; t.K = w.vk; t.Vt = w.vvt; t.ctx = w.vctx; t.B = N; t.H = H; t.Sq = P; t.Sk = P; t.Sq_cap = Pc; t.Sk_cap = Pc;
-        t.mode = ATT_CROSS; t.kmask = nullptr;
+        t.mode = ATT_CROSS; t.kmask = patch_mask ? w.vmask : nullptr;      // padded frames: masked patches are not attended as keys
         attention(t, st);
         GemmArgs o = ga(w.vctx, m->at<uint16_t>(l.wo), MV, vh, vh);
         o.out_f32 = w.vh; o.ldo = vh;
@@ -506,21 +508,23 @@ int mg_ocr_workspace_bytes(const mg_ocr_model* m, int B, int n_img, int L, int m
     return MG_OK;
 }
 
-int mg_ocr_image_features(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, const float* pixel_values, int N, float* out) {
+int mg_ocr_image_features(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, const float* pixel_values, const int32_t* patch_pos,
+                          const uint8_t* patch_mask, int N, float* out) {
     int rc = check_args(m, N, 1, 1, "mg_ocr_image_features");
     if (rc != MG_OK) return rc;
     Ws w;
     carve(m, (char*)ws, N, 1, 1, 0, false, &w);
     if (!ws || ws_bytes < w.total) return failf(MG_E_WORKSPACE, "mg_ocr_image_features: workspace %zu < %zu bytes", ws_bytes, w.total);
     mgStream_t st = (mgStream_t)stream;
-    image_features(m, w, pixel_values, N, st);
+    if ((patch_pos == nullptr) != (patch_mask == nullptr)) return failf(MG_E_ARG, "mg_ocr_image_features: patch_pos and patch_mask go together");
+    image_features(m, w, pixel_values, patch_pos, patch_mask, N, st);
     const size_t n = (size_t)N * m->T_img * m->c.t_hidden;
     MG_LAUNCH(copy_f32_kernel, dim3(256), dim3(256), 0, st, (const float*)w.feats, out, n);
     return check("mg_ocr_image_features");
 }
 
-int mg_ocr_forward(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* input_ids, const float* pixel_values, int B,
-                   int n_img, int L, float* logits) {
+int mg_ocr_forward(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* input_ids, const float* pixel_values,
+                   const int32_t* patch_pos, const uint8_t* patch_mask, int B, int n_img, int L, float* logits) {
     int rc = check_args(m, B, n_img, L, "mg_ocr_forward");
     if (rc != MG_OK) return rc;
     Ws w;
@@ -529,7 +533,8 @@ int mg_ocr_forward(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, con
     mgStream_t st = (mgStream_t)stream;
     const mg_ocr_config& c = m->c;
     mg_memset_async(w.counters, 0, 16 * sizeof(int), st);
-    if (pixel_values && n_img > 0) image_features(m, w, pixel_values, B * n_img, st);
+    if ((patch_pos == nullptr) != (patch_mask == nullptr)) return failf(MG_E_ARG, "mg_ocr_forward: patch_pos and patch_mask go together");
+    if (pixel_values && n_img > 0) image_features(m, w, pixel_values, patch_pos, patch_mask, B * n_img, st);
     prefill(m, w, input_ids, (pixel_values && n_img > 0) ? w.feats : nullptr, B, n_img, L, round_up(L, 64), st);
     const int T_cap = round_up(L, 64);
     rmsnorm_pack_rows(w.h, m->rawp("model.text_model.norm.weight"), w.xc, w.all_rows, B * T_cap, c.t_hidden, c.rms_eps, 1.0f, st);
@@ -545,8 +550,9 @@ int mg_ocr_forward(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, con
     return MG_OK;
 }
 
-int mg_ocr_generate(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* input_ids, const float* pixel_values, int B,
-                    int n_img, int L, int max_new_tokens, int64_t* out_ids, int* out_cols_host, float* step_logits, int capture_steps) {
+int mg_ocr_generate(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* input_ids, const float* pixel_values,
+                    const int32_t* patch_pos, const uint8_t* patch_mask, int B, int n_img, int L, int max_new_tokens, int64_t* out_ids,
+                    int* out_cols_host, float* step_logits, int capture_steps) {
     int rc = check_args(m, B, n_img, L, "mg_ocr_generate");
     if (rc != MG_OK) return rc;
     if (max_new_tokens < 1 || !out_ids || !out_cols_host) return failf(MG_E_ARG, "mg_ocr_generate: bad output arguments");
@@ -569,7 +575,8 @@ int mg_ocr_generate(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, co
     const int cap = round_up(L + max_new_tokens, 64), T_cap = round_up(L, 64);
     mg_memset_async(w.counters, 0, 16 * sizeof(int), st);
     ocr_init(out_ids, w.unfinished, w.counters, B, max_new_tokens, c.pad_token_id, st);
-    if (pixel_values && n_img > 0) image_features(m, w, pixel_values, B * n_img, st);
+    if ((patch_pos == nullptr) != (patch_mask == nullptr)) return failf(MG_E_ARG, "mg_ocr_generate: patch_pos and patch_mask go together");
+    if (pixel_values && n_img > 0) image_features(m, w, pixel_values, patch_pos, patch_mask, B * n_img, st);
     prefill(m, w, input_ids, (pixel_values && n_img > 0) ? w.feats : nullptr, B, n_img, L, cap, st);
     // logits of the last prompt position
     rmsnorm_pack_rows(w.h, m->rawp("model.text_model.norm.weight"), w.xc, w.last_rows, B * T_cap, c.t_hidden, c.rms_eps, 1.0f, st);

@@ -42,11 +42,11 @@ class OcrEngine:
         L.mg_ocr_finalize.argtypes = [C.c_void_p, C.c_void_p]
         L.mg_ocr_load_tensor.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]
         L.mg_ocr_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
-        L.mg_ocr_image_features.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]
-        L.mg_ocr_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
-                                     C.c_void_p]
-        L.mg_ocr_generate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
-                                      C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_int]
+        L.mg_ocr_image_features.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.mg_ocr_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                     C.c_int, C.c_void_p]
+        L.mg_ocr_generate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_int]
         s = shape
         cfg = MgOcrConfig(s.v_hidden, s.v_inter, s.v_layers, s.v_heads, s.image_size, s.patch_size, s.t_hidden, s.t_inter, s.t_layers,
                           s.t_heads, s.t_kv_heads, s.vocab, s.scale_factor, s.image_token_id, s.eos_token_id, s.pad_token_id,
@@ -98,6 +98,33 @@ class OcrEngine:
             self._ws_bytes = need.value
         return self._ws, self._ws_bytes
 
+    def patch_inputs(self, pixel_attention_mask):
+        """pixel_attention_mask [..., I, I] (bool, as the Idefics3 processor returns it) -> (patch_pos int32 [N][P], patch_mask u8 [N][P])
+        device arrays, or (None, None) when every pixel is valid.  The patch grid of get_image_features (modeling_idefics3.py:605-608)
+        and the bucketed fractional coordinates of Idefics3VisionEmbeddings (:128-172), evaluated on the host with the same torch ops
+        in fp32 - a few hundred integers per frame, not worth a kernel and exact by construction."""
+        if pixel_attention_mask is None:
+            return None, None
+        import torch
+        s = self.shape
+        pam = torch.as_tensor(pixel_attention_mask).detach().cpu().bool()
+        pam = pam.reshape(-1, s.image_size, s.image_size)
+        if bool(pam.all()):
+            return None, None
+        ps, g = s.patch_size, s.image_size // s.patch_size
+        N = pam.shape[0]
+        pmask = pam.unfold(1, ps, ps).unfold(2, ps, ps).sum(dim=(-1, -2)) > 0
+        boundaries = torch.arange(1 / g, 1.0, 1 / g)
+        nb_h, nb_w = pmask[:, :, 0].sum(dim=1), pmask[:, 0, :].sum(dim=1)
+        idx = torch.arange(g, dtype=torch.float32)
+        fh = torch.clamp(idx[None, :] * (1.0 / nb_h)[:, None], max=(1.0 - 1e-6)).to(torch.float32)
+        fw = torch.clamp(idx[None, :] * (1.0 / nb_w)[:, None], max=(1.0 - 1e-6)).to(torch.float32)
+        bh, bw = torch.bucketize(fh, boundaries, right=True), torch.bucketize(fw, boundaries, right=True)
+        pos = (bh[:, :, None] * g + bw[:, None, :]).reshape(N, -1)
+        flat = pmask.reshape(N, -1)
+        pos = torch.where(flat, pos, torch.zeros_like(pos))
+        return (self.mem.asarray(pos.to(torch.int32).numpy(), np.int32), self.mem.asarray(flat.to(torch.uint8).numpy(), np.uint8))
+
     def _inputs(self, input_ids, pixel_values):
         ids = self.mem.asarray(input_ids, np.int64)
         B, L = int(ids.shape[0]), int(ids.shape[1])
@@ -109,32 +136,39 @@ class OcrEngine:
             raise MgError(f"pixel_values must be [B={B}][n_img][3][{s.image_size}][{s.image_size}], got {tuple(pv.shape)}")
         return ids, pv, B, int(pv.shape[1]), L
 
-    def image_features(self, pixel_values):
+    def image_features(self, pixel_values, pixel_attention_mask=None):
         """[N][3][I][I] -> [N][image_seq_len][t_hidden] fp32 (get_image_features, modeling_idefics3.py:563-622)."""
         pv = self.mem.asarray(pixel_values, np.float32)
         N = int(pv.shape[0])
+        pos, msk = self.patch_inputs(pixel_attention_mask)
         ws, nb = self._workspace(N, 1, 1, 0, False)
         out = self.mem.empty((N, self.shape.image_seq_len, self.shape.t_hidden), np.float32)
-        self._chk(self.lib.mg_ocr_image_features(self.model, self.mem.stream(), self.mem.ptr(ws), nb, self.mem.ptr(pv), N, self.mem.ptr(out)))
+        self._chk(self.lib.mg_ocr_image_features(self.model, self.mem.stream(), self.mem.ptr(ws), nb, self.mem.ptr(pv),
+                                                 self.mem.ptr(pos) if pos is not None else None, self.mem.ptr(msk) if msk is not None else None,
+                                                 N, self.mem.ptr(out)))
         return out
 
-    def forward_logits(self, input_ids, pixel_values=None):
+    def forward_logits(self, input_ids, pixel_values=None, pixel_attention_mask=None):
         ids, pv, B, n_img, L = self._inputs(input_ids, pixel_values)
+        pos, msk = self.patch_inputs(pixel_attention_mask) if pv is not None else (None, None)
         ws, nb = self._workspace(B, n_img, L, 0, True)
         out = self.mem.empty((B, L, self.shape.vocab), np.float32)
         self._chk(self.lib.mg_ocr_forward(self.model, self.mem.stream(), self.mem.ptr(ws), nb, self.mem.ptr(ids),
-                                          self.mem.ptr(pv) if pv is not None else None, B, n_img, L, self.mem.ptr(out)))
+                                          self.mem.ptr(pv) if pv is not None else None, self.mem.ptr(pos) if pos is not None else None,
+                                          self.mem.ptr(msk) if msk is not None else None, B, n_img, L, self.mem.ptr(out)))
         return out
 
-    def generate(self, input_ids, pixel_values=None, max_new_tokens=4096, capture_steps=0):
+    def generate(self, input_ids, pixel_values=None, max_new_tokens=4096, capture_steps=0, pixel_attention_mask=None):
         """-> (new_ids [B][n], step_logits or None): the tokens after the prompt, as generated_ids[:, prompt_len:] of the reference."""
         ids, pv, B, n_img, L = self._inputs(input_ids, pixel_values)
+        pos, msk = self.patch_inputs(pixel_attention_mask) if pv is not None else (None, None)
         ws, nb = self._workspace(B, n_img, L, max_new_tokens, False)
         out = self.mem.empty((B, max_new_tokens), np.int64)
         cap = self.mem.empty((capture_steps, B, self.shape.vocab), np.float32) if capture_steps else None
         cols = C.c_int()
         self._chk(self.lib.mg_ocr_generate(self.model, self.mem.stream(), self.mem.ptr(ws), nb, self.mem.ptr(ids),
-                                           self.mem.ptr(pv) if pv is not None else None, B, n_img, L, max_new_tokens, self.mem.ptr(out),
+                                           self.mem.ptr(pv) if pv is not None else None, self.mem.ptr(pos) if pos is not None else None,
+                                           self.mem.ptr(msk) if msk is not None else None, B, n_img, L, max_new_tokens, self.mem.ptr(out),
                                            C.byref(cols), self.mem.ptr(cap) if cap is not None else None, capture_steps))
         return out[:, :cols.value], cap
 
@@ -212,8 +246,6 @@ class OcrModel:
             raise MgError("only greedy search (do_sample=False) is implemented, as the reference calls it")
         if attention_mask is not None and not bool(torch.as_tensor(attention_mask).bool().all()):
             raise MgError("padded prompts are not supported (v1): batch prompts of equal length, as one page per call produces")
-        if pixel_attention_mask is not None and not bool(torch.as_tensor(pixel_attention_mask).bool().all()):
-            raise MgError("partially masked images are not supported (v1): full image_size x image_size frames only")
-        new, _ = self.engine.generate(input_ids, pixel_values, max_new_tokens)
+        new, _ = self.engine.generate(input_ids, pixel_values, max_new_tokens, pixel_attention_mask=pixel_attention_mask)
         ids = torch.as_tensor(input_ids).to(new.device)
         return torch.cat([ids, new], dim=1)

@@ -151,3 +151,22 @@ def synth_inputs(s: OcrShape, B: int, prompt_text_tokens: int = 12, seed: int = 
     blocks = uniform_pm1("ocr/blocks", (B, n_frames, 1, s.image_size // 8, s.image_size // 8), seed)
     pix = np.where(np.repeat(np.repeat(blocks, 8, -1), 8, -2) > 0.7, pix, np.float32(1.0) - np.float32(0.05) * np.abs(pix))
     return ids, pix.astype(np.float32)
+
+
+def synth_pixel_mask(s: OcrShape, B: int, n_img: int = 1, seed: int = 20260929):
+    """pixel_attention_mask [B][n][I][I] of non-square pages as the Idefics3 processor pads them: valid region = top-left
+    (rows < h, columns < w) with h, w not multiples of the patch size for some frames; frame 0 of sequence 0 stays full."""
+    from .synth import randint
+    I = s.image_size
+    m = np.zeros((B, n_img, I, I), bool)
+    hs = randint("ocr/mask_h", B * n_img, I // 4, 3 * I // 4, seed).reshape(B, n_img)      # at least a quarter of the patch rows / columns
+    ws = randint("ocr/mask_w", B * n_img, I // 4, 3 * I // 4, seed).reshape(B, n_img)      # of a padded frame are fully masked
+    for b in range(B):
+        for j in range(n_img):
+            h, w = (I, I) if (b == 0 and j == 0) else (int(hs[b, j]), int(ws[b, j]))
+            if (b + j) % 2:
+                h = I                  # landscape / portrait alternate: one side stays full, as longest-edge resizing gives
+            else:
+                w = I if not (b == 0 and j == 0) else I
+            m[b, j, :h, :w] = True
+    return m

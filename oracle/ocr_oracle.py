@@ -45,8 +45,32 @@ class OcrOracle:
         return y
 
     # ---- vision tower (modeling_idefics3.py:98-172, 199-356, 433-505) -------------------------------------------------
-    def vision(self, pixel_values):
-        """pixel_values [N][3][I][I] -> last_hidden_state [N][P][v_hidden] (after post_layernorm)."""
+    def patch_inputs(self, pixel_attention_mask):
+        """pixel_attention_mask [N][I][I] bool -> (patch mask [N][P] bool, position ids [N][P] long): the patch grid of
+        get_image_features (modeling_idefics3.py:605-608) and the fractional-coordinate buckets of Idefics3VisionEmbeddings
+        (:128-172), evaluated with the same torch ops in fp32."""
+        s = self.s
+        ps, g = s.patch_size, s.image_size // s.patch_size
+        pam = torch.as_tensor(pixel_attention_mask).bool()
+        N = pam.shape[0]
+        sub = pam.unfold(1, ps, ps).unfold(2, ps, ps)
+        pmask = (sub.sum(dim=(-1, -2)) > 0)                                   # [N][g][g]
+        boundaries = torch.arange(1 / g, 1.0, 1 / g)
+        nb_h, nb_w = pmask[:, :, 0].sum(dim=1), pmask[:, 0, :].sum(dim=1)
+        step_h, step_w = 1.0 / nb_h, 1.0 / nb_w
+        idx = torch.arange(g, dtype=torch.float32)
+        fh = torch.clamp(idx[None, :] * step_h[:, None], max=(1.0 - 1e-6)).to(torch.float32)
+        fw = torch.clamp(idx[None, :] * step_w[:, None], max=(1.0 - 1e-6)).to(torch.float32)
+        bh, bw = torch.bucketize(fh, boundaries, right=True), torch.bucketize(fw, boundaries, right=True)
+        pos = (bh[:, :, None] * g + bw[:, None, :]).reshape(N, -1)
+        flat = pmask.reshape(N, -1)
+        position_ids = torch.zeros_like(pos)
+        position_ids[flat] = pos[flat]
+        return flat, position_ids
+
+    def vision(self, pixel_values, pixel_attention_mask=None):
+        """pixel_values [N][3][I][I] -> last_hidden_state [N][P][v_hidden] (after post_layernorm); pixel_attention_mask [N][I][I]
+        (None = full frames): masked patches take position id 0 and are not attended as keys."""
         s, w = self.s, self.w
         N = pixel_values.shape[0]
         ps, g = s.patch_size, s.image_size // s.patch_size
@@ -55,7 +79,13 @@ class OcrOracle:
         x = pixel_values.reshape(N, 3, g, ps, g, ps).permute(0, 2, 4, 1, 3, 5).reshape(N, g * g, 3 * ps * ps)
         wk = w[v + "embeddings.patch_embedding.weight"].reshape(s.v_hidden, -1)
         h = self._r(x) @ wk.T + w[v + "embeddings.patch_embedding.bias"]
-        h = h + w[v + "embeddings.position_embedding.weight"][None]          # full image: position ids = arange(P)
+        kmask = None
+        if pixel_attention_mask is None:
+            h = h + w[v + "embeddings.position_embedding.weight"][None]      # full image: position ids = arange(P)
+        else:
+            pmask, pos_ids = self.patch_inputs(pixel_attention_mask)
+            h = h + w[v + "embeddings.position_embedding.weight"][pos_ids]
+            kmask = pmask[:, None, None, :]                                      # keys of masked patches are excluded (bidirectional mask)
         H = s.v_heads
         for i in range(s.v_layers):
             p = f"{v}encoder.layers.{i}."
@@ -63,7 +93,10 @@ class OcrOracle:
             q = self._r(self._lin(x, p + "self_attn.q_proj") * (64 ** -0.5)).reshape(N, -1, H, 64).transpose(1, 2)
             k = self._r(self._lin(x, p + "self_attn.k_proj")).reshape(N, -1, H, 64).transpose(1, 2)
             vv = self._r(self._lin(x, p + "self_attn.v_proj")).reshape(N, -1, H, 64).transpose(1, 2)
-            a = torch.softmax(q @ k.transpose(-1, -2), dim=-1)
+            sc = q @ k.transpose(-1, -2)
+            if kmask is not None:
+                sc = sc.masked_fill(~kmask, float("-inf"))
+            a = torch.softmax(sc, dim=-1)
             ctx = (a @ vv).transpose(1, 2).reshape(N, -1, s.v_hidden)
             h = h + self._lin(ctx, p + "self_attn.out_proj")
             x = torch.nn.functional.layer_norm(h, (s.v_hidden,), w[p + "layer_norm2.weight"], w[p + "layer_norm2.bias"], s.v_eps)
@@ -79,11 +112,15 @@ class OcrOracle:
         x = x.reshape(b, ww // sf, hh // sf, e * sf * sf).permute(0, 2, 1, 3)
         return x.reshape(b, seq // (sf * sf), e * sf * sf)
 
-    def image_features(self, pixel_values):
-        """pixel_values [B][n][3][I][I] -> [B*n][image_seq_len][t_hidden] (modeling_idefics3.py:563-622, all images real)."""
+    def image_features(self, pixel_values, pixel_attention_mask=None):
+        """pixel_values [B][n][3][I][I] (+ pixel_attention_mask [B][n][I][I]) -> [B*n][image_seq_len][t_hidden]
+        (modeling_idefics3.py:563-622, all images real)."""
         pv = torch.as_tensor(pixel_values, dtype=torch.float32)
         pv = pv.reshape(-1, *pv.shape[2:])
-        return self._lin(self.pixel_shuffle(self.vision(pv)), "model.connector.modality_projection.proj", bias=False)
+        pam = None
+        if pixel_attention_mask is not None:
+            pam = torch.as_tensor(pixel_attention_mask).reshape(-1, *pv.shape[2:])
+        return self._lin(self.pixel_shuffle(self.vision(pv, pam)), "model.connector.modality_projection.proj", bias=False)
 
     # ---- text model (modeling_llama.py) -------------------------------------------------------------------------------
     def _rope(self, x, pos):               # x [B][H][T][64], pos [T]
@@ -131,27 +168,27 @@ class OcrOracle:
             h = h + self._lin(y, p + "mlp.down_proj")
         return self._rms(h, "model.text_model.norm.weight"), new_cache
 
-    def embed(self, input_ids, pixel_values):
+    def embed(self, input_ids, pixel_values, pixel_attention_mask=None):
         ids = torch.as_tensor(input_ids, dtype=torch.long)
         h = self.w["model.text_model.embed_tokens.weight"][ids]
         if pixel_values is not None:
-            feats = self.image_features(pixel_values)
+            feats = self.image_features(pixel_values, pixel_attention_mask)
             m = ids == self.s.image_token_id
             h = h.clone()
             h[m] = feats.reshape(-1, feats.shape[-1])          # masked_scatter: row-major order of the <image> positions
         return h
 
-    def forward(self, input_ids, pixel_values):
+    def forward(self, input_ids, pixel_values, pixel_attention_mask=None):
         """Teacher-forced logits [B][L][V] (Idefics3ForConditionalGeneration.forward, modeling_idefics3.py:750-840)."""
-        hs, _ = self.text(self.embed(input_ids, pixel_values))
+        hs, _ = self.text(self.embed(input_ids, pixel_values, pixel_attention_mask))
         return self._r(hs) @ self.w["lm_head.weight"].T
 
-    def generate(self, input_ids, pixel_values, max_new_tokens, return_logits=False):
+    def generate(self, input_ids, pixel_values, max_new_tokens, return_logits=False, pixel_attention_mask=None):
         """Greedy search (generation/utils.py:2783-2975): returns new ids [B][n <= max_new_tokens] (pad after EOS)."""
         s = self.s
         ids = torch.as_tensor(input_ids, dtype=torch.long)
         B, L = ids.shape
-        hs, cache = self.text(self.embed(ids, pixel_values))
+        hs, cache = self.text(self.embed(ids, pixel_values, pixel_attention_mask))
         logits = self._r(hs[:, -1]) @ self.w["lm_head.weight"].T
         unfinished = torch.ones(B, dtype=torch.bool)
         out, step_logits = [], []

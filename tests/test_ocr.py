@@ -265,3 +265,28 @@ def test_ocr_more_than_one_row_tile():
             assert new[b, t] == ref[b, t], (b, t)
             checked += 1
     assert checked >= B // 2          # (every row's logits were compared at least at step 0; ids wherever the margin allows)
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+def test_ocr_padded_frames(be_name):
+    """Non-square pages: the processor pads the frame and masks the padding.  Masked patches take position id 0 and are not attended
+    as keys in the vision tower (modeling_idefics3.py:128-172, 462-505); the patch grid comes from OcrEngine.patch_inputs."""
+    from markushgrapher_amd.ocr_shapes import synth_pixel_mask
+    g, s, sd, ids, pix = _setup("tiny3")
+    pam = synth_pixel_mask(s, int(g["B"]), 1)
+    assert not pam.all() and pam[0, 0].all()
+    pix = np.where(pam[:, :, None], pix, np.float32(0.0)).astype(np.float32)
+    eng = make_ocr(be_name, s, sd)
+    feats = eng.mem.numpy(eng.image_features(pix[:, 0], pam[:, 0]))
+    step = max(1, feats.shape[1] // 4)
+    assert np.abs(feats[:, ::step] - g["feats_probe"]).max() < 0.05 * float(g["feats_abs_mean"])
+    logits = eng.mem.numpy(eng.forward_logits(ids, pix, pam))
+    tol = logit_tol(g["logits_absmax"])
+    got = np.take_along_axis(logits, g["logits_top8_idx"], axis=-1)
+    assert np.abs(got - g["logits_top8_val"]).max() < tol
+    n = int(g["new_tokens"])
+    new, cap = eng.generate(ids, pix, n, capture_steps=n, pixel_attention_mask=pam)
+    _check_generate(g, s, eng.mem.numpy(new), eng.mem.numpy(cap))
+    # and the mask matters: without it the features of the padded frames differ
+    plain = eng.mem.numpy(eng.image_features(pix[:, 0]))
+    assert np.abs(plain[1:] - feats[1:]).max() > 10 * 0.05 * float(g["feats_abs_mean"]) or np.abs(plain[1:] - feats[1:]).max() > 0.01

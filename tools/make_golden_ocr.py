@@ -35,7 +35,7 @@ def stock_model(s, sd):
     return m
 
 
-def mint(name, B, new_tokens, gain, eos_from_step=None, n_img=1, tag=None):
+def mint(name, B, new_tokens, gain, eos_from_step=None, n_img=1, tag=None, masked=False):
     import dataclasses
     s = PRESETS[name]
     sd = recipe_state_dict(s, gain=gain)
@@ -43,8 +43,13 @@ def mint(name, B, new_tokens, gain, eos_from_step=None, n_img=1, tag=None):
     t0 = time.time()
     m = stock_model(s, sd)
     tid, tpix = torch.from_numpy(ids), torch.from_numpy(pix)
-    kw = dict(input_ids=tid, attention_mask=torch.ones_like(tid), pixel_values=tpix,
-              pixel_attention_mask=torch.ones(B, n_img, s.image_size, s.image_size, dtype=torch.bool))
+    pam = torch.ones(B, n_img, s.image_size, s.image_size, dtype=torch.bool)
+    if masked:       # non-square pages: the processor pads the frame and masks the padding (rows at the bottom / columns at the right)
+        from markushgrapher_amd.ocr_shapes import synth_pixel_mask
+        pam = torch.from_numpy(synth_pixel_mask(s, B, n_img))
+        tpix = torch.where(pam[:, :, None], tpix, torch.zeros_like(tpix))
+        pix = tpix.numpy()
+    kw = dict(input_ids=tid, attention_mask=torch.ones_like(tid), pixel_values=tpix, pixel_attention_mask=pam)
     with torch.no_grad():
         feats = m.model.get_image_features(tpix, kw["pixel_attention_mask"], return_dict=True).pooler_output
         logits = m(**kw).logits
@@ -63,9 +68,10 @@ def mint(name, B, new_tokens, gain, eos_from_step=None, n_img=1, tag=None):
     print(f"[{name}] stock ran in {time.time() - t0:.1f}s; new ids row 0: {new[0].tolist()}")
     orc = OcrOracle(s, sd)
     with torch.no_grad():
-        of = orc.image_features(pix)
-        ol = orc.forward(ids, pix)
-        on, osc = orc.generate(ids, pix, new_tokens, return_logits=True)
+        opam = pam.numpy() if masked else None
+        of = orc.image_features(pix, opam)
+        ol = orc.forward(ids, pix, opam)
+        on, osc = orc.generate(ids, pix, new_tokens, return_logits=True, pixel_attention_mask=opam)
     e_f = float((of - feats).abs().max()); e_l = float((ol - logits).abs().max())
     n = min(on.shape[1], new.shape[1])
     same = bool((on[:, :n] == new[:, :n]).all()) and on.shape[1] == new.shape[1]
@@ -76,7 +82,7 @@ def mint(name, B, new_tokens, gain, eos_from_step=None, n_img=1, tag=None):
     top = torch.topk(scores, 8, dim=-1)
     ltop = torch.topk(logits, 8, dim=-1)
     srt = torch.sort(scores, dim=-1, descending=True).values
-    out = dict(shape=np.array(name), n_img=n_img, B=B, new_tokens=new_tokens, gain=np.float32(gain), eos_token_id=s.eos_token_id,
+    out = dict(shape=np.array(name), n_img=n_img, masked=int(masked), B=B, new_tokens=new_tokens, gain=np.float32(gain), eos_token_id=s.eos_token_id,
                input_ids=ids, new_ids=new.numpy(), step_top8_val=top.values.numpy(), step_top8_idx=top.indices.numpy(),
                step_margin=(srt[..., 0] - srt[..., 1]).numpy(), logits_top8_val=ltop.values.numpy(), logits_top8_idx=ltop.indices.numpy(),
                logits_absmax=np.float32(logits.abs().max()), feats_probe=feats[:, ::max(1, feats.shape[1] // 4)].numpy(),
@@ -96,5 +102,7 @@ if __name__ == "__main__":
         mint("tiny", B=3, new_tokens=12, gain=0.7, eos_from_step=5)
     if "tiny2" in what or not sys.argv[1:]:
         mint("tiny", B=2, new_tokens=6, gain=0.7, n_img=2, tag="tiny2")      # two frames per page (a page split by the processor)
+    if "tiny3" in what or not sys.argv[1:]:
+        mint("tiny", B=3, new_tokens=6, gain=0.7, tag="tiny3", masked=True)   # partially masked frames (non-square pages)
     if "smoldocling" in what:
         mint("smoldocling", B=2, new_tokens=8, gain=1.0)
