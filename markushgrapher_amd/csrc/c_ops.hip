@@ -30,7 +30,8 @@ int mgk_im2col_pack(void* stream, const float* pix, void* x_pk, int B, int C, in
 int mgk_set_rows_split(int mode) { gemm_rows_set_split(mode); return MG_OK; }
 int mgk_gemm(void* stream, int mode, int epi, const void* X_pk, const void* W_pk, int M, int N, int K, float* out_f32,
              int ldo, const float* bias, void* out_pk) {
-    if ((K & 63) || epi < 0 || epi > EPI_PK) return MG_E_SHAPE;
+    if ((K & 63) || epi < 0 || (epi > EPI_PK && epi != EPI_PK_GELU)) return MG_E_SHAPE;
+    if (epi == EPI_PK_GELU && !(mode == 0 && gemm_has_gelu_epilogue(M, N))) return MG_E_UNSUPPORTED;
     GemmArgs a{};
     a.X = (const uint16_t*)X_pk; a.W = (const uint16_t*)W_pk; a.M = M; a.N = N; a.K = K;
     a.out_f32 = out_f32; a.ldo = ldo; a.bias = bias; a.out_pk = (uint16_t*)out_pk;

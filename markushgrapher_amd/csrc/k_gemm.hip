@@ -141,7 +141,7 @@ template <int EPI, bool TOR, bool APPLY_RS = false>
 MG_DEV void tile_epilogue(const GemmArgs& a, const f32x16& acc_in, int m0, int n0, int lane, int qmask = 3, float rsl = 1.0f) {
     const int half = lane >> 5, l32 = lane & 31;
     f32x16 acc = acc_in;
-    if constexpr (APPLY_RS && (EPI == EPI_PK || EPI == EPI_PK_RELU || EPI == EPI_HEADS)) {
+    if constexpr (APPLY_RS && (EPI == EPI_PK || EPI == EPI_PK_RELU || EPI == EPI_PK_GELU || EPI == EPI_HEADS)) {
         if (a.rs.part) {                                              // rsl: the scale of token m0 + lane%32 (both half-waves)
             if (TOR) {
 #pragma unroll
@@ -166,11 +166,18 @@ MG_DEV void tile_epilogue(const GemmArgs& a, const f32x16& acc_in, int m0, int n
                 else *p = acc[r] + bv;
             }
         }
-    } else if constexpr (EPI == EPI_PK || EPI == EPI_PK_RELU) {
+    } else if constexpr (EPI == EPI_PK || EPI == EPI_PK_RELU || EPI == EPI_PK_GELU) {
         f32x16 v = acc;
         if (EPI == EPI_PK_RELU) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (EPI == EPI_PK_GELU) {        // torch gelu(approximate="tanh"): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))) = x sigmoid(2 u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float x = v[r], u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+                v[r] = x / (1.0f + fast_exp(-2.0f * u));
+            }
         }
         uint4 ch[2];
         acc_to_chunks(v, half, ch);
@@ -691,6 +698,8 @@ static void launch_wide(const GemmArgs& a, mgStream_t stream) {
 static int g_gemm_variant = 3;
 void gemm_set_variant(int v) { g_gemm_variant = v; }
 
+bool gemm_has_gelu_epilogue(int M, int N) { return g_gemm_variant >= 2 && M >= 320 && N >= GX_N; }
+
 void gemm(const GemmArgs& a, int epi, mgStream_t stream) {
     static bool env_read = false;
     if (!env_read) { env_read = true; if (const char* e = getenv("MG_GEMM_VARIANT")) g_gemm_variant = atoi(e); }   // A/B runs
@@ -704,6 +713,7 @@ void gemm(const GemmArgs& a, int epi, mgStream_t stream) {
                 case EPI_F32_STORE: launch_xl<EPI_F32_STORE, 5>(a, stream); break;
                 case EPI_F32_RESID: launch_xl<EPI_F32_RESID, 5>(a, stream); break;
                 case EPI_PK_RELU: launch_xl<EPI_PK_RELU, 5>(a, stream); break;
+                case EPI_PK_GELU: launch_xl<EPI_PK_GELU, 5>(a, stream); break;
                 case EPI_PK: launch_xl<EPI_PK, 5>(a, stream); break;
                 case EPI_RESID_NORM: launch_xl<EPI_RESID_NORM, 5>(a, stream); break;
                 default: launch_xl<EPI_HEADS, 5>(a, stream); break;
@@ -715,6 +725,7 @@ void gemm(const GemmArgs& a, int epi, mgStream_t stream) {
                 case EPI_F32_STORE: launch_xl<EPI_F32_STORE, 4>(a, stream); break;
                 case EPI_F32_RESID: launch_xl<EPI_F32_RESID, 4>(a, stream); break;
                 case EPI_PK_RELU: launch_xl<EPI_PK_RELU, 4>(a, stream); break;
+                case EPI_PK_GELU: launch_xl<EPI_PK_GELU, 4>(a, stream); break;
                 case EPI_PK: launch_xl<EPI_PK, 4>(a, stream); break;
                 case EPI_RESID_NORM: launch_xl<EPI_RESID_NORM, 4>(a, stream); break;
                 default: launch_xl<EPI_HEADS, 4>(a, stream); break;

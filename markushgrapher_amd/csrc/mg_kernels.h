@@ -22,6 +22,8 @@ enum GemmEpi : int {
     // decode-step kernels only (gemm_rows): W rows interleaved gate_0, up_0, gate_1, up_1, ...; out_pk packed [M][N/2] =
     // bf16(silu(r g_j) * (r u_j)) with r the deferred RMSNorm scale of the row (Llama MLP, modeling_llama.py LlamaMLP)
     EPI_PK_SWIGLU = 6,
+    // large-M tile kernel only (gemm_has_gelu_epilogue): out_pk packed [M][N] = bf16(gelu_tanh(acc))   (vision-tower MLP, SiglipMLP)
+    EPI_PK_GELU = 7,
 };
 // Destination formats for per-head projections (head dim fixed at 64):
 enum HeadFmt : int {
@@ -71,6 +73,7 @@ struct GemmArgs {
     int out_ld, out_col0;
 };
 void gemm(const GemmArgs& a, int epi, mgStream_t stream);
+bool gemm_has_gelu_epilogue(int M, int N);     // EPI_PK_GELU exists in the 320x256 / 256x256 tile kernels only
 void gemm_set_variant(int v);   // 0: 128x128 kernel only; 1: + 256x128 three-stage; 2: + 256x256; 4: + 320x256 wherever it fits; 3 (default): by shape
 
 // small-M (decode step) GEMM: M <= 32*MT rows of live sequences, weights streamed once.

@@ -188,9 +188,14 @@ void image_features(const mg_ocr_model* m, const Ws& w, const float* pix, const 
         ocr_layernorm_pack(w.vh, m->rawp(p + "layer_norm2.weight"), m->rawp(p + "layer_norm2.bias"), m->rawp(p + "mlp.fc2.bias"), w.vx,
                            nullptr, MV, vh, m->vka, c.v_eps, st);
         GemmArgs f1 = ga(w.vx, m->at<uint16_t>(l.fc1), MV, vi, m->vka);
-        f1.out_f32 = w.vtmp; f1.ldo = vi;
-        gemm(f1, EPI_F32_STORE, st);
-        ocr_gelu_pack(w.vtmp, w.vy, MV, vi, vi, st);
+        if (gemm_has_gelu_epilogue(MV, vi)) {          // GELU in the GEMM epilogue: no fp32 round trip of [rows][v_inter]
+            f1.out_pk = w.vy;
+            gemm(f1, EPI_PK_GELU, st);
+        } else {                                       // small shapes (test fixtures): fp32 store + activation kernel
+            f1.out_f32 = w.vtmp; f1.ldo = vi;
+            gemm(f1, EPI_F32_STORE, st);
+            ocr_gelu_pack(w.vtmp, w.vy, MV, vi, vi, st);
+        }
         GemmArgs f2 = ga(w.vy, m->at<uint16_t>(l.fc2), MV, vh, vi);
         f2.out_f32 = w.vh; f2.ldo = vh;
         gemm(f2, EPI_F32_RESID, st);

@@ -99,6 +99,11 @@ def test_gemm_256x256_tile_kernel(be_name, M, N, K, variant):
             outp = be.zeros((Mp * N,), np.uint16)
             assert be.lib.mgk_gemm(be.stream, 0, EPI_PK_RELU, be.p(X), be.p(W), M, N, K, None, 0, None, be.p(outp)) == 0
             np.testing.assert_allclose(pk.unpack_tiles(outp.numpy(), M, N), np.maximum(ref, 0), rtol=1.0 / 128, atol=1e-3)
+            if M >= 320:      # GELU(tanh) epilogue (ChemicalOCR vision MLP), large-M tile kernels only
+                outg = be.zeros((Mp * N,), np.uint16)
+                assert be.lib.mgk_gemm(be.stream, 0, 7, be.p(X), be.p(W), M, N, K, None, 0, None, be.p(outg)) == 0
+                gl = 0.5 * ref * (1.0 + np.tanh(0.7978845608028654 * (ref + 0.044715 * ref ** 3)))
+                np.testing.assert_allclose(pk.unpack_tiles(outg.numpy(), M, N), gl, rtol=1.0 / 128, atol=2e-3)
         if M % 64 == 0 and N % 384 == 0:      # per-head epilogue: Q, K packed rows, V packed transposed
             S, H = 64, N // 192
             B = M // S
