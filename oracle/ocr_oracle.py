@@ -18,7 +18,6 @@ offline: parity is pinned on the stock architecture, the checkp
 """
 from __future__ import annotations
 
-import math
 
 import torch
 
