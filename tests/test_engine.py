@@ -435,17 +435,20 @@ def test_more_than_256_live_rows_is_rejected(be_name):
                      num_beams=5, max_length=4)
     # straight through the C ABI (no Python-side check): MG_E_UNSUPPORTED, nothing launched
     ids, bb, am, pv, B, L = eng._inputs(big["input_ids"], big["bbox"], big["attention_mask"], big["pixel_values"])
-    ws, nb = eng.workspace(B, L, 1, 4, 0)
+    need = C.c_size_t()
+    assert eng.lib.mg_workspace_bytes(eng.model, B, L, 1, 4, 0, 0, C.byref(need)) == 0
+    ws, nb = eng.mem.empty((256,), np.uint8), need.value      # the call is refused before it looks at the workspace: no need to allocate it
     out = eng.mem.empty((B, 4), np.int64)
     cols = C.c_int(0)
     rc = eng.lib.mg_generate(eng.model, eng.mem.stream(), eng.mem.ptr(ws), nb, eng.mem.ptr(ids), eng.mem.ptr(bb), eng.mem.ptr(am),
                              eng.mem.ptr(pv), None, 0, B, L, 1, 4, 0, C.c_float(1.0), 0, eng.mem.ptr(out), C.byref(cols), None, None)
     assert rc == -5 and b"256" in eng.lib.mg_last_error()
-    # 256 rows are fine and row-independent
-    ok = {k: rep(v, 256) for k, v in inp.items()}
+    # 256 rows are fine and row-independent (the emulator runs 64 = two row tiles: the 8-tile case is the GPU's, 26 s saved here)
+    nr = 256 if be_name == "hip" else 64
+    ok = {k: rep(v, nr) for k, v in inp.items()}
     ids256, _, _ = eng.generate(ok["input_ids"], ok["bbox"], ok["attention_mask"], ok["pixel_values"], max_length=6)
     ids256 = _np(eng, ids256)
-    assert np.array_equal(ids256[:6], g["greedy_ids"][:, :ids256.shape[1]]) and np.array_equal(ids256[252:256], ids256[:4])
+    assert np.array_equal(ids256[:6], g["greedy_ids"][:, :ids256.shape[1]]) and np.array_equal(ids256[nr - 4:nr], ids256[(nr - 4) % 6:(nr - 4) % 6 + 4])
 
 
 @pytest.mark.parametrize("be_name", BACKENDS)
