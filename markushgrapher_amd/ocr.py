@@ -116,6 +116,9 @@ class OcrEngine:
         pmask = pam.unfold(1, ps, ps).unfold(2, ps, ps).sum(dim=(-1, -2)) > 0
         boundaries = torch.arange(1 / g, 1.0, 1 / g)
         nb_h, nb_w = pmask[:, :, 0].sum(dim=1), pmask[:, 0, :].sum(dim=1)
+        if bool((nb_h == 0).any()) or bool((nb_w == 0).any()):
+            raise MgError("a frame without valid pixels in its first row / column (a padding image): sequences with different numbers of "
+                          "frames are not supported - pass the real frames only")
         idx = torch.arange(g, dtype=torch.float32)
         fh = torch.clamp(idx[None, :] * (1.0 / nb_h)[:, None], max=(1.0 - 1e-6)).to(torch.float32)
         fw = torch.clamp(idx[None, :] * (1.0 / nb_w)[:, None], max=(1.0 - 1e-6)).to(torch.float32)

@@ -290,3 +290,24 @@ def test_ocr_padded_frames(be_name):
     # and the mask matters: without it the features of the padded frames differ
     plain = eng.mem.numpy(eng.image_features(pix[:, 0]))
     assert np.abs(plain[1:] - feats[1:]).max() > 10 * 0.05 * float(g["feats_abs_mean"]) or np.abs(plain[1:] - feats[1:]).max() > 0.01
+
+
+def test_patch_inputs_rejects_padding_frames():
+    """A fully masked frame (the processor's padding image for sequences with fewer frames) has no patch grid: loud error, not NaNs."""
+    from markushgrapher_amd.engine import MgError
+    from markushgrapher_amd.ocr import OcrEngine
+    s = PRESETS["tiny"]
+
+    class _Mem:                                    # patch_inputs only converts its two results through the memory provider
+        def asarray(self, x, dtype):
+            return np.asarray(x, dtype)
+    eng = OcrEngine.__new__(OcrEngine)
+    eng.shape, eng.mem = s, _Mem()
+    m = np.ones((2, 1, s.image_size, s.image_size), bool)
+    assert eng.patch_inputs(m) == (None, None)
+    m[1] = False
+    with pytest.raises(MgError):
+        eng.patch_inputs(m)
+    m[1, 0, :20, :40] = True
+    pos, msk = eng.patch_inputs(m)
+    assert msk.shape == (2, s.patches) and msk[0].all() and msk[1].sum() == 2 * 3 and pos[1][msk[1] == 0].max() == 0
