@@ -180,8 +180,7 @@ def pmc_traffic(args):
         rows = sqlite3.connect(db).execute(
             "select kernel_name, value from counters_collection where counter_name = 'FETCH_SIZE'").fetchall()
         xa = [v for n, v in rows if "attn_step_kernel<1, 8, true" in n]
-        dec = [v for n, v in rows if any(k in n for k in ("attn_step_kernel", "gemm_rows", "greedy_select", "embed_norm_rows",
-                                                          "qkv_attn_step"))]
+        dec = [v for n, v in rows if any(k in n for k in ("attn_step_kernel", "gemm_rows", "greedy_select", "embed_norm_rows"))]
         if not xa or not dec:
             return None
         return {"cross_attention_bytes_per_launch": int(sum(xa) / len(xa) * 1024 * 2),

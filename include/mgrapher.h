@@ -205,13 +205,6 @@ int mgk_gemm_set_variant(int v);
  * statistic rs_*), x_pk = bf16(h*gain*gscale) un-normalised, part[m][N/8] = per-block sums of h^2 */
 int mgk_gemm_resid(void* stream, const void* X_pk, const void* W_pk, float* h, const float* gain, float gscale, void* x_pk,
                    float* part, int M, int N, int K, const float* rs_part, int rs_nparts, float rs_inv_d, float rs_eps);
-/* Phase-stamped copy of the decoder cross-attention kernel (tools/trace_attn.py): trace[(workgroup*8 + wave)*8 + k]. */
-int mgk_attention_step_trace(void* stream, const void* q, const void* Kc, const void* Vc, void* ctx_pk, int rows, int H, int cap,
-                             const int* len, long long* trace);
-/* Phase-stamped copy of the FFN-wo residual projection (32 rows, 16 waves): trace[(workgroup*16 + wave)*8 + k] = shader
- * clock at phase k (tools/trace_resid.py). */
-int mgk_gemm_resid_trace(void* stream, const void* X_pk, const void* W_pk, float* h, const float* gain, void* x_pk, float* part, int N,
-                         int K, const float* rs_part, long long* trace);
 /* Pair projection of the decode step with its product weight (test entry for gemm_rows_pair / the mg_finalize helpers):
  *   W2_pk  <- pack([Wn*diag(gain) | Wn*diag(gain)*Wr])   built on the device from Wn_pk [N2][d], Wr_pk [d][inner]
  *             (scratch_f32: at least N2*(2*d+inner) + d*inner floats);

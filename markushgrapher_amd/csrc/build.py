@@ -1,6 +1,8 @@
 """Build the native library.
 
   build_hip()  hipcc --offload-arch=gfx950 -> markushgrapher_amd/libmgrapher_hip.so   (THE product library)
+  build_tools() hipcc -DMG_TOOLS          -> tools/_build/libmgrapher_tools.so        (profiling tools only: trace kernels,
+               what-if GEMM variants; never loaded by the product)
   build_emu()  g++ -DMG_EMU               -> tools/simt_emu/_build/libmgrapher_emu.so (test infrastructure:
                same sources on the CPU SIMT emulator, to check index math without a GPU; never loaded by the
                product)
@@ -12,9 +14,10 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
-SOURCES = ["k_gemm.hip", "k_pack.hip", "k_embed.hip", "k_attn.hip", "k_decode.hip", "k_fused.hip", "k_beam.hip", "k_prep.hip", "c_ops.hip",
+SOURCES = ["k_gemm.hip", "k_pack.hip", "k_embed.hip", "k_attn.hip", "k_decode.hip", "k_beam.hip", "k_prep.hip", "c_ops.hip",
            "engine.hip", "k_ocr.hip", "ocr.hip"]
 HIP_SO = os.path.join(ROOT, "markushgrapher_amd", "libmgrapher_hip.so")
+TOOLS_SO = os.path.join(ROOT, "tools", "_build", "libmgrapher_tools.so")
 EMU_DIR = os.path.join(ROOT, "tools", "simt_emu")
 EMU_SO = os.path.join(EMU_DIR, "_build", "libmgrapher_emu.so")
 
@@ -43,8 +46,14 @@ def _run(cmd):
     return r.stdout
 
 
-def build_hip(force=False, verbose=False):
-    objdir = os.path.join(HERE, "_obj")
+def build_tools(force=False, verbose=False):
+    """The product sources with -DMG_TOOLS: adds the phase-stamped trace kernels and the what-if GEMM variants (tools/*.py only)."""
+    return build_hip(force, verbose, objdir=os.path.join(ROOT, "tools", "_build", "obj_tools"), out=TOOLS_SO, defines=["-DMG_TOOLS"])
+
+
+def build_hip(force=False, verbose=False, objdir=None, out=None, defines=()):
+    objdir = objdir or os.path.join(HERE, "_obj")
+    out = out or HIP_SO
     os.makedirs(objdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     jobs = []
@@ -54,15 +63,15 @@ def build_hip(force=False, verbose=False):
         obj = os.path.join(objdir, s + ".o")
         objs.append(obj)
         if force or _newer(obj, [src] + _headers()):
-            jobs.append([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result",
+            jobs.append([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", *defines,
                          "-c", src, "-o", obj])
     with ThreadPoolExecutor(max_workers=8) as ex:
-        for out in ex.map(_run, jobs):
-            if verbose and out.strip():
-                print(out)
-    if jobs or not os.path.exists(HIP_SO):
-        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_SO] + objs)
-    return HIP_SO
+        for log in ex.map(_run, jobs):
+            if verbose and log.strip():
+                print(log)
+    if jobs or not os.path.exists(out):
+        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    return out
 
 
 def build_emu(force=False, opt="-O1"):
@@ -90,3 +99,5 @@ if __name__ == "__main__":
         print(build_emu())
     if "hip" in what:
         print(build_hip(verbose=True))
+    if "tools" in what:
+        print(build_tools(verbose=True))

@@ -113,6 +113,7 @@ int mgk_attention_step(void* stream, const void* q, const void* Kc, const void* 
     return MG_OK;
 }
 
+#ifdef MG_TOOLS
 int mgk_attention_step_trace(void* stream, const void* q, const void* Kc, const void* Vc, void* ctx_pk, int rows, int H, int cap,
                              const int* len, long long* trace) {
     AttnStepArgs a{};
@@ -121,6 +122,7 @@ int mgk_attention_step_trace(void* stream, const void* q, const void* Kc, const 
     attention_step_trace(a, trace, (mgStream_t)stream);
     return MG_OK;
 }
+#endif
 
 size_t mgk_embed_meta_bytes(int B, int S_cap) { return embed_meta_bytes(B, S_cap); }
 
@@ -170,6 +172,7 @@ int mgk_gemm_resid(void* stream, const void* X_pk, const void* W_pk, float* h, c
     return MG_OK;
 }
 
+#ifdef MG_TOOLS
 int mgk_gemm_resid_trace(void* stream, const void* X_pk, const void* W_pk, float* h, const float* gain, void* x_pk, float* part, int N,
                          int K, const float* rs_part, long long* trace) {
     ResidArgs r{};
@@ -178,6 +181,7 @@ int mgk_gemm_resid_trace(void* stream, const void* X_pk, const void* W_pk, float
     gemm_rows_resid_trace(r, trace, (mgStream_t)stream);
     return MG_OK;
 }
+#endif
 
 int mgk_gemm_pair(void* stream, const void* Wn_pk, const void* Wr_pk, const float* gain, int N2, int d, int inner, void* W2_pk,
                   float* scratch_f32, const void* xwin_pk, float* h, void* hb_out_pk, float* part, void* out2_pk, int M, int relu) {

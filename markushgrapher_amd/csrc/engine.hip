@@ -102,10 +102,6 @@ struct mg_model {
     float* dbg_logits = nullptr;
     int dbg_steps = 0;
     const int64_t* dbg_forced = nullptr;
-    // decode step: head-owned QKV + cache append + self-attention in one launch (k_fused.hip), MG_DECODE_FUSED_QKV=1.
-    // Measured and NOT the default (profiles/r02_fused_qkv_ab.txt): one launch of 18.6 us replaces two of 5.2 + 7.1 us - every
-    // workgroup must pull its head's whole 192 x d weight slice (384 KB at d = 1024) through its CU's 64 B/clk L1 path.
-    bool fused_qkv = false;
     bool tied = true;          // tie_word_embeddings: lm_head = shared.weight and logits scaled by d_model^-0.5 (stock:1554-1557)
 #ifndef MG_EMU
     hipStream_t own_stream = nullptr;
@@ -392,7 +388,6 @@ int mg_create(const mg_config* cfg, mg_model** out) {
     m->M2 = c.max_2d_position_embeddings;
     m->T_cap = round_up(c.max_decode_len > 0 ? c.max_decode_len : 512, 64);
     m->tied = c.tie_word_embeddings != 0;
-    { const char* e = getenv("MG_DECODE_FUSED_QKV"); m->fused_qkv = e && e[0] == '1'; }
     // arena layout
     size_t off = 0;
     auto take = [&](size_t bytes) { off = align_up(off, 256); size_t o = off; off += bytes; return o; };
@@ -891,14 +886,7 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
             const DecLayer& l = m->dec[li];
             uint16_t* sk = w.sk + li * skv_stride;
             uint16_t* sv = w.sv + li * skv_stride;
-            if (m->fused_qkv) {   // QKV projection + cache append + self-attention, head-owned, one launch (k_fused.hip)
-                QkvStepArgs q{};
-                q.X = w.dx_pk; q.W = m->at<uint16_t>(l.wqkv); q.rs = li == 0 ? none : rs0;
-                q.Kc = sk; q.Vc = sv; q.Kc_w = sk; q.Vc_w = sv; q.ctx = w.xa; q.ctx_ld = K2; q.ctx_col0 = d;
-                q.rows = R; q.H = H; q.d = d; q.cap = T_cap; q.bias = m->at<float>(m->dec_tab); q.anc = K > 1 ? w.anc : nullptr;
-                q.t = t; q.t_dev = tdev; q.rg = qkv_attention_rows_per_group(R, H);
-                qkv_attention_step(q, st);
-            } else {
+            {
                 {
                     GemmArgs a = gemm_args(w.dx_pk, m->at<uint16_t>(l.wqkv), R, 3 * inner, d);
                     set_heads(a, H, R, T_cap, w.dq, HF_STEP_Q, sk, HF_STEP_KV, sv, HF_STEP_KV);

@@ -299,11 +299,13 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a, long
     stamp(6);
 }
 
+#ifdef MG_TOOLS
 // instrumented cross-attention (G = 1), tools/trace_attn.py
 void attention_step_trace(const AttnStepArgs& a, long long* trace, mgStream_t stream) {
     const dim3 grid(a.rows * a.H), block(512);
     MG_LAUNCH((attn_step_kernel<1, 8, true, true>), grid, block, (size_t)8 * 8 * 10 * sizeof(float), stream, a, trace);
 }
+#endif
 
 void attention_step(const AttnStepArgs& a, mgStream_t stream) {
     const int G = a.group;

@@ -109,30 +109,36 @@ MG_DEV float row_scale_of(const RowScale& rs, int m, int M) {
     return rsqrtf(s * rs.inv_d + rs.eps);
 }
 
-// the scales of NT consecutive 32-token row tiles for this lane's token (m0 + 32 i + lane%32): all partial-sum loads are
-// unconditional and issued together (one L2 round trip at the start of the epilogue); nparts is a multiple of 4, at most 16
-// (groups past nparts re-read the last one with weight 0)
+// the scales of NT consecutive 32-token row tiles for this lane's token (m0 + 32 i + lane%32): the partial-sum loads of a
+// group of 16 partials are unconditional and issued together for all NT tiles (one L2 round trip at the start of the epilogue
+// for d_model <= 1024; one more per further 1024 columns); nparts is a multiple of 4 (groups past nparts re-read the last one
+// with weight 0)
 template <int NT>
 MG_DEV void row_scales_tiles(const RowScale& rs, int m0, int M, int lane, float (&out)[NT]) {
 #pragma unroll
     for (int i = 0; i < NT; ++i) out[i] = 1.0f;
     if (!rs.part) return;
-    float4 v[NT][4];
+    float s[NT];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        int m = m0 + 32 * i + (lane & 31);
-        m = m < M ? m : M - 1;
-        const float* p = rs.part + (size_t)m * rs.nparts;
+    for (int i = 0; i < NT; ++i) s[i] = 0.f;
+    for (int g0 = 0; g0 < rs.nparts; g0 += 16) {
+        float4 v[NT][4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[i][k] = *(const float4*)(p + (4 * k < rs.nparts ? 4 * k : rs.nparts - 4));
+        for (int i = 0; i < NT; ++i) {
+            int m = m0 + 32 * i + (lane & 31);
+            m = m < M ? m : M - 1;
+            const float* p = rs.part + (size_t)m * rs.nparts;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[i][k] = *(const float4*)(p + (g0 + 4 * k < rs.nparts ? g0 + 4 * k : rs.nparts - 4));
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s[i] += (g0 + 4 * k < rs.nparts) ? (v[i][k].x + v[i][k].y) + (v[i][k].z + v[i][k].w) : 0.f;
+        }
     }
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) s += (4 * k < rs.nparts) ? (v[i][k].x + v[i][k].y) + (v[i][k].z + v[i][k].w) : 0.f;
-        out[i] = rsqrtf(s * rs.inv_d + rs.eps);
-    }
+    for (int i = 0; i < NT; ++i) out[i] = rsqrtf(s[i] * rs.inv_d + rs.eps);
 }
 
 // APPLY_RS (tiled large-M kernels only; the decode-step kernels scale their sums themselves): multiply the rows of the
@@ -670,6 +676,7 @@ static void launch_xl(const GemmArgs& a, mgStream_t stream) {
     const size_t sh = (size_t)2 * (2 * TI + 8) * 4 * TILE_BYTES;
     static bool once = false;
     if (!once) { MG_SET_MAX_SMEM((&gemm_xl_kernel<EPI, TI>), sh); once = true; }
+#ifdef MG_TOOLS      // what-if variants with WRONG results: tools builds only (build.py tools), never in the product library
     if constexpr (EPI == EPI_PK && TI == 5) {          // timing experiments (see the kernel's XP parameter)
         static int xp = -1;
         if (xp < 0) { const char* e = getenv("MG_GEMM_EXP"); xp = e ? atoi(e) : 0; }
@@ -681,6 +688,7 @@ static void launch_xl(const GemmArgs& a, mgStream_t stream) {
             return;
         }
     }
+#endif
     MG_LAUNCH((gemm_xl_kernel<EPI, TI>), dim3(nblk), dim3(512), sh, stream, a);
 }
 
@@ -1586,6 +1594,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_rows_resid_split_kernel(ResidArg
     }
 }
 
+#ifdef MG_TOOLS
 // instrumented copy of the 16-wave, one-row-tile form (tools/trace_resid.py)
 __global__ __launch_bounds__(1024) void gemm_rows_resid_trace_kernel(ResidArgs a, long long* trace) {
     MG_DYN_SMEM(smem);
@@ -1595,6 +1604,7 @@ void gemm_rows_resid_trace(const ResidArgs& r, long long* trace, mgStream_t stre
     const size_t sh = (size_t)16 * 8 * 64 * sizeof(float) + 32 * sizeof(float);
     MG_LAUNCH(gemm_rows_resid_trace_kernel, dim3(r.N / 8), dim3(1024), sh, stream, r, trace);
 }
+#endif
 
 void gemm_rows_resid(const ResidArgs& r, mgStream_t stream) {
     int mt = (r.M + 31) / 32;

@@ -253,28 +253,6 @@ struct AttnStepArgs {
 void attention_step(const AttnStepArgs& a, mgStream_t stream);
 void attention_step_trace(const AttnStepArgs& a, long long* trace, mgStream_t stream);   // phase stamps, cross form, group 1
 
-// Head-owned fusion of the decode step's QKV projection, KV-cache append and self-attention (k_fused.hip)
-struct QkvStepArgs {
-    const uint16_t* X;        // packed bf16 [rows_pad][x_kts * 16]: bf16(h * gain) un-normalised (or normalised with rs.part == null)
-    int x_kts;                // 16-wide k-tiles per row tile of X (0: d / 16); the projection reads the first d columns
-    const uint16_t* W;        // packed [3 * H * 64][d]: q | k | v
-    RowScale rs;              // deferred RMSNorm scale of the rows of X
-    const uint16_t* Kc;       // cache [rows_phys][H][cap][64] (read)
-    const uint16_t* Vc;
-    uint16_t* Kc_w;           // same buffers, written at position t
-    uint16_t* Vc_w;
-    uint16_t* ctx;            // packed context rows; window ctx_ld / ctx_col0 as in AttnStepArgs
-    int ctx_ld, ctx_col0;
-    int rows, H, d, cap;
-    const float* bias;        // [cap][H] by distance t - j (nullable)
-    const int* anc;           // beams: [cap][rows] physical row holding position j (nullable)
-    int t;                    // position produced by this step (keys [0, t] are attended)
-    const int* t_dev;         // if non-null t is read from device memory (graph replay)
-    int rg;                   // rows per workgroup: qkv_attention_rows_per_group()
-};
-int qkv_attention_rows_per_group(int rows, int H);
-void qkv_attention_step(const QkvStepArgs& a, mgStream_t stream);
-
 // h[rows][d] = tok_emb[ids[row]]
 // embed_rows + rmsnorm_pack(h, gain, x_pk) in one launch (decode step); x2_pk (nullable) = the embedding rows, packed window
 void embed_norm_rows(const int64_t* ids, const uint16_t* tok_emb, float* h, const float* gain, uint16_t* x_pk, uint16_t* x2_pk, int x2_ld,

@@ -77,9 +77,8 @@ struct mg_ocr_model {
     // one decode step (30 layers x 9 launches + lm_head + selection) captured as a HIP graph whose kernels read the position from the
     // device step counter; replayed while the call's buffers and sizes match (MG_OCR_GRAPH=0: eager launches, same kernels)
     int use_graph = 1;
-    int fused = 1;            // decode step on the deferred-norm kernels (MG_OCR_FUSED=0: one kernel per operation, same arithmetic points)
     bool graph_active = false;
-    struct Key { const void *ws, *out, *stream; int B, L, max_new; bool operator==(const Key& o) const { return ws == o.ws && out == o.out && stream == o.stream && B == o.B && L == o.L && max_new == o.max_new; } } gkey{};
+    struct Key { const void *ws, *out, *stream; int B, n_img, L, max_new; bool operator==(const Key& o) const { return ws == o.ws && out == o.out && stream == o.stream && B == o.B && n_img == o.n_img && L == o.L && max_new == o.max_new; } } gkey{};   // n_img: the text-side buffers are carved behind the vision buffers
     bool gvalid = false;
 #ifndef MG_EMU
     hipGraphExec_t gexec = nullptr;
@@ -242,48 +241,12 @@ void prefill(const mg_ocr_model* m, const Ws& w, const int64_t* ids, const float
     }
 }
 
-// one decode step for B rows: token ids in w.next_ids, position `pos`; logits -> w.logits
-// pos_dev != null: position = *pos_dev + pos (graph replay: pos_dev = the step counter, pos = prompt length - 1)
-void decode_step(const mg_ocr_model* m, const Ws& w, int B, int pos, const int* pos_dev, int cap, mgStream_t st) {
-    const mg_ocr_config& c = m->c;
-    const int td = c.t_hidden, ti = c.t_inter, H = c.t_heads, KV = c.t_kv_heads;
-    embed_rows(w.next_ids, m->at<uint16_t>(m->tok_emb), w.h, B, td, c.vocab, w.counters + 3, st);
-    for (int i = 0; i < c.t_layers; ++i) {
-        const std::string p = "model.text_model.layers." + std::to_string(i) + ".";
-        const TLayer& l = m->tl[i];
-        uint16_t* Kc = w.Kc + (size_t)i * w.kv_layer;
-        uint16_t* Vc = w.Vc + (size_t)i * w.kv_layer;
-        rmsnorm_pack(w.h, m->rawp(p + "input_layernorm.weight"), w.x, nullptr, B, td, c.rms_eps, 1.0f, st);
-        GemmArgs a = ga(w.x, m->at<uint16_t>(l.wqkv), B, m->qkvn, td);
-        a.out_f32 = w.qkv; a.ldo = m->qkvn;
-        gemm_rows(a, EPI_F32_STORE, st);
-        AttnStepArgs s{};         // rotary embedding, cache append and grouped-query attention over [0, pos]
-        s.Kc = Kc; s.Vc = Vc; s.Kc_w = Kc; s.Vc_w = Vc; s.ctx = w.ctx; s.rows = B; s.H = KV; s.group = H / KV; s.cap = cap; s.n_keys = pos + 1; s.t = pos;
-        s.t_dev = pos_dev; s.t_off = pos;
-        s.rope.qkv = w.qkv; s.rope.ld = m->qkvn; s.rope.cs = m->at<float>(m->rope_cs); s.rope.qscale = 0.125f;
-        attention_step(s, st);
-        GemmArgs o = ga(w.ctx, m->at<uint16_t>(l.wo), B, td, H * 64);
-        o.out_f32 = w.h; o.ldo = td;
-        gemm_rows(o, EPI_F32_RESID, st);
-        rmsnorm_pack(w.h, m->rawp(p + "post_attention_layernorm.weight"), w.x, nullptr, B, td, c.rms_eps, 1.0f, st);
-        GemmArgs gu = ga(w.x, m->at<uint16_t>(l.wgu), B, 2 * ti, td);
-        gu.out_f32 = w.gu; gu.ldo = 2 * ti;
-        gemm_rows(gu, EPI_F32_STORE, st);
-        ocr_silu_mul_pack(w.gu, w.y, B, ti, st);
-        GemmArgs dn = ga(w.y, m->at<uint16_t>(l.wd), B, td, ti);
-        dn.out_f32 = w.h; dn.ldo = td;
-        gemm_rows(dn, EPI_F32_RESID, st);
-    }
-    rmsnorm_pack(w.h, m->rawp("model.text_model.norm.weight"), w.xc, nullptr, B, td, c.rms_eps, 1.0f, st);
-    GemmArgs lg = ga(w.xc, m->at<uint16_t>(m->lm_head), B, c.vocab, td);
-    lg.out_f32 = w.logits; lg.ldo = c.vocab;
-    gemm_rows(lg, EPI_F32_STORE, st);
-}
-
-// The same step on the decode path's deferred-RMSNorm kernels (7 launches per layer instead of 9): the residual projections
+// One decode step for B rows: token ids in w.next_ids, position `pos`; logits -> w.logits.
+// pos_dev != null: position = *pos_dev + pos (graph replay: pos_dev = the step counter, pos = prompt length - 1).
+// Runs on the decode path's deferred-RMSNorm kernels: the residual projections
 // (o_proj, down_proj) leave bf16(h * gain_next) un-normalised plus per-row partial sums of h^2, and the consumers of the
 // projections that read it (rotary / cache kernel, SiLU kernel, lm_head) apply r(row) = rsqrt(mean h^2 + eps) themselves.
-void decode_step_fused(const mg_ocr_model* m, const Ws& w, int B, int pos, const int* pos_dev, int cap, mgStream_t st) {
+void decode_step(const mg_ocr_model* m, const Ws& w, int B, int pos, const int* pos_dev, int cap, mgStream_t st) {
     const mg_ocr_config& c = m->c;
     const int td = c.t_hidden, ti = c.t_inter, H = c.t_heads, KV = c.t_kv_heads, K2 = td + ti;
     const RowScale none{};
@@ -415,7 +378,6 @@ int mg_ocr_create(const mg_ocr_config* cfg, mg_ocr_model** out) {
     off = align_up(off, 256); m->rope_cs = off; off += (size_t)mg_ocr_model::MAX_POS * 64 * sizeof(float);
     m->arena_bytes = align_up(off, 256);
     { const char* e = getenv("MG_OCR_GRAPH"); if (e && e[0] == '0') m->use_graph = 0; }
-    { const char* e = getenv("MG_OCR_FUSED"); if (e && e[0] == '0') m->fused = 0; }
     *out = m;
     return MG_OK;
 }
@@ -600,12 +562,12 @@ int mg_ocr_generate(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, co
     bool graphed = false;
 #ifndef MG_EMU
     if (m->use_graph == 1 && !step_logits && max_new_tokens > 1) {
-        const mg_ocr_model::Key key{ws, out_ids, (const void*)st, B, L, max_new_tokens};
+        const mg_ocr_model::Key key{ws, out_ids, (const void*)st, B, n_img, L, max_new_tokens};
         if (!(m->gvalid && m->gkey == key)) {
             m->greset();
             hipGraph_t graph = nullptr;
             if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                (m->fused ? decode_step_fused : decode_step)(m, w, B, L - 1, w.counters + 2, cap, st);   // position = L - 1 + step counter (>= 1 here)
+                decode_step(m, w, B, L - 1, w.counters + 2, cap, st);   // position = L - 1 + step counter (>= 1 here)
                 select(0, w.counters + 2);
                 if (hipStreamEndCapture(st, &graph) == hipSuccess && graph &&
                     hipGraphInstantiate(&m->gexec, graph, nullptr, nullptr, 0) == hipSuccess) { m->gkey = key; m->gvalid = true; }
@@ -633,7 +595,7 @@ int mg_ocr_generate(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, co
         } else
 #endif
         {
-            (m->fused ? decode_step_fused : decode_step)(m, w, B, L + t - 1, nullptr, cap, st);
+            decode_step(m, w, B, L + t - 1, nullptr, cap, st);
             if (step_logits && t < capture_steps)
                 MG_LAUNCH(copy_f32_kernel, dim3(256), dim3(256), 0, st, (const float*)w.logits, step_logits + (size_t)t * B * c.vocab, (size_t)B * c.vocab);
             select(t, nullptr);

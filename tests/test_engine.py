@@ -505,33 +505,6 @@ def test_tied_and_untied_lm_head(be_name):
 
 
 @pytest.mark.parametrize("be_name", BACKENDS)
-def test_fused_qkv_self_attention_form_is_equivalent(be_name, monkeypatch):
-    """MG_DECODE_FUSED_QKV=1 (k_fused.hip: QKV projection + cache append + self-attention in one head-owned launch - measured
-    slower, profiles/r02_fused_qkv_ab.txt, kept as an alternative form): same ids as the two-launch form on the trained
-    fixture, greedy and beam-5, and logits within tolerance of the golden vectors through the capture hook."""
-    g = load_golden("g3_trained_tiny.npz")
-    shape, sd = _weights(g)
-    inp = _inputs(g, shape)
-    monkeypatch.setenv("MG_DECODE_FUSED_QKV", "1")
-    eng = make_engine(be_name, shape, sd)          # the switch is read at mg_create
-    monkeypatch.delenv("MG_DECODE_FUSED_QKV")
-    args = (inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"])
-    T = int(g["max_length"])
-    ids, _, top2 = eng.generate(*args, max_length=T, return_top2=True)
-    assert np.array_equal(_np(eng, ids), g["greedy_ids"])
-    bids, bsc, _ = eng.generate(*args, num_beams=5, max_length=T)
-    assert np.array_equal(_np(eng, bids), g["beam_ids"])
-    np.testing.assert_allclose(_np(eng, bsc), g["beam_scores"], atol=1e-2)
-    ref = g["greedy_step_logits"]
-    t2 = _np(eng, top2)
-    idn = _np(eng, ids)
-    for b in range(idn.shape[0]):
-        for t in range(1, idn.shape[1]):
-            if np.all(idn[b, 1:t] != shape.eos_token_id):
-                assert abs(t2[t, b, 0] - ref[b, t - 1].max()) < logit_tol(ref)
-
-
-@pytest.mark.parametrize("be_name", BACKENDS)
 def test_e1_tokens_are_fused_into_the_cross_attention(be_name):
     """optional precomputed OCSR-branch embeddings e1 [B, M, d].  The decoder cross-attends over
     [e1 | VTL states]; teacher-forced logits and greedy / beam ids against the oracle's statement of the same fusion

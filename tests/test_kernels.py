@@ -650,3 +650,48 @@ def test_decode_projections_row_tile_split_modes_are_bit_identical(be_name):
     for mode in (1,):
         for a, b in zip(results[0], results[mode]):
             assert np.array_equal(a, b), mode
+
+
+def _tile_f32(h):
+    """[M][N] fp32 -> the encoder's tiled residual layout [M/32][N/4][32][4] (mg_device.h ht_off), flattened."""
+    M, N = h.shape
+    return np.ascontiguousarray(h.reshape(M // 32, 32, N // 4, 4).transpose(0, 2, 1, 3)).reshape(-1)
+
+
+def _untile_f32(t, M, N):
+    return np.ascontiguousarray(np.asarray(t).reshape(M // 32, N // 4, 32, 4).transpose(0, 2, 1, 3)).reshape(M, N)
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+@pytest.mark.parametrize("M,d,K,N2", [(320, 128, 64, 256), (320, 2048, 64, 256), (640, 1536, 128, 256)])
+def test_gemm_encoder_deferred_norm(be_name, M, d, K, N2):
+    """Encoder deferred RMSNorm (EPI_RESID_NORM + a row-scaled consumer), large-M tile kernels: h (tiled fp32) += X W^T,
+    x = bf16(h * gain) un-normalised, part[m][d/64] partial sums of h^2; then relu(W2 x) * rsqrt(mean h^2 + eps) per row must
+    equal relu(W2 (RMSNorm(h) * gain)).  d = 2048 / 1536 give 32 / 24 partial sums per row: more than one group of 16 in
+    row_scales_tiles (they were silently truncated to the first 16)."""
+    if be_name == "emu" and d > 128:
+        M = 320                                         # the emulator checks the index math of the wide case on one block row
+    be = get_backend(be_name)
+    be.lib.mgk_gemm_norm.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 2 + [C.c_int] * 3 + [C.c_void_p] * 4 + \
+                                    [C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float]
+    x, w = rnd((M, K), 300), rnd((d, K), 301, 0.2)
+    h0, g = rnd((M, d), 302), 1 + 0.2 * rnd((d,), 303)
+    h0[:, d // 2:] *= 3.0                                # the late partial sums carry most of the energy: truncation would show
+    ref_h = h0 + pk.bf16_round(x) @ pk.bf16_round(w).T
+    np4 = (d // 64 + 3) // 4 * 4
+    h = be.buf(_tile_f32(h0))
+    xo = be.zeros((M * d,), np.uint16)
+    part = be.zeros((M, np4), np.float32)
+    assert be.lib.mgk_gemm_norm(be.stream, 5, be.p(be.buf(pk.pack_tiles(x))), be.p(be.buf(pk.pack_tiles(w))), M, d, K, be.p(h),
+                                be.p(be.buf(g)), be.p(xo), be.p(part), np4, None, 0, 0.0, 0.0) == 0
+    np.testing.assert_allclose(_untile_f32(h.numpy(), M, d), ref_h, rtol=1e-4, atol=1e-4)
+    xg = pk.unpack_tiles(xo.numpy(), M, d)
+    np.testing.assert_allclose(xg, ref_h * g, rtol=1 / 128, atol=2e-3)
+    np.testing.assert_allclose(part.numpy().sum(1), (ref_h ** 2).sum(1), rtol=1e-4)
+    w2 = rnd((N2, d), 304, 0.1)
+    y = be.zeros((M * N2,), np.uint16)
+    assert be.lib.mgk_gemm_norm(be.stream, 2, be.p(xo), be.p(be.buf(pk.pack_tiles(w2))), M, N2, d, None, None, be.p(y), None, 0,
+                                be.p(part), np4, 1.0 / d, 1e-6) == 0
+    r = 1.0 / np.sqrt((ref_h ** 2).mean(-1, keepdims=True) + 1e-6)
+    want = np.maximum((xg @ pk.bf16_round(w2).T) * r, 0)
+    np.testing.assert_allclose(pk.unpack_tiles(y.numpy(), M, N2), want, rtol=1 / 100, atol=2e-3 * np.abs(want).max())

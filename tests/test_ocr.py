@@ -210,18 +210,6 @@ def test_ocr_model_from_pretrained_generates_like_stock(tmp_path, bf16):
 
 
 @pytest.mark.parametrize("be_name", BACKENDS)
-def test_ocr_unfused_decode_step_agrees(be_name, monkeypatch):
-    """MG_OCR_FUSED=0 (one kernel per operation, explicit RMSNorm launches) against the same stock vectors: the two decode-step
-    forms differ only in where the per-row norm scale is applied."""
-    monkeypatch.setenv("MG_OCR_FUSED", "0")
-    g, s, sd, ids, pix = _setup("tiny")
-    eng = make_ocr(be_name, s, sd)
-    n = int(g["new_tokens"])
-    new, cap = eng.generate(ids, pix, n, capture_steps=n)
-    _check_generate(g, s, eng.mem.numpy(new), eng.mem.numpy(cap))
-
-
-@pytest.mark.parametrize("be_name", BACKENDS)
 def test_ocr_two_frames_per_page(be_name):
     """pixel_values [B][2][3][I][I]: a page the processor split into two frames - 2 x image_seq_len <image> tokens per sequence,
     features scattered in frame order (inputs_merger's masked_scatter)."""

@@ -9,7 +9,7 @@ import torch
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
-from markushgrapher_amd import _lib  # noqa: E402
+from tools import _toolslib as _lib  # noqa: E402  (tools build: trace kernels / what-if variants)
 
 lib = _lib.load()
 dev = torch.device("cuda:0")
