@@ -239,6 +239,9 @@ typedef struct mg_ocr_config {
     /* Idefics3Config */
     int scale_factor, image_token_id, eos_token_id, pad_token_id, tie_word_embeddings;
     float v_eps, rms_eps, rope_theta;
+    /* further stop tokens: generation_config.json's eos_token_id may be a list (e.g. <|im_end|> and <end_of_utterance>); a row
+     * finishes on eos_token_id or any of eos_extra[0 .. n_eos_extra) (generation/utils.py:2927-2937 with a list of EOS ids) */
+    int n_eos_extra, eos_extra[3];
 } mg_ocr_config;
 
 int mg_ocr_create(const mg_ocr_config* cfg, mg_ocr_model** out);

@@ -353,6 +353,11 @@ __global__ __launch_bounds__(GS_THREADS) void greedy_select_kernel(ArgmaxArgs a)
     const float* lg = a.logits + (size_t)row * a.ldl;
     const int pos = a.pos_dev ? *a.pos_dev + a.pos : a.pos;
     const bool no_eos = a.suppress_eos || pos < a.min_len;
+    auto is_eos = [&](int i) {
+        bool e = i == a.eos;
+        for (int k = 0; k < a.n_eos_more; ++k) e = e || i == a.eos_more[k];
+        return e;
+    };
     float b1 = -3.0e38f, b2 = -3.0e38f;
     int i1 = 0x7fffffff;
     const int nq = (a.V + 3) >> 2;      // rows are padded to a multiple of 32 floats, so the last float4 is readable
@@ -373,7 +378,7 @@ __global__ __launch_bounds__(GS_THREADS) void greedy_select_kernel(ArgmaxArgs a)
             for (int j = 0; j < 4; ++j) {
                 const int i = c * 4 + j;
                 float v = vv[j];
-                if (i >= a.V || (no_eos && i == a.eos)) v = -3.0e38f;
+                if (i >= a.V || (no_eos && is_eos(i))) v = -3.0e38f;
                 if (v > b1 || (v == b1 && i < i1)) { b2 = b1; b1 = v; i1 = i; }
                 else if (v > b2) b2 = v;
             }
@@ -395,7 +400,7 @@ __global__ __launch_bounds__(GS_THREADS) void greedy_select_kernel(ArgmaxArgs a)
         const int64_t tok = unf ? (int64_t)i1 : (int64_t)a.pad;
         a.next_ids[row] = tok;
         if (pos < a.max_len) a.out_ids[(size_t)row * a.max_len + pos] = tok;
-        const int still = unf && tok != a.eos;
+        const int still = unf && !is_eos((int)tok);
         a.unfinished[row] = still;
         if (still) atomicAdd(a.n_unfinished, 1);
         if (a.top2) {

@@ -248,7 +248,11 @@ struct AttnStepArgs {
     // [rows][H][cap][64] and attends over [0, t] for the group's query heads in one pass over the cache.  qkv == null: not used.
     struct Rope { const float* qkv; int ld; const float* cs; RowScale rs; float qscale; } rope;
     const int* live;          // group == 1 only, nullable: rows with live[row] == 0 (finished: they emit pad whatever their
-                              // logits are, gen:2927-2937) are skipped - their K/V streams are not read
+                              // logits are, gen:2927-2937) are skipped - their K/V streams are not read.
+                              // INVARIANT this relies on: a skipped row's context columns keep stale values, so everything
+                              // computed for that row afterwards (h, partial sums, logits, top-2 record) is meaningless and may
+                              // be Inf/NaN - harmless only because every downstream kernel is ROW-INDEPENDENT (MFMA rows,
+                              // per-row scales, per-row selection).  A kernel that reduces ACROSS rows must mask dead rows.
 };
 void attention_step(const AttnStepArgs& a, mgStream_t stream);
 void attention_step_trace(const AttnStepArgs& a, long long* trace, mgStream_t stream);   // phase stamps, cross form, group 1
@@ -265,6 +269,7 @@ struct ArgmaxArgs {
     const float* logits;     // [rows][ldl]
     int rows, V, ldl;
     int eos, pad, suppress_eos;
+    int n_eos_more, eos_more[3];   // further stop tokens (a list of EOS ids in generation_config.json): treated exactly as `eos`
     int64_t* next_ids;       // [rows] token fed to the next step
     int64_t* out_ids;        // [rows][max_len]
     int max_len, pos;        // column written

@@ -314,6 +314,7 @@ int mg_ocr_create(const mg_ocr_config* cfg, mg_ocr_model** out) {
     { const int rep = c.t_heads / c.t_kv_heads;
       if (!(rep == 1 || rep == 2 || rep == 3 || rep == 4 || rep == 6 || rep == 8))
           return failf(MG_E_SHAPE, "mg_ocr_create: %d query heads per key/value head (supported: 1, 2, 3, 4, 6, 8)", rep); }
+    if (c.n_eos_extra < 0 || c.n_eos_extra > 3) return failf(MG_E_SHAPE, "mg_ocr_create: at most 4 stop tokens (eos_token_id + 3 extra), got %d extra", c.n_eos_extra);
     const int g = c.image_size / c.patch_size;
     if (g % c.scale_factor) return failf(MG_E_SHAPE, "mg_ocr_create: patch grid %d not divisible by scale_factor %d", g, c.scale_factor);
     mg_ocr_model* m = new mg_ocr_model();
@@ -557,6 +558,8 @@ int mg_ocr_generate(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, co
         g.logits = w.logits; g.rows = B; g.V = c.vocab; g.ldl = c.vocab; g.eos = c.eos_token_id; g.pad = c.pad_token_id;
         g.next_ids = w.next_ids; g.out_ids = out_ids; g.max_len = max_new_tokens; g.pos = pos_dev ? 0 : t; g.pos_dev = pos_dev; g.min_len = 0;
         g.unfinished = w.unfinished; g.n_unfinished = w.counters + 5; g.step_ctr = w.counters;
+        g.n_eos_more = c.n_eos_extra;
+        for (int k = 0; k < c.n_eos_extra; ++k) g.eos_more[k] = c.eos_extra[k];
         greedy_select(g, st);
     };
     bool graphed = false;

@@ -25,7 +25,7 @@ class MgOcrConfig(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "v_hidden", "v_inter", "v_layers", "v_heads", "image_size", "patch_size", "t_hidden", "t_inter", "t_layers", "t_heads",
         "t_kv_heads", "vocab", "scale_factor", "image_token_id", "eos_token_id", "pad_token_id", "tie_word_embeddings")] + [
-        ("v_eps", C.c_float), ("rms_eps", C.c_float), ("rope_theta", C.c_float)]
+        ("v_eps", C.c_float), ("rms_eps", C.c_float), ("rope_theta", C.c_float), ("n_eos_extra", C.c_int), ("eos_extra", C.c_int * 3)]
 
 
 class OcrEngine:
@@ -51,6 +51,12 @@ class OcrEngine:
         cfg = MgOcrConfig(s.v_hidden, s.v_inter, s.v_layers, s.v_heads, s.image_size, s.patch_size, s.t_hidden, s.t_inter, s.t_layers,
                           s.t_heads, s.t_kv_heads, s.vocab, s.scale_factor, s.image_token_id, s.eos_token_id, s.pad_token_id,
                           1 if s.tie_word_embeddings else 0, s.v_eps, s.rms_eps, s.rope_theta)
+        extra = tuple(int(e) for e in getattr(s, "eos_extra", ()))
+        if len(extra) > 3:
+            raise MgError(f"at most 4 stop tokens are supported (eos_token_id + 3), got {1 + len(extra)}")
+        cfg.n_eos_extra = len(extra)
+        for i, e in enumerate(extra):
+            cfg.eos_extra[i] = e
         self.model = C.c_void_p()
         self._chk(L.mg_ocr_create(C.byref(cfg), C.byref(self.model)))
         self.arena = self.mem.zeros((int(L.mg_ocr_weights_bytes(self.model)),), np.uint8)
@@ -176,11 +182,16 @@ class OcrEngine:
         return out[:, :cols.value], cap
 
 
-def shape_from_hf_config(cfg) -> OcrShape:
-    """OcrShape from an Idefics3 `config.json` (a dict, a path to the file, or a checkpoint directory)."""
+def shape_from_hf_config(cfg, generation_config=None) -> OcrShape:
+    """OcrShape from an Idefics3 `config.json` (a dict, a path to the file, or a checkpoint directory).  The stop tokens are those
+    `model.generate()` uses: `generation_config.json`'s `eos_token_id` when the checkpoint has one (an int or a list, e.g.
+    <|im_end|> + <end_of_utterance>), else config.json's (generation/configuration_utils.py from_model_config)."""
     import json
     import os
     if not isinstance(cfg, dict):
+        if os.path.isdir(cfg) and generation_config is None and os.path.exists(os.path.join(cfg, "generation_config.json")):
+            with open(os.path.join(cfg, "generation_config.json")) as f:
+                generation_config = json.load(f)
         path = os.path.join(cfg, "config.json") if os.path.isdir(cfg) else cfg
         with open(path) as f:
             cfg = json.load(f)
@@ -188,8 +199,13 @@ def shape_from_hf_config(cfg) -> OcrShape:
     rope = t.get("rope_parameters") or {}
     d = PRESETS["smoldocling"]
     eos = cfg.get("eos_token_id", t.get("eos_token_id", d.eos_token_id))
-    if isinstance(eos, (list, tuple)):
-        eos = eos[0]
+    if generation_config and generation_config.get("eos_token_id") is not None:
+        eos = generation_config["eos_token_id"]
+    eos_list = [int(e) for e in (eos if isinstance(eos, (list, tuple)) else [eos])]
+    eos_list = list(dict.fromkeys(eos_list))
+    if len(eos_list) > 4:
+        raise MgError(f"{len(eos_list)} stop tokens configured; at most 4 are supported")
+    eos = eos_list[0]
     if v.get("hidden_act", "gelu_pytorch_tanh") != "gelu_pytorch_tanh" or t.get("hidden_act", "silu") != "silu":
         raise MgError("unsupported activation (vision: gelu_pytorch_tanh, text: silu)")
     if t.get("model_type", "llama") != "llama" or t.get("attention_bias", False) or t.get("mlp_bias", False):
@@ -203,6 +219,7 @@ def shape_from_hf_config(cfg) -> OcrShape:
         vocab=t.get("vocab_size", cfg.get("vocab_size", d.vocab)), rms_eps=float(t.get("rms_norm_eps", 1e-6)),
         rope_theta=float(rope.get("rope_theta", t.get("rope_theta", 10000.0))),
         scale_factor=cfg.get("scale_factor", 2), image_token_id=cfg.get("image_token_id", d.image_token_id), eos_token_id=int(eos),
+        eos_extra=tuple(eos_list[1:]),
         pad_token_id=int(cfg.get("pad_token_id", t.get("pad_token_id", 0)) or 0),
         tie_word_embeddings=bool(cfg.get("tie_word_embeddings", t.get("tie_word_embeddings", False))))
 
@@ -234,8 +251,6 @@ class OcrModel:
             del sd["lm_head.weight"]
         return cls(shape, sd, device=device)
 
-    def eval(self):
-        return self
     def eval(self):
         return self
 

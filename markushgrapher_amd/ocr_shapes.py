@@ -42,6 +42,7 @@ class OcrShape:
     eos_token_id: int = 49279
     pad_token_id: int = 2
     tie_word_embeddings: bool = False
+    eos_extra: Tuple[int, ...] = ()      # further stop tokens (generation_config.json may list several EOS ids); at most 3
 
     @property
     def patches(self) -> int:

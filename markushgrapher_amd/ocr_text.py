@@ -17,14 +17,16 @@ _PAGE = "<loc_0><loc_0><loc_500><loc_500>"
 
 
 def clean_ocr_text(text: str, start_tag: str = "<ocr>", end_tag: str = "</ocr>") -> str:
-    """Drop everything before the first start tag and after the first end tag (both kept); a missing tag leaves that side alone."""
+    """Drop everything before the first start tag and after the first end tag (both kept); a missing tag leaves that side alone.
+    As the reference's `re.sub(r"(</ocr>).*?$", ...)` without MULTILINE, whose `$` also matches in front of a final newline: a
+    text that ends with a newline keeps that one newline behind the end tag."""
     i = text.find(start_tag)
     if i >= 0:
         text = text[i:]
     if end_tag:
         j = text.find(end_tag)
         if j >= 0:
-            text = text[:j + len(end_tag)]
+            text = text[:j + len(end_tag)] + ("\n" if text.endswith("\n") else "")
     return text
 
 

@@ -196,7 +196,8 @@ class OcrOracle:
             nxt = logits.argmax(-1)
             nxt = torch.where(unfinished, nxt, torch.full_like(nxt, s.pad_token_id))
             out.append(nxt)
-            unfinished = unfinished & (nxt != s.eos_token_id)
+            for e in (s.eos_token_id,) + tuple(getattr(s, "eos_extra", ())):      # a list of EOS ids stops on any of them (gen:2927-2937)
+                unfinished = unfinished & (nxt != e)
             if not bool(unfinished.any()) or t + 1 == max_new_tokens:
                 break
             h = self.w["model.text_model.embed_tokens.weight"][nxt][:, None]

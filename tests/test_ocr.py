@@ -299,3 +299,60 @@ def test_patch_inputs_rejects_padding_frames():
     m[1, 0, :20, :40] = True
     pos, msk = eng.patch_inputs(m)
     assert msk.shape == (2, s.patches) and msk[0].all() and msk[1].sum() == 2 * 3 and pos[1][msk[1] == 0].max() == 0
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+def test_ocr_several_stop_tokens(be_name):
+    """generation_config.json may list several EOS ids: a row ends on ANY of them.  The second stop id is a token the
+    golden run emits mid-sequence with a safe margin, so that row must now end there (pad afterwards, fewer columns overall)."""
+    import dataclasses
+    import torch
+    from oracle.ocr_oracle import OcrOracle
+    g, s, sd, ids, pix = _setup("tiny")
+    n = int(g["new_tokens"])
+    tonp = lambda x: np.asarray(x if isinstance(x, np.ndarray) else x.cpu().numpy())
+    base = tonp(make_ocr(be_name, s, sd).generate(ids, pix, n)[0])
+    b0, t0 = 1, 3                                               # a row that does not end by itself; its 4th new token becomes a stop id
+    extra = int(base[b0, t0])
+    assert extra not in (s.eos_token_id, s.pad_token_id) and not (base[b0, :t0] == extra).any()
+    s2 = dataclasses.replace(s, eos_extra=(extra,))
+    new = tonp(make_ocr(be_name, s2, sd).generate(ids, pix, n)[0])
+    for b in range(base.shape[0]):                              # every row: unchanged up to its first stop token, pad afterwards
+        hits = np.nonzero((base[b] == extra) | (base[b] == s.eos_token_id))[0]
+        end = int(hits[0]) if len(hits) else base.shape[1] - 1
+        end = min(end, new.shape[1] - 1)
+        assert np.array_equal(new[b, :end + 1], base[b, :end + 1]) and (new[b, end + 1:] == s.pad_token_id).all(), (b, new[b], base[b])
+    assert new[b0, t0] == extra
+    with torch.no_grad():                                       # the oracle states the same rule
+        o0 = OcrOracle(s, sd).generate(ids, pix, n).numpy()
+        e2 = int(o0[b0, t0])
+        o2 = OcrOracle(dataclasses.replace(s, eos_extra=(e2,)), sd).generate(ids, pix, n).numpy()
+    assert o2[b0, t0] == e2 and (o2[b0, t0 + 1:] == s.pad_token_id).all() and np.array_equal(o2[b0, :t0], o0[b0, :t0])
+    from markushgrapher_amd.engine import MgError
+    with pytest.raises(MgError, match="stop tokens"):
+        make_ocr(be_name, dataclasses.replace(s, eos_extra=(5, 6, 7, 8)), sd)
+
+
+def test_ocr_shape_from_hf_config_reads_generation_config(tmp_path):
+    """Stop tokens come from generation_config.json when the checkpoint has one (what model.generate() uses), else config.json."""
+    import json
+    from markushgrapher_amd.ocr import shape_from_hf_config
+    from markushgrapher_amd.engine import MgError
+    cfg = {"vision_config": {"hidden_size": 768, "intermediate_size": 3072, "num_hidden_layers": 12, "num_attention_heads": 12,
+                             "image_size": 512, "patch_size": 16},
+           "text_config": {"hidden_size": 576, "intermediate_size": 1536, "num_hidden_layers": 30, "num_attention_heads": 9,
+                           "num_key_value_heads": 3, "vocab_size": 49280, "rope_theta": 100000.0, "rms_norm_eps": 1e-5},
+           "scale_factor": 4, "image_token_id": 49190, "eos_token_id": 49279, "pad_token_id": 2}
+    d = tmp_path / "ckpt"
+    d.mkdir()
+    (d / "config.json").write_text(json.dumps(cfg))
+    s = shape_from_hf_config(str(d))
+    assert s.eos_token_id == 49279 and s.eos_extra == () and s.t_kv_heads == 3 and s.image_seq_len == 64
+    (d / "generation_config.json").write_text(json.dumps({"eos_token_id": [49279, 49154], "max_new_tokens": 40}))
+    s = shape_from_hf_config(str(d))
+    assert s.eos_token_id == 49279 and s.eos_extra == (49154,)
+    (d / "generation_config.json").write_text(json.dumps({"eos_token_id": 49154}))
+    assert shape_from_hf_config(str(d)).eos_token_id == 49154
+    (d / "generation_config.json").write_text(json.dumps({"eos_token_id": [1, 2, 3, 4, 5]}))
+    with pytest.raises(MgError, match="stop tokens"):
+        shape_from_hf_config(str(d))

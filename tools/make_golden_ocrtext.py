@@ -26,7 +26,8 @@ CASES = [
     "0>0>500>500>",
     "500>500>500>500>X\r\n1>1>2>2>Y",
 ]
-CLEAN = ["junk<ocr>abc</ocr>tail", "no tags", "<ocr>only start", "only end</ocr>x", "a<ocr>b<ocr>c</ocr>d</ocr>e", "x\n<ocr>multi\nline</ocr>\ny"]
+CLEAN = ["junk<ocr>abc</ocr>tail", "no tags", "<ocr>only start", "only end</ocr>x", "a<ocr>b<ocr>c</ocr>d</ocr>e", "x\n<ocr>multi\nline</ocr>\ny",
+         "<ocr>a</ocr>\n", "<ocr>a</ocr>tail\n", "<ocr>a</ocr>t\n\n", "pre<ocr>a\n", "<ocr>a</ocr>\nmore", "\n<ocr>a</ocr>x\ny\n"]
 
 out = {"parse": [], "clean": []}
 for c in CASES:
