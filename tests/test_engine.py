@@ -42,6 +42,12 @@ def test_bucket_tables_match_torch(be_name):
     lo = int(g["dec_1d_lo"])
     dec = eng.bucket_table(2, 64)
     assert np.array_equal(dec, g["dec_1d"][[-i - lo for i in range(64)]])
+    # every distance a 512-token decode can reach (ref: utils_evaluation.py:280 max_length=512): exact range 0..15, the
+    # log-spaced buckets 16..127 and the saturated range >= 128 (stock:422-468), against the torch-evaluated table
+    eng512 = make_engine(be_name, shape, sd, max_decode_len=512)
+    dec = eng512.bucket_table(2, 512)
+    assert dec.shape == (512,) and np.array_equal(dec, g["dec_1d"][[-i - lo for i in range(512)]])
+    assert dec[15] == 15 and dec[16] == 16 and dec[64] < 31 and dec[128] == 31 and dec[511] == 31 and np.all(np.diff(dec) >= 0)
 
 
 @pytest.mark.parametrize("be_name", BACKENDS)
@@ -95,23 +101,48 @@ def test_greedy_bit_exact_on_trained_fixture(be_name):
                 assert abs(t2[t, b, 0] - ref[b, t - 1].max()) < logit_tol(ref)
 
 
+def _forced_path_check(be_name, g, shape, sd, inp):
+    """Teacher-force the KV-cached decode path along stock's greedy ids: every step's logits against stock's raw step logits
+    (logit tolerance), the step's argmax against stock's token wherever stock's top-1/top-2 margin exceeds twice the tolerance;
+    then the free-running ids up to the first step whose margin is inside that band.  Returns (#argmax checks, #free-run ids)."""
+    ref_ids, margin, ref_logits = g["greedy_ids"], g["greedy_margin"], g["greedy_step_logits"]
+    B, T = ref_ids.shape
+    tol = logit_tol(ref_logits)
+    eng = make_engine(be_name, shape, sd)
+    cap = eng.debug_decode_capture(T - 1, B, ref_ids)
+    eng.generate(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"], max_length=T, min_length=0)
+    cap = _np(eng, cap).copy().transpose(1, 0, 2)                 # [B, T-1, V]
+    eng.debug_decode_capture()
+    live = np.ones((B, T - 1), bool)
+    for b in range(B):
+        e = np.nonzero(ref_ids[b, 1:] == shape.eos_token_id)[0]
+        if len(e):
+            live[b, e[0] + 1:] = False                            # stock's logits after a row ended come from pad inputs: still compared
+    err = np.abs(cap - ref_logits)
+    assert err.max() < tol, (float(err.max()), tol)
+    safe = (margin > 2 * tol) & live
+    assert np.array_equal(cap.argmax(-1)[safe], ref_ids[:, 1:][safe])
+    ids, _, _ = eng.generate(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"], num_beams=1, max_length=T)
+    ids = _np(eng, ids)
+    free = 0
+    for b in range(B):
+        for t in range(1, min(T, ids.shape[1])):
+            if margin[b, t - 1] < 2 * tol:
+                break
+            assert ids[b, t] == ref_ids[b, t], (b, t)
+            free += 1
+    return int(safe.sum()), free, float(err.max()), tol
+
+
 @pytest.mark.parametrize("be_name", BACKENDS)
 def test_greedy_random_weights_margin_rule(be_name):
-    """Random-init weights give top-1/top-2 margins far below bf16 noise, so ids are compared up to
-    the first step whose oracle margin is below 4x the logit tolerance; logits are compared step by step."""
+    """G0 (recipe weights, non-degenerate sequences, edge-case inputs).  Random-weight margins are ~0.01-0.2 on logits of
+    magnitude 1, so free-running ids are only comparable up to the first near-tie; the forced path compares EVERY step."""
     g = load_golden("g0_tiny.npz")
     shape, sd = _weights(g)
     inp = _inputs(g, shape)
-    eng = make_engine(be_name, shape, sd)
-    ids, _, top2 = eng.generate(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"], num_beams=1,
-                                max_length=int(g["max_length"]), return_top2=True)
-    ids = _np(eng, ids)
-    ref, margin = g["greedy_ids"], g["greedy_margin"]
-    for b in range(ref.shape[0]):
-        for t in range(1, ref.shape[1]):
-            if margin[b, t - 1] < 4 * logit_tol(g["greedy_step_logits"]):
-                break
-            assert ids[b, t] == ref[b, t], (b, t)
+    n_argmax, n_free, err, tol = _forced_path_check(be_name, g, shape, sd, inp)
+    assert n_argmax >= 8 and n_free >= 1, (n_argmax, n_free)
 
 
 @pytest.mark.parametrize("be_name", BACKENDS)
@@ -142,8 +173,25 @@ def test_beam_search_bit_exact_on_trained_fixture(be_name):
     np.testing.assert_allclose(scores, g["beam_scores"], atol=1e-2)
 
 
+def _oracle_sequence_score(o, inp, ids):
+    """Length-normalised log-probability of full decoder sequences `ids` [B, T] (start token first) under the fp32 oracle:
+    sum_t log p(ids[t] | ids[:t]) / (T - 1)^1.0 (the generated tokens; the start token is not counted) - what stock's beam search reports as sequences_scores for hypotheses that run to
+    max_length (generation/utils.py:3153-3206; checked against the fixture's own scores by the caller)."""
+    import torch
+    with torch.no_grad():
+        logits = o.forward(inp["input_ids"], inp["bbox"], inp["pixel_values"], inp["attention_mask"], decoder_input_ids=ids[:, :-1])
+        lp = torch.log_softmax(logits, dim=-1)
+        tok = torch.gather(lp, 2, torch.from_numpy(ids[:, 1:, None].astype(np.int64)))[..., 0]
+    return (tok.sum(-1) / (ids.shape[1] - 1)).numpy()
+
+
 @pytest.mark.parametrize("be_name", BACKENDS)
 def test_beam_search_random_weights_scores(be_name):
+    """G0, beam-5 on recipe weights.  The two best hypotheses of an image are ~0.003 apart in score (fixture `beam_gap`), far
+    inside bf16 noise, so the ids themselves cannot be pinned.  What CAN be: (i) the reported scores equal stock's within
+    tolerance, and (ii) the ids the HIP path returns are a hypothesis the fp32 ORACLE scores as well as stock's best (within the
+    same tolerance) - i.e. the returned sequence is checked, not just its score."""
+    from oracle.udop_oracle import Oracle
     g = load_golden("g0_tiny.npz")
     shape, sd = _weights(g)
     inp = _inputs(g, shape)
@@ -152,8 +200,16 @@ def test_beam_search_random_weights_scores(be_name):
                                   max_length=int(g["max_length"]))
     ids, scores = _np(eng, ids), _np(eng, scores)
     assert ids.shape == g["beam_ids"].shape and np.all(ids[:, 0] == 0)
-    # near-tied random-weight beams may swap, but the best score found must be as good as stock's within tolerance
-    np.testing.assert_allclose(scores, g["beam_scores"], atol=5e-2)
+    SCORE_TOL = 5e-2
+    np.testing.assert_allclose(scores, g["beam_scores"], atol=SCORE_TOL)
+    o = Oracle(shape, sd)
+    assert np.abs(_oracle_sequence_score(o, inp, g["beam_ids"]) - g["beam_scores"]).max() < 1e-3     # the scoring rule is stock's
+    mine = _oracle_sequence_score(o, inp, ids)
+    assert np.all(mine > g["beam_scores"] - SCORE_TOL), (mine, g["beam_scores"])
+    np.testing.assert_allclose(mine, scores, atol=SCORE_TOL)                                         # and the HIP score is that sequence's score
+    for b in range(ids.shape[0]):                # where stock's best is clear of the runner-up by more than the noise, the ids are pinned
+        if g["beam_gap"][b] > 2 * SCORE_TOL:
+            assert np.array_equal(ids[b], g["beam_ids"][b])
 
 
 @pytest.mark.parametrize("be_name", BACKENDS)
@@ -209,14 +265,8 @@ def test_mid_fixture_g1_on_gpu():
     logits, _, _ = eng.forward_logits(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"], dec_ids,
                                       (labels != -100).astype(np.uint8))
     assert np.abs(_np(eng, logits) - g["logits"]).max() < logit_tol(g["logits"])
-    ids, _, _ = eng.generate(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"], num_beams=1,
-                             max_length=int(g["max_length"]))
-    ids = _np(eng, ids)
-    for b in range(ids.shape[0]):
-        for t in range(1, ids.shape[1]):
-            if g["greedy_margin"][b, t - 1] < 4 * logit_tol(g["greedy_step_logits"]):
-                break
-            assert ids[b, t] == g["greedy_ids"][b, t]
+    n_argmax, n_free, err, tol = _forced_path_check("hip", g, shape, sd, inp)
+    assert n_argmax >= 10 and n_free >= 1, (n_argmax, n_free)
 
 
 @pytest.mark.gpu
@@ -297,7 +347,21 @@ def test_edge_single_token_single_image(be_name):
     eo, mo = Oracle(shape, sd).encode(inp["input_ids"], inp["bbox"], inp["pixel_values"], inp["attention_mask"])
     assert np.array_equal(_np(eng, mask), mo.numpy().astype(np.uint8))
     assert np.abs(_np(eng, enc) - eo.numpy())[mo.numpy().astype(bool)].max() < ENC_MAX
-    assert _np(eng, ids).shape[1] == ref.shape[1]
+    got = _np(eng, ids)
+    assert got.shape[1] == ref.shape[1]
+    # ids: an out-of-distribution input for the trained model, so compare under the margin rule against the oracle's own step logits
+    rec = []
+    ref2 = Oracle(shape, sd).greedy(inp["input_ids"], inp["bbox"], inp["pixel_values"], inp["attention_mask"], max_length=10, record=rec)
+    assert np.array_equal(ref2, ref)
+    tol = logit_tol(np.stack([r.numpy() for r in rec]))
+    checked = 0
+    for t in range(1, ref.shape[1]):
+        srt = np.sort(rec[t - 1][0].numpy())
+        if srt[-1] - srt[-2] < 4 * tol:
+            break
+        assert got[0, t] == ref[0, t], (t, got.tolist(), ref.tolist())
+        checked += 1
+    assert checked >= 1
 
 
 @pytest.mark.parametrize("be_name", BACKENDS)
@@ -415,6 +479,57 @@ def test_forced_decode_capture_matches_teacher_forced_oracle(be_name):
     # instrumentation cleared: the plain call is unaffected
     ids2, _, _ = eng.generate(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"], max_length=int(g["max_length"]))
     assert np.array_equal(_np(eng, ids2), g["greedy_ids"])
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+@pytest.mark.parametrize("ids_kind", ["golden-cycle", "random"])
+def test_long_positions_forced_decode(be_name, ids_kind):
+    """Decode positions far beyond the fixtures' 11-16 steps: the KV-cached decode path is teacher-forced
+    through 260 (emulator) / 511 (GPU) positions - the bench runs 256, the reference generate(max_length=512) - and every
+    step's logits are compared with the oracle's teacher-forced decoder.  The positional bias passes through its exact
+    (< 16), log-bucketed (16..127) and saturated (>= 128) ranges; the self-attention cache grows past one 128-key round.
+    Tolerance: the standard logit tolerance for in-distribution ids (the golden sequences, cycled); for random ids the trained
+    tiny model is far out of distribution and bf16 storage alone moves its logits by more than that (the fp32 and the
+    bf16-emulating oracle differ by ~0.2), so the bound is re-derived per run as 2 x max|oracle_fp32 - oracle_bf16| (never
+    below the standard one).  Argmax must agree wherever the fp32 margin exceeds twice the tolerance."""
+    from oracle.udop_oracle import Oracle
+    import torch
+    g = load_golden("g3_trained_tiny.npz")
+    shape, sd = _weights(g)
+    B = 2 if be_name == "emu" else 6
+    inp = {k: v[:B] for k, v in _inputs(g, shape).items()}
+    T = (261 if ids_kind == "golden-cycle" else 151) if be_name == "emu" else 512
+    if ids_kind == "random":
+        forced = synth.randint("forced.long", B * T, 2, shape.vocab_size - 1, 1).reshape(B, T)
+    else:
+        gi = g["greedy_ids"][:B]
+        forced = np.stack([np.resize(gi[b][gi[b] > 1], T) for b in range(B)])
+    forced[:, 0] = shape.decoder_start_token_id
+    eng = make_engine(be_name, shape, sd, max_decode_len=512)
+    cap = eng.debug_decode_capture(T - 1, B, forced)
+    ids, _, _ = eng.generate(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"], max_length=T, min_length=T)
+    cap, ids = _np(eng, cap).copy().transpose(1, 0, 2), _np(eng, ids).copy()
+    eng.debug_decode_capture()
+    ref = {}
+    for bf in (False, True):
+        o = Oracle(shape, sd, emulate_bf16=bf)
+        with torch.no_grad():
+            enc, mask = o.encode(inp["input_ids"], inp["bbox"], inp["pixel_values"], inp["attention_mask"])
+            hid, _ = o.decoder_stack(torch.from_numpy(forced[:, :T - 1]), mask, o.cross_kv(enc))
+            ref[bf] = o.lm_logits(hid).numpy()                     # [B, T-1, V]
+    tol = logit_tol(ref[False])
+    if ids_kind == "random":
+        tol = max(tol, 2.0 * float(np.abs(ref[False] - ref[True]).max()))
+    err = np.abs(cap - ref[False]).max(axis=(0, 2))                # per step
+    assert err.max() < tol, (int(err.argmax()), float(err.max()), tol)
+    # no drift with position: the late steps are no worse than the early ones (beyond noise)
+    assert err[128:].max() < max(1.5 * err[:64].max(), 0.5 * tol)
+    masked = ref[False].copy()
+    masked[:, :, shape.eos_token_id] = -np.inf                     # min_length = max_length suppresses EOS in the selection
+    srt = np.sort(masked, axis=-1)
+    safe = (srt[..., -1] - srt[..., -2]) > 2 * tol
+    assert safe.sum() > (T - 1) * B // 4
+    assert np.array_equal(ids[:, 1:][safe], masked.argmax(-1)[safe])
 
 
 @pytest.mark.parametrize("be_name", BACKENDS)

@@ -12,6 +12,9 @@ import os
 
 def _weights(g):
     shape = synth.SHAPES[str(g["shape"])]
+    if "recipe" in g:
+        r = dict(zip(("gain", "embed_gain", "ffn_gain", "xq_gain"), (float(x) for x in g["recipe"])))
+        return shape, synth.recipe_state_dict(shape, **r)
     if "gain" in g:
         return shape, synth.recipe_state_dict(shape, gain=float(g["gain"]))
     return shape, dict(np.load(os.path.join(GOLDEN, "g3_weights.npz")))
@@ -47,6 +50,16 @@ def test_oracle_matches_stock_fixture(name):
                               num_beams=5, max_length=ml)
     assert np.array_equal(bids, g["beam_ids"])
     assert np.abs(bsc - g["beam_scores"]).max() < 1e-3
+
+
+@pytest.mark.parametrize("name", ["g0_tiny.npz", "g1_mid.npz"])
+def test_random_weight_fixtures_are_not_degenerate(name):
+    """G0 / G1 (recipe weights): greedy and beam rows are varied, image-dependent sequences - not the all-start-token rows that
+    plain random init gives, on which an id comparison says nothing."""
+    g = load_golden(name)
+    for ids, distinct in ((g["greedy_ids"], 5), (g["beam_ids"], 2)):
+        assert (ids[:, 1:] != 0).all() and all(len(set(r[1:].tolist())) >= distinct for r in ids)
+        assert len({tuple(r.tolist()) for r in ids}) == ids.shape[0]
 
 
 def test_g3_has_early_eos_and_margins():

@@ -72,6 +72,12 @@ def run_stock(m, inp, labels, max_length, beams=5):
         gb = m.generate(input_ids=t["input_ids"], bbox=t["bbox"].clone(), pixel_values=t["pixel_values"],
                         attention_mask=t["attention_mask"], num_beams=beams, max_length=max_length,
                         do_sample=False, return_dict_in_generate=True, output_scores=True)
+        # the two best finished hypotheses per image: their score gap says whether the best one is stable under bf16 noise
+        gb2 = m.generate(input_ids=t["input_ids"], bbox=t["bbox"].clone(), pixel_values=t["pixel_values"],
+                         attention_mask=t["attention_mask"], num_beams=beams, num_return_sequences=2, max_length=max_length,
+                         do_sample=False, return_dict_in_generate=True, output_scores=True)
+    sc2 = gb2.sequences_scores.reshape(-1, 2)
+    assert torch.allclose(sc2[:, 0], gb.sequences_scores)
     step_logits = torch.stack(g.logits, dim=1)             # [B, steps, V]
     top2 = torch.topk(step_logits, 2, dim=-1).values
     return {
@@ -81,6 +87,7 @@ def run_stock(m, inp, labels, max_length, beams=5):
         "greedy_ids": g.sequences.numpy(), "greedy_step_logits": step_logits.numpy(),
         "greedy_margin": (top2[..., 0] - top2[..., 1]).numpy(),
         "beam_ids": gb.sequences.numpy(), "beam_scores": gb.sequences_scores.numpy(),
+        "beam_gap": (sc2[:, 0] - sc2[:, 1]).numpy(),
     }
 
 
@@ -113,17 +120,26 @@ def save(name, **arrs):
     print("   wrote", p, os.path.getsize(p), "bytes")
 
 
+# G0 / G1: the non-degenerate recipe of the benchmark fixture (small token embeddings, x6 FFNs, x3 cross-attention queries).  With
+# plain random init the tied-embedding model decodes the start token forever (the round-1/2 fixtures held
+# all-zero greedy rows, which made the id comparisons on them vacuous - VERDICT r2 weak #4).
+G01_RECIPE = synth.BENCH_RECIPE
+RECIPE_VEC = lambda r: np.array([r[k] for k in ("gain", "embed_gain", "ffn_gain", "xq_gain")], np.float32)
+
+
 def g0():
     print("G0 tiny / recipe weights / edge-case inputs")
     shape = synth.SHAPES["tiny"]
-    sd = synth.recipe_state_dict(shape, gain=1.0)
+    sd = synth.recipe_state_dict(shape, **G01_RECIPE)
     m = stock_model(shape, sd)
     inp = edge_case_inputs(shape)
     labels = synth.randint("g0.lab", 2 * 10, 2, shape.vocab_size - 1, 3).reshape(2, 10)
     labels[1, 7:] = -100
     ref = run_stock(m, inp, labels, 16)
     check_oracle(Oracle(shape, sd), inp, labels, ref, 16)
-    save("g0_tiny.npz", shape=np.array("tiny"), gain=np.float32(1.0), labels=labels, max_length=np.int64(16),
+    print("   greedy", ref["greedy_ids"].tolist(), "min margin", float(ref["greedy_margin"].min()))
+    print("   beam  ", ref["beam_ids"].tolist(), "gap", ref["beam_gap"].tolist())
+    save("g0_tiny.npz", shape=np.array("tiny"), recipe=RECIPE_VEC(G01_RECIPE), labels=labels, max_length=np.int64(16),
          **inp, **ref)
 
 
@@ -145,14 +161,16 @@ def g3():
 def g1():
     print("G1 mid / recipe weights (not stored)")
     shape = synth.SHAPES["mid"]
-    sd = synth.recipe_state_dict(shape, gain=1.0)
+    sd = synth.recipe_state_dict(shape, **G01_RECIPE)
     m = stock_model(shape, sd)
     inp = synth.synth_batch(shape, 3, L_min=9, L_max=40, seed=11)
     labels = synth.randint("g1.lab", 3 * 16, 2, shape.vocab_size - 1, 3).reshape(3, 16)
     labels[2, 9:] = -100
     ref = run_stock(m, inp, labels, 24)
     check_oracle(Oracle(shape, sd), inp, labels, ref, 24, ids_strict=False)
-    save("g1_mid.npz", shape=np.array("mid"), gain=np.float32(1.0), labels=labels, max_length=np.int64(24),
+    print("   greedy", ref["greedy_ids"].tolist(), "min margin", float(ref["greedy_margin"].min()))
+    print("   beam  ", ref["beam_ids"].tolist(), "gap", ref["beam_gap"].tolist())
+    save("g1_mid.npz", shape=np.array("mid"), recipe=RECIPE_VEC(G01_RECIPE), labels=labels, max_length=np.int64(24),
          synth_args=np.array([3, 9, 40, 11]), **{k: v for k, v in ref.items()})
 
 
