@@ -175,3 +175,37 @@ def test_g4_beam5_subset_and_full_batch():
     assert sum(np.array_equal(ids32[b], g["beam_ids"][b]) for b in range(nb)) >= nb // 2
     again, sc_again, _ = eng.generate(*args, num_beams=5, max_length=new + 1, min_length=new + 1)
     assert np.array_equal(eng.mem.numpy(again), ids32) and np.array_equal(eng.mem.numpy(sc_again), sc32)
+
+
+def test_g4_long_256_forced_steps_top8():
+    """The benchmark's own decode length: 256 forced steps (bench.py: max_length = min_length = 257) on 4 of the bench images,
+    teacher-forced along stock's ids through the KV-cached decode path; EVERY step's logits at stock's top-8 indices within
+    LOGIT_TOL, ranks under the margin rule - positions 17..256 included (self-attention cache beyond one 128-key round, the
+    log-bucketed and the saturated range of the decoder's positional bias).  Fixture: tests/golden/g4_long.npz (tools/make_golden.py
+    g4long, stock UDOP; the oracle agrees with stock on the same 256 positions to `oracle_top8_maxdiff`)."""
+    g, shape, eng0, args = _setup()
+    gl = load_golden("g4_long.npz")
+    rows, new = gl["rows"], int(gl["new_tokens"])
+    assert new == 256 and np.array_equal(gl["greedy_ids"][:, :17], g["greedy_ids"][rows])
+    sd = synth.recipe_state_dict(shape, **synth.BENCH_RECIPE)
+    eng = make_engine("hip", shape, sd, max_decode_len=new + 1)
+    sub = tuple(np.asarray(a[rows]) if isinstance(a, np.ndarray) else a[rows.tolist()] for a in args)
+    cap = eng.debug_decode_capture(new, len(rows), gl["greedy_ids"])
+    try:
+        ids, _, _ = eng.generate(*sub, max_length=new + 1, min_length=new + 1)
+        logits = eng.mem.numpy(cap).transpose(1, 0, 2).copy()          # [4, 256, V]
+    finally:
+        eng.debug_decode_capture()
+    err = _check_top8(logits, gl["step_top_vals"], gl["step_top_idx"])
+    # no drift with position: the last 128 steps are no worse than the first 64 (beyond noise)
+    per_step = err.max(axis=(0, 2))
+    assert per_step[128:].max() < max(1.5 * per_step[:64].max(), 0.5 * LOGIT_TOL), (per_step[:64].max(), per_step[128:].max())
+    # free-running (what bench.py runs): ids equal stock's up to each row's first near-tie; report how far that is
+    ids_free, _, _ = eng.generate(*sub, max_length=new + 1, min_length=new + 1)
+    ids_free = eng.mem.numpy(ids_free)
+    margin = gl["step_top_vals"][..., 0] - gl["step_top_vals"][..., 1]
+    for b in range(len(rows)):
+        for t in range(1, new + 1):
+            if margin[b, t - 1] < MARGIN_TOL:
+                break
+            assert ids_free[b, t] == gl["greedy_ids"][b, t], (b, t)

@@ -356,3 +356,41 @@ def test_ocr_shape_from_hf_config_reads_generation_config(tmp_path):
     (d / "generation_config.json").write_text(json.dumps({"eos_token_id": [1, 2, 3, 4, 5]}))
     with pytest.raises(MgError, match="stop tokens"):
         shape_from_hf_config(str(d))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [35, 128])
+def test_ocr_bench_batches_at_smoldocling_geometry(B):
+    """The OCR bench shapes under an oracle check: SmolDocling-256M geometry at 35 pages (two row tiles) and
+    128 pages (four: `gemm_rows_split_kernel` / `gemm_rows_resid_rowsplit_kernel` at production dimensions), 16 greedy steps.
+    Rows are independent, so the oracle runs on a subset that spans every row tile (first / last row of each tile, plus the odd
+    tail rows at 35); per-step logits within the logit tolerance, ids under the margin rule."""
+    import dataclasses
+    import torch
+    from oracle.ocr_oracle import OcrOracle
+    s = dataclasses.replace(PRESETS["smoldocling"], eos_token_id=-1)          # EOS cannot occur: every row runs all steps
+    g = load_golden("ocr_smoldocling.npz")
+    sd = recipe_state_dict(s, gain=float(g["gain"]))
+    n = 16
+    ids, pix = synth_inputs(s, B)
+    eng = make_ocr("hip", s, sd)
+    new, cap = eng.generate(ids, pix, n, capture_steps=n)
+    new, cap = eng.mem.numpy(new), eng.mem.numpy(cap)              # [B, n], [n, B, V]
+    assert new.shape == (B, n)
+    rows = sorted({r for t in range((B + 31) // 32) for r in (32 * t, min(32 * t + 31, B - 1))} | {B - 2, B - 1})
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    with torch.no_grad():
+        ref, sc = OcrOracle(s, sd).generate(ids[rows], pix[rows], n, return_logits=True)
+    ref, sc = ref.numpy(), sc.numpy()                              # [R, n], [R, n, V]
+    tol = logit_tol(np.abs(sc).max())
+    srt = np.sort(sc, axis=-1)
+    margin = srt[..., -1] - srt[..., -2]
+    checked = 0
+    for i, b in enumerate(rows):
+        for t in range(n):
+            assert np.abs(cap[t, b] - sc[i, t]).max() < tol, (b, t, float(np.abs(cap[t, b] - sc[i, t]).max()), tol)
+            if margin[i, t] <= 4 * tol:
+                break                                              # the continuation of this row legitimately differs from here
+            assert new[b, t] == ref[i, t], (b, t)
+            checked += 1
+    assert checked >= len(rows), checked

@@ -327,6 +327,45 @@ def g4():
          new_tokens=np.int64(NEW), labels=labels, beam_rows=np.int64(NB), oracle_greedy_rows_equal=np.array(same), **ref)
 
 
+def g4long():
+    """G4-long: the benchmark's 256 forced decode steps (bench.py: max_length = min_length = 257) on 4 of the bench images, from
+    stock UDOP: ids and the top-8 logits of EVERY step (positions 17..256 of the bench configuration were not
+    under an oracle check).  Images 0, 7, 17, 31 of the batch at the batch's padded text length."""
+    print("G4-long: 256 greedy steps, 4 bench images, stock UDOP-large")
+    shape = synth.SHAPES["large"]
+    sd = synth.recipe_state_dict(shape, **synth.BENCH_RECIPE)
+    m = stock_model(shape, sd)
+    inp = bench_inputs(shape)
+    rows = np.array([0, 7, 17, 31])
+    NEW = 256
+    t = {k: torch.from_numpy(v[rows]) for k, v in inp.items()}
+    t0 = time.time()
+    with torch.no_grad():
+        g = m.generate(input_ids=t["input_ids"], bbox=t["bbox"].clone(), pixel_values=t["pixel_values"], attention_mask=t["attention_mask"],
+                       num_beams=1, max_length=NEW + 1, min_length=NEW + 1, do_sample=False, return_dict_in_generate=True, output_logits=True)
+    print(f"   stock ran in {time.time() - t0:.0f}s")
+    logits = torch.stack(g.logits, dim=1)                       # [4, 256, V] raw
+    top = torch.topk(logits, 8, dim=-1)
+    ids = g.sequences.numpy()
+    g4 = dict(np.load(os.path.join(OUT, "g4_bench.npz")))
+    assert np.array_equal(ids[:, :17], g4["greedy_ids"][rows])  # continues the 16-step fixture
+    mg = (top.values[..., 0] - top.values[..., 1]).numpy()
+    print(f"   margins: min {mg.min():.4f} median {np.median(mg):.3f}; max |logit| {float(top.values.abs().max()):.2f}; distinct tokens {len(set(ids[:, 1:].ravel().tolist()))}")
+    # the oracle on the same 256 steps (teacher-forced along stock's ids): pins the oracle at long positions of the large shape
+    del m
+    o = Oracle(shape, sd)
+    sub = {k: v[rows[:2]] for k, v in inp.items()}
+    with torch.no_grad():
+        enc, mask = o.encode(sub["input_ids"], sub["bbox"], sub["pixel_values"], sub["attention_mask"])
+        hid, _ = o.decoder_stack(torch.from_numpy(ids[:2, :NEW]), mask, o.cross_kv(enc))
+        lo = o.lm_logits(hid).numpy()
+    d = float(np.abs(np.take_along_axis(lo, top.indices[:2].numpy(), -1) - top.values[:2].numpy()).max())
+    print(f"   oracle vs stock over 256 positions (2 images): top-8 logits {d:.2e}")
+    assert d < 5e-3
+    save("g4_long.npz", rows=rows, new_tokens=np.int64(NEW), greedy_ids=ids, step_top_vals=top.values.numpy(),
+         step_top_idx=top.indices.numpy().astype(np.int32), oracle_top8_maxdiff=np.float32(d))
+
+
 def tables():
     print("bucket tables (stock:422-468 evaluated by torch on every integer distance)")
     save("bucket_tables.npz",
