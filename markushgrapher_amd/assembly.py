@@ -11,9 +11,12 @@ Pinning status:
                                 own `split_bounding_box_for_words` / `prepare_cells_to_text`, executed from
                                 /root/reference by `tools/make_golden_wordboxes.py` (a deterministic piece tokenizer stands
                                 in for the sentencepiece model, which is not available offline).
-  * id->text decoding (f-4)       - **parity unpinned**: `markush_tokenizer.py` / `utils_evaluation.py` import rdkit and
-                                SmilesPE, absent from this image; the tests are known-answer cases written from the
-                                reference's documented behaviour.
+  * id->text decoding (f-4)       - `IdDecoder` pinned: `tests/golden/host_idtext.json` holds inputs and outputs of the
+                                reference's own `MarkushTokenizer.decode_plus_decode_other_tokens`, executed from
+                                /root/reference by `tools/make_golden_idtext.py` (rdkit / SmilesPE stubbed as empty modules:
+                                the method touches neither; stand-in id -> token table).  `text_to_cxsmiles_opt` restates a
+                                few inline `str.replace` / `re.search` lines of `get_smiles_metrics`
+                                (utils_evaluation.py:303-345) that are not callable on their own: known-answer tests.
 
 Reference: markushgrapher/core/trainers/data_collator.py:11-108 (DataCollator, pad_sequence_native),
 markushgrapher/core/common/data_preprocessing.py:11-104 (word boxes, prepare_cells_to_text),
@@ -196,7 +199,7 @@ def collate_item(item, tokenizer, normalize_bbox):
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# f-4: generated ids -> text -> CXSMILES string (markush_tokenizer.py:615-670, utils_evaluation.py:286-345) [unpinned]
+# f-4: generated ids -> text -> CXSMILES string (markush_tokenizer.py:615-670 [pinned], utils_evaluation.py:286-345)
 # ---------------------------------------------------------------------------------------------------------------
 class IdDecoder:
     """Table-driven form of `decode_plus_decode_other_tokens`.  Every vocabulary id is classified once:

@@ -165,3 +165,21 @@ def test_ocr_text_parser_matches_reference_outputs():
     for c in g["clean"]:
         assert ocr_text.clean_ocr_text(c["in"]) == c["out"], c["in"]
         assert ocr_text.clean_ocr_text(c["in"], end_tag=None) == c["out_no_end"], c["in"]
+
+
+def test_id_decoder_matches_the_reference_method():
+    """f-4, pinned: IdDecoder.decode against outputs of the REFERENCE's own MarkushTokenizer.decode_plus_decode_other_tokens
+    (ref: core/common/markush_tokenizer.py:615-670), executed unmodified by tools/make_golden_idtext.py (rdkit / SmilesPE stubbed as
+    empty modules - the method touches neither; stand-in id -> token table with every token class the method distinguishes).
+    Both encode_index settings (ref: config/datasets/datasets_predict.yaml:8 uses True)."""
+    import json
+    from markushgrapher_amd import assembly as A
+    with open(os.path.join(GOLDEN, "host_idtext.json")) as f:
+        g = json.load(f)
+    first, voc = g["first_other"], g["markush_vocabulary"]
+    vocabulary = {v: f"<other_{first + i}>" for i, v in enumerate(voc)}
+    inverse = {v: k for k, v in vocabulary.items()}
+    dec = {ei: A.IdDecoder(g["tokens"], vocabulary, inverse, encode_index=ei) for ei in (False, True)}
+    assert len(g["cases"]) >= 20
+    for c in g["cases"]:
+        assert dec[c["encode_index"]].decode(c["ids"]) == c["text"], (c["encode_index"], [g["tokens"][i] for i in c["ids"]], c["text"])
