@@ -367,6 +367,145 @@ void ffn_block(const mg_model* m, bool rows_mode, float* hidden, uint16_t* x_pk,
 
 }  // namespace
 
+// Everything one decode step needs besides the model: the buffers of the live rows, the cross K/V streams they read and the
+// selection state.  Two users: mg_generate (one batch, all rows at the same position) and mg_generate_stream (continuous
+// decoding: `slots.pos` non-null, every row at its own position on its own image, K/V streams in a pool).
+struct DecodeCtx {
+    uint16_t *xk, *xv;        // cross K/V: [layer][owner][H][Sx_cap][64]
+    size_t xkv_stride;        // elements between layers
+    int Sx_cap;
+    const int* xlen;          // keys per K/V owner
+    uint16_t *sk, *sv;        // self-attention caches [layer][row][H][T_cap][64]
+    size_t skv_stride;
+    uint16_t *dq, *dx_pk, *dy_pk, *xa, *xb;
+    float *dh, *logits, *rs_part, *rs_part1, *rs_part2;
+    int64_t* next_ids;
+    int *unfinished, *anc, *beam_idx;
+    float* beam_div;
+    void* beam_state;
+    int* counters;
+    int B, K, R, max_length, min_length, early_stopping;
+    float length_penalty;
+    int64_t* out_ids;
+    float* step_top2;
+    const int* live;          // rows skipped by the attention launches (finished / idle), nullable
+    SlotTable slots;          // continuous decoding
+};
+
+// Decode step, 6 launches per layer: QKV -> self-attention -> [O residual | cross-Q] -> cross-attention ->
+// [cross-O residual | FFN wi] -> FFN wo residual.  Residual projections run with complete sums per workgroup and
+// leave per-row partial sums of squares; RMSNorm being a per-row scalar, every consumer applies
+// rsqrt(mean(h^2)+eps) itself (RowScale) — there are no norm launches.  The two bracketed pairs use the product
+// weights built by mg_finalize: the second projection of a pair reads [bf16(h before the residual) | context]
+// and so does not wait for the residual projection next to it.
+// tdev == nullptr: step-dependent values are passed by value (eager launches); otherwise the kernels read the step from the
+// device counter, which makes the launch sequence capturable as a graph.  Continuous decoding (c.slots.pos): positions,
+// images and K/V owners come from the device slot table, t / tdev are not used.
+static void decode_step(mg_model* m, const DecodeCtx& c, int t, const int* tdev, bool time_cross, mgStream_t st) {
+    const int d = m->d, H = m->H, inner = m->inner, T_cap = m->T_cap, R = c.R, K = c.K;
+    const size_t nl = m->dec.size();
+    const float eps = m->c.layer_norm_epsilon;
+    const int ldl = round_up(m->V, 32);
+    const int K2 = d + inner, kts2 = K2 >> 4, kt_ctx = d >> 4;
+    const int64_t pad = m->c.pad_token_id;
+    const bool stream = c.slots.pos != nullptr;
+    int* counters = c.counters;
+    const int max_length = c.max_length, min_length = c.min_length;
+    const int* live = c.live;
+    const size_t skv_stride = c.skv_stride, xkv_stride = c.xkv_stride;
+    const int Sx_cap = c.Sx_cap, B = c.B;
+    int64_t* out_ids = c.out_ids;
+    float* step_top2 = c.step_top2;
+    const float length_penalty = c.length_penalty;
+    const int early_stopping = c.early_stopping;
+    RowScale none{};
+    RowScale rs0{c.rs_part, d / 8, 1.0f / (float)d, eps};     // after the FFN output (next layer's ln0 / final norm)
+    RowScale rs1{c.rs_part1, d / 8, 1.0f / (float)d, eps};    // after the self-attention output (cross-attention norm)
+    RowScale rs2{c.rs_part2, d / 8, 1.0f / (float)d, eps};    // after the cross-attention output (FFN norm)
+    embed_norm_rows(c.next_ids, m->at<uint16_t>(m->tok_emb), c.dh, m->at<float>(m->dec[0].ln0), c.dx_pk, c.xa, K2, 0, R, d, m->V,
+                    counters + 3, eps, st);
+    for (size_t li = 0; li < nl; ++li) {
+        const DecLayer& l = m->dec[li];
+        uint16_t* sk = c.sk + li * skv_stride;
+        uint16_t* sv = c.sv + li * skv_stride;
+        {
+            {
+                GemmArgs a = gemm_args(c.dx_pk, m->at<uint16_t>(l.wqkv), R, 3 * inner, d);
+                set_heads(a, H, R, T_cap, c.dq, HF_STEP_Q, sk, HF_STEP_KV, sv, HF_STEP_KV);
+                a.heads.pos = t; a.heads.pos_dev = tdev; a.heads.pos_rows = c.slots.pos;
+                a.rs = li == 0 ? none : rs0;      // layer 0 reads the explicitly normalised embedding
+                gemm_rows(a, EPI_HEADS, st);      // q -> dq, k/v appended to the cache at position t
+            }
+            AttnStepArgs s{};
+            s.q = c.dq; s.Kc = sk; s.Vc = sv; s.ctx = c.xa; s.ctx_ld = K2; s.ctx_col0 = d; s.rows = R; s.H = H; s.group = 1;
+            s.cap = T_cap; s.n_keys = t + 1; s.bias = m->at<float>(m->dec_tab); s.anc = K > 1 ? c.anc : nullptr; s.t = t; s.t_dev = tdev;
+            s.live = live; s.pos_rows = c.slots.pos;
+            attention_step(s, st);
+        }
+        {   // h += Wo·ctx (partials of sum h^2 -> rs1, bf16(h) -> xb)   |   cross-attention q (un-normalised) -> dq
+            ResidArgs r{};
+            r.X = c.xa; r.x_kts = kts2; r.x_k0 = kt_ctx; r.W = m->at<uint16_t>(l.wo); r.h = c.dh; r.x2_pk = c.xb; r.x2_ld = K2;
+            r.part = c.rs_part1; r.M = R; r.N = d; r.K = inner;
+            GemmArgs g = gemm_args(c.xa, m->at<uint16_t>(l.xq2), R, inner, K2);
+            set_heads(g, H, R, T_cap, c.dq, HF_STEP_Q, nullptr, HF_NONE, nullptr, HF_NONE);
+            gemm_rows_pair(r, g, EPI_HEADS, st);
+        }
+        // cross-attention over the image's compacted K/V stream (all beams of an image share one pass)
+        AttnStepArgs x{};
+        x.q = c.dq; x.qrs = rs1; x.Kc = c.xk + li * xkv_stride; x.Vc = c.xv + li * xkv_stride; x.ctx = c.xb; x.ctx_ld = K2;
+        x.ctx_col0 = d; x.rows = R; x.H = H; x.group = K; x.cap = Sx_cap; x.len = c.xlen;
+        x.live = live; x.kv_owner = c.slots.pool;
+        const bool timed = time_cross && m->prof_used + 3 <= m->prof_ev.size();
+        if (timed) mg_event_record(m->prof_ev[m->prof_used], st);
+        attention_step(x, st);
+        if (timed) {   // third event right behind the second: the empty bracket calibrates what two records alone cost
+            mg_event_record(m->prof_ev[m->prof_used + 1], st);
+            mg_event_record(m->prof_ev[m->prof_used + 2], st);
+            m->prof_used += 3;
+        }
+        {   // h += Wxo·ctx_x (partials -> rs2)   |   y = relu(wi·...) un-normalised -> dy_pk
+            ResidArgs r{};
+            r.X = c.xb; r.x_kts = kts2; r.x_k0 = kt_ctx; r.W = m->at<uint16_t>(l.xo); r.h = c.dh; r.part = c.rs_part2;
+            r.M = R; r.N = d; r.K = inner;
+            GemmArgs g = gemm_args(c.xb, m->at<uint16_t>(l.wi2), R, m->dff, K2);
+            g.out_pk = c.dy_pk;
+            gemm_rows_pair(r, g, EPI_PK_RELU, st);
+        }
+        {   // FFN output (input scaled by rs2); leaves bf16(h·gain) for the next QKV / lm_head (gain = next layer's ln0,
+            // or the final norm with the d_model^-0.5 of the tied head), bf16(h) for the next pair, partials -> rs0
+            const bool last = li + 1 == nl;
+            ResidArgs r{};
+            r.X = c.dy_pk; r.W = m->at<uint16_t>(l.wo2); r.h = c.dh; r.gain = m->at<float>(last ? m->dec_ln : m->dec[li + 1].ln0);
+            r.gscale = (last && m->tied) ? 1.0f / sqrtf((float)d) : 1.0f; r.x_pk = c.dx_pk; r.x2_pk = c.xa; r.x2_ld = K2; r.part = c.rs_part;
+            r.M = R; r.N = d; r.K = m->dff; r.rs = rs2;
+            gemm_rows_resid(r, st);
+        }
+    }
+    gemm_rows_splitk(c.dx_pk, m->at<uint16_t>(m->lm_head), c.logits, R, m->V, d, ldl, 0, 1, rs0, st);
+    if (m->dbg_logits && t < m->dbg_steps)
+        MG_LAUNCH(capture_logits_kernel, dim3(1024), dim3(256), 0, st, (const float*)c.logits, ldl,
+                  m->dbg_logits + (size_t)t * R * m->V, R, m->V);
+    if (K == 1) {
+        ArgmaxArgs g{};
+        g.logits = c.logits; g.rows = R; g.V = m->V; g.ldl = ldl; g.eos = m->c.eos_token_id; g.pad = (int)pad;
+        g.min_len = min_length; g.next_ids = c.next_ids; g.out_ids = out_ids; g.max_len = max_length;
+        g.pos = tdev ? 1 : t + 1; g.pos_dev = tdev;
+        g.unfinished = c.unfinished; g.n_unfinished = counters + 5;
+        g.top2 = step_top2 ? (tdev ? step_top2 : step_top2 + (size_t)(t + 1) * R * 2) : nullptr;
+        g.step_ctr = stream ? nullptr : counters;      // the last workgroup to finish does the step bookkeeping (no step_end launch)
+        g.slots = c.slots;
+        greedy_select(g, st);
+        if (stream) slot_refill(c.slots, c.next_ids, c.unfinished, R, st);
+        if (m->dbg_forced && t + 1 < max_length)
+            MG_LAUNCH(force_ids_kernel, dim3((R + 63) / 64), dim3(64), 0, st, c.next_ids, m->dbg_forced, R, max_length, t + 1);
+    } else {
+        beam_step(c.beam_state, c.logits, ldl, m->V, B, K, max_length, t + 1, tdev, c.beam_div, m->c.eos_token_id, min_length,
+                  length_penalty, early_stopping, c.next_ids, c.beam_idx, counters, st);
+        beam_reorder_anc(c.anc, c.beam_idx, R, tdev ? max_length - 1 : t + 1, tdev, counters, st);
+    }
+    if (K > 1) MG_LAUNCH(step_end_kernel, dim3(1), dim3(64), 0, st, counters, 0);
+}
+
 extern "C" {
 
 const char* mg_last_error(void) { return g_err.c_str(); }
@@ -861,106 +1000,19 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
     }
     int steps_done = 0;
     int host_flag[4] = {0, 0, 0, 0};
-    // Decode step, 6 launches per layer: QKV -> self-attention -> [O residual | cross-Q] -> cross-attention ->
-    // [cross-O residual | FFN wi] -> FFN wo residual.  Residual projections run with complete sums per workgroup and
-    // leave per-row partial sums of squares; RMSNorm being a per-row scalar, every consumer applies
-    // rsqrt(mean(h^2)+eps) itself (RowScale) — there are no norm launches.  The two bracketed pairs use the product
-    // weights built by mg_finalize: the second projection of a pair reads [bf16(h before the residual) | context]
-    // and so does not wait for the residual projection next to it.
-    const float eps = m->c.layer_norm_epsilon;
-    const int ldl = round_up(m->V, 32);
-    const int K2 = d + inner, kts2 = K2 >> 4, kt_ctx = d >> 4;
     // greedy with EOS enabled: finished rows emit pad whatever they compute, their attention launches skip them
     // (not under the parity instrumentation, which compares every row's logits at every captured step)
     const int* live = (K == 1 && min_length < max_length && !m->dbg_logits && !m->dbg_forced) ? w.unfinished : nullptr;
-    RowScale none{};
-    RowScale rs0{w.rs_part, d / 8, 1.0f / (float)d, eps};     // after the FFN output (next layer's ln0 / final norm)
-    RowScale rs1{w.rs_part1, d / 8, 1.0f / (float)d, eps};    // after the self-attention output (cross-attention norm)
-    RowScale rs2{w.rs_part2, d / 8, 1.0f / (float)d, eps};    // after the cross-attention output (FFN norm)
-    // One decode step.  tdev == nullptr: step-dependent values are passed by value (eager launches); otherwise the
-    // kernels read the step from the device counter, which makes the launch sequence capturable as a graph.
-    auto decode_step = [&](int t, const int* tdev, bool time_cross) {
-        embed_norm_rows(w.next_ids, m->at<uint16_t>(m->tok_emb), w.dh, m->at<float>(m->dec[0].ln0), w.dx_pk, w.xa, K2, 0, R, d, m->V,
-                        counters + 3, eps, st);
-        for (size_t li = 0; li < nl; ++li) {
-            const DecLayer& l = m->dec[li];
-            uint16_t* sk = w.sk + li * skv_stride;
-            uint16_t* sv = w.sv + li * skv_stride;
-            {
-                {
-                    GemmArgs a = gemm_args(w.dx_pk, m->at<uint16_t>(l.wqkv), R, 3 * inner, d);
-                    set_heads(a, H, R, T_cap, w.dq, HF_STEP_Q, sk, HF_STEP_KV, sv, HF_STEP_KV);
-                    a.heads.pos = t; a.heads.pos_dev = tdev;
-                    a.rs = li == 0 ? none : rs0;      // layer 0 reads the explicitly normalised embedding
-                    gemm_rows(a, EPI_HEADS, st);      // q -> dq, k/v appended to the cache at position t
-                }
-                AttnStepArgs s{};
-                s.q = w.dq; s.Kc = sk; s.Vc = sv; s.ctx = w.xa; s.ctx_ld = K2; s.ctx_col0 = d; s.rows = R; s.H = H; s.group = 1;
-                s.cap = T_cap; s.n_keys = t + 1; s.bias = m->at<float>(m->dec_tab); s.anc = K > 1 ? w.anc : nullptr; s.t = t; s.t_dev = tdev;
-                s.live = live;
-                attention_step(s, st);
-            }
-            {   // h += Wo·ctx (partials of sum h^2 -> rs1, bf16(h) -> xb)   |   cross-attention q (un-normalised) -> dq
-                ResidArgs r{};
-                r.X = w.xa; r.x_kts = kts2; r.x_k0 = kt_ctx; r.W = m->at<uint16_t>(l.wo); r.h = w.dh; r.x2_pk = w.xb; r.x2_ld = K2;
-                r.part = w.rs_part1; r.M = R; r.N = d; r.K = inner;
-                GemmArgs g = gemm_args(w.xa, m->at<uint16_t>(l.xq2), R, inner, K2);
-                set_heads(g, H, R, T_cap, w.dq, HF_STEP_Q, nullptr, HF_NONE, nullptr, HF_NONE);
-                gemm_rows_pair(r, g, EPI_HEADS, st);
-            }
-            // cross-attention over the image's compacted K/V stream (all beams of an image share one pass)
-            AttnStepArgs x{};
-            x.q = w.dq; x.qrs = rs1; x.Kc = w.xk + li * xkv_stride; x.Vc = w.xv + li * xkv_stride; x.ctx = w.xb; x.ctx_ld = K2;
-            x.ctx_col0 = d; x.rows = R; x.H = H; x.group = K; x.cap = Sx_cap; x.len = w.xlen;
-            x.live = live;
-            const bool timed = time_cross && m->prof_used + 3 <= m->prof_ev.size();
-            if (timed) mg_event_record(m->prof_ev[m->prof_used], st);
-            attention_step(x, st);
-            if (timed) {   // third event right behind the second: the empty bracket calibrates what two records alone cost
-                mg_event_record(m->prof_ev[m->prof_used + 1], st);
-                mg_event_record(m->prof_ev[m->prof_used + 2], st);
-                m->prof_used += 3;
-            }
-            {   // h += Wxo·ctx_x (partials -> rs2)   |   y = relu(wi·...) un-normalised -> dy_pk
-                ResidArgs r{};
-                r.X = w.xb; r.x_kts = kts2; r.x_k0 = kt_ctx; r.W = m->at<uint16_t>(l.xo); r.h = w.dh; r.part = w.rs_part2;
-                r.M = R; r.N = d; r.K = inner;
-                GemmArgs g = gemm_args(w.xb, m->at<uint16_t>(l.wi2), R, m->dff, K2);
-                g.out_pk = w.dy_pk;
-                gemm_rows_pair(r, g, EPI_PK_RELU, st);
-            }
-            {   // FFN output (input scaled by rs2); leaves bf16(h·gain) for the next QKV / lm_head (gain = next layer's ln0,
-                // or the final norm with the d_model^-0.5 of the tied head), bf16(h) for the next pair, partials -> rs0
-                const bool last = li + 1 == nl;
-                ResidArgs r{};
-                r.X = w.dy_pk; r.W = m->at<uint16_t>(l.wo2); r.h = w.dh; r.gain = m->at<float>(last ? m->dec_ln : m->dec[li + 1].ln0);
-                r.gscale = (last && m->tied) ? 1.0f / sqrtf((float)d) : 1.0f; r.x_pk = w.dx_pk; r.x2_pk = w.xa; r.x2_ld = K2; r.part = w.rs_part;
-                r.M = R; r.N = d; r.K = m->dff; r.rs = rs2;
-                gemm_rows_resid(r, st);
-            }
-        }
-        gemm_rows_splitk(w.dx_pk, m->at<uint16_t>(m->lm_head), w.logits, R, m->V, d, ldl, 0, 1, rs0, st);
-        if (m->dbg_logits && t < m->dbg_steps)
-            MG_LAUNCH(capture_logits_kernel, dim3(1024), dim3(256), 0, st, (const float*)w.logits, ldl,
-                      m->dbg_logits + (size_t)t * R * m->V, R, m->V);
-        if (K == 1) {
-            ArgmaxArgs g{};
-            g.logits = w.logits; g.rows = R; g.V = m->V; g.ldl = ldl; g.eos = m->c.eos_token_id; g.pad = (int)pad;
-            g.min_len = min_length; g.next_ids = w.next_ids; g.out_ids = out_ids; g.max_len = max_length;
-            g.pos = tdev ? 1 : t + 1; g.pos_dev = tdev;
-            g.unfinished = w.unfinished; g.n_unfinished = counters + 5;
-            g.top2 = step_top2 ? (tdev ? step_top2 : step_top2 + (size_t)(t + 1) * R * 2) : nullptr;
-            g.step_ctr = counters;      // the last workgroup to finish does the step bookkeeping (no step_end launch)
-            greedy_select(g, st);
-            if (m->dbg_forced && t + 1 < max_length)
-                MG_LAUNCH(force_ids_kernel, dim3((R + 63) / 64), dim3(64), 0, st, w.next_ids, m->dbg_forced, R, max_length, t + 1);
-        } else {
-            beam_step(w.beam_state, w.logits, ldl, m->V, B, K, max_length, t + 1, tdev, w.beam_div, m->c.eos_token_id, min_length,
-                      length_penalty, early_stopping, w.next_ids, w.beam_idx, counters, st);
-            beam_reorder_anc(w.anc, w.beam_idx, R, tdev ? max_length - 1 : t + 1, tdev, counters, st);
-        }
-        if (K > 1) MG_LAUNCH(step_end_kernel, dim3(1), dim3(64), 0, st, counters, 0);
-    };
+    DecodeCtx dc{};
+    dc.xk = w.xk; dc.xv = w.xv; dc.xkv_stride = xkv_stride; dc.Sx_cap = Sx_cap; dc.xlen = w.xlen;
+    dc.sk = w.sk; dc.sv = w.sv; dc.skv_stride = skv_stride;
+    dc.dq = w.dq; dc.dx_pk = w.dx_pk; dc.dy_pk = w.dy_pk; dc.xa = w.xa; dc.xb = w.xb;
+    dc.dh = w.dh; dc.logits = w.logits; dc.rs_part = w.rs_part; dc.rs_part1 = w.rs_part1; dc.rs_part2 = w.rs_part2;
+    dc.next_ids = w.next_ids; dc.unfinished = w.unfinished; dc.anc = w.anc; dc.beam_idx = w.beam_idx; dc.beam_div = w.beam_div;
+    dc.beam_state = w.beam_state; dc.counters = counters;
+    dc.B = B; dc.K = K; dc.R = R; dc.max_length = max_length; dc.min_length = min_length; dc.early_stopping = early_stopping;
+    dc.length_penalty = length_penalty; dc.out_ids = out_ids; dc.step_top2 = step_top2; dc.live = live;
+    auto decode_step = [&](int t, const int* tdev, bool time_cross) { ::decode_step(m, dc, t, tdev, time_cross, st); };
     bool graphed = false;
     const bool instrumented = m->dbg_logits || m->dbg_forced;      // by-value eager launches of the same kernels
 #ifndef MG_EMU

@@ -34,8 +34,9 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a, long
     const int sub = lane & 7, ks = lane >> 3;
     const int owner = blockIdx.x / a.H, h = blockIdx.x - owner * a.H;
     if constexpr (G == 1) { if (a.live && a.live[owner] == 0) return; }       // finished row (whole workgroup: uniform)
-    const int tcur = a.t_dev ? *a.t_dev + a.t_off : a.t;
-    const int nkeys_all = XA ? a.len[owner] : (a.t_dev ? tcur + 1 : a.n_keys);
+    const int tcur = a.pos_rows ? a.pos_rows[owner] : (a.t_dev ? *a.t_dev + a.t_off : a.t);
+    const int kvo = (XA && a.kv_owner) ? a.kv_owner[owner] : owner;       // cross form: the K/V stream this row reads (pool entry)
+    const int nkeys_all = XA ? a.len[kvo] : ((a.t_dev || a.pos_rows) ? tcur + 1 : a.n_keys);
     // with an in-kernel append the newest key (position t) comes from registers, the cache holds [0, t)
     const bool app0 = ROPE || ((G == 1) && a.qkv.P && a.self_append);
     const int nkeys = app0 ? nkeys_all - 1 : nkeys_all;
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a, long
         for (int u = 0; u < U; ++u) {
             int kc = kb + u * 8 + ks;
             kc = kc < nkeys ? kc : nkeys - 1;
-            const int prow = (!XA && a.anc) ? a.anc[(size_t)kc * a.rows + owner] : owner;
+            const int prow = XA ? kvo : (a.anc ? a.anc[(size_t)kc * a.rows + owner] : owner);
             const size_t off = (((size_t)prow * a.H + h) * (size_t)a.cap + (size_t)kc) * 64 + sub * 8;
             kv[u] = (NW >= 8) ? ld16_stream(a.Kc + off) : ld16(a.Kc + off);
             vv[u] = (NW >= 8) ? ld16_stream(a.Vc + off) : ld16(a.Vc + off);
@@ -351,7 +352,8 @@ __global__ __launch_bounds__(GS_THREADS) void greedy_select_kernel(ArgmaxArgs a)
     MG_DYN_SMEM(smem);
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const float* lg = a.logits + (size_t)row * a.ldl;
-    const int pos = a.pos_dev ? *a.pos_dev + a.pos : a.pos;
+    const bool stream = a.slots.pos != nullptr;
+    const int pos = stream ? a.slots.pos[row] + 1 : (a.pos_dev ? *a.pos_dev + a.pos : a.pos);     // column written
     const bool no_eos = a.suppress_eos || pos < a.min_len;
     auto is_eos = [&](int i) {
         bool e = i == a.eos;
@@ -396,6 +398,24 @@ __global__ __launch_bounds__(GS_THREADS) void greedy_select_kernel(ArgmaxArgs a)
     __syncthreads();
     if (tid == 0) {
         for (int ww = 1; ww < GS_THREADS / 64; ++ww) top2_merge(b1, b2, i1, rv[ww * 2], rv[ww * 2 + 1], ri[ww]);
+        if (stream) {
+            // continuous decoding: the row writes column `pos` of ITS image; a row that ends frees the slot (slot_refill hands
+            // it the next image).  Idle slots computed on stale inputs: nothing is written for them.
+            if (a.unfinished[row]) {
+                const int img = a.slots.img[row];
+                const int64_t tok = (int64_t)i1;
+                a.next_ids[row] = tok;
+                a.slots.pos[row] = pos;
+                if (pos < a.max_len) a.out_ids[(size_t)img * a.max_len + pos] = tok;
+                if (is_eos((int)tok) || pos + 1 >= a.max_len) {
+                    a.unfinished[row] = 0;
+                    a.slots.img[row] = -1;
+                    a.slots.out_len[img] = pos + 1 < a.max_len ? pos + 1 : a.max_len;
+                    atomicAdd(a.slots.ctr + 1, 1);
+                }
+            }
+            return;
+        }
         const int unf = a.unfinished[row];
         const int64_t tok = unf ? (int64_t)i1 : (int64_t)a.pad;
         a.next_ids[row] = tok;
@@ -420,6 +440,34 @@ __global__ __launch_bounds__(GS_THREADS) void greedy_select_kernel(ArgmaxArgs a)
             }
         }
     }
+}
+
+// one thread walks the slots in order: the assignment of images to slots is deterministic (it does not change any image's
+// result - rows are independent - but it keeps runs reproducible to the byte, K/V cache contents included)
+__global__ __launch_bounds__(64) void slot_refill_kernel(SlotTable s, int64_t* next_ids, int* unfinished, int rows) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int* c = s.ctr;
+    int head = c[4];
+    const int ready = c[5];
+    int n_live = 0, oldest = 0x7fffffff;
+    for (int r = 0; r < rows; ++r) {
+        if (!unfinished[r] && head < ready) {
+            const int i = head++;
+            s.img[r] = i;
+            s.pool[r] = i % s.pool_cap;
+            s.pos[r] = 0;
+            next_ids[r] = (int64_t)s.start_id;
+            unfinished[r] = 1;
+        }
+        if (unfinished[r]) { ++n_live; oldest = s.img[r] < oldest ? s.img[r] : oldest; }
+    }
+    c[4] = head;
+    c[0] = n_live;
+    c[7] = n_live ? oldest : head;      // every image below this index has finished
+    c[2] += 1;
+}
+void slot_refill(const SlotTable& s, int64_t* next_ids, int* unfinished, int rows, mgStream_t stream) {
+    MG_LAUNCH(slot_refill_kernel, dim3(1), dim3(64), 0, stream, s, next_ids, unfinished, rows);
 }
 
 void greedy_select(const ArgmaxArgs& a, mgStream_t stream) {

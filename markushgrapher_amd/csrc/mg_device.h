@@ -36,6 +36,7 @@ typedef __bf16 mg_bf16x2 __attribute__((ext_vector_type(2)));
 // host-side runtime shims (the emulator "device" is host memory)
 #ifdef MG_EMU
 #include <string.h>
+#include <stdlib.h>
 static inline int mg_memset_async(void* p, int v, size_t n, mgStream_t) { memset(p, v, n); return 0; }
 static inline int mg_memcpy_async(void* d, const void* s, size_t n, mgStream_t) { memmove(d, s, n); return 0; }
 static inline int mg_stream_sync(mgStream_t) { return 0; }
@@ -46,6 +47,16 @@ static inline int mg_event_create(mgEvent_t* e) { *e = nullptr; return 0; }
 static inline int mg_event_record(mgEvent_t, mgStream_t) { return 0; }
 static inline float mg_event_elapsed_ms(mgEvent_t, mgEvent_t) { return 0.f; }
 static inline void mg_event_destroy(mgEvent_t) {}
+// second stream / ordering shims: the emulator executes every launch synchronously, so a "stream" is the null stream,
+// every event has already happened and waiting is a no-op
+static inline int mg_stream_create(mgStream_t* s, int, const uint32_t*, int) { *s = nullptr; return 0; }
+static inline void mg_stream_destroy(mgStream_t) {}
+static inline int mg_event_create_notiming(mgEvent_t* e) { *e = nullptr; return 0; }
+static inline int mg_stream_wait_event(mgStream_t, mgEvent_t) { return 0; }
+static inline int mg_event_done(mgEvent_t) { return 1; }
+static inline int mg_event_sync(mgEvent_t) { return 0; }
+static inline void* mg_host_alloc(size_t n) { return malloc(n); }
+static inline void mg_host_free(void* p) { free(p); }
 #else
 static inline int mg_memset_async(void* p, int v, size_t n, mgStream_t st) { return (int)hipMemsetAsync(p, v, n, st); }
 static inline int mg_memcpy_async(void* d, const void* s, size_t n, mgStream_t st) {
@@ -59,6 +70,22 @@ static inline int mg_event_create(mgEvent_t* e) { return (int)hipEventCreate(e);
 static inline int mg_event_record(mgEvent_t e, mgStream_t st) { return (int)hipEventRecord(e, st); }
 static inline float mg_event_elapsed_ms(mgEvent_t a, mgEvent_t b) { float ms = 0.f; (void)hipEventElapsedTime(&ms, a, b); return ms; }
 static inline void mg_event_destroy(mgEvent_t e) { (void)hipEventDestroy(e); }
+// A second stream for work that overlaps the caller's stream.  low_priority: lowest stream priority (the dispatcher prefers the
+// other streams' workgroups when both have some ready); cu_mask (nwords x 32 bits, nullable): restrict the stream to a subset of
+// the compute units (hipExtStreamCreateWithCUMask).
+static inline int mg_stream_create(mgStream_t* s, int low_priority, const uint32_t* cu_mask, int nwords) {
+    if (cu_mask && nwords > 0) return (int)hipExtStreamCreateWithCUMask(s, (uint32_t)nwords, cu_mask);
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);          // lo = numerically greatest = lowest priority
+    return (int)hipStreamCreateWithPriority(s, hipStreamNonBlocking, low_priority ? lo : hi);
+}
+static inline void mg_stream_destroy(mgStream_t s) { (void)hipStreamDestroy(s); }
+static inline int mg_event_create_notiming(mgEvent_t* e) { return (int)hipEventCreateWithFlags(e, hipEventDisableTiming); }
+static inline int mg_stream_wait_event(mgStream_t s, mgEvent_t e) { return (int)hipStreamWaitEvent(s, e, 0); }
+static inline int mg_event_done(mgEvent_t e) { const hipError_t r = hipEventQuery(e); if (r == hipErrorNotReady) { (void)hipGetLastError(); return 0; } return 1; }
+static inline int mg_event_sync(mgEvent_t e) { return (int)hipEventSynchronize(e); }
+static inline void* mg_host_alloc(size_t n) { void* p = nullptr; return hipHostMalloc(&p, n, hipHostMallocDefault) == hipSuccess ? p : nullptr; }
+static inline void mg_host_free(void* p) { (void)hipHostFree(p); }
 #endif
 
 // raw workgroup barrier / counted vector-memory wait: let direct global->LDS copies stay in flight ACROSS a barrier

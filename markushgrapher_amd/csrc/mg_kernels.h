@@ -45,6 +45,7 @@ struct HeadsOut {
     int s_off;             // HF_PK_ROWS / HF_PK_T: destination token index = s + s_off (key blocks laid side by side)
     int pos;               // HF_STEP: cache position written
     const int* pos_dev;    // if non-null the position is read from device memory (graph replay)
+    const int* pos_rows;   // if non-null: per-row positions [rows] (continuous decoding: every slot is at its own position)
 };
 // Deferred RMSNorm statistic of the decode step: the activations X were stored UN-normalised (bf16(h * gain)) by the
 // previous residual projection, which also left per-row partial sums of squares; since RMSNorm is a per-row scalar,
@@ -247,6 +248,8 @@ struct AttnStepArgs {
     // the rotation of position t (cs: [positions][64] = cos[32] | sin[32]), q * qscale, rounds to bf16, appends k, v to the cache
     // [rows][H][cap][64] and attends over [0, t] for the group's query heads in one pass over the cache.  qkv == null: not used.
     struct Rope { const float* qkv; int ld; const float* cs; RowScale rs; float qscale; } rope;
+    const int* pos_rows;      // continuous decoding (group 1): the row's own position t (self: keys [0, t], bias by t - j); overrides t / t_dev
+    const int* kv_owner;      // continuous decoding, cross form: entry of the K/V pool that row `owner` reads (len is indexed by it too)
     const int* live;          // group == 1 only, nullable: rows with live[row] == 0 (finished: they emit pad whatever their
                               // logits are, gen:2927-2937) are skipped - their K/V streams are not read.
                               // INVARIANT this relies on: a skipped row's context columns keep stale values, so everything
@@ -265,6 +268,17 @@ void embed_norm_rows(const int64_t* ids, const uint16_t* tok_emb, float* h, cons
 void embed_rows(const int64_t* ids, const uint16_t* tok_emb, float* h, int rows, int d, int V, int* err,
                 mgStream_t stream, uint16_t* x_pk = nullptr, int x_ld = 0, int x_col0 = 0);
 
+// Slot table of the continuous decoder (mg_generate_stream, engine.hip): `slots` decode rows work through a queue of images; a
+// row that ends (EOS or max_length) frees its slot, the refill kernel hands it the next image whose cross K/V is in the pool.
+struct SlotTable {
+    int* pos;          // [slots] position of the token fed to this step (0 = the start token); null = batch mode (no slot table)
+    int* img;          // [slots] image decoded in the slot (row of out_ids), -1 = idle
+    int* pool;         // [slots] cross K/V pool entry of that image
+    int* ctr;          // stream counters (layout: engine.hip)
+    int* out_len;      // [N] valid columns of every finished image
+    int pool_cap;      // entries of the K/V pool (image i lives in entry i % pool_cap)
+    int start_id;
+};
 struct ArgmaxArgs {
     const float* logits;     // [rows][ldl]
     int rows, V, ldl;
@@ -283,8 +297,12 @@ struct ArgmaxArgs {
     // publishes the unfinished count, records the first all-finished step and advances the step counter
     // (counters layout: engine.hip); step_ctr[6] is the arrival counter
     int* step_ctr;
+    SlotTable slots;         // continuous decoding: per-row positions / images (slots.pos == null: batch mode)
 };
 void greedy_select(const ArgmaxArgs& a, mgStream_t stream);
+// continuous decoding, after the selection of a step: idle slots take the next ready images of the queue (in slot order:
+// deterministic), live count / oldest live image / step counter are published for the host
+void slot_refill(const SlotTable& s, int64_t* next_ids, int* unfinished, int rows, mgStream_t stream);
 
 // beam search on the device (k_beam.hip; restates stock generation/utils.py:3208-3525)
 size_t beam_state_bytes(int B, int K, int max_len);

@@ -385,12 +385,14 @@ def test_ocr_bench_batches_at_smoldocling_geometry(B):
     tol = logit_tol(np.abs(sc).max())
     srt = np.sort(sc, axis=-1)
     margin = srt[..., -1] - srt[..., -2]
-    checked = 0
+    steps = ids_eq = 0
     for i, b in enumerate(rows):
         for t in range(n):
+            # same prefix so far: this step's logits are comparable
             assert np.abs(cap[t, b] - sc[i, t]).max() < tol, (b, t, float(np.abs(cap[t, b] - sc[i, t]).max()), tol)
-            if margin[i, t] <= 4 * tol:
+            steps += 1
+            if new[b, t] != ref[i, t]:
+                assert margin[i, t] <= 4 * tol, (b, t, float(margin[i, t]))      # only a near-tie may part the two runs
                 break                                              # the continuation of this row legitimately differs from here
-            assert new[b, t] == ref[i, t], (b, t)
-            checked += 1
-    assert checked >= len(rows), checked
+            ids_eq += 1
+    assert steps >= 3 * len(rows) and ids_eq >= 2 * len(rows), (steps, ids_eq)
