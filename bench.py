@@ -382,7 +382,30 @@ def main():
                                     "decode_steps_run": int(ie.shape[1] - 1), "mean_row_length": round(float(lens.mean()), 1),
                                     "min_row_length": int(lens.min()), "max_row_length": int(lens.max()), "eos_row_scale": chosen,
                                     "config": "greedy, EOS enabled (generate(max_length=512) as the reference calls it), same inputs; EOS "
-                                              "embedding row scaled so rows end at different steps"}
+                                              "embedding row scaled so rows end at different steps; one mg_generate call per 32 images: the batch "
+                                              "walks to its longest row"}
+            # the same workload through the continuous decoder (mg_generate_stream): a queue of 16 batches' worth of images (the same 32
+            # pages repeated - a row's cost depends on its length only), 32 decode slots; a row that ends hands its slot to the next
+            # image, the encoder of the next 32 runs ahead on its own stream.  ids per image identical to the batch call (checked here).
+            QB = 16
+            qd = {k: torch.cat([dev[k]] * QB, dim=0) for k in ("input_ids", "bbox", "attention_mask")}
+
+            def stream_eos():
+                pix = torch.cat([eng.preprocess(dev["pages_u8"]) for _ in range(QB)], dim=0)
+                return eng.generate_stream(qd["input_ids"], qd["bbox"], qd["attention_mask"], pix, max_length=512, min_length=0,
+                                           chunk=B, slots=B, pool_chunks=3)
+            stream_eos()
+            torch.cuda.synchronize(); ts = time.time()
+            ids_s, len_s, steps_s = stream_eos()
+            torch.cuda.synchronize(); ts = time.time() - ts
+            ids_s, len_s = ids_s.cpu().numpy(), len_s.cpu().numpy()
+            same = all(np.array_equal(ids_s[n, :len_s[n]], ie[n % B, :len_s[n]]) for n in range(QB * B))
+            extra["eos_enabled_continuous"] = {
+                "images_per_s": round(QB * B / ts, 2), "queue_images": QB * B, "slots": B, "decode_steps_run": int(steps_s),
+                "mean_row_length": round(float(len_s.mean() - 1), 1), "speedup_vs_batch_calls": round(QB * B / ts / (B / te), 2),
+                "ids_equal_batch_calls": bool(same),
+                "config": "mg_generate_stream: continuous decoding of a queue of images on 32 slots (finished rows free their slot; encoder + "
+                          "cross-K/V of the next 32 images on a second stream), device preprocessing of all pages inside the timed region"}
             eng.load_state_dict({"shared.weight": sd["shared.weight"]})
             extra["ocr_stage"] = ocr_stage_run()
             if not args.no_cpu_baseline:

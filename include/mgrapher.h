@@ -102,6 +102,24 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
 
 /* Limits: B * num_beams <= 256 live sequences per call (MG_E_UNSUPPORTED beyond; split the batch), num_beams <= 8. */
 
+/* Continuous greedy decoding of N images - what the reference's evaluation loop does one image at a time with
+ * model.generate(**encoding, num_beams=1, max_length=512) until EOS (/root/reference/markushgrapher/utils/ocsr/utils_evaluation.py:140,
+ * 269-285), for a whole queue of images: `slots` decode rows work through the queue, a row that ends (EOS / max_length) frees its
+ * slot for the next image (no step is spent on finished rows, the batch does not wait for its longest member), and the encoder +
+ * cross-K/V projection of the next `chunk` images run ahead on a second stream underneath the launch-bound decode steps.
+ *   inputs   input_ids [N][L] i64, bbox [N][L][4] f32, attention_mask [N][L] u8 (nullable), pixel_values [N][3][I][I] f32, all resident
+ *   outputs  out_ids [N][max_length] i64 (row = [start, tok..., eos, pad...]), out_len [N] i32 = valid columns per image (device)
+ *   chunk    images per encoder pass (32); slots = live decode rows (<= 256); pool_chunks >= 2: the cross-K/V pool holds
+ *            pool_chunks * chunk images (the encoder runs at most that far ahead of the oldest unfinished image)
+ * Every image's ids equal mg_generate's for that image.  *steps_host (nullable) = decode steps run.  SYNCHRONISES before returning. */
+int mg_stream_workspace_bytes(const mg_model* m, int chunk, int L, int slots, int pool_chunks, size_t* out_bytes);
+int mg_generate_stream(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* input_ids, const float* bbox,
+                       const uint8_t* attention_mask, const float* pixel_values, int N, int L, int chunk, int slots, int pool_chunks,
+                       int max_length, int min_length, int64_t* out_ids, int32_t* out_len, long* steps_host);
+/* Where the encoder of mg_generate_stream runs: 0 = on the caller's stream (serial), 1 = own stream at the lowest priority
+ * (default), 2 = own stream restricted to the compute units of cu_mask (nwords x 32 bits, hipExtStreamCreateWithCUMask). */
+int mg_stream_encoder_mode(mg_model* m, int mode, const uint32_t* cu_mask, int nwords);
+
 /* Parity-test instrumentation of mg_generate (tests only; while set, the decode steps are launched eagerly with by-value
  * arguments instead of replaying the captured graph - the same kernels).  logits_capture [capture_steps][B*num_beams][vocab]
  * fp32 (device) receives the pre-argmax logits of decode steps 0 .. capture_steps-1.  forced_ids [B][max_length] i64

@@ -102,6 +102,18 @@ struct mg_model {
     float* dbg_logits = nullptr;
     int dbg_steps = 0;
     const int64_t* dbg_forced = nullptr;
+    // continuous decoding (mg_generate_stream): the encoder runs ahead on its own stream
+    StepGraph stream_graph;
+    int* stream_host = nullptr;          // pinned read-back ring of the stream counters
+    int enc_mode = 1;                    // 0: encoder on the caller's stream (no overlap); 1: own low-priority stream; 2: own stream restricted to enc_mask
+    std::vector<uint32_t> enc_mask;
+    bool enc_stream_ready = false;
+    mgStream_t enc_stream = nullptr;
+    std::vector<mgEvent_t> chunk_ev;     // per pool chunk: encoder + cross-K/V of the chunk done
+    std::vector<mgEvent_t> rb_ev;        // read-back ring
+    mgEvent_t start_ev = nullptr;
+    long stream_steps = 0, stream_idle_steps = 0;      // statistics of the last mg_generate_stream call
+    double stream_enc_ms = 0.0;
     bool tied = true;          // tie_word_embeddings: lm_head = shared.weight and logits scaled by d_model^-0.5 (stock:1554-1557)
 #ifndef MG_EMU
     hipStream_t own_stream = nullptr;
@@ -109,6 +121,12 @@ struct mg_model {
 #endif
     ~mg_model() {
         step_graph.reset();
+        stream_graph.reset();
+        if (stream_host) mg_host_free(stream_host);
+        if (enc_stream_ready && enc_stream) mg_stream_destroy(enc_stream);
+        for (mgEvent_t e : chunk_ev) mg_event_destroy(e);
+        for (mgEvent_t e : rb_ev) mg_event_destroy(e);
+        if (start_ev) mg_event_destroy(start_ev);
 #ifndef MG_EMU
         if (own_stream) (void)hipStreamDestroy(own_stream);
         if (fork_ev) (void)hipEventDestroy(fork_ev);
@@ -334,6 +352,81 @@ void carve(const mg_model* m, char* base, int B, int L, int K, int max_len, int 
         w->tf_xc = c.take<uint16_t>((size_t)round_up(B * T, 32) * d);
     }
     w->total = align_up(c.off, 256);
+}
+
+// ---- continuous decoding (mg_generate_stream) ---------------------------------------------------------------------------
+// stream counters (device, `ctr`): [0] live slots after the last step, [1] images finished, [2] steps run, [3] unused,
+// [4] queue head (next image to hand to a slot), [5] images whose cross K/V are in the pool, [7] oldest live image
+// (every image below it has finished: its pool entry may be overwritten), [8] N
+struct StreamWs {
+    Ws enc;                   // encoder workspace of one chunk
+    uint16_t *xk, *xv;        // K/V pool [layer][pool entry][H][Sx_cap][64]
+    size_t pool_stride;       // elements between layers
+    int* xlen_pool;           // [pool entries]
+    uint16_t *sk, *sv, *dq, *dx_pk, *dy_pk, *xa, *xb;
+    float *dh, *logits, *rs_part, *rs_part1, *rs_part2;
+    int64_t* next_ids;
+    int *unfinished, *pos, *img, *pool, *ctr, *err;
+    size_t total;
+};
+void carve_stream(const mg_model* m, char* base, int chunk, int L, int slots, int pool_chunks, StreamWs* w) {
+    carve(m, base, chunk, L, 1, 0, 0, 0, &w->enc);
+    Carver c{base};
+    c.off = w->enc.total;
+    const int d = m->d, inner = m->inner, H = m->H;
+    const int Sx_cap = round_up(L + m->P, 64), Rp = round_up(slots, 32);
+    const size_t nl = m->dec.size(), entries = (size_t)pool_chunks * chunk;
+    w->pool_stride = entries * H * Sx_cap * 64;
+    w->xk = c.take<uint16_t>(nl * w->pool_stride);
+    w->xv = c.take<uint16_t>(nl * w->pool_stride);
+    w->xlen_pool = c.take<int>(entries);
+    w->sk = c.take<uint16_t>(nl * slots * H * (size_t)m->T_cap * 64);
+    w->sv = c.take<uint16_t>(nl * slots * H * (size_t)m->T_cap * 64);
+    w->dq = c.take<uint16_t>((size_t)Rp * inner);
+    w->dx_pk = c.take<uint16_t>((size_t)Rp * d);
+    w->dy_pk = c.take<uint16_t>((size_t)Rp * m->dff);
+    w->dh = c.take<float>((size_t)Rp * d);
+    w->logits = c.take<float>((size_t)Rp * round_up(m->V, 32));
+    w->rs_part = c.take<float>((size_t)Rp * (d / 8));
+    w->rs_part1 = c.take<float>((size_t)Rp * (d / 8));
+    w->rs_part2 = c.take<float>((size_t)Rp * (d / 8));
+    w->xa = c.take<uint16_t>((size_t)Rp * (d + inner));
+    w->xb = c.take<uint16_t>((size_t)Rp * (d + inner));
+    w->next_ids = c.take<int64_t>(Rp);
+    w->unfinished = c.take<int>(Rp);
+    w->pos = c.take<int>(Rp);
+    w->img = c.take<int>(Rp);
+    w->pool = c.take<int>(Rp);
+    w->ctr = c.take<int>(64);
+    w->err = c.take<int>(64);
+    w->total = align_up(c.off, 256);
+}
+__global__ __launch_bounds__(256) void stream_init_kernel(int64_t* out_ids, int* out_len, int N, int max_len, int64_t start, int64_t pad,
+                                                     int* unfinished, int* pos, int* img, int* pool, int64_t* next_ids, int slots, int* ctr) {
+    const size_t n = (size_t)N * max_len;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out_ids[i] = (i % max_len) == 0 ? start : pad;
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < N; i += blockDim.x) out_len[i] = 0;
+        for (int r = threadIdx.x; r < slots; r += blockDim.x) { unfinished[r] = 0; pos[r] = 0; img[r] = -1; pool[r] = 0; next_ids[r] = start; }
+        if (threadIdx.x < 16) ctr[threadIdx.x] = threadIdx.x == 8 ? N : 0;
+        if (threadIdx.x < 2) ctr[64 + threadIdx.x] = 0;          // the accumulators `err` are carved right behind the 64 counters
+    }
+}
+// a chunk's cross K/V are in the pool: publish its key counts and make its images available to the slots
+// encoder stream, end of a chunk: its key counts go to the pool entries, its input-error count is accumulated
+__global__ __launch_bounds__(64) void stream_chunk_done_kernel(const int* xlen_chunk, int* xlen_pool, int entry0, int n, const int* enc_counters, int* err) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) xlen_pool[entry0 + i] = xlen_chunk[i];
+    if (threadIdx.x == 0) {
+        err[0] += enc_counters[3];
+        int keys = 0;
+        for (int i = 0; i < n; ++i) keys += xlen_chunk[i];
+        err[1] += keys;                    // attended positions over all images (statistics: K/V bytes a step streams)
+    }
+}
+// decode stream, after the chunk's event: its images may be handed to slots
+__global__ __launch_bounds__(64) void stream_ready_kernel(int n, int* ctr) {
+    if (threadIdx.x == 0) ctr[5] += n;
 }
 
 int check_launch(const char* what) {
@@ -1094,6 +1187,209 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
     if (host_flag[3] != 0) return fail(MG_E_INPUT, "mg_generate: %d token ids outside [0, vocab)", host_flag[3]);
     if (K == 1) *out_cols_host = 1 + (host_flag[1] >= 0 ? host_flag[1] + 1 : steps_done);
     else *out_cols_host = beam_cols;
+    return MG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Continuous greedy decoding of N images (SURVEY.md section 7 "early-exit compaction of finished sequences", section 8e
+// stragglers).  What the reference does one image at a time - generate(max_length=512) until EOS (utils_evaluation.py:269-285) -
+// on `slots` decode rows that work through the queue of images: a row that ends frees its slot for the next image, so no step
+// is spent on finished rows and the batch never waits for its longest member.  The encoder + cross-K/V projection of the next
+// `chunk` images run AHEAD on a second stream (low priority or CU-masked), under the launch-bound decode steps of the current
+// ones; their K/V land in a pool of pool_chunks x chunk entries that the decode rows read through the slot table.  All slot
+// bookkeeping is on the device (k_decode.hip: selection + slot_refill), the step is one replayed HIP graph; the host only
+// feeds the encoder stream and reads the counters back a few steps late.  Every image's ids equal what mg_generate returns for
+// it: rows of the decode kernels are independent of each other and of the slot they sit in (tests/test_stream.py).
+int mg_stream_workspace_bytes(const mg_model* m, int chunk, int L, int slots, int pool_chunks, size_t* out_bytes) {
+    if (!m || !out_bytes || chunk < 1 || L < 1 || slots < 1 || pool_chunks < 2) return fail(MG_E_ARG, "mg_stream_workspace_bytes: bad argument");
+    StreamWs w;
+    carve_stream(m, nullptr, chunk, L, slots, pool_chunks, &w);
+    *out_bytes = w.total;
+    return MG_OK;
+}
+
+// mode 0: encoder on the caller's stream (serial: for A/B runs and the emulator); 1 (default): own stream at the lowest
+// priority; 2: own stream restricted to the compute units of cu_mask (nwords x 32 bits).  Takes effect at the next call.
+int mg_stream_encoder_mode(mg_model* m, int mode, const uint32_t* cu_mask, int nwords) {
+    if (!m || mode < 0 || mode > 2 || (mode == 2 && (!cu_mask || nwords < 1))) return fail(MG_E_ARG, "mg_stream_encoder_mode: bad argument");
+    if (m->enc_stream_ready && m->enc_stream) { mg_stream_sync(m->enc_stream); mg_stream_destroy(m->enc_stream); }
+    m->enc_stream = nullptr; m->enc_stream_ready = false;
+    m->enc_mode = mode;
+    m->enc_mask.assign(cu_mask, cu_mask + (mode == 2 ? nwords : 0));
+    return MG_OK;
+}
+
+int mg_generate_stream(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* input_ids, const float* bbox,
+                       const uint8_t* attention_mask, const float* pixel_values, int N, int L, int chunk, int slots, int pool_chunks,
+                       int max_length, int min_length, int64_t* out_ids, int32_t* out_len, long* steps_host) {
+    if (!m || !ws || !input_ids || !bbox || !pixel_values || !out_ids || !out_len) return fail(MG_E_ARG, "mg_generate_stream: null argument");
+    if (!m->finalized) return fail(MG_E_STATE, "mg_generate_stream: call mg_finalize first");
+    if (N < 1 || L < 1 || chunk < 1 || pool_chunks < 2) return fail(MG_E_SHAPE, "mg_generate_stream: N, L, chunk must be >= 1, pool_chunks >= 2");
+    if (slots < 1 || slots > 256) return fail(MG_E_UNSUPPORTED, "mg_generate_stream: slots must be in [1, 256]");
+    if (slots > pool_chunks * chunk) return fail(MG_E_SHAPE, "mg_generate_stream: slots (%d) exceed the %d pool entries", slots, pool_chunks * chunk);
+    if (max_length < 2 || max_length > m->T_cap) return fail(MG_E_SHAPE, "mg_generate_stream: max_length must be in [2, %d]", m->T_cap);
+    if (m->dbg_logits || m->dbg_forced) return fail(MG_E_STATE, "mg_generate_stream: the decode-capture instrumentation is for mg_generate");
+    StreamWs w;
+    carve_stream(m, (char*)ws, chunk, L, slots, pool_chunks, &w);
+    if (w.total > ws_bytes) return fail(MG_E_WORKSPACE, "mg_generate_stream: workspace too small (%zu < %zu)", ws_bytes, w.total);
+    mgStream_t st = (mgStream_t)stream;
+    const int d = m->d, H = m->H, inner = m->inner, P = m->P;
+    const int S_cap = round_up(L + P, 64), Sx_cap = S_cap;
+    const size_t nl = m->dec.size();
+    const int n_chunks = (N + chunk - 1) / chunk;
+    const int entries = pool_chunks * chunk;
+    const size_t img_in = (size_t)m->c.num_channels * m->c.image_size * m->c.image_size;
+    // streams and events
+    if (m->enc_mode != 0 && !m->enc_stream_ready) {
+        if (mg_stream_create(&m->enc_stream, m->enc_mode == 1, m->enc_mode == 2 ? m->enc_mask.data() : nullptr, (int)m->enc_mask.size()) != 0)
+            return fail(MG_E_HIP, "mg_generate_stream: could not create the encoder stream");
+        m->enc_stream_ready = true;
+    }
+#ifndef MG_EMU
+    if (st == nullptr) {       // the legacy null stream synchronises with every other stream and cannot be captured: own stream
+        if (!m->own_stream && hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking) != hipSuccess) m->own_stream = nullptr;
+        if (!m->fork_ev && hipEventCreateWithFlags(&m->fork_ev, hipEventDisableTiming) != hipSuccess) m->fork_ev = nullptr;
+        if (m->own_stream && m->fork_ev && hipEventRecord(m->fork_ev, st) == hipSuccess && hipStreamWaitEvent(m->own_stream, m->fork_ev, 0) == hipSuccess)
+            st = m->own_stream;
+    }
+#endif
+    mgStream_t es = m->enc_mode == 0 ? st : m->enc_stream;
+    while ((int)m->chunk_ev.size() < 2 * pool_chunks + 2) { mgEvent_t e; if (mg_event_create(&e) != 0) return fail(MG_E_HIP, "event"); m->chunk_ev.push_back(e); }
+    constexpr int RB = 4, GROUP = 4;          // read-back ring depth, steps per host iteration
+    while ((int)m->rb_ev.size() < RB) { mgEvent_t e; if (mg_event_create_notiming(&e) != 0) return fail(MG_E_HIP, "event"); m->rb_ev.push_back(e); }
+    if (!m->start_ev && mg_event_create_notiming(&m->start_ev) != 0) return fail(MG_E_HIP, "event");
+    if (!m->stream_host && !(m->stream_host = (int*)mg_host_alloc(RB * 16 * sizeof(int)))) return fail(MG_E_HIP, "pinned host buffer");
+    // slot table, outputs
+    const int64_t start = m->c.decoder_start_token_id, pad = m->c.pad_token_id;
+    MG_LAUNCH(stream_init_kernel, dim3(64), dim3(256), 0, st, out_ids, out_len, N, max_length, start, pad, w.unfinished, w.pos, w.img, w.pool,
+              w.next_ids, slots, w.ctr);
+    mg_event_record(m->start_ev, st);
+    if (es != st) mg_stream_wait_event(es, m->start_ev);      // inputs / workspace are ordered behind the caller's earlier work
+    DecodeCtx dc{};
+    dc.xk = w.xk; dc.xv = w.xv; dc.xkv_stride = w.pool_stride; dc.Sx_cap = Sx_cap; dc.xlen = w.xlen_pool;
+    dc.sk = w.sk; dc.sv = w.sv; dc.skv_stride = (size_t)slots * H * m->T_cap * 64;
+    dc.dq = w.dq; dc.dx_pk = w.dx_pk; dc.dy_pk = w.dy_pk; dc.xa = w.xa; dc.xb = w.xb;
+    dc.dh = w.dh; dc.logits = w.logits; dc.rs_part = w.rs_part; dc.rs_part1 = w.rs_part1; dc.rs_part2 = w.rs_part2;
+    dc.next_ids = w.next_ids; dc.unfinished = w.unfinished; dc.counters = w.ctr;
+    dc.B = slots; dc.K = 1; dc.R = slots; dc.max_length = max_length; dc.min_length = min_length; dc.length_penalty = 1.0f;
+    dc.out_ids = out_ids; dc.live = w.unfinished;
+    dc.slots = SlotTable{w.pos, w.img, w.pool, w.ctr, out_len, entries, (int)start};
+    // the step as a graph (every step-dependent value lives in the slot table)
+    bool graphed = false;
+#ifndef MG_EMU
+    if (m->use_graph == 1) {
+        const StepGraph::Key key{ws, out_ids, out_len, (const void*)st, slots, L, chunk * 1000 + pool_chunks, max_length, min_length, N, 0, 0.0f};
+        StepGraph& sg = m->stream_graph;
+        if (!(sg.valid && sg.key == key)) {
+            sg.reset();
+            hipGraph_t graph = nullptr;
+            if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                decode_step(m, dc, 0, nullptr, false, st);
+                if (hipStreamEndCapture(st, &graph) == hipSuccess && graph && hipGraphInstantiate(&sg.exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                    sg.key = key; sg.valid = true;
+                }
+                if (graph) (void)hipGraphDestroy(graph);
+            }
+            (void)hipGetLastError();
+        }
+        graphed = sg.valid;
+    }
+#endif
+    m->graph_active = graphed;
+    int submitted = 0, announced = 0;           // chunks handed to the encoder stream / made visible to the slots
+    int oldest_host = 0, done_host = 0, live_host = 0, head_host = 0;
+    long steps = 0, rb_issued = 0, rb_seen = 0;
+    m->stream_enc_ms = 0.0;
+    auto submit_chunk = [&]() -> int {
+        const int c0 = submitted * chunk, n = (N - c0) < chunk ? (N - c0) : chunk;
+        const int entry0 = (submitted % pool_chunks) * chunk;
+        mgEvent_t e0 = m->chunk_ev[2 * (submitted % pool_chunks)], e1 = m->chunk_ev[2 * (submitted % pool_chunks) + 1];
+        mg_event_record(e0, es);
+        int rc = mg_encode(m, es, ws, ws_bytes, input_ids + (size_t)c0 * L, bbox + (size_t)c0 * L * 4, attention_mask ? attention_mask + (size_t)c0 * L : nullptr,
+                           pixel_values + (size_t)c0 * img_in, nullptr, 0, n, L, nullptr, nullptr);
+        if (rc != MG_OK) return rc;
+        Ws we;
+        carve(m, (char*)ws, n, L, 1, 0, 0, 0, &we);         // the chunk's own carving (a short last chunk uses less of the region)
+        const size_t ent_off = (size_t)entry0 * H * Sx_cap * 64;
+        for (size_t li = 0; li < nl; ++li) {
+            GemmArgs kv = gemm_args(we.enc_pk, m->at<uint16_t>(m->dec[li].xkv), n * S_cap, 2 * inner, d);
+            set_heads(kv, H, S_cap, Sx_cap, w.xk + li * w.pool_stride + ent_off, HF_NATURAL, w.xv + li * w.pool_stride + ent_off, HF_NATURAL, nullptr, HF_NONE);
+            kv.heads.row_map = we.xrow;
+            gemm(kv, EPI_HEADS, es);
+        }
+        MG_LAUNCH(stream_chunk_done_kernel, dim3(1), dim3(64), 0, es, (const int*)we.xlen, w.xlen_pool, entry0, n, (const int*)we.counters, w.err);
+        mg_event_record(e1, es);
+        ++submitted;
+        return MG_OK;
+    };
+    auto announce = [&](bool wait) {
+        mgEvent_t e1 = m->chunk_ev[2 * (announced % pool_chunks) + 1];
+        if (es != st) {
+            if (!wait && !mg_event_done(e1)) return false;
+            mg_stream_wait_event(st, e1);
+        }
+        const int c0 = announced * chunk, n = (N - c0) < chunk ? (N - c0) : chunk;
+        MG_LAUNCH(stream_ready_kernel, dim3(1), dim3(64), 0, st, n, w.ctr);
+        ++announced;
+        return true;
+    };
+    int rc = MG_OK;
+    while (done_host < N) {
+        // feed the encoder stream: chunk c overwrites the pool entries of chunk c - pool_chunks, whose images must all have
+        // finished (oldest live image known to the host, a few steps late: conservative)
+        while (submitted < n_chunks && (submitted < pool_chunks || oldest_host >= (submitted - pool_chunks + 1) * chunk) &&
+               (es != st || submitted == announced)) {
+            if ((rc = submit_chunk()) != MG_OK) return rc;
+            if (es == st) break;              // serial mode: one chunk, then decode until the slots run dry
+        }
+        // hand finished chunks to the slots; when no slot is live and the queue is empty the decode stream has to wait for one
+        const bool starving = live_host == 0 && head_host >= announced * chunk;     // (late view; still true now: nothing was announced since)
+        while (announced < submitted && announce(starving && announced * chunk <= head_host)) {}
+        if (announced == 0) { announce(true); }
+        for (int g = 0; g < GROUP; ++g) {
+            const bool timed_step = m->prof_every > 0 && (steps % m->prof_every) == 0;
+#ifndef MG_EMU
+            if (graphed && !timed_step) {
+                if (hipGraphLaunch(m->stream_graph.exec, st) != hipSuccess) return fail(MG_E_HIP, "mg_generate_stream: hipGraphLaunch failed");
+            } else
+#endif
+                decode_step(m, dc, 0, nullptr, timed_step, st);
+            ++steps;
+        }
+        // counters back to the host, asynchronously; look at the oldest outstanding copy only when the ring is full
+        int* slot = m->stream_host + (rb_issued % RB) * 16;
+        mg_memcpy_async(slot, w.ctr, 16 * sizeof(int), st);
+        mg_event_record(m->rb_ev[rb_issued % RB], st);
+        ++rb_issued;
+        while (rb_seen < rb_issued && (rb_issued - rb_seen >= RB - 1 || mg_event_done(m->rb_ev[rb_seen % RB]))) {
+            mg_event_sync(m->rb_ev[rb_seen % RB]);
+            const int* h = m->stream_host + (rb_seen % RB) * 16;
+            live_host = h[0]; done_host = h[1]; head_host = h[4]; oldest_host = h[7];
+            ++rb_seen;
+        }
+        if (steps > (long)N * max_length + 64L * n_chunks + 1024) return fail(MG_E_HIP, "mg_generate_stream: no progress (%d of %d images after %ld steps)", done_host, N, steps);
+    }
+    int err2[2] = {0, 0};
+    int& err_host = err2[0];
+    if (es != st) mg_stream_sync(es);
+    mg_memcpy_async(err2, w.err, 2 * sizeof(int), st);
+    mg_stream_sync(st);
+    rc = check_launch("mg_generate_stream");
+    if (rc != MG_OK) return rc;
+    for (int c = 0; c < (n_chunks < pool_chunks ? n_chunks : pool_chunks); ++c)
+        m->stream_enc_ms += mg_event_elapsed_ms(m->chunk_ev[2 * c], m->chunk_ev[2 * c + 1]);     // the last pool_chunks chunks (statistics)
+    if (m->prof_used) {      // cross-attention brackets of the timed steps: keys streamed = live slots' pool entries at that step (approximated by the mean)
+        for (size_t i = 0; i + 2 < m->prof_used; i += 3) {
+            m->prof_ms += mg_event_elapsed_ms(m->prof_ev[i], m->prof_ev[i + 1]);
+            m->prof_empty_ms += mg_event_elapsed_ms(m->prof_ev[i + 1], m->prof_ev[i + 2]);
+            m->prof_n += 1;
+            m->prof_keys += (double)err2[1] / N * (N < slots ? N : slots);
+        }
+        m->prof_used = 0;
+    }
+    m->stream_steps = steps;
+    if (steps_host) *steps_host = steps;
+    if (err_host != 0) return fail(MG_E_INPUT, "mg_generate_stream: %d token ids outside [0, vocab)", err_host);
     return MG_OK;
 }
 

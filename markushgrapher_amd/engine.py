@@ -124,6 +124,10 @@ class Engine:
         L.mg_generate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
                                   C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
+        L.mg_stream_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
+        L.mg_generate_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + \
+                                        [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.POINTER(C.c_long)]
+        L.mg_stream_encoder_mode.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.mg_debug_bucket_table.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int]
         L.mg_debug_decode_capture.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
 
@@ -263,6 +267,40 @@ class Engine:
         self._chk(self.lib.mg_debug_decode_capture(self.model, self.mem.ptr(cap) if cap is not None else None, capture_steps,
                                                    self.mem.ptr(frc) if frc is not None else None))
         return cap
+
+    def set_stream_encoder(self, mode=1, cu_mask=None):
+        """Where generate_stream's encoder runs: 0 the caller's stream (serial), 1 its own low-priority stream, 2 its own stream on
+        the compute units of `cu_mask` (iterable of CU bit indices)."""
+        if mode == 2:
+            bits = sorted(set(int(b) for b in cu_mask))
+            nw = bits[-1] // 32 + 1
+            arr = (C.c_uint32 * nw)()
+            for b in bits:
+                arr[b // 32] |= 1 << (b % 32)
+            self._chk(self.lib.mg_stream_encoder_mode(self.model, 2, arr, nw))
+        else:
+            self._chk(self.lib.mg_stream_encoder_mode(self.model, int(mode), None, 0))
+
+    def generate_stream(self, input_ids, bbox, attention_mask, pixel_values, max_length=512, min_length=0, chunk=32, slots=32,
+                        pool_chunks=3):
+        """Continuous greedy decoding of N images (include/mgrapher.h mg_generate_stream): -> (ids [N, max_length] padded with the pad
+        id, lengths [N] = valid columns, decode steps run).  Row n equals generate()'s row for image n."""
+        ids, bb, am, pv, N, L = self._inputs(input_ids, bbox, attention_mask, pixel_values)
+        need = C.c_size_t()
+        self._chk(self.lib.mg_stream_workspace_bytes(self.model, chunk, L, slots, pool_chunks, C.byref(need)))
+        if getattr(self, "_sws_bytes", 0) < need.value:
+            self._sws = None
+            self._sws = self.mem.empty((need.value,), np.uint8)
+            self._sws_bytes = need.value
+        okey = ("stream", N, max_length)
+        out = self._gen_out.get(okey)
+        if out is None:
+            out = self._gen_out[okey] = (self.mem.empty((N, max_length), np.int64), self.mem.empty((N,), np.int32))
+        steps = C.c_long(0)
+        self._chk(self.lib.mg_generate_stream(self.model, self.mem.stream(), self.mem.ptr(self._sws), self._sws_bytes, self.mem.ptr(ids),
+                                              self.mem.ptr(bb), self.mem.ptr(am) if am is not None else None, self.mem.ptr(pv), N, L, chunk, slots,
+                                              pool_chunks, max_length, min_length, self.mem.ptr(out[0]), self.mem.ptr(out[1]), C.byref(steps)))
+        return self.mem.copy(out[0]), self.mem.copy(out[1]), int(steps.value)
 
     def generate(self, input_ids, bbox, attention_mask, pixel_values, num_beams=1, max_length=512, min_length=0,
                  length_penalty=1.0, early_stopping=False, return_top2=False, e1=None):
