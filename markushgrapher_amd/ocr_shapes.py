@@ -171,3 +171,93 @@ def synth_pixel_mask(s: OcrShape, B: int, n_img: int = 1, seed: int = 20260929):
                 w = I if not (b == 0 and j == 0) else I
             m[b, j, :h, :w] = True
     return m
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Scripted OCR output (end-to-end tests and the configs[4] bench loop): no ChemicalOCR checkpoint and no tokenizer model exist
+# offline, and a random-weight model emits noise that parses to no cells.  To let REAL cell strings flow from the OCR stage into
+# the VTL stage, the lm_head / embedding of an otherwise ordinary recipe model are set so that greedy decoding walks a scripted
+# chain of tokens per page (lm_head[succ(t)] = direction of embed[t]; the embeddings dominate the residual stream).  The compute
+# is that of any model of the shape - only WHICH token wins is scripted.  The id -> piece table is the stand-in tokenizer.
+# ---------------------------------------------------------------------------------------------------------------------------
+def script_texts(s: OcrShape, texts: List[str], piece_len: int = 3):
+    """-> (id_to_piece [vocab], chains: per text the token ids it is emitted as (EOS last), starts: the prompt-final token selecting
+    each chain).  Every chain position has its own token id, so a chain never revisits a token."""
+    reserved = {s.eos_token_id, s.pad_token_id, s.image_token_id}
+    free = [i for i in range(3, s.vocab) if i not in reserved]
+    need = sum(1 + (len(t) + piece_len - 1) // piece_len for t in texts)
+    if need > len(free):
+        raise ValueError(f"{need} scripted tokens do not fit the vocabulary ({len(free)} free ids)")
+    id_to_piece = [f"<t{i}>" for i in range(s.vocab)]
+    chains, starts, nxt = [], [], 0
+    for k, text in enumerate(texts):
+        start = free[nxt]; nxt += 1
+        id_to_piece[start] = f"<start_{k}>"
+        ids = []
+        for i in range(0, len(text), piece_len):
+            id_to_piece[free[nxt]] = text[i:i + piece_len]
+            ids.append(free[nxt]); nxt += 1
+        chains.append(ids + [s.eos_token_id])
+        starts.append(start)
+    return id_to_piece, chains, starts
+
+
+def scripted_state_dict(s: OcrShape, chains, starts, gain: float = 0.5, embed_scale: float = 48.0, seed: int = 20260929):
+    sd = recipe_state_dict(s, seed=seed, gain=gain)
+    emb = round_bf16(sd["model.text_model.embed_tokens.weight"] * np.float32(embed_scale))
+    sd["model.text_model.embed_tokens.weight"] = emb
+    head = round_bf16(uniform_pm1("ocr/script/lm_head", emb.shape, seed) * np.float32(0.05))
+    eos_row = np.zeros(emb.shape[1], np.float32)
+    for start, chain in zip(starts, chains):
+        prev = start
+        for tid in chain[:-1]:
+            head[tid] = round_bf16(emb[prev] / np.float32(embed_scale))
+            prev = tid
+        eos_row += emb[prev] / np.float32(embed_scale)      # all chains end in the one EOS token: its row points at every last piece
+    head[s.eos_token_id] = round_bf16(eos_row / np.float32(max(1.0, np.sqrt(len(chains)) / 2)))
+    sd["lm_head.weight"] = head
+    return sd
+
+
+def scripted_prompts(s: OcrShape, chains, starts, prompt_text_tokens: int = 10):
+    """input_ids [pages][L]: the stock prompt layout with the page's start token last; no prompt token is part of a chain."""
+    ids, _ = synth_inputs(s, len(starts), prompt_text_tokens=prompt_text_tokens)
+    used = np.array(sorted({t for c in chains for t in c} | set(starts)))
+    neutral = next(i for i in range(s.vocab - 1, 2, -1) if i not in set(used.tolist()) and i not in (s.image_token_id, s.eos_token_id, s.pad_token_id))
+    text_pos = ids != s.image_token_id
+    ids = np.where(np.isin(ids, used) & text_pos, neutral, ids)
+    for b, st in enumerate(starts):
+        ids[b, -1] = st
+    return ids
+
+
+def detokenize(id_to_piece, row, eos_id, pad_id):
+    """Stand-in for processor.batch_decode(generated_ids[:, prompt_len:], skip_special_tokens=True) (ref: chemical_ocr.py:386-390)."""
+    out = []
+    for t in row:
+        t = int(t)
+        if t == eos_id:
+            break
+        if t != pad_id:
+            out.append(id_to_piece[t])
+    return "".join(out)
+
+
+_CELL_WORDS = ["R1", "R2", "R3", "R4", "alkyl", "group", "hydrogen", "atom", "halogen", "represents", "wherein", "and", "or", "same", "different",
+               "each", "may", "be", "methyl", "ethyl", "phenyl", "alkoxy", "C1-C6", "OH", "NH", "Cl", "Br", "Me", "Et", "Ph", "Ar", "Het", "ring",
+               "aryl", "selected", "from", "of", "a", "is", "="]
+
+
+def synth_cell_text(n_cells: int, seed: int, name: str = "page") -> str:
+    """A page's OCR output in the current grammar (`<ocr>x1>y1>x2>y2>text\n...</ocr>`, ref: chemical_ocr.py:165-199): n_cells cells of 1-6
+    words in boxes on the 500-unit grid, IP5-M-like (10-120 cells per page)."""
+    from .synth import randint
+    r = randint(f"ocr/cells/{name}", n_cells * 12, 0, 1 << 20, seed).reshape(n_cells, 12)
+    lines = []
+    for c in r:
+        x0, y0 = int(c[0] % 420), int(c[1] % 470)
+        w, h = 20 + int(c[2] % 60), 10 + int(c[3] % 15)
+        nw = 1 + int(c[4] % 6)
+        words = " ".join(_CELL_WORDS[int(c[5 + j] % len(_CELL_WORDS))] for j in range(nw))
+        lines.append(f"{x0}>{y0}>{min(x0 + w, 499)}>{min(y0 + h, 499)}>{words}")
+    return "<ocr>" + "\n".join(lines) + "</ocr>"

@@ -1,0 +1,128 @@
+"""BASELINE.json configs[4] as ONE path: page crops -> ChemicalOCR (prefill + greedy decode) -> OCR cells -> VTL inputs -> VTL encoder +
+CXSMILES decoder -> token ids (-> text).  What the reference runs as two processes with a dataset on disk in between
+(ref: scripts/inference/inference.sh:165-184: image_dir_to_hf_dataset.py --apply_ocr, then eval.py) happens here in one loop on one GPU,
+the intermediate staying in memory:
+
+    pages u8 [B,H,W,3] (device)
+      -> mg_preprocess_pages                    Pillow-exact LANCZOS to 512 px, x/255, mean = std = 0.5            (both models read it:
+                                                Idefics3ImageProcessor resamples with LANCZOS and normalises with 0.5 / 0.5 too, and a
+                                                512-px page is one frame at max_image_size 512)
+      -> OcrEngine.generate                     ref: ocr/chemical_ocr.py:366-392
+      -> detokenise, clean_ocr_text, parse_ocr_string -> cells            ref: chemical_ocr.py:386-390, 438-446     (ocr_text.py)
+      -> order_cells, TaskCollator.collate, tokenizer(text, text_pair, boxes)   ref: mdu_dataset.py:78-80, 210; task_collator.py:28-107;
+                                                                                utils/common.py:34-42               (assembly.py)
+      -> collate_for_generate (pad to the longest of the batch)
+      -> Engine.generate / generate_stream      ref: utils/ocsr/utils_evaluation.py:269-285
+      -> ids (-> IdDecoder text, optional)
+
+Host work (string parsing, tokenising ~20-400 pieces per page) is the stock tokenizer's and a few list operations per page; it is not
+accelerated.  There is no CPU fallback for the two model stages: both engines raise without the HIP library.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional
+
+import numpy as np
+
+from . import assembly, ocr_text
+
+QUESTION = "What markush structure is in the image?"            # ref: core/datasets/mdu_dataset.py:120-124
+
+
+def order_cells(cells):
+    """ref: mdu_dataset.py:78-80 - reading order by (y0, x0)."""
+    return sorted(cells, key=lambda d: (d["bbox"][1], d["bbox"][0]))
+
+
+def cells_from_ocr_text(text: str):
+    """ref: chemical_ocr.py:438-446."""
+    words, boxes = ocr_text.parse_ocr_string(ocr_text.clean_ocr_text(text))
+    return [{"bbox": b, "text": w} for w, b in zip(words, boxes)]
+
+
+class _Size:
+    def __init__(self, w, h):
+        self.size = (w, h)
+
+
+def encode_cells(cells, tokenizer, image_size: int, question: str = QUESTION, normalize_bbox: bool = True):
+    """One page's OCR cells -> (input_ids [L] int64, bbox [L,4] float32): `encode_item` without the pixel part (ref: utils/common.py:
+    14-42): TaskCollator.collate's words / boxes, then the tokenizer call the processor makes."""
+    item = {"image": _Size(image_size, image_size), "cells": order_cells(cells), "entities": {"question": question, "answer": ""}}
+    _, instruction, words, boxes, _ = assembly.collate_item(item, tokenizer, normalize_bbox)
+    enc = tokenizer(text=[instruction], text_pair=[words], boxes=[[list(map(float, b)) for b in boxes]], return_tensors="np", padding=False,
+                    truncation=False)
+    return np.asarray(enc["input_ids"][0], np.int64), np.asarray(enc["bbox"][0], np.float32)
+
+
+@dataclass
+class PipelineResult:
+    ids: np.ndarray                   # [B, T] decoder ids (start token first, pad after EOS)
+    ocr_new_ids: np.ndarray           # [B, n] what the OCR stage generated
+    ocr_texts: List[str]
+    cells: List[list]
+    input_ids: np.ndarray             # [B, L] what the VTL model read
+    bbox: np.ndarray
+    attention_mask: np.ndarray
+    timings: dict = field(default_factory=dict)
+
+
+class Configs4Pipeline:
+    """ocr: OcrEngine; main: Engine; tokenizer: the main model's tokenizer (UdopTokenizer-compatible call); ocr_detok: new-token ids of
+    one page -> text (the OCR processor's batch_decode); ocr_prompt_ids [L] or [B, L]: the tokenised chat prompt with the <image>
+    block (equal length for every page: one prompt, one 512-px frame)."""
+
+    def __init__(self, ocr, main, tokenizer, ocr_detok: Callable, ocr_prompt_ids, ocr_max_new_tokens: int = 4096, question: str = QUESTION,
+                 max_length: int = 512, min_length: int = 0, num_beams: int = 1, continuous: bool = False, main_batch: int = 32):
+        self.ocr, self.main, self.tokenizer, self.ocr_detok = ocr, main, tokenizer, ocr_detok
+        self.ocr_prompt_ids = np.asarray(ocr_prompt_ids, np.int64)
+        self.ocr_max_new_tokens, self.question = int(ocr_max_new_tokens), question
+        self.max_length, self.min_length, self.num_beams, self.continuous = int(max_length), int(min_length), int(num_beams), bool(continuous)
+        self.main_batch = int(main_batch)      # pages per VTL call (the OCR stage may take more pages per call: its model is 6x smaller)
+        if ocr.shape.image_size != main.shape.image_size:
+            raise ValueError("the two stages share the preprocessed page: equal input sizes expected (512 px in the reference)")
+
+    def __call__(self, pages_u8, timer: Optional[Callable[[], float]] = None) -> PipelineResult:
+        import torch
+        t = {}
+        now = timer or (lambda: 0.0)
+        t0 = now()
+        pix = self.main.preprocess(pages_u8)                                  # [B, 3, I, I] f32 on the device, read by both stages
+        B = int(pix.shape[0])
+        prompt = self.ocr_prompt_ids if self.ocr_prompt_ids.ndim == 2 else np.repeat(self.ocr_prompt_ids[None], B, axis=0)
+        new, _ = self.ocr.generate(prompt[:B], pix[:, None], self.ocr_max_new_tokens)
+        new = new.cpu().numpy() if hasattr(new, "cpu") else np.asarray(new)
+        t["ocr_s"] = now() - t0
+        t1 = now()
+        texts = [self.ocr_detok(row) for row in new]
+        cells = [cells_from_ocr_text(x) for x in texts]
+        feats = []
+        I = self.main.shape.image_size
+        for c in cells:
+            ids, bb = encode_cells(c, self.tokenizer, I, self.question)
+            feats.append({"input_ids": torch.from_numpy(ids), "bbox": torch.from_numpy(bb)})
+        batch = assembly.collate_for_generate(feats)
+        ids_in = batch["input_ids"].numpy().astype(np.int64)
+        bbox = batch["bbox"].numpy().astype(np.float32)
+        mask = batch["attention_mask"].numpy().astype(np.int64)
+        t["host_s"] = now() - t1
+        t2 = now()
+        mb = min(B, self.main_batch)
+        if self.continuous and self.num_beams == 1:
+            out, lens, _ = self.main.generate_stream(ids_in, bbox, mask, pix, max_length=self.max_length, min_length=self.min_length,
+                                                     chunk=mb, slots=mb, pool_chunks=3 if B > 2 * mb else 2)
+            out = out.cpu().numpy() if hasattr(out, "cpu") else np.asarray(out)
+            lens = lens.cpu().numpy() if hasattr(lens, "cpu") else np.asarray(lens)
+            out = out[:, :int(lens.max())]
+        else:
+            rows = []
+            for c0 in range(0, B, mb):
+                o, _, _ = self.main.generate(ids_in[c0:c0 + mb], bbox[c0:c0 + mb], mask[c0:c0 + mb], pix[c0:c0 + mb], num_beams=self.num_beams,
+                                             max_length=self.max_length, min_length=self.min_length)
+                rows.append(o.cpu().numpy() if hasattr(o, "cpu") else np.asarray(o))
+            width = max(r.shape[1] for r in rows)
+            pad = self.main.shape.pad_token_id
+            out = np.concatenate([np.pad(r, ((0, 0), (0, width - r.shape[1])), constant_values=pad) for r in rows], axis=0)
+        t["main_s"] = now() - t2
+        return PipelineResult(ids=out, ocr_new_ids=new, ocr_texts=texts, cells=cells, input_ids=ids_in, bbox=bbox, attention_mask=mask, timings=t)

@@ -1,0 +1,85 @@
+"""BASELINE.json configs[4] as one path (markushgrapher_amd/pipeline.py): pages -> device preprocessing -> ChemicalOCR generate -> text ->
+cells -> VTL inputs -> VTL generate.  A tiny OCR model with SCRIPTED weights (tests/pipeline_fixture.py) deterministically 'reads' a fixed
+cell string per page; everything downstream of that string is compared with tests/golden/pipeline_host.json, which holds what the
+REFERENCE's own host code (parse_ocr_string, clean_ocr_text, TaskCollator.collate, encode_item with the stock UDOP processor) makes of
+the same strings (tools/make_golden_pipeline.py).  `emu`: both engines on the CPU SIMT emulator; `hip`: MI355X."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from markushgrapher_amd import synth
+from markushgrapher_amd.pipeline import Configs4Pipeline, cells_from_ocr_text, encode_cells, order_cells
+from tests import pipeline_fixture as F
+from tests.backends import get_backend, make_engine, NumpyMem
+from tests.conftest import GOLDEN, load_golden
+from tests.test_oracle_golden import _weights
+
+BACKENDS = [pytest.param("emu"), pytest.param("hip", marks=pytest.mark.gpu)]
+
+
+def _golden():
+    with open(os.path.join(GOLDEN, "pipeline_host.json")) as f:
+        return json.load(f)
+
+
+def test_host_chain_matches_the_reference_outputs():
+    """OCR string -> cells -> input_ids / bbox: the build's restatements + the stock tokenizer against the reference's own chain."""
+    g = _golden()
+    tok = F.make_udop_tokenizer()
+    assert [p["ocr_text"] for p in g["pages"]] == F.OCR_TEXTS
+    for p in g["pages"]:
+        cells = cells_from_ocr_text(p["ocr_text"])
+        assert order_cells(cells) == p["cells"]
+        ids, bb = encode_cells(cells, tok, g["image_size"])
+        assert ids.tolist() == p["input_ids"]
+        assert np.array_equal(bb, np.asarray(p["bbox"], np.float32))
+    assert any(c["bbox"][1] > n["bbox"][1] for p in g["pages"] for c, n in zip(cells_from_ocr_text(p["ocr_text"]), cells_from_ocr_text(p["ocr_text"])[1:]))
+
+
+def _engines(be_name):
+    from markushgrapher_amd.ocr import OcrEngine
+    g3 = load_golden("g3_trained_tiny.npz")
+    shape, sd = _weights(g3)
+    main = make_engine(be_name, shape, sd)
+    s = F.scripted_ocr_shape()
+    be = get_backend(be_name)
+    ocr = OcrEngine(s, lib=be.lib, mem=NumpyMem()) if be_name == "emu" else OcrEngine(s)
+    ocr.load_state_dict(F.scripted_ocr_state_dict())
+    return main, ocr, shape, s
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+@pytest.mark.parametrize("continuous", [False, True])
+def test_pages_to_ids_in_one_path(be_name, continuous):
+    g = _golden()
+    main, ocr, shape, s = _engines(be_name)
+    id_to_piece, chains, starts = F.ocr_vocab_and_chains()
+    pipe = Configs4Pipeline(ocr, main, F.make_udop_tokenizer(), lambda row: F.detokenize(id_to_piece, row, s.eos_token_id, s.pad_token_id),
+                            F.ocr_prompts(), ocr_max_new_tokens=64, max_length=16, continuous=continuous)
+    pages = F.pages_u8(len(F.OCR_TEXTS))
+    res = pipe(pages)
+    # stage 1: the scripted OCR model walked its chains (ids), the stand-in detokeniser gives the designed strings
+    for b, chain in enumerate(chains):
+        assert res.ocr_new_ids[b, :len(chain)].tolist() == chain, b
+    assert res.ocr_texts == F.OCR_TEXTS
+    # in between: cells and VTL inputs equal the reference's
+    L = res.input_ids.shape[1]
+    assert L == max(len(p["input_ids"]) for p in g["pages"])
+    for b, p in enumerate(g["pages"]):
+        n = len(p["input_ids"])
+        assert order_cells(res.cells[b]) == p["cells"]
+        assert res.input_ids[b, :n].tolist() == p["input_ids"] and np.all(res.input_ids[b, n:] == 0)
+        assert np.array_equal(res.bbox[b, :n], np.asarray(p["bbox"], np.float32)) and np.all(res.bbox[b, n:] == 0)
+        assert res.attention_mask[b].tolist() == [1] * n + [0] * (L - n)
+    # the device preprocessing is the reference's pixel path (PIL LANCZOS + 1/255 + 0.5/0.5): checksums of its pixel_values
+    pix = main.mem.numpy(main.preprocess(pages))
+    for b, p in enumerate(g["pages"]):
+        assert abs(float(pix[b].astype(np.float64).sum()) - p["pixel_sum"]) < 1e-3
+        assert np.array_equal(pix[b][:, ::9, ::7].ravel()[:64], np.asarray(p["pixel_probe"], np.float32))
+    # stage 2: the ids are what the VTL engine returns for the reference-made inputs (same engine, same pixel values)
+    want, _, _ = main.generate(res.input_ids, res.bbox, res.attention_mask, pix, max_length=16)
+    want = main.mem.numpy(want)
+    assert res.ids.shape == want.shape and np.array_equal(res.ids, want)
+    assert np.all(res.ids[:, 0] == shape.decoder_start_token_id) and len({tuple(r) for r in res.ids.tolist()}) > 1
