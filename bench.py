@@ -290,10 +290,10 @@ def main():
     L = inp["input_ids"].shape[1]
     # the exchange: static [B, 512] int32 ids + [B] int32 lengths per rank, posted asynchronously and
     # double-buffered (markushgrapher_amd/dist.py), so the gather of batch i overlaps the encoder of batch i+1
-    ex = None
-    if world > 1:
-        from markushgrapher_amd.dist import IdExchange
-        ex = IdExchange(B, torch.device("cuda", local_rank), pad_token_id=shape.pad_token_id)
+    # (at world == 1 the exchange degenerates to its single-rank copy path, which runs all the same: the packing of the static
+    #  [32, 512] int32 block + lengths is part of the step on every node size)
+    from markushgrapher_amd.dist import IdExchange
+    ex = IdExchange(B, torch.device("cuda", local_rank), pad_token_id=shape.pad_token_id)
     handles = []
 
     def step(beams=args.beams, max_len=max_length, min_len=max_length):
