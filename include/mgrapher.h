@@ -71,7 +71,10 @@ int mg_workspace_bytes(const mg_model* m, int B, int L, int num_beams, int max_l
 /* Encoder (stock modeling_udop.py:1102-1246 for the encoder stack).  attention_mask may be NULL (= everything
  * attended, incl. the zero-padded visual slots: stock:1183-1186).  Leaves the encoder state (final hidden states,
  * mask, compaction map) in the workspace for mg_decoder_forward.
- * enc_out [B][L+P][d_model] fp32 and enc_mask [B][L+P] u8 are optional outputs (the VTL states e2 only).
+ * enc_out [B][L+P][d_model] fp32 and enc_mask [B][L+P] u8 are optional outputs (the VTL states e2 only).  Rows of enc_out at
+ * positions with enc_mask == 0 (padded text slots, the slots of dropped patches) are UNSPECIFIED: nothing downstream reads them
+ * (the decoder's cross-attention masks them), and the encoder GEMMs skip whole 32-row tiles of such positions.  Attended rows are
+ * bit-identical with the skip off (environment MG_ENC_ROW_TILES=0, which also makes the unattended rows follow the reference).
  * e1 (nullable, with M_e1 = 0): [B][M_e1][d_model] fp32, the projected embeddings of MarkushGrapher-2's OCSR vision branch
  * (`encoder.molscribe_encoder` Swin-B + `encoder.molscribe_projector`, /root/reference/markushgrapher/utils/model/
  * utils_model_loading.py:23,36), computed by the caller: that branch lives only in the reference's un-vendored fork and is
@@ -187,6 +190,11 @@ int mgk_gemm(void* stream, int mode, int epi, const void* X_pk, const void* W_pk
  * rsqrt(sum(rs_part[m][0..rs_nparts)) * rs_inv_d + rs_eps) (rs_part NULL: no scale). */
 int mgk_gemm_norm(void* stream, int epi, const void* X_pk, const void* W_pk, int M, int N, int K, float* h_tiled, const float* gain,
                   void* out_pk, float* part, int part_ld, const float* rs_part, int rs_nparts, float rs_inv_d, float rs_eps);
+/* mgk_gemm / mgk_gemm_norm restricted to the 32-row tiles that hold a non-zero entry of row_mask [M] (the encoder's row-tile list:
+ * whole tiles of padded text slots / dropped patch slots are neither read nor written).  list_scratch: M/32 + 1 ints. */
+int mgk_gemm_row_tiles(void* stream, int epi, const void* X_pk, const void* W_pk, int M, int N, int K, float* out_f32, const float* gain,
+                       void* out_pk, float* part, int part_ld, const float* rs_part, int rs_nparts, float rs_inv_d, float rs_eps,
+                       const uint8_t* row_mask, int* list_scratch);
 int mgk_gemm_heads(void* stream, int mode, const void* X_pk, const void* W_pk, int M, int N, int K, void* p0, void* p1,
                    void* p2, int f0, int f1, int f2, int H, int S_in, int S_cap, const int* row_map, int pos);
 /* mode 0 (encoder): tab1/tabh/tabv are the RAW bucket tables [32][H]; bk1[257] / bkhv[201] the bucket ids of integer

@@ -53,6 +53,23 @@ int mgk_gemm_norm(void* stream, int epi, const void* X_pk, const void* W_pk, int
     return MG_OK;
 }
 
+// Large-M GEMM restricted to the 32-row tiles with a non-zero entry in row_mask [M] (M a multiple of 32): the row-tile list form
+// the encoder uses.  list_scratch: M/32 + 1 ints.  epi as mgk_gemm_norm (5: tiled residual + packed x + partial sums; 2 / 3: packed
+// outputs, rows scaled by rs_*) or 0 / 1 (fp32 store / accumulate, row-major ldo = N).
+int mgk_gemm_row_tiles(void* stream, int epi, const void* X_pk, const void* W_pk, int M, int N, int K, float* out_f32, const float* gain,
+                       void* out_pk, float* part, int part_ld, const float* rs_part, int rs_nparts, float rs_inv_d, float rs_eps,
+                       const uint8_t* row_mask, int* list_scratch) {
+    if ((K & 63) || (N & 31) || (M & 31) || !row_mask || !list_scratch) return MG_E_SHAPE;
+    row_tile_list(row_mask, M, list_scratch + 1, list_scratch, (mgStream_t)stream);
+    GemmArgs a{};
+    a.X = (const uint16_t*)X_pk; a.W = (const uint16_t*)W_pk; a.M = M; a.N = N; a.K = K;
+    a.out_f32 = out_f32; a.gain = gain; a.out_pk = (uint16_t*)out_pk; a.part = part; a.ldo = (epi == EPI_RESID_NORM) ? part_ld : N;
+    a.rs = RowScale{rs_part, rs_nparts, rs_inv_d, rs_eps};
+    a.row_tiles = list_scratch + 1; a.n_row_tiles = list_scratch;
+    gemm(a, epi, (mgStream_t)stream);
+    return MG_OK;
+}
+
 int mgk_gemm_heads(void* stream, int mode, const void* X_pk, const void* W_pk, int M, int N, int K, void* p0, void* p1,
                    void* p2, int f0, int f1, int f2, int H, int S_in, int S_cap, const int* row_map, int pos) {
     if ((K & 63) || (N % (H * 64))) return MG_E_SHAPE;

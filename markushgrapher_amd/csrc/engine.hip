@@ -114,6 +114,9 @@ struct mg_model {
     mgEvent_t start_ev = nullptr;
     long stream_steps = 0, stream_idle_steps = 0;      // statistics of the last mg_generate_stream call
     double stream_enc_ms = 0.0;
+    // encoder GEMMs skip 32-row tiles without an attended position (padded text slots, slots of dropped patches); MG_ENC_ROW_TILES=0
+    // computes every row (A/B; results of attended rows are bit-identical either way)
+    bool row_tiles = true;
     bool tied = true;          // tie_word_embeddings: lm_head = shared.weight and logits scaled by d_model^-0.5 (stock:1554-1557)
 #ifndef MG_EMU
     hipStream_t own_stream = nullptr;
@@ -232,7 +235,7 @@ struct Ws {
     void* meta;
     double *cx, *cy;
     uint8_t* mask;
-    int *xrow, *xlen, *counters, *att_kst;
+    int *xrow, *xlen, *counters, *att_kst, *row_tiles;
     uint8_t* att_qbv;
     // OCSR-branch tokens e1, packed for the cross-K/V projections
     uint16_t* e1_pk;
@@ -300,6 +303,7 @@ void carve(const mg_model* m, char* base, int B, int L, int K, int max_len, int 
     w->counters = c.take<int>(16);
     w->att_kst = c.take<int>((size_t)B * (1 + (S_cap >> 6)));
     w->att_qbv = c.take<uint8_t>((size_t)B * ((S_cap + 127) / 128));
+    w->row_tiles = c.take<int>(M / 32 + 1);           // [0] = count, then the live 32-row tiles (GemmArgs::row_tiles)
     w->e1_pk = c.take<uint16_t>((size_t)B * M64 * d);
     w->e1_map = c.take<int>((size_t)B * M64);
     w->xmask = c.take<uint8_t>((size_t)B * Sx_cap);
@@ -620,6 +624,7 @@ int mg_create(const mg_config* cfg, mg_model** out) {
     m->M2 = c.max_2d_position_embeddings;
     m->T_cap = round_up(c.max_decode_len > 0 ? c.max_decode_len : 512, 64);
     m->tied = c.tie_word_embeddings != 0;
+    { const char* e = getenv("MG_ENC_ROW_TILES"); if (e && e[0] == '0') m->row_tiles = false; }
     // arena layout
     size_t off = 0;
     auto take = [&](size_t bytes) { off = align_up(off, 256); size_t o = off; off += bytes; return o; };
@@ -914,6 +919,19 @@ int mg_encode(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_
     // bucket indices of the three relative biases: shared by all layers and heads, computed once per batch
     bias_index(w.bidx, w.cx, w.cy, w.mask, m->at<int>(m->bk1), m->at<int>(m->bkhv), B, S, S_cap, st);
     attn_lists(w.mask, B, S, S_cap, w.att_kst, w.att_qbv, st);
+    // Row tiles without any attended position are skipped by every encoder GEMM: their rows are never read as attended keys
+    // (masked in the bias index / skipped stages), never produce cross K/V (xrow = -1) and their encoder output is not attended.
+    // Q / K / V^T of such tiles are then never written: clear the three buffers so that a dead tile inside a live 64-key stage
+    // holds finite values (its keys are masked by the -1e30 table entry, which a NaN would survive).
+    const int* tiles = nullptr;
+    const int* n_tiles = nullptr;
+    if (m->row_tiles) {
+        row_tile_list(w.mask, M, w.row_tiles + 1, w.row_tiles, st);
+        tiles = w.row_tiles + 1; n_tiles = w.row_tiles;
+        mg_memset_async(w.q_pk, 0, (size_t)M * inner * 2, st);
+        mg_memset_async(w.k_pk, 0, (size_t)M * inner * 2, st);
+        mg_memset_async(w.vt_pk, 0, (size_t)M * inner * 2, st);
+    }
     // Encoder stack (stock:1061-1246, 644-720).  The residual stream h is fp32 in the tiled layout (ht_off); RMSNorm is
     // deferred as in the decode step: the residual projections (attention O, FFN wo) leave bf16(h * gain_next) and per-row
     // partial sums of h^2, the consuming projections (QKV, FFN wi, cross-K/V) scale their output rows by rsqrt(mean h^2 + eps).
@@ -930,6 +948,7 @@ int mg_encode(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_
         GemmArgs a = gemm_args(w.x_pk, m->at<uint16_t>(l.wqkv), M, 3 * inner, d);
         set_heads(a, H, S_cap, S_cap, w.q_pk, HF_PK_ROWS, w.k_pk, HF_PK_ROWS, w.vt_pk, HF_PK_T);
         if (li > 0) a.rs = rs_a;                   // layer 0 reads the explicitly normalised embedding
+        a.row_tiles = tiles; a.n_row_tiles = n_tiles;
         gemm(a, EPI_HEADS, st);
         AttnArgs t{};
         t.Q = w.q_pk; t.K = w.k_pk; t.Vt = w.vt_pk; t.ctx = w.ctx_pk; t.B = B; t.H = H; t.Sq = S; t.Sk = S;
@@ -939,13 +958,16 @@ int mg_encode(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_
         attention(t, st);
         GemmArgs o = gemm_args(w.ctx_pk, m->at<uint16_t>(l.wo), M, d, inner);       // h += Wo ctx; x = bf16(h * ln1); partials -> b
         o.out_f32 = w.hidden; o.gain = m->at<float>(l.ln1); o.out_pk = w.x_pk; o.part = w.enc_part_b; o.ldo = np4;
+        o.row_tiles = tiles; o.n_row_tiles = n_tiles;
         gemm(o, EPI_RESID_NORM, st);
         GemmArgs f = gemm_args(w.x_pk, m->at<uint16_t>(l.wi), M, m->dff, d);
         f.out_pk = w.y_pk; f.rs = rs_b;
+        f.row_tiles = tiles; f.n_row_tiles = n_tiles;
         gemm(f, EPI_PK_RELU, st);
         GemmArgs g = gemm_args(w.y_pk, m->at<uint16_t>(l.wo2), M, d, m->dff);        // h += Wo2 y; x = bf16(h * next ln0); partials -> a
         g.out_f32 = w.hidden; g.ldo = np4;
         if (!last) { g.gain = m->at<float>(m->enc[li + 1].ln0); g.out_pk = w.x_pk; g.part = w.enc_part_a; }
+        g.row_tiles = tiles; g.n_row_tiles = n_tiles;
         gemm(g, EPI_RESID_NORM, st);
     }
     rmsnorm_pack_tiled(w.hidden, m->at<float>(m->enc_ln), w.enc_pk, w.enc_f32, M, d, m->c.layer_norm_epsilon, st);
@@ -1066,6 +1088,7 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
         GemmArgs kv = gemm_args(w.enc_pk, m->at<uint16_t>(m->dec[li].xkv), M, 2 * inner, d);
         set_heads(kv, H, S_cap, Sx_cap, w.xk + li * xkv_stride, HF_NATURAL, w.xv + li * xkv_stride, HF_NATURAL, nullptr, HF_NONE);
         kv.heads.row_map = w.xrow;
+        if (m->row_tiles) { kv.row_tiles = w.row_tiles + 1; kv.n_row_tiles = w.row_tiles; }      // left by mg_encode
         gemm(kv, EPI_HEADS, st);
     }
     if (m->phase_on) mg_event_record(m->phase_ev[1], st);
@@ -1315,6 +1338,7 @@ int mg_generate_stream(mg_model* m, void* stream, void* ws, size_t ws_bytes, con
             GemmArgs kv = gemm_args(we.enc_pk, m->at<uint16_t>(m->dec[li].xkv), n * S_cap, 2 * inner, d);
             set_heads(kv, H, S_cap, Sx_cap, w.xk + li * w.pool_stride + ent_off, HF_NATURAL, w.xv + li * w.pool_stride + ent_off, HF_NATURAL, nullptr, HF_NONE);
             kv.heads.row_map = we.xrow;
+            if (m->row_tiles) { kv.row_tiles = we.row_tiles + 1; kv.n_row_tiles = we.row_tiles; }
             gemm(kv, EPI_HEADS, es);
         }
         MG_LAUNCH(stream_chunk_done_kernel, dim3(1), dim3(64), 0, es, (const int*)we.xlen, w.xlen_pool, entry0, n, (const int*)we.counters, w.err);

@@ -604,6 +604,31 @@ void attn_lists(const uint8_t* kmask, int B, int Sk, int S_cap, int* kst, uint8_
     MG_LAUNCH(attn_lists_kernel, dim3(B), dim3(64), (size_t)((S_cap >> 6) + 16), stream, kmask, Sk, S_cap, kst, qbv);
 }
 
+// Ascending list of the 32-row tiles of the [B][S_cap] row space that hold at least one attended position, and its length
+// (GemmArgs::row_tiles).  One workgroup: flags in parallel, the compaction by one thread in tile order (deterministic; a few
+// thousand tiles at most).
+__global__ __launch_bounds__(256) void row_tile_list_kernel(const uint8_t* kmask, int n_tiles, int* list, int* count) {
+    MG_DYN_SMEM(smem);
+    unsigned char* flag = (unsigned char*)smem;
+    for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) {
+        const uint4* p = (const uint4*)(kmask + (size_t)t * 32);
+        const uint4 a = p[0], b = p[1];
+        flag[t] = (a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w) ? 1 : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int n = 0;
+        for (int t = 0; t < n_tiles; ++t)
+            if (flag[t]) list[n++] = t;
+        if (n == 0) { list[0] = 0; n = 1; }                     // nothing attended anywhere: keep one tile (the GEMMs need M >= 1)
+        *count = n;
+    }
+}
+void row_tile_list(const uint8_t* kmask, int rows, int* list, int* count, mgStream_t stream) {
+    const int n_tiles = rows >> 5;                               // rows is a multiple of 32
+    MG_LAUNCH(row_tile_list_kernel, dim3(1), dim3(256), (size_t)(n_tiles + 16), stream, kmask, n_tiles, list, count);
+}
+
 void attention(const AttnArgs& a_in, mgStream_t stream) {
     AttnArgs a = a_in;
     static int dbg = -1;

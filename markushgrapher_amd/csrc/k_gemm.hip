@@ -114,7 +114,7 @@ MG_DEV float row_scale_of(const RowScale& rs, int m, int M) {
 // for d_model <= 1024; one more per further 1024 columns); nparts is a multiple of 4 (groups past nparts re-read the last one
 // with weight 0)
 template <int NT>
-MG_DEV void row_scales_tiles(const RowScale& rs, int m0, int M, int lane, float (&out)[NT]) {
+MG_DEV void row_scales_tiles(const RowScale& rs, const int (&mrow)[NT], int M, int lane, float (&out)[NT]) {
 #pragma unroll
     for (int i = 0; i < NT; ++i) out[i] = 1.0f;
     if (!rs.part) return;
@@ -125,7 +125,7 @@ MG_DEV void row_scales_tiles(const RowScale& rs, int m0, int M, int lane, float 
         float4 v[NT][4];
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
-            int m = m0 + 32 * i + (lane & 31);
+            int m = mrow[i] + (lane & 31);
             m = m < M ? m : M - 1;
             const float* p = rs.part + (size_t)m * rs.nparts;
 #pragma unroll
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void gemm_big_kernel(GemmArgs a) {
         return;
     }
     float rsv[2];
-    row_scales_tiles<2>(a.rs, m0w, a.M, lane, rsv);
+    { const int mrow2[2] = {m0w, m0w + 32}; row_scales_tiles<2>(a.rs, mrow2, a.M, lane, rsv); }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmArgs a) {
         return;
     }
     float rsv[2];
-    row_scales_tiles<2>(a.rs, m0w, a.M, lane, rsv);
+    { const int mrow2[2] = {m0w, m0w + 32}; row_scales_tiles<2>(a.rs, mrow2, a.M, lane, rsv); }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -480,27 +480,27 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmArgs a) {
         }
 }
 
-// epilogue of a wave's TI x 2 accumulator tiles (token rows m0w + 32 i, feature columns n0w + 32 j) of the large-M kernels
+// epilogue of a wave's TI x 2 accumulator tiles (token rows mrow[i] .. mrow[i] + 31, feature columns n0w + 32 j) of the large-M kernels
 template <int EPI, int TI, int XP = 0>
-MG_DEV void xl_epilogue(const GemmArgs& a, f32x16 (&acc)[TI][2], int m0w, int n0w, bool tor, int lane) {
+MG_DEV void xl_epilogue(const GemmArgs& a, f32x16 (&acc)[TI][2], const int (&mrow)[TI], int n0w, bool tor, int lane) {
     if constexpr (EPI == EPI_RESID_NORM) {
 #pragma unroll
-        for (int i = 0; i < TI; ++i) resid_norm_epilogue(a, acc[i][0], acc[i][1], m0w + 32 * i, n0w, lane);
+        for (int i = 0; i < TI; ++i) resid_norm_epilogue(a, acc[i][0], acc[i][1], mrow[i], n0w, lane);
         return;
     }
     float rsv[TI];
-    row_scales_tiles<TI>(a.rs, m0w, a.M, lane, rsv);
+    row_scales_tiles<TI>(a.rs, mrow, a.M, lane, rsv);
     if constexpr (EPI == EPI_HEADS) {          // (the operand order is a property of the whole tile: one branch around the loops)
         if (tor) {
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) tile_epilogue<EPI_HEADS, true, true>(a, acc[i][j], m0w + 32 * i, n0w + 32 * j, lane, 3, rsv[i]);
+                for (int j = 0; j < 2; ++j) tile_epilogue<EPI_HEADS, true, true>(a, acc[i][j], mrow[i], n0w + 32 * j, lane, 3, rsv[i]);
         } else {
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) tile_epilogue<EPI_HEADS, false, true>(a, acc[i][j], m0w + 32 * i, n0w + 32 * j, lane, 3, rsv[i]);
+                for (int j = 0; j < 2; ++j) tile_epilogue<EPI_HEADS, false, true>(a, acc[i][j], mrow[i], n0w + 32 * j, lane, 3, rsv[i]);
         }
         return;
     }
@@ -508,7 +508,7 @@ MG_DEV void xl_epilogue(const GemmArgs& a, f32x16 (&acc)[TI][2], int m0w, int n0
     for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int m0 = m0w + 32 * i, n0 = n0w + 32 * j;
+            const int m0 = mrow[i], n0 = n0w + 32 * j;
             if constexpr ((XP & 4) != 0) { if ((i || j) && acc[i][j][0] != 123456.789f) continue; }
             if constexpr (EPI == EPI_F32_STORE || EPI == EPI_F32_RESID) {
                 tile_epilogue<EPI, false>(a, acc[i][j], m0, n0, lane);
@@ -542,9 +542,14 @@ __global__ __launch_bounds__(512) void gemm_xl_kernel(GemmArgs a) {
     constexpr int PER_WAVE = (FRAGS + 7) / 8;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nbn = (a.N + GX_N - 1) / GX_N;
-    const int nbm = (a.M + BM - 1) / BM;
+    // row-tile list (GemmArgs::row_tiles): the block's XT row tiles are entries bm*XT .. of the list instead of consecutive tiles;
+    // the grid is sized for all rows, blocks beyond the list's end leave at once
+    const int n_list = a.row_tiles ? *a.n_row_tiles : 0;
+    const int M_run = a.row_tiles ? n_list * 32 : a.M;
+    const int nbm = (M_run + BM - 1) / BM;
     int bid = blockIdx.x;
     const int nblk = nbm * nbn;
+    if (bid >= nblk) return;
     if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);   // XCD-contiguous tile ranges (speed only)
     const int bm = bid / nbn, bn = bid - bm * nbn;
     const int mt32 = (a.M + 31) >> 5, nt32 = (a.N + 31) >> 5;
@@ -559,6 +564,7 @@ __global__ __launch_bounds__(512) void gemm_xl_kernel(GemmArgs a) {
         const bool isW = f >= 4 * XT;
         const int ff = isW ? f - 4 * XT : f, rt = ff >> 2, kt = ff & 3;
         int trow = isW ? (bn * 8 + rt) : (bm * XT + rt);
+        if (!isW && a.row_tiles) trow = a.row_tiles[trow < n_list ? trow : n_list - 1];      // (entries past the end re-read the last live tile)
         const int tmax = isW ? nt32 - 1 : mt32 - 1;
         trow = trow < tmax ? trow : tmax;
         src[i] = (const char*)((isW ? a.W : a.X) + pk_tile_off(trow, kt, a.K)) + lane * 16;
@@ -667,7 +673,17 @@ __global__ __launch_bounds__(512) void gemm_xl_kernel(GemmArgs a) {
         MG_SCHED_FENCE();
     }
 
-    xl_epilogue<EPI, TI, XP>(a, acc, m0w, n0w, tor, lane);
+    int mrow[TI];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        if (a.row_tiles) {
+            const int e = bm * XT + wr * TI + i;
+            mrow[i] = e < n_list ? a.row_tiles[e] * 32 : a.M;        // past the list's end: row index M, every store is guarded by m < M
+        } else {
+            mrow[i] = m0w + 32 * i;
+        }
+    }
+    xl_epilogue<EPI, TI, XP>(a, acc, mrow, n0w, tor, lane);
 }
 template <int EPI, int TI>
 static void launch_xl(const GemmArgs& a, mgStream_t stream) {

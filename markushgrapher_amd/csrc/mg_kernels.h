@@ -72,6 +72,12 @@ struct GemmArgs {
     int x_kts, x_k0;
     // EPI_PK_SWIGLU: the packed output as a column window of a wider buffer (out_ld columns, first column out_col0); out_ld = 0: N/2, 0
     int out_ld, out_col0;
+    // Large-M tile kernel (320x256 / 256x256) only, optional: compute only the 32-row tiles listed in row_tiles[0 .. *n_row_tiles)
+    // (ascending tile ids; rows of other tiles are neither read nor written).  The encoder passes the tiles that hold at least one
+    // attended position: padded text slots and the slots of dropped patches form whole dead tiles (16 % of the rows at the
+    // benchmark's length distribution).  Kernels without list support ignore it and compute every row - the list is an optimisation.
+    const int* row_tiles;
+    const int* n_row_tiles;
 };
 void gemm(const GemmArgs& a, int epi, mgStream_t stream);
 bool gemm_has_gelu_epilogue(int M, int N);     // EPI_PK_GELU exists in the 320x256 / 256x256 tile kernels only
@@ -214,6 +220,8 @@ void bias_index(uint16_t* out, const double* cx, const double* cy, const uint8_t
                 int Sk, int S_cap, mgStream_t stream);
 // stage / query-block lists for AttnArgs::kst / qbv from the key mask (one launch per batch)
 void attn_lists(const uint8_t* kmask, int B, int Sk, int S_cap, int* kst, uint8_t* qbv, mgStream_t stream);
+// live 32-row tiles of a [rows] key mask (rows a multiple of 32, mask 16-byte aligned) -> ascending tile ids + count (GemmArgs::row_tiles)
+void row_tile_list(const uint8_t* kmask, int rows, int* list, int* count, mgStream_t stream);
 void attention(const AttnArgs& a, mgStream_t stream);
 
 // ---------------------------------------------------------------------------------------------

@@ -281,9 +281,13 @@ def test_large_shape_fixture_g2_on_gpu():
     enc, mask = eng.encode(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"])
     enc, mask = _np(eng, enc)[0], _np(eng, mask)[0]
     assert np.array_equal(mask, g["enc_mask"][0].astype(np.uint8))
-    err = np.abs(enc[g["enc_rows"]] - g["enc_probe"])
-    assert err.max() < ENC_MAX and err.mean() < ENC_MEAN, (err.max(), err.mean())
     valid = mask.astype(bool)
+    # (probe rows at attended positions: rows of positions that are not attended - here the slots of dropped patches at the end -
+    #  are unspecified in mg_encode's output; the encoder skips whole 32-row tiles of them, include/mgrapher.h)
+    att = valid[g["enc_rows"]]
+    assert att.sum() >= 12
+    err = np.abs(enc[g["enc_rows"]] - g["enc_probe"])[att]
+    assert err.max() < ENC_MAX and err.mean() < ENC_MEAN, (err.max(), err.mean())
     s_abs = np.abs(enc[valid]).astype(np.float64).sum()
     assert abs(s_abs - float(g["enc_abs_sum"])) / float(g["enc_abs_sum"]) < 2e-3      # checksum over all valid rows
     ids, _, top2 = eng.generate(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"], num_beams=1,

@@ -695,3 +695,64 @@ def test_gemm_encoder_deferred_norm(be_name, M, d, K, N2):
     r = 1.0 / np.sqrt((ref_h ** 2).mean(-1, keepdims=True) + 1e-6)
     want = np.maximum((xg @ pk.bf16_round(w2).T) * r, 0)
     np.testing.assert_allclose(pk.unpack_tiles(y.numpy(), M, N2), want, rtol=1 / 100, atol=2e-3 * np.abs(want).max())
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+@pytest.mark.parametrize("M,N,K", [(640, 256, 64), (1280, 512, 128)])
+def test_gemm_row_tile_list(be_name, M, N, K):
+    """The encoder's row-tile list (GemmArgs::row_tiles): only 32-row tiles with an attended position are computed.  Live tiles must
+    equal the full GEMM bit for bit (same kernel, same K order), dead tiles must be left untouched - for the fp32 store, the packed
+    relu output with deferred row scales, and the tiled residual + packed + partial-sum epilogue."""
+    be = get_backend(be_name)
+    be.lib.mgk_gemm_row_tiles.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 2 + [C.c_int] * 3 + [C.c_void_p] * 4 + \
+                                         [C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    be.lib.mgk_gemm_norm.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 2 + [C.c_int] * 3 + [C.c_void_p] * 4 + \
+                                    [C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float]
+    x, w = rnd((M, K), 400), rnd((N, K), 401, 0.2)
+    nt = M // 32
+    live = np.ones(nt, bool)
+    live[[1, 2, 5, nt - 1]] = False                       # dead tiles inside a block, across a block boundary (tiles 9/10) and at the end
+    live[9:12] = False
+    mask = np.zeros(M, np.uint8)
+    for t in np.nonzero(live)[0]:
+        mask[32 * t + (7 * t) % 32] = 1                   # one attended position is enough to make a tile live
+    rowlive = np.repeat(live, 32)
+    X, W = be.buf(pk.pack_tiles(x)), be.buf(pk.pack_tiles(w))
+    mk, scratch = be.buf(mask), be.zeros((nt + 1,), np.int32)
+    ref = pk.bf16_round(x) @ pk.bf16_round(w).T
+    # fp32 store
+    out = be.buf(np.full((M, N), -7.0, np.float32))
+    assert be.lib.mgk_gemm_row_tiles(be.stream, 0, be.p(X), be.p(W), M, N, K, be.p(out), None, None, None, 0, None, 0, 0.0, 0.0, be.p(mk), be.p(scratch)) == 0
+    full = be.zeros((M, N), np.float32)
+    assert be.lib.mgk_gemm(be.stream, 0, 0, be.p(X), be.p(W), M, N, K, be.p(full), N, None, None) == 0
+    o, f = out.numpy(), full.numpy()
+    assert np.array_equal(o[rowlive], f[rowlive]) and np.all(o[~rowlive] == -7.0)
+    np.testing.assert_allclose(f, ref, rtol=1e-4, atol=1e-4)
+    sc = scratch.numpy()
+    assert sc[0] == live.sum() and np.array_equal(sc[1:1 + sc[0]], np.nonzero(live)[0])
+    # tiled residual + packed x + partial sums (epi 5), then a row-scaled relu consumer (epi 2) on the same list
+    d = N
+    h0, g = rnd((M, d), 402), 1 + 0.2 * rnd((d,), 403)
+    np4 = (d // 64 + 3) // 4 * 4
+    res = {}
+    for name, use_list in (("list", True), ("full", False)):
+        h = be.buf(_tile_f32(h0))
+        xo = be.buf(np.full((M * d,), 0x7fc0, np.uint16))           # bf16 NaN pattern: a dead tile's rows must not reach a live result
+        part = be.zeros((M, np4), np.float32)
+        y = be.buf(np.full((M * N,), 0x1234, np.uint16))
+        if use_list:
+            assert be.lib.mgk_gemm_row_tiles(be.stream, 5, be.p(X), be.p(W), M, d, K, be.p(h), be.p(be.buf(g)), be.p(xo), be.p(part), np4, None, 0,
+                                             0.0, 0.0, be.p(mk), be.p(scratch)) == 0
+            w2 = be.buf(pk.pack_tiles(rnd((N, d), 404, 0.1)))
+            assert be.lib.mgk_gemm_row_tiles(be.stream, 2, be.p(xo), be.p(w2), M, N, d, None, None, be.p(y), None, 0, be.p(part), np4, 1.0 / d,
+                                             1e-6, be.p(mk), be.p(scratch)) == 0
+        else:
+            assert be.lib.mgk_gemm_norm(be.stream, 5, be.p(X), be.p(W), M, d, K, be.p(h), be.p(be.buf(g)), be.p(xo), be.p(part), np4, None, 0, 0.0, 0.0) == 0
+            w2 = be.buf(pk.pack_tiles(rnd((N, d), 404, 0.1)))
+            assert be.lib.mgk_gemm_norm(be.stream, 2, be.p(xo), be.p(w2), M, N, d, None, None, be.p(y), None, 0, be.p(part), np4, 1.0 / d, 1e-6) == 0
+        res[name] = (_untile_f32(h.numpy(), M, d).copy(), pk.unpack_tiles(xo.numpy(), M, d).view(np.uint32).copy(), part.numpy().copy(),
+                     pk.unpack_tiles(y.numpy(), M, N).view(np.uint32).copy())
+    for a_, b_ in zip(res["list"], res["full"]):
+        assert np.array_equal(a_[rowlive], b_[rowlive])
+    assert np.array_equal(res["list"][0][~rowlive], h0[~rowlive])                   # dead rows of the residual stream untouched
+    assert np.all(res["list"][2][~rowlive] == 0)
