@@ -117,6 +117,7 @@ struct mg_model {
     // encoder GEMMs skip 32-row tiles without an attended position (padded text slots, slots of dropped patches); MG_ENC_ROW_TILES=0
     // computes every row (A/B; results of attended rows are bit-identical either way)
     bool row_tiles = true;
+    bool fused_tail = true;    // MG_DECODE_FUSED_TAIL=0: separate embedding / selection launches (A/B; identical results)
     bool tied = true;          // tie_word_embeddings: lm_head = shared.weight and logits scaled by d_model^-0.5 (stock:1554-1557)
 #ifndef MG_EMU
     hipStream_t own_stream = nullptr;
@@ -245,6 +246,8 @@ struct Ws {
     uint16_t *xk, *xv, *sk, *sv, *dq, *dx_pk, *dy_pk;
     uint16_t *xa, *xb;        // packed [rows][d + inner] operand windows of the pair projections: [bf16(h) | attention context]
     float *dh, *logits, *slabs, *rs_part, *rs_part1, *rs_part2;
+    float4* ptop;             // fused greedy tail: per-workgroup top-2 partials of the lm_head launch [rows][V/32]
+    float* stopv;             // [rows][4] logits of the stop tokens
     size_t slab_stride;
     int64_t* next_ids;
     int *unfinished, *anc, *beam_idx;
@@ -319,6 +322,8 @@ void carve(const mg_model* m, char* base, int B, int L, int K, int max_len, int 
         w->dy_pk = c.take<uint16_t>((size_t)Rp * m->dff);
         w->dh = c.take<float>((size_t)Rp * d);
         w->logits = c.take<float>((size_t)Rp * round_up(m->V, 32));
+        w->ptop = c.take<float4>((size_t)Rp * (round_up(m->V, 32) / 32));
+        w->stopv = c.take<float>((size_t)Rp * 4);
         {
             int ldmax = 3 * inner;
             if (m->dff > ldmax) ldmax = m->dff;
@@ -476,6 +481,8 @@ struct DecodeCtx {
     size_t skv_stride;
     uint16_t *dq, *dx_pk, *dy_pk, *xa, *xb;
     float *dh, *logits, *rs_part, *rs_part1, *rs_part2;
+    float4* ptop;             // fused greedy tail (null: separate embed / selection launches)
+    float* stopv;
     int64_t* next_ids;
     int *unfinished, *anc, *beam_idx;
     float* beam_div;
@@ -519,8 +526,12 @@ static void decode_step(mg_model* m, const DecodeCtx& c, int t, const int* tdev,
     RowScale rs0{c.rs_part, d / 8, 1.0f / (float)d, eps};     // after the FFN output (next layer's ln0 / final norm)
     RowScale rs1{c.rs_part1, d / 8, 1.0f / (float)d, eps};    // after the self-attention output (cross-attention norm)
     RowScale rs2{c.rs_part2, d / 8, 1.0f / (float)d, eps};    // after the cross-attention output (FFN norm)
-    embed_norm_rows(c.next_ids, m->at<uint16_t>(m->tok_emb), c.dh, m->at<float>(m->dec[0].ln0), c.dx_pk, c.xa, K2, 0, R, d, m->V,
-                    counters + 3, eps, st);
+    // Fused tail (greedy batch calls): the selection kernel of step t has already left the embedding + first norm of step t + 1
+    // (the caller embeds the start token once in front of the first step); otherwise a step starts with its own embedding launch.
+    const bool fused_tail = c.ptop != nullptr;
+    if (!fused_tail)
+        embed_norm_rows(c.next_ids, m->at<uint16_t>(m->tok_emb), c.dh, m->at<float>(m->dec[0].ln0), c.dx_pk, c.xa, K2, 0, R, d, m->V,
+                        counters + 3, eps, st);
     for (size_t li = 0; li < nl; ++li) {
         const DecLayer& l = m->dec[li];
         uint16_t* sk = c.sk + li * skv_stride;
@@ -578,7 +589,12 @@ static void decode_step(mg_model* m, const DecodeCtx& c, int t, const int* tdev,
             gemm_rows_resid(r, st);
         }
     }
-    gemm_rows_splitk(c.dx_pk, m->at<uint16_t>(m->lm_head), c.logits, R, m->V, d, ldl, 0, 1, rs0, st);
+    if (fused_tail) {          // lm_head with per-workgroup top-2 partials (no fp32 logits), stop token kept apart for MinLength
+        TopOut top{c.ptop, c.stopv, {m->c.eos_token_id, -1, -1, -1}, 0};
+        gemm_rows_splitk(c.dx_pk, m->at<uint16_t>(m->lm_head), c.logits, R, m->V, d, ldl, 0, 1, rs0, st, &top);
+    } else {
+        gemm_rows_splitk(c.dx_pk, m->at<uint16_t>(m->lm_head), c.logits, R, m->V, d, ldl, 0, 1, rs0, st);
+    }
     if (m->dbg_logits && t < m->dbg_steps)
         MG_LAUNCH(capture_logits_kernel, dim3(1024), dim3(256), 0, st, (const float*)c.logits, ldl,
                   m->dbg_logits + (size_t)t * R * m->V, R, m->V);
@@ -591,7 +607,14 @@ static void decode_step(mg_model* m, const DecodeCtx& c, int t, const int* tdev,
         g.top2 = step_top2 ? (tdev ? step_top2 : step_top2 + (size_t)(t + 1) * R * 2) : nullptr;
         g.step_ctr = stream ? nullptr : counters;      // the last workgroup to finish does the step bookkeeping (no step_end launch)
         g.slots = c.slots;
-        greedy_select(g, st);
+        if (fused_tail) {
+            g.ptop = c.ptop; g.stopv = c.stopv; g.ntiles = ldl / 32;
+            g.tok_emb = m->at<uint16_t>(m->tok_emb); g.h = c.dh; g.gain = m->at<float>(m->dec[0].ln0); g.x_pk = c.dx_pk;
+            g.x2_pk = c.xa; g.x2_ld = K2; g.x2_col0 = 0; g.d = d; g.eps = eps;
+            greedy_select_fused(g, st);
+        } else {
+            greedy_select(g, st);
+        }
         if (stream) slot_refill(c.slots, c.next_ids, c.unfinished, R, st);
         if (m->dbg_forced && t + 1 < max_length)
             MG_LAUNCH(force_ids_kernel, dim3((R + 63) / 64), dim3(64), 0, st, c.next_ids, m->dbg_forced, R, max_length, t + 1);
@@ -625,6 +648,7 @@ int mg_create(const mg_config* cfg, mg_model** out) {
     m->T_cap = round_up(c.max_decode_len > 0 ? c.max_decode_len : 512, 64);
     m->tied = c.tie_word_embeddings != 0;
     { const char* e = getenv("MG_ENC_ROW_TILES"); if (e && e[0] == '0') m->row_tiles = false; }
+    { const char* e = getenv("MG_DECODE_FUSED_TAIL"); if (e && e[0] == '0') m->fused_tail = false; }
     // arena layout
     size_t off = 0;
     auto take = [&](size_t bytes) { off = align_up(off, 256); size_t o = off; off += bytes; return o; };
@@ -1128,6 +1152,14 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
     dc.beam_state = w.beam_state; dc.counters = counters;
     dc.B = B; dc.K = K; dc.R = R; dc.max_length = max_length; dc.min_length = min_length; dc.early_stopping = early_stopping;
     dc.length_penalty = length_penalty; dc.out_ids = out_ids; dc.step_top2 = step_top2; dc.live = live;
+    // greedy batch calls run the fused tail (lm_head top-2 partials -> selection + next embedding in one launch); the parity
+    // instrumentation needs the full logits / overrides the fed token, and d_model > 2048 would change the norm's summation order
+    const bool fused_tail = K == 1 && m->fused_tail && !m->dbg_logits && !m->dbg_forced && d <= 2048;
+    if (fused_tail) {
+        dc.ptop = w.ptop; dc.stopv = w.stopv;
+        embed_norm_rows(w.next_ids, m->at<uint16_t>(m->tok_emb), w.dh, m->at<float>(m->dec[0].ln0), w.dx_pk, w.xa, d + inner, 0, R, d, m->V,
+                        counters + 3, m->c.layer_norm_epsilon, st);      // the start token; later steps: greedy_select_fused
+    }
     auto decode_step = [&](int t, const int* tdev, bool time_cross) { ::decode_step(m, dc, t, tdev, time_cross, st); };
     bool graphed = false;
     const bool instrumented = m->dbg_logits || m->dbg_forced;      // by-value eager launches of the same kernels

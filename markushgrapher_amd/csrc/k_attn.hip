@@ -609,24 +609,34 @@ void attn_lists(const uint8_t* kmask, int B, int Sk, int S_cap, int* kst, uint8_
 // thousand tiles at most).
 __global__ __launch_bounds__(256) void row_tile_list_kernel(const uint8_t* kmask, int n_tiles, int* list, int* count) {
     MG_DYN_SMEM(smem);
-    unsigned char* flag = (unsigned char*)smem;
-    for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) {
+    int* base = (int*)smem;                                  // [256] live tiles in front of each thread's chunk
+    const int tid = threadIdx.x;
+    const int per = (n_tiles + 255) / 256, t0 = tid * per, t1 = (t0 + per < n_tiles) ? t0 + per : n_tiles;
+    int mine = 0;
+    for (int t = t0; t < t1; ++t) {
         const uint4* p = (const uint4*)(kmask + (size_t)t * 32);
         const uint4 a = p[0], b = p[1];
-        flag[t] = (a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w) ? 1 : 0;
+        mine += (a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w) ? 1 : 0;
+    }
+    base[tid] = mine;
+    __syncthreads();
+    if (tid == 0) {                                          // exclusive scan over the 256 chunk counts (ascending tile order)
+        int run = 0;
+        for (int i = 0; i < 256; ++i) { const int c = base[i]; base[i] = run; run += c; }
+        if (run == 0) { list[0] = 0; run = 1; }              // nothing attended anywhere: keep one tile (the GEMMs need M >= 1)
+        *count = run;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int n = 0;
-        for (int t = 0; t < n_tiles; ++t)
-            if (flag[t]) list[n++] = t;
-        if (n == 0) { list[0] = 0; n = 1; }                     // nothing attended anywhere: keep one tile (the GEMMs need M >= 1)
-        *count = n;
+    int n = base[tid];
+    for (int t = t0; t < t1; ++t) {
+        const uint4* p = (const uint4*)(kmask + (size_t)t * 32);
+        const uint4 a = p[0], b = p[1];
+        if (a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w) list[n++] = t;
     }
 }
 void row_tile_list(const uint8_t* kmask, int rows, int* list, int* count, mgStream_t stream) {
     const int n_tiles = rows >> 5;                               // rows is a multiple of 32
-    MG_LAUNCH(row_tile_list_kernel, dim3(1), dim3(256), (size_t)(n_tiles + 16), stream, kmask, n_tiles, list, count);
+    MG_LAUNCH(row_tile_list_kernel, dim3(1), dim3(256), (size_t)(256 * sizeof(int)), stream, kmask, n_tiles, list, count);
 }
 
 void attention(const AttnArgs& a_in, mgStream_t stream) {

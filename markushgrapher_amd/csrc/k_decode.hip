@@ -355,11 +355,11 @@ __global__ __launch_bounds__(GS_THREADS) void greedy_select_kernel(ArgmaxArgs a)
     const bool stream = a.slots.pos != nullptr;
     const int pos = stream ? a.slots.pos[row] + 1 : (a.pos_dev ? *a.pos_dev + a.pos : a.pos);     // column written
     const bool no_eos = a.suppress_eos || pos < a.min_len;
-    auto is_eos = [&](int i) {
-        bool e = i == a.eos;
-        for (int k = 0; k < a.n_eos_more; ++k) e = e || i == a.eos_more[k];
-        return e;
-    };
+    // stop tokens in registers (the argument block lives in device memory: no loads from it inside the scan)
+    const int e0 = a.eos, e1 = a.n_eos_more > 0 ? a.eos_more[0] : -1, e2 = a.n_eos_more > 1 ? a.eos_more[1] : -1,
+              e3 = a.n_eos_more > 2 ? a.eos_more[2] : -1;
+    const bool one_eos = a.n_eos_more == 0;
+    auto is_eos = [&](int i) { return i == e0 || (!one_eos && (i == e1 || i == e2 || i == e3)); };
     float b1 = -3.0e38f, b2 = -3.0e38f;
     int i1 = 0x7fffffff;
     const int nq = (a.V + 3) >> 2;      // rows are padded to a multiple of 32 floats, so the last float4 is readable
@@ -468,6 +468,111 @@ __global__ __launch_bounds__(64) void slot_refill_kernel(SlotTable s, int64_t* n
 }
 void slot_refill(const SlotTable& s, int64_t* next_ids, int* unfinished, int rows, mgStream_t stream) {
     MG_LAUNCH(slot_refill_kernel, dim3(1), dim3(64), 0, stream, s, next_ids, unfinished, rows);
+}
+
+// Fused tail of the greedy decode step: reduce the lm_head launch's per-workgroup top-2 partials (ArgmaxArgs::ptop) instead of
+// scanning V logits, do the row's bookkeeping exactly as greedy_select_kernel, then produce the next step's first activations
+// for the selected token (embedding row -> h, bf16(RMSNorm(h) * gain) -> x_pk, bf16(h) -> x2 window) - embed_norm_rows' work.
+// One workgroup of 256 threads per row; batch mode only (the continuous decoder refills slots between selection and embedding).
+__global__ __launch_bounds__(256) void greedy_select_fused_kernel(ArgmaxArgs a) {
+    MG_DYN_SMEM(smem);
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int pos = a.pos_dev ? *a.pos_dev + a.pos : a.pos;
+    const bool no_eos = a.suppress_eos || pos < a.min_len;
+    float b1 = -3.0e38f, b2 = -3.0e38f;
+    int i1 = 0x7fffffff;
+    const float4* pt = a.ptop + (size_t)row * a.ntiles;
+    for (int c0 = tid; c0 < a.ntiles; c0 += 4 * 256) {          // batches of independent loads (one L2 round trip per batch)
+        float4 q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u * 256;
+            q[u] = c < a.ntiles ? pt[c] : make_float4(-3.0e38f, -3.0e38f, __int_as_float(0x7fffffff), 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) top2_merge(b1, b2, i1, q[u].x, q[u].y, __float_as_int(q[u].z));
+    }
+    if (tid < 4 && !no_eos) {                                    // the stop tokens rank with everybody else unless suppressed
+        const int e = tid == 0 ? a.eos : (tid - 1 < a.n_eos_more ? a.eos_more[tid - 1] : -1);
+        if (e >= 0) top2_merge(b1, b2, i1, a.stopv[(size_t)row * 4 + tid], -3.0e38f, e);
+    }
+#pragma unroll
+    for (int step = 1; step < 64; step <<= 1) {
+        const float o1 = __shfl_xor(b1, step), o2 = __shfl_xor(b2, step);
+        const int oi = __shfl_xor(i1, step);
+        top2_merge(b1, b2, i1, o1, o2, oi);
+    }
+    float* rv = (float*)smem;                 // [4][2]
+    int* ri = (int*)(smem + 64);              // [4], then [8] = the selected token
+    if (lane == 0) { rv[w * 2] = b1; rv[w * 2 + 1] = b2; ri[w] = i1; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int ww = 1; ww < 4; ++ww) top2_merge(b1, b2, i1, rv[ww * 2], rv[ww * 2 + 1], ri[ww]);
+        const int e0 = a.eos, e1 = a.n_eos_more > 0 ? a.eos_more[0] : -1, e2 = a.n_eos_more > 1 ? a.eos_more[1] : -1, e3 = a.n_eos_more > 2 ? a.eos_more[2] : -1;
+        const int unf = a.unfinished[row];
+        const int64_t tok = unf ? (int64_t)i1 : (int64_t)a.pad;
+        a.next_ids[row] = tok;
+        ri[8] = (int)tok;
+        if (pos < a.max_len) a.out_ids[(size_t)row * a.max_len + pos] = tok;
+        const int t = (int)tok;
+        const int still = unf && !(t == e0 || t == e1 || t == e2 || t == e3);
+        a.unfinished[row] = still;
+        if (still) atomicAdd(a.n_unfinished, 1);
+        if (a.top2) {
+            float* tp = a.top2 + (a.pos_dev ? (size_t)pos * a.rows * 2 : 0);
+            tp[row * 2] = b1; tp[row * 2 + 1] = b2;
+        }
+        if (a.step_ctr) {
+            int* c = a.step_ctr;
+            __threadfence();
+            if (atomicAdd(c + 6, 1) == a.rows - 1) {
+                const int unf_total = atomicAdd(a.n_unfinished, 0);
+                *a.n_unfinished = 0;
+                c[0] = unf_total;
+                if (unf_total == 0 && c[1] < 0) c[1] = c[2];
+                c[2] += 1;
+                c[6] = 0;
+            }
+        }
+    }
+    __syncthreads();
+    // the next step's embedding + first RMSNorm for this row (embed_norm_rows_kernel, one row): thread c < d/8 owns 8 columns
+    const int tok = ri[8], d = a.d, nch = d >> 3;
+    const uint16_t* src = a.tok_emb + (size_t)tok * d;
+    float ss = 0.f;
+    for (int c = tid; c < nch; c += 256) {
+        const uint4 t = ld16(src + c * 8);
+        const float a0 = bf16lo(t.x), a1 = bf16hi(t.x), a2 = bf16lo(t.y), a3 = bf16hi(t.y);
+        const float c0 = bf16lo(t.z), c1 = bf16hi(t.z), c2 = bf16lo(t.w), c3 = bf16hi(t.w);
+        ss += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3 + c0 * c0 + c1 * c1 + c2 * c2 + c3 * c3;
+    }
+    // NOTE: embed_norm_rows_kernel sums a row in ONE wave (lane c % 64 takes chunks c, c + 64, ...; wave_sum).  The same order
+    // here: the sum of squares is over bf16 values, so regrouping could change the last bit of r and with it a rounded output.
+    float* red = (float*)(smem + 128);        // [256]
+    red[tid] = ss;
+    __syncthreads();
+    if (w == 0) {
+        float t = 0.f;
+        for (int k = lane; k < 256; k += 64) t += red[k];      // = what lane `lane` of the single-wave form accumulates (d <= 2048)
+        t = wave_sum(t);
+        if (lane == 0) red[0] = t;
+    }
+    __syncthreads();
+    const float r = rsqrtf(red[0] / (float)d + a.eps);
+    for (int c = tid; c < nch; c += 256) {
+        const uint4 t = ld16(src + c * 8);
+        const float v[8] = {bf16lo(t.x), bf16hi(t.x), bf16lo(t.y), bf16hi(t.y), bf16lo(t.z), bf16hi(t.z), bf16lo(t.w), bf16hi(t.w)};
+        const float4 g0 = *(const float4*)(a.gain + c * 8), g1 = *(const float4*)(a.gain + c * 8 + 4);
+        *(float4*)(a.h + (size_t)row * d + c * 8) = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)(a.h + (size_t)row * d + c * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        st16(a.x_pk + pk_off(row, c * 8, d),
+             make_uint4(pack_bf16(g0.x * (v[0] * r), g0.y * (v[1] * r)), pack_bf16(g0.z * (v[2] * r), g0.w * (v[3] * r)),
+                        pack_bf16(g1.x * (v[4] * r), g1.y * (v[5] * r)), pack_bf16(g1.z * (v[6] * r), g1.w * (v[7] * r))));
+        if (a.x2_pk) st16(a.x2_pk + pk_off(row, a.x2_col0 + c * 8, a.x2_ld), t);
+    }
+}
+void greedy_select_fused(const ArgmaxArgs& a, mgStream_t stream) {
+    MG_LAUNCH(greedy_select_fused_kernel, dim3(a.rows), dim3(256), 128 + 256 * sizeof(float), stream, a);
 }
 
 void greedy_select(const ArgmaxArgs& a, mgStream_t stream) {

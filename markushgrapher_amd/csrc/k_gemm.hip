@@ -1193,7 +1193,7 @@ static void gemm_rows_mt_half(const GemmArgs& a, int mt, mgStream_t stream) {
 // ---------------------------------------------------------------------------------------------------------
 template <int MT>
 __global__ __launch_bounds__(256) void gemm_rows_splitk_kernel(const uint16_t* X, const uint16_t* W, float* P, int M, int N, int K, int ldp,
-                                                          size_t slab_stride, int KS, RowScale rs) {
+                                                          size_t slab_stride, int KS, RowScale rs, TopOut top) {
     MG_DYN_SMEM(smem);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     float* rsl = (float*)(smem + 4 * 16 * 64 * sizeof(float));     // [32*MT] deferred RMSNorm scale per row
@@ -1255,7 +1255,27 @@ __global__ __launch_bounds__(256) void gemm_rows_splitk_kernel(const uint16_t* X
             v += slab[(2 * 16 + r) * 64 + lane];
             v += slab[(3 * 16 + r) * 64 + lane];
             const int m = 32 * i + acc_row(r, half);
-            if (m < M && n < N) out[(size_t)m * ldp + n] = v * rsl[m];
+            const float lg = v * rsl[m < M ? m : 0];
+            if (m < M && n < N && (!top.ptop || top.write_logits)) out[(size_t)m * ldp + n] = lg;
+            if (top.ptop) {
+                // top-2 of this row over the workgroup's 32 features (the 32 lanes of this half-wave), stop tokens apart;
+                // ties go to the lower index (torch.argmax)
+                const bool is_stop = n == top.stop[0] || n == top.stop[1] || n == top.stop[2] || n == top.stop[3];
+                if (is_stop && m < M) {
+                    const int k = n == top.stop[0] ? 0 : (n == top.stop[1] ? 1 : (n == top.stop[2] ? 2 : 3));
+                    top.stopv[(size_t)m * 4 + k] = lg;
+                }
+                float b1 = (n < N && !is_stop) ? lg : -3.0e38f, b2 = -3.0e38f;
+                int i1 = (n < N && !is_stop) ? n : 0x7fffffff;
+#pragma unroll
+                for (int st = 1; st < 32; st <<= 1) {
+                    const float o1 = __shfl_xor(b1, st), o2 = __shfl_xor(b2, st);
+                    const int oi = __shfl_xor(i1, st);
+                    if (o1 > b1 || (o1 == b1 && oi < i1)) { b2 = fmaxf(b1, o2); b1 = o1; i1 = oi; }
+                    else b2 = fmaxf(b2, o1);
+                }
+                if ((lane & 31) == 0 && m < M) top.ptop[(size_t)m * ntiles + nt] = make_float4(b1, b2, __int_as_float(i1), 0.f);
+            }
         }
         __syncthreads();
     }
@@ -1782,19 +1802,21 @@ int splitk_factor(int N, int K) {
 }
 
 void gemm_rows_splitk(const uint16_t* X, const uint16_t* W, float* P, int M, int N, int K, int ldp, size_t slab_stride, int KS,
-                      const RowScale& rs, mgStream_t stream) {
+                      const RowScale& rs, mgStream_t stream, const TopOut* top_in) {
+    TopOut top{};
+    if (top_in && KS == 1) top = *top_in;
     const int mt = (M + 31) / 32;
     const dim3 grid(((N + 31) / 32) * KS), block(256);
     const size_t sh = (size_t)4 * 16 * 64 * sizeof(float) + (size_t)32 * mt * sizeof(float);
     switch (mt) {
-        case 1: MG_LAUNCH((gemm_rows_splitk_kernel<1>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS, rs); break;
-        case 2: MG_LAUNCH((gemm_rows_splitk_kernel<2>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS, rs); break;
-        case 3: MG_LAUNCH((gemm_rows_splitk_kernel<3>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS, rs); break;
-        case 4: MG_LAUNCH((gemm_rows_splitk_kernel<4>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS, rs); break;
-        case 5: MG_LAUNCH((gemm_rows_splitk_kernel<5>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS, rs); break;
-        case 6: MG_LAUNCH((gemm_rows_splitk_kernel<6>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS, rs); break;
-        case 7: MG_LAUNCH((gemm_rows_splitk_kernel<7>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS, rs); break;
-        case 8: MG_LAUNCH((gemm_rows_splitk_kernel<8>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS, rs); break;
+        case 1: MG_LAUNCH((gemm_rows_splitk_kernel<1>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS, rs, top); break;
+        case 2: MG_LAUNCH((gemm_rows_splitk_kernel<2>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS, rs, top); break;
+        case 3: MG_LAUNCH((gemm_rows_splitk_kernel<3>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS, rs, top); break;
+        case 4: MG_LAUNCH((gemm_rows_splitk_kernel<4>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS, rs, top); break;
+        case 5: MG_LAUNCH((gemm_rows_splitk_kernel<5>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS, rs, top); break;
+        case 6: MG_LAUNCH((gemm_rows_splitk_kernel<6>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS, rs, top); break;
+        case 7: MG_LAUNCH((gemm_rows_splitk_kernel<7>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS, rs, top); break;
+        case 8: MG_LAUNCH((gemm_rows_splitk_kernel<8>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS, rs, top); break;
         default: break;
     }
 }

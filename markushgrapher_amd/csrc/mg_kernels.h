@@ -89,8 +89,19 @@ void gemm_rows_set_split(int mode);   // row-tile split policy of the decode pro
 
 // split-K decode GEMM: P[ks][m*ldp + n] (ks < KS) = partial sums over the ks-th K range; consumers add the slabs
 int splitk_factor(int N, int K);
+// lm_head form with the greedy selection started in the epilogue (KS = 1): every workgroup (32 output features) also leaves, per
+// row, the top-2 of ITS features - ptop[(m * ntiles + nt)] = {best value, second value, index of the best (int bits), -} - with the
+// stop tokens stop[0..3] (-1 = unused) left out of the ranking and their logits stored apart in stopv[m][4], so that the selection
+// kernel can apply MinLength suppression without the step position being known here.  The selection then reduces N/32 partials per
+// row instead of N logits.  write_logits = 0: the fp32 logits are not stored at all.
+struct TopOut {
+    float4* ptop;          // [M][ceil(N/32)]; null = plain projection
+    float* stopv;          // [M][4]
+    int stop[4];
+    int write_logits;
+};
 void gemm_rows_splitk(const uint16_t* X, const uint16_t* W, float* P, int M, int N, int K, int ldp, size_t slab_stride, int KS,
-                      const RowScale& rs, mgStream_t stream);
+                      const RowScale& rs, mgStream_t stream, const TopOut* top = nullptr);
 // Residual projection of the decode step with the NEXT sub-layer's RMSNorm folded in (no separate norm launch):
 //   h[m][n] += sum_k X[m][k] W[n][k];   x_pk = pack(bf16(h * gain * gscale))  (un-normalised);
 //   part[m*(N/8) + n/8] = sum over the block's 8 features of h^2  (consumers turn them into r(m), see RowScale).
@@ -306,8 +317,21 @@ struct ArgmaxArgs {
     // (counters layout: engine.hip); step_ctr[6] is the arrival counter
     int* step_ctr;
     SlotTable slots;         // continuous decoding: per-row positions / images (slots.pos == null: batch mode)
+    // fused tail (greedy_select_fused): the logits come as per-workgroup top-2 partials of the lm_head launch (TopOut), and the
+    // selected token's embedding + first RMSNorm of the next step are produced here (what embed_norm_rows does at a step's start)
+    const float4* ptop;      // [rows][ntiles]
+    const float* stopv;      // [rows][4] logits of the stop tokens (left out of the partials)
+    int ntiles;
+    const uint16_t* tok_emb; // [V][d] bf16
+    float* h;                // [rows][d] fp32 residual stream of the next step
+    const float* gain;       // first RMSNorm gain
+    uint16_t* x_pk;          // packed bf16(RMSNorm(h) * gain)
+    uint16_t* x2_pk;         // packed window: bf16(h)
+    int x2_ld, x2_col0, d;
+    float eps;
 };
 void greedy_select(const ArgmaxArgs& a, mgStream_t stream);
+void greedy_select_fused(const ArgmaxArgs& a, mgStream_t stream);
 // continuous decoding, after the selection of a step: idle slots take the next ready images of the queue (in slot order:
 // deterministic), live count / oldest live image / step counter are published for the host
 void slot_refill(const SlotTable& s, int64_t* next_ids, int* unfinished, int rows, mgStream_t stream);

@@ -246,6 +246,32 @@ def test_decode_graph_modes_are_bit_identical(be_name, fixture):
     eng.set_decode_graph(1)
 
 
+@pytest.mark.parametrize("be_name", BACKENDS)
+def test_fused_decode_tail_is_bit_identical(be_name, monkeypatch):
+    """The greedy step's fused tail (lm_head epilogue leaves per-workgroup top-2 partials, one launch selects AND embeds the next token)
+    against the separate lm_head / selection / embedding launches (MG_DECODE_FUSED_TAIL=0, also what the parity instrumentation and the
+    continuous decoder run): ids, per-step top-2 logits and lengths identical - with EOS live, with EOS suppressed by min_length (the
+    stop token's logit is kept out of the partials and re-enters in the selection), and through the min_length boundary."""
+    g = load_golden("g3_trained_tiny.npz")
+    shape, sd = _weights(g)
+    inp = _inputs(g, shape)
+    args = (inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"])
+    T = int(g["max_length"])
+    res = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("MG_DECODE_FUSED_TAIL", fused)
+        eng = make_engine(be_name, shape, sd)            # the switch is read at mg_create
+        cur = []
+        for kw in (dict(max_length=T), dict(max_length=T, min_length=T), dict(max_length=T, min_length=5), dict(max_length=3)):
+            ids, _, top2 = eng.generate(*args, return_top2=True, **kw)
+            cur += [_np(eng, ids).copy(), _np(eng, top2).copy()]
+        res.append(cur)
+    monkeypatch.delenv("MG_DECODE_FUSED_TAIL")
+    assert np.array_equal(res[0][0], g["greedy_ids"])
+    for a_, b_ in zip(*res):
+        assert a_.shape == b_.shape and np.array_equal(a_, b_)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # larger shapes (GPU only: the emulator is for index checks on tiny shapes)
 # ---------------------------------------------------------------------------------------------------------
