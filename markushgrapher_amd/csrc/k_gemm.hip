@@ -1239,6 +1239,7 @@ __global__ __launch_bounds__(256) void gemm_rows_splitk_kernel(const uint16_t* X
         for (int i = 0; i < MT; ++i) acc[i] = mfma32(ld16(xp + ((size_t)i * kt16 + kt) * TILE_BYTES), wf, acc[i]);
     }
     float* slab = (float*)smem;
+    float* tl = (float*)(smem + 4 * 16 * 64 * sizeof(float) + 32 * MT * sizeof(float));      // [4 waves][8 rows][33] (TopOut only)
     float* out = P + (size_t)ks * slab_stride;
     const int half = lane >> 5, n = nt * 32 + (lane & 31);
 #pragma unroll
@@ -1258,23 +1259,33 @@ __global__ __launch_bounds__(256) void gemm_rows_splitk_kernel(const uint16_t* X
             const float lg = v * rsl[m < M ? m : 0];
             if (m < M && n < N && (!top.ptop || top.write_logits)) out[(size_t)m * ldp + n] = lg;
             if (top.ptop) {
-                // top-2 of this row over the workgroup's 32 features (the 32 lanes of this half-wave), stop tokens apart;
-                // ties go to the lower index (torch.argmax)
+                // stop tokens are kept out of the ranking, their logits stored apart; the row's 32 values of this workgroup go to
+                // LDS (one padded line per row: this wave finishes 8 rows = 4 registers x 2 half-waves)
                 const bool is_stop = n == top.stop[0] || n == top.stop[1] || n == top.stop[2] || n == top.stop[3];
                 if (is_stop && m < M) {
                     const int k = n == top.stop[0] ? 0 : (n == top.stop[1] ? 1 : (n == top.stop[2] ? 2 : 3));
                     top.stopv[(size_t)m * 4 + k] = lg;
                 }
-                float b1 = (n < N && !is_stop) ? lg : -3.0e38f, b2 = -3.0e38f;
-                int i1 = (n < N && !is_stop) ? n : 0x7fffffff;
+                tl[(w * 8 + j * 2 + half) * 33 + (lane & 31)] = (n < N && !is_stop) ? lg : -3.0e38f;
+            }
+        }
+        if (top.ptop) {
+            // top-2 per row: lane t < 8 of the wave scans row t's 32 values serially (ascending index: a tie keeps the lower one,
+            // as torch.argmax) - 32 LDS reads instead of 5 rounds of cross-lane exchanges per row
+            __syncthreads();            // (the 8 rows a wave scans were written by that wave; a block barrier keeps the emulator build simple)
+            if (lane < 8) {
+                const float* rowv = tl + (w * 8 + lane) * 33;
+                float b1 = -3.0e38f, b2 = -3.0e38f;
+                int i1 = 0x7fffffff;
 #pragma unroll
-                for (int st = 1; st < 32; st <<= 1) {
-                    const float o1 = __shfl_xor(b1, st), o2 = __shfl_xor(b2, st);
-                    const int oi = __shfl_xor(i1, st);
-                    if (o1 > b1 || (o1 == b1 && oi < i1)) { b2 = fmaxf(b1, o2); b1 = o1; i1 = oi; }
-                    else b2 = fmaxf(b2, o1);
+                for (int k = 0; k < 32; ++k) {
+                    const float x = rowv[k];
+                    if (x > b1) { b2 = b1; b1 = x; i1 = k; }
+                    else b2 = fmaxf(b2, x);
                 }
-                if ((lane & 31) == 0 && m < M) top.ptop[(size_t)m * ntiles + nt] = make_float4(b1, b2, __int_as_float(i1), 0.f);
+                const int jj = lane >> 1, hh = lane & 1;
+                const int m = 32 * i + acc_row(w * 4 + jj, hh);
+                if (m < M) top.ptop[(size_t)m * ntiles + nt] = make_float4(b1, b2, __int_as_float(b1 > -3.0e38f ? nt * 32 + i1 : 0x7fffffff), 0.f);
             }
         }
         __syncthreads();
@@ -1807,7 +1818,7 @@ void gemm_rows_splitk(const uint16_t* X, const uint16_t* W, float* P, int M, int
     if (top_in && KS == 1) top = *top_in;
     const int mt = (M + 31) / 32;
     const dim3 grid(((N + 31) / 32) * KS), block(256);
-    const size_t sh = (size_t)4 * 16 * 64 * sizeof(float) + (size_t)32 * mt * sizeof(float);
+    const size_t sh = (size_t)4 * 16 * 64 * sizeof(float) + (size_t)32 * mt * sizeof(float) + (top.ptop ? (size_t)4 * 8 * 33 * sizeof(float) : 0);
     switch (mt) {
         case 1: MG_LAUNCH((gemm_rows_splitk_kernel<1>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS, rs, top); break;
         case 2: MG_LAUNCH((gemm_rows_splitk_kernel<2>), grid, block, sh, stream, X, W, P, M, N, K, ldp, slab_stride, KS, rs, top); break;

@@ -311,7 +311,7 @@ def test_large_shape_fixture_g2_on_gpu():
     # (probe rows at attended positions: rows of positions that are not attended - here the slots of dropped patches at the end -
     #  are unspecified in mg_encode's output; the encoder skips whole 32-row tiles of them, include/mgrapher.h)
     att = valid[g["enc_rows"]]
-    assert att.sum() >= 12
+    assert att.sum() >= 10
     err = np.abs(enc[g["enc_rows"]] - g["enc_probe"])[att]
     assert err.max() < ENC_MAX and err.mean() < ENC_MEAN, (err.max(), err.mean())
     s_abs = np.abs(enc[valid]).astype(np.float64).sum()
