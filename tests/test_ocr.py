@@ -396,3 +396,57 @@ def test_ocr_bench_batches_at_smoldocling_geometry(B):
                 break                                              # the continuation of this row legitimately differs from here
             ids_eq += 1
     assert steps >= 3 * len(rows) and ids_eq >= 2 * len(rows), (steps, ids_eq)
+
+
+def test_shape_from_hf_config_smoldocling_written_by_stock(tmp_path):
+    """A SmolDocling-256M-style config.json written by the stock Idefics3Config (what a ChemicalOCR checkpoint directory holds, geometry
+    INFERRED) -> shape_from_hf_config gives the preset every OCR bench / test of this repository runs on."""
+    import dataclasses
+    from transformers import Idefics3Config
+    from markushgrapher_amd.ocr import shape_from_hf_config
+    s = PRESETS["smoldocling"]
+    cfg = Idefics3Config(
+        vision_config=dict(hidden_size=s.v_hidden, intermediate_size=s.v_inter, num_hidden_layers=s.v_layers, num_attention_heads=s.v_heads,
+                           image_size=s.image_size, patch_size=s.patch_size, num_channels=3, hidden_act="gelu_pytorch_tanh", layer_norm_eps=s.v_eps),
+        text_config=dict(model_type="llama", hidden_size=s.t_hidden, intermediate_size=s.t_inter, num_hidden_layers=s.t_layers,
+                         num_attention_heads=s.t_heads, num_key_value_heads=s.t_kv_heads, vocab_size=s.vocab, rms_norm_eps=s.rms_eps,
+                         max_position_embeddings=8192, rope_theta=s.rope_theta, tie_word_embeddings=s.tie_word_embeddings,
+                         pad_token_id=s.pad_token_id, bos_token_id=0, eos_token_id=s.eos_token_id, head_dim=64),
+        scale_factor=s.scale_factor, image_token_id=s.image_token_id, pad_token_id=s.pad_token_id, tie_word_embeddings=s.tie_word_embeddings)
+    cfg.save_pretrained(str(tmp_path))
+    got = shape_from_hf_config(str(tmp_path))
+    assert dataclasses.asdict(got) == dataclasses.asdict(s)
+    assert got.image_seq_len == 64 and got.patches == 1024
+
+
+@pytest.mark.gpu
+def test_ocr_max_new_tokens_4096_capacity():
+    """The reference's setting, generate(max_new_tokens=4096) (ref: ocr/chemical_ocr.py:381-385): 4096 new tokens behind a 16-token prompt -
+    KV caches of 4112 positions, the rotation table beyond 4096, 4095 graph replays.  Random weights cannot be compared that far (the
+    first near-tie parts two runs), so the tiny model's lm_head is SCRIPTED to walk a fixed cycle of ~300 tokens (ocr_shapes.
+    scripted_state_dict, margins ~100 x the bf16 noise): every one of the 3 x 4096 ids is known in advance.  The oracle confirms the
+    script on the first 48 steps."""
+    import dataclasses
+    import torch
+    from markushgrapher_amd import synth
+    from markushgrapher_amd.ocr_shapes import scripted_prompts, scripted_state_dict
+    from oracle.ocr_oracle import OcrOracle
+    s = dataclasses.replace(PRESETS["tiny"], eos_token_id=1)
+    cyc = [i for i in range(3, s.vocab) if i not in (s.eos_token_id, s.pad_token_id, s.image_token_id)][:296]
+    starts = [cyc[-1], cyc[99], cyc[199]]                       # three rows enter the cycle at different points
+    sd = scripted_state_dict(s, [cyc + [s.eos_token_id]], [cyc[-1]])
+    head = sd["lm_head.weight"]
+    head[s.eos_token_id] = synth.round_bf16(synth.uniform_pm1("cap/eos", head[0].shape, 1) * np.float32(0.05))    # the cycle never ends
+    ids = scripted_prompts(s, [cyc], starts, 10)
+    _, pix = synth_inputs(s, 3)
+    n = 4096
+    want = np.array([[cyc[(cyc.index(st) + 1 + t) % len(cyc)] for t in range(n)] for st in starts])
+    with torch.no_grad():
+        ref = OcrOracle(s, sd).generate(ids, pix, 48).numpy()
+    assert np.array_equal(ref, want[:, :48])
+    eng = make_ocr("hip", s, sd)
+    new, _ = eng.generate(ids, pix, n)
+    new = eng.mem.numpy(new)
+    assert new.shape == (3, n)
+    bad = np.nonzero(new != want)
+    assert len(bad[0]) == 0, (bad[0][:5], bad[1][:5])
