@@ -115,7 +115,7 @@ def ocr_stage_run(B=32, new_tokens=256):
                       "greedy, EOS impossible; vision tower / prefill: one kernel per operation with fp32 intermediates; decode step: 4 launches per layer at one row tile (rotary grouped-query attention + cache append, o_proj + norm, gate/up + SwiGLU, [down_proj + norm | next QKV]), replayed as a HIP graph"}
 
 
-def configs4_run(eng, B, new_tokens, ocr_pages=128, n_scripts=32):
+def configs4_run(eng, B, new_tokens, ocr_pages=128, n_scripts=32, ocr_slots=0):
     """BASELINE configs[4] measured as ONE loop on one GPU (markushgrapher_amd/pipeline.py): 128 IP5-M-shaped pages (1024 px u8 crops,
     resident) -> device LANCZOS -> ChemicalOCR (SmolDocling-256M geometry, 128 pages per call) -> text -> cells -> tokens -> VTL encoder +
     256-token greedy decode (continuous decoder, 32 slots).  No OCR checkpoint / tokenizer model exists offline: the OCR model's lm_head
@@ -137,9 +137,10 @@ def configs4_run(eng, B, new_tokens, ocr_pages=128, n_scripts=32):
     prompts = np.concatenate([scripted_prompts(s, chains, starts)] * (ocr_pages // n_scripts), axis=0)
     longest = max(len(c) for c in chains)
     pipe = Configs4Pipeline(ocr, eng, make_udop_tokenizer(), lambda row: detokenize(id_to_piece, row, s.eos_token_id, s.pad_token_id), prompts,
-                            ocr_max_new_tokens=longest + 8, max_length=new_tokens + 1, min_length=new_tokens + 1, continuous=True, main_batch=B)
-    pages = torch.from_numpy(synth.synth_pages_u8(ocr_pages // 4, 1024, synth.BENCH_SEED)).cuda()
-    pages = torch.cat([pages] * 4, dim=0)
+                            ocr_max_new_tokens=longest + 8, max_length=new_tokens + 1, min_length=new_tokens + 1, continuous=True, main_batch=B,
+                            ocr_slots=ocr_slots)
+    pages = torch.from_numpy(synth.synth_pages_u8(32, 1024, synth.BENCH_SEED)).cuda()
+    pages = torch.cat([pages] * (ocr_pages // 32), dim=0)
 
     def clock():
         torch.cuda.synchronize()
@@ -152,10 +153,11 @@ def configs4_run(eng, B, new_tokens, ocr_pages=128, n_scripts=32):
     L = res.attention_mask.sum(axis=1)
     return {"pages_per_s": round(ocr_pages / dt, 2), "pages": ocr_pages, "ms_total": round(dt * 1e3, 1),
             "ocr_s": round(res.timings["ocr_s"], 3), "host_s": round(res.timings["host_s"], 3), "main_s": round(res.timings["main_s"], 3),
+            "ocr_form": (f"queue form, {ocr_slots} decode rows, {res.timings.get('ocr_steps')} steps" if ocr_slots else "batch form: every call walks to its longest page"),
             "ocr_steps_longest_page": longest, "ocr_tokens_mean": round(float(np.mean([len(c) for c in chains])), 1),
             "cells_per_page": [int(n_cells.min()), int(n_cells.max())], "vtl_text_tokens_mean": round(float(L.mean()), 1),
             "vtl_text_tokens_max": int(L.max()), "ocr_strings_as_scripted": f"{ok}/{ocr_pages}", "main_new_tokens": new_tokens,
-            "config": "configs[4] as one loop on one GPU: 128 pages per OCR call (SmolDocling-256M geometry, scripted lm_head so that real cell "
+            "config": f"configs[4] as one loop on one GPU: {ocr_pages} pages per OCR call (SmolDocling-256M geometry, scripted lm_head so that real cell "
                       "strings flow), host text stage (stock UdopTokenizer class, stand-in vocabulary), VTL stage = headline model through the "
                       "continuous decoder (32 slots, forced 256 new tokens); preprocessing, both models and the host stage inside the timed region"}
 
@@ -455,7 +457,9 @@ def main():
             extra["ocr_stage"] = ocr_stage_run()
             if not args.no_cpu_baseline:
                 extra["ocr_stage"]["cpu_baseline"] = ocr_cpu_baseline()
-            extra["configs4_end_to_end_1gpu"] = configs4_run(eng, B, new_tokens)
+            extra["configs4_end_to_end_1gpu_batch_ocr"] = configs4_run(eng, B, new_tokens)
+            # the same loop with the OCR stage's queue form and a longer queue (512 pages, 128 OCR decode rows)
+            extra["configs4_end_to_end_1gpu"] = configs4_run(eng, B, new_tokens, ocr_pages=512, ocr_slots=128)
         out = {
             "metric": METRIC, "value": round(world * B * args.steps / dt, 3), "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),

@@ -294,6 +294,17 @@ int mg_ocr_generate(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, co
                     const int32_t* patch_pos, const uint8_t* patch_mask, int B, int n_img, int L, int max_new_tokens, int64_t* out_ids,
                     int* out_cols_host, float* step_logits, int capture_steps);
 
+/* Queue form of mg_ocr_generate (continuous decoding): N pages, `slots` decode rows (<= 256).  Vision tower + prompt prefill of all
+ * pages first (chunk <= 256 pages per pass) into per-page KV caches, each prefill selecting its page's first token; then a row whose
+ * page emits a stop token / reaches max_new_tokens takes the next page (a pointer change: the cache is already there), so the
+ * call runs sum(lengths) / slots steps instead of walking every row to the longest page.  Per-page ids equal mg_ocr_generate's.
+ * out_ids [N][max_new_tokens] i64 (pad after the stop token), out_len [N] i32 (device), *steps_host decode steps (nullable).
+ * Same input contract as mg_ocr_generate (equal prompt length L and n_img frames for every page).  SYNCHRONISES. */
+int mg_ocr_stream_workspace_bytes(const mg_ocr_model* m, int N, int n_img, int L, int max_new_tokens, int slots, int chunk, size_t* out_bytes);
+int mg_ocr_generate_stream(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* input_ids, const float* pixel_values,
+                           const int32_t* patch_pos, const uint8_t* patch_mask, int N, int n_img, int L, int max_new_tokens, int slots, int chunk,
+                           int64_t* out_ids, int32_t* out_len, long* steps_host);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,9 +33,11 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a, long
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int sub = lane & 7, ks = lane >> 3;
     const int owner = blockIdx.x / a.H, h = blockIdx.x - owner * a.H;
-    if constexpr (G == 1) { if (a.live && a.live[owner] == 0) return; }       // finished row (whole workgroup: uniform)
-    const int tcur = a.pos_rows ? a.pos_rows[owner] : (a.t_dev ? *a.t_dev + a.t_off : a.t);
-    const int kvo = (XA && a.kv_owner) ? a.kv_owner[owner] : owner;       // cross form: the K/V stream this row reads (pool entry)
+    if constexpr (G == 1 || ROPE) { if (a.live && a.live[owner] == 0) return; }       // finished / idle row (whole workgroup: uniform)
+    const int tcur = a.pos_rows ? a.pos_rows[owner] + a.t_off : (a.t_dev ? *a.t_dev + a.t_off : a.t);
+    // the K/V stream this row reads (and, for self-attention, appends to): a pool entry of the continuous decoders (cross form: the
+    // image's encoder K/V; rotary form: the page's own cache), else the row itself
+    const int kvo = a.kv_owner ? a.kv_owner[owner] : owner;
     const int nkeys_all = XA ? a.len[kvo] : ((a.t_dev || a.pos_rows) ? tcur + 1 : a.n_keys);
     // with an in-kernel append the newest key (position t) comes from registers, the cache holds [0, t)
     const bool app0 = ROPE || ((G == 1) && a.qkv.P && a.self_append);
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a, long
         const float4 v0 = *(const float4*)vb, v1 = *(const float4*)(vb + 4);
         vnew = make_uint4(pack_bf16(v0.x * r, v0.y * r), pack_bf16(v0.z * r, v0.w * r), pack_bf16(v1.x * r, v1.y * r), pack_bf16(v1.z * r, v1.w * r));
         if (w == 0 && ks == 0) {
-            const size_t off = (((size_t)owner * a.H + h) * (size_t)a.cap + (size_t)tcur) * 64 + sub * 8;
+            const size_t off = (((size_t)kvo * a.H + h) * (size_t)a.cap + (size_t)tcur) * 64 + sub * 8;
             st16(a.Kc_w + off, knew);
             st16(a.Vc_w + off, vnew);
         }
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a, long
         for (int u = 0; u < U; ++u) {
             int kc = kb + u * 8 + ks;
             kc = kc < nkeys ? kc : nkeys - 1;
-            const int prow = XA ? kvo : (a.anc ? a.anc[(size_t)kc * a.rows + owner] : owner);
+            const int prow = (!XA && a.anc) ? a.anc[(size_t)kc * a.rows + owner] : kvo;
             const size_t off = (((size_t)prow * a.H + h) * (size_t)a.cap + (size_t)kc) * 64 + sub * 8;
             kv[u] = (NW >= 8) ? ld16_stream(a.Kc + off) : ld16(a.Kc + off);
             vv[u] = (NW >= 8) ? ld16_stream(a.Vc + off) : ld16(a.Vc + off);
@@ -451,12 +453,21 @@ __global__ __launch_bounds__(64) void slot_refill_kernel(SlotTable s, int64_t* n
     const int ready = c[5];
     int n_live = 0, oldest = 0x7fffffff;
     for (int r = 0; r < rows; ++r) {
-        if (!unfinished[r] && head < ready) {
+        while (!unfinished[r] && head < ready) {
             const int i = head++;
+            int64_t tok = (int64_t)s.start_id;
+            if (s.first_tok) {
+                // the sequence's first token was selected by its prefill (column 0 is written): it may already be a stop token
+                tok = s.first_tok[i];
+                const int t = (int)tok;
+                bool stop = s.max_len <= 1;
+                for (int k = 0; k < s.n_stop; ++k) stop = stop || t == s.stop[k];
+                if (stop) { s.out_len[i] = 1; c[1] += 1; continue; }
+            }
             s.img[r] = i;
             s.pool[r] = i % s.pool_cap;
             s.pos[r] = 0;
-            next_ids[r] = (int64_t)s.start_id;
+            next_ids[r] = tok;
             unfinished[r] = 1;
         }
         if (unfinished[r]) { ++n_live; oldest = s.img[r] < oldest ? s.img[r] : oldest; }

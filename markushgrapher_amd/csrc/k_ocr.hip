@@ -301,6 +301,21 @@ void ocr_pack_aug(const float* W, const float* bias, float scale, uint16_t* dst,
 void ocr_init(int64_t* out_ids, int* unfinished, int* counters, int rows, int max_new, int64_t pad, mgStream_t st) {
     MG_LAUNCH(ocr_init_kernel, dim3(rows), dim3(256), 0, st, out_ids, unfinished, counters, rows, max_new, pad);
 }
+__global__ __launch_bounds__(256) void ocr_slots_init_kernel(int* unfinished, int* pos, int* img, int* pool, int64_t* next_ids, int slots, int* ctr, int N) {
+    for (int r = threadIdx.x; r < slots; r += blockDim.x) { unfinished[r] = 0; pos[r] = 0; img[r] = -1; pool[r] = 0; next_ids[r] = 0; }
+    if (threadIdx.x == 0) ctr[8] = N;
+}
+__global__ __launch_bounds__(256) void ocr_fill_ints_kernel(int* p, int v, int n) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) p[i] = v;
+}
+__global__ void ocr_add_int_kernel(int* dst, const int* src) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst += *src; }
+__global__ void ocr_set_int_kernel(int* dst, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = v; }
+void ocr_slots_init(int* unfinished, int* pos, int* img, int* pool, int64_t* next_ids, int slots, int* ctr, int N, mgStream_t st) {
+    MG_LAUNCH(ocr_slots_init_kernel, dim3(1), dim3(256), 0, st, unfinished, pos, img, pool, next_ids, slots, ctr, N);
+}
+void ocr_fill_ints(int* p, int v, int n, mgStream_t st) { MG_LAUNCH(ocr_fill_ints_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, st, p, v, n); }
+void ocr_add_int(int* dst, const int* src, mgStream_t st) { MG_LAUNCH(ocr_add_int_kernel, dim3(1), dim3(64), 0, st, dst, src); }
+void ocr_set_int(int* dst, int v, mgStream_t st) { MG_LAUNCH(ocr_set_int_kernel, dim3(1), dim3(64), 0, st, dst, v); }
 void ocr_row_maps(int* last_rows, int* all_rows, uint8_t* key_mask, int B, int T, int T_cap, mgStream_t st) {
     const int g = grid_for((size_t)B * T_cap);
     MG_LAUNCH(last_rows_kernel, dim3(g), dim3(256), 0, st, last_rows, B, T, T_cap);

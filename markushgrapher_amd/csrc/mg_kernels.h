@@ -267,8 +267,9 @@ struct AttnStepArgs {
     // the rotation of position t (cs: [positions][64] = cos[32] | sin[32]), q * qscale, rounds to bf16, appends k, v to the cache
     // [rows][H][cap][64] and attends over [0, t] for the group's query heads in one pass over the cache.  qkv == null: not used.
     struct Rope { const float* qkv; int ld; const float* cs; RowScale rs; float qscale; } rope;
-    const int* pos_rows;      // continuous decoding (group 1): the row's own position t (self: keys [0, t], bias by t - j); overrides t / t_dev
-    const int* kv_owner;      // continuous decoding, cross form: entry of the K/V pool that row `owner` reads (len is indexed by it too)
+    const int* pos_rows;      // continuous decoding: the row's own position t = pos_rows[row] + t_off (self: keys [0, t], bias by t - j); overrides t / t_dev
+    const int* kv_owner;      // continuous decoding: entry of the K/V pool that row `owner` reads - cross form: the image's stream (len is
+                              // indexed by it too); rotary form: the page's own cache, which the row also appends to
     const int* live;          // group == 1 only, nullable: rows with live[row] == 0 (finished: they emit pad whatever their
                               // logits are, gen:2927-2937) are skipped - their K/V streams are not read.
                               // INVARIANT this relies on: a skipped row's context columns keep stale values, so everything
@@ -297,6 +298,10 @@ struct SlotTable {
     int* out_len;      // [N] valid columns of every finished image
     int pool_cap;      // entries of the K/V pool (image i lives in entry i % pool_cap)
     int start_id;
+    // ChemicalOCR queue form: a sequence enters a slot with the token its PREFILL selected (column 0 already written) instead of a
+    // start token; one that began with a stop token (or max_len 1) is finished before it ever takes a slot
+    const int64_t* first_tok;   // [N], null = start_id
+    int n_stop, stop[4], max_len;
 };
 struct ArgmaxArgs {
     const float* logits;     // [rows][ldl]

@@ -18,6 +18,10 @@ void ocr_rope_table(float* cs, int positions, float theta, mgStream_t st);
 void ocr_silu_mul_rows(const float* in, const RowScale& rs, uint16_t* y_pk, int M, int I, mgStream_t st);
 void ocr_pack_aug(const float* W, const float* bias, float scale, uint16_t* dst, int row0, int N, int K, int Kaug, int Nfill, int rstride, mgStream_t st);
 void ocr_init(int64_t* out_ids, int* unfinished, int* counters, int rows, int max_new, int64_t pad, mgStream_t st);
+void ocr_slots_init(int* unfinished, int* pos, int* img, int* pool, int64_t* next_ids, int slots, int* ctr, int N, mgStream_t st);
+void ocr_fill_ints(int* p, int v, int n, mgStream_t st);
+void ocr_add_int(int* dst, const int* src, mgStream_t st);
+void ocr_set_int(int* dst, int v, mgStream_t st);
 void ocr_row_maps(int* last_rows, int* all_rows, uint8_t* key_mask, int B, int T, int T_cap, mgStream_t st);
 // engine.hip: sets the thread-local message mg_last_error() returns
 int fail_msg(int code, const char* msg);

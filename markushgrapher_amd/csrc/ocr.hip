@@ -80,14 +80,19 @@ struct mg_ocr_model {
     bool graph_active = false;
     struct Key { const void *ws, *out, *stream; int B, n_img, L, max_new; bool operator==(const Key& o) const { return ws == o.ws && out == o.out && stream == o.stream && B == o.B && n_img == o.n_img && L == o.L && max_new == o.max_new; } } gkey{};   // n_img: the text-side buffers are carved behind the vision buffers
     bool gvalid = false;
+    struct SKey { const void *ws, *out, *stream; int N, slots, L, max_new; bool operator==(const SKey& o) const { return ws == o.ws && out == o.out && stream == o.stream && N == o.N && slots == o.slots && L == o.L && max_new == o.max_new; } } skey{};
+    bool svalid = false;
 #ifndef MG_EMU
+    hipGraphExec_t sexec = nullptr;
     hipGraphExec_t gexec = nullptr;
     hipStream_t own_stream = nullptr;
     hipEvent_t fork_ev = nullptr;
     void greset() { if (gexec) (void)hipGraphExecDestroy(gexec); gexec = nullptr; gvalid = false; }
-    ~mg_ocr_model() { greset(); if (own_stream) (void)hipStreamDestroy(own_stream); if (fork_ev) (void)hipEventDestroy(fork_ev); }
+    void sreset() { if (sexec) (void)hipGraphExecDestroy(sexec); sexec = nullptr; svalid = false; }
+    ~mg_ocr_model() { greset(); sreset(); if (own_stream) (void)hipStreamDestroy(own_stream); if (fork_ev) (void)hipEventDestroy(fork_ev); }
 #else
     void greset() { gvalid = false; }
+    void sreset() { svalid = false; }
 #endif
     template <typename T> T* at(size_t off) const { return (T*)(arena + off); }
     const float* rawp(const std::string& k) const { return (const float*)(arena + raw.at(k).off); }
@@ -246,7 +251,10 @@ void prefill(const mg_ocr_model* m, const Ws& w, const int64_t* ids, const float
 // Runs on the decode path's deferred-RMSNorm kernels: the residual projections
 // (o_proj, down_proj) leave bf16(h * gain_next) un-normalised plus per-row partial sums of h^2, and the consumers of the
 // projections that read it (rotary / cache kernel, SiLU kernel, lm_head) apply r(row) = rsqrt(mean h^2 + eps) themselves.
-void decode_step(const mg_ocr_model* m, const Ws& w, int B, int pos, const int* pos_dev, int cap, mgStream_t st) {
+// q != null (queue form, mg_ocr_generate_stream): the B rows are SLOTS - row r decodes page q->pool[r] at its own position
+// pos + q->pos[r] and reads / appends to that page's cache; idle slots are skipped by the attention launches.
+struct SlotView { const int* pos; const int* pool; const int* live; };
+void decode_step(const mg_ocr_model* m, const Ws& w, int B, int pos, const int* pos_dev, int cap, mgStream_t st, const SlotView* q = nullptr) {
     const mg_ocr_config& c = m->c;
     const int td = c.t_hidden, ti = c.t_inter, H = c.t_heads, KV = c.t_kv_heads, K2 = td + ti;
     const RowScale none{};
@@ -270,6 +278,7 @@ void decode_step(const mg_ocr_model* m, const Ws& w, int B, int pos, const int* 
         AttnStepArgs s{};         // rotary embedding, cache append and grouped-query attention over [0, pos] in one launch
         s.Kc = Kc; s.Vc = Vc; s.Kc_w = Kc; s.Vc_w = Vc; s.ctx = w.ctx; s.rows = B; s.H = KV; s.group = H / KV; s.cap = cap; s.n_keys = pos + 1; s.t = pos;
         s.t_dev = pos_dev; s.t_off = pos;
+        if (q) { s.pos_rows = q->pos; s.kv_owner = q->pool; s.live = q->live; }
         s.rope.qkv = w.qkv; s.rope.ld = m->qkvn; s.rope.cs = m->at<float>(m->rope_cs); s.rope.rs = i == 0 ? none : rs_a;
         s.rope.qscale = 0.125f;
         attention_step(s, st);
@@ -611,6 +620,170 @@ int mg_ocr_generate(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, co
     if (rc != MG_OK) return rc;
     if (host_flag[3]) return failf(MG_E_INPUT, "mg_ocr_generate: %d bad inputs (token id outside the vocabulary, or a sequence whose <image> count differs from n_img * %d)", host_flag[3], m->T_img);
     *out_cols_host = host_flag[1] >= 0 ? host_flag[1] + 1 : steps;
+    return MG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Queue form of generate (continuous decoding, as mg_generate_stream for the main model): N pages, `slots` decode rows.  The
+// vision tower + prompt prefill run first, `chunk` pages at a time, into per-PAGE KV caches [layer][N][kv heads][cap][64] (29 MB
+// per page at the SmolDocling geometry with 1 200 positions: 512 pages = 15 GB of the 288 GB), each prefill also selecting its
+// page's first token; then `slots` rows work through the pages: a row whose page emits a stop token (or max_new_tokens) takes the
+// next page - a pointer change in the slot table, its cache is already there.  A call of the batch form walks every row to the
+// longest page's length (OCR outputs of 10-120 cells differ by 10x); here the step count is sum(lengths) / slots.  Greedy ids per
+// page equal the batch form's (rows are independent).  out_ids [N][max_new_tokens] (pad after the stop token), out_len [N] device.
+int mg_ocr_stream_workspace_bytes(const mg_ocr_model* m, int N, int n_img, int L, int max_new_tokens, int slots, int chunk, size_t* out_bytes) {
+    if (!m || !out_bytes || N < 1 || slots < 1 || chunk < 1) return failf(MG_E_ARG, "mg_ocr_stream_workspace_bytes: bad argument");
+    Ws a, b;
+    carve(m, nullptr, chunk, n_img, L, 0, false, &a);
+    carve(m, nullptr, slots, 0, 1, 0, false, &b);
+    const int cap = round_up(L + max_new_tokens, 64);
+    const size_t kv = (size_t)N * m->c.t_kv_heads * cap * 64 * m->c.t_layers * sizeof(uint16_t);
+    *out_bytes = align_up(a.total, 256) + align_up(b.total, 256) + 2 * align_up(kv, 256) + align_up((size_t)N * 8, 256) + 8 * 4096;
+    return MG_OK;
+}
+
+int mg_ocr_generate_stream(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* input_ids, const float* pixel_values,
+                           const int32_t* patch_pos, const uint8_t* patch_mask, int N, int n_img, int L, int max_new_tokens, int slots, int chunk,
+                           int64_t* out_ids, int32_t* out_len, long* steps_host) {
+    int rc = check_args(m, chunk < N ? chunk : N, n_img, L, "mg_ocr_generate_stream");
+    if (rc != MG_OK) return rc;
+    if (N < 1 || slots < 1 || slots > 256 || chunk < 1 || chunk > 256) return failf(MG_E_SHAPE, "mg_ocr_generate_stream: N >= 1, slots and chunk in [1, 256]");
+    if (max_new_tokens < 1 || !out_ids || !out_len) return failf(MG_E_ARG, "mg_ocr_generate_stream: bad output arguments");
+    if (L + max_new_tokens > mg_ocr_model::MAX_POS) return failf(MG_E_SHAPE, "mg_ocr_generate_stream: %d + %d positions exceed %d", L, max_new_tokens, mg_ocr_model::MAX_POS);
+    if ((patch_pos == nullptr) != (patch_mask == nullptr)) return failf(MG_E_ARG, "mg_ocr_generate_stream: patch_pos and patch_mask go together");
+    size_t need = 0;
+    mg_ocr_stream_workspace_bytes(m, N, n_img, L, max_new_tokens, slots, chunk, &need);
+    if (!ws || ws_bytes < need) return failf(MG_E_WORKSPACE, "mg_ocr_generate_stream: workspace %zu < %zu bytes", ws_bytes, need);
+    mgStream_t st = (mgStream_t)stream;
+#ifndef MG_EMU
+    if (m->use_graph == 1 && st == nullptr) {
+        if (!m->own_stream && hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking) != hipSuccess) m->own_stream = nullptr;
+        if (!m->fork_ev && hipEventCreateWithFlags(&m->fork_ev, hipEventDisableTiming) != hipSuccess) m->fork_ev = nullptr;
+        if (m->own_stream && m->fork_ev && hipEventRecord(m->fork_ev, st) == hipSuccess && hipStreamWaitEvent(m->own_stream, m->fork_ev, 0) == hipSuccess)
+            st = m->own_stream;
+    }
+#endif
+    const mg_ocr_config& c = m->c;
+    const int cap = round_up(L + max_new_tokens, 64), T_cap = round_up(L, 64);
+    // workspace: [prefill chunk | decode rows | K pages | V pages | first tokens | slot table]
+    char* base = (char*)ws;
+    Ws wp, wd;
+    carve(m, base, chunk, n_img, L, 0, false, &wp);
+    base += align_up(wp.total, 256);
+    carve(m, base, slots, 0, 1, 0, false, &wd);
+    base += align_up(wd.total, 256);
+    const size_t page_kv = (size_t)c.t_kv_heads * cap * 64;              // elements of one page's keys (or values) in one layer
+    const size_t kv_layer = (size_t)N * page_kv;
+    uint16_t* Kbig = (uint16_t*)base; base += align_up(kv_layer * c.t_layers * sizeof(uint16_t), 256);
+    uint16_t* Vbig = (uint16_t*)base; base += align_up(kv_layer * c.t_layers * sizeof(uint16_t), 256);
+    int64_t* first_tok = (int64_t*)base; base += align_up((size_t)N * 8, 256);
+    int* spos = (int*)base; base += 4096;
+    int* simg = (int*)base; base += 4096;
+    int* spool = (int*)base; base += 4096;
+    int* sctr = (int*)base; base += 4096;
+    int* scratch_unf = (int*)base; base += 4096;          // prefill-side selection: flags / counter it needs but nobody reads
+    int* err = (int*)base; base += 4096;
+    mg_memset_async(sctr, 0, 4096, st);
+    mg_memset_async(err, 0, 4096, st);
+    mg_memset_async(out_len, 0, (size_t)N * sizeof(int32_t), st);
+    ocr_init(out_ids, scratch_unf, sctr + 512, N < 1024 ? N : 1024, max_new_tokens, c.pad_token_id, st);      // (pads the first rows; the rest below)
+    if (N > 1024) for (int r0 = 1024; r0 < N; r0 += 1024)
+        ocr_init(out_ids + (size_t)r0 * max_new_tokens, scratch_unf, sctr + 512, (N - r0) < 1024 ? (N - r0) : 1024, max_new_tokens, c.pad_token_id, st);
+    ocr_slots_init(wd.unfinished, spos, simg, spool, wd.next_ids, slots, sctr, N, st);
+    const size_t img_in = (size_t)n_img * 3 * c.image_size * c.image_size;
+    const int P = m->P;
+    // 1. vision tower + prefill of every page (chunks), first token of every page
+    for (int c0 = 0; c0 < N; c0 += chunk) {
+        const int n = (N - c0) < chunk ? (N - c0) : chunk;
+        Ws w;
+        carve(m, (char*)ws, n, n_img, L, 0, false, &w);            // the chunk's own carving (a short last chunk uses less of the region)
+        mg_memset_async(w.counters, 0, 16 * sizeof(int), st);
+        if (pixel_values && n_img > 0)
+            image_features(m, w, pixel_values + (size_t)c0 * img_in, patch_pos ? patch_pos + (size_t)c0 * n_img * P : nullptr,
+                           patch_mask ? patch_mask + (size_t)c0 * n_img * P : nullptr, n * n_img, st);
+        Ws wc = w;
+        wc.Kc = Kbig + (size_t)c0 * page_kv; wc.Vc = Vbig + (size_t)c0 * page_kv; wc.kv_layer = kv_layer;
+        prefill(m, wc, input_ids + (size_t)c0 * L, (pixel_values && n_img > 0) ? w.feats : nullptr, n, n_img, L, cap, st);
+        rmsnorm_pack_rows(w.h, m->rawp("model.text_model.norm.weight"), w.xc, w.last_rows, n * T_cap, c.t_hidden, c.rms_eps, 1.0f, st);
+        GemmArgs lg = ga(w.xc, m->at<uint16_t>(m->lm_head), n, c.vocab, c.t_hidden);
+        lg.out_f32 = w.logits; lg.ldo = c.vocab;
+        gemm_rows(lg, EPI_F32_STORE, st);
+        ArgmaxArgs g{};          // batch-mode selection of column 0: token -> first_tok[page] and out_ids[page][0]
+        g.logits = w.logits; g.rows = n; g.V = c.vocab; g.ldl = c.vocab; g.eos = c.eos_token_id; g.pad = c.pad_token_id;
+        g.next_ids = first_tok + c0; g.out_ids = out_ids + (size_t)c0 * max_new_tokens; g.max_len = max_new_tokens; g.pos = 0; g.min_len = 0;
+        ocr_fill_ints(scratch_unf, 1, n, st);
+        g.unfinished = scratch_unf; g.n_unfinished = sctr + 600;
+        g.n_eos_more = c.n_eos_extra;
+        for (int k = 0; k < c.n_eos_extra; ++k) g.eos_more[k] = c.eos_extra[k];
+        greedy_select(g, st);
+        ocr_add_int(err, w.counters + 3, st);
+    }
+    ocr_set_int(sctr + 5, N, st);              // every page's cache is ready: the slots may take them all
+    // 2. the slots
+    SlotTable tab{};
+    tab.pos = spos; tab.img = simg; tab.pool = spool; tab.ctr = sctr; tab.out_len = out_len; tab.pool_cap = N; tab.start_id = 0;
+    tab.first_tok = first_tok; tab.n_stop = 1 + c.n_eos_extra; tab.stop[0] = c.eos_token_id;
+    for (int k = 0; k < c.n_eos_extra; ++k) tab.stop[1 + k] = c.eos_extra[k];
+    tab.max_len = max_new_tokens;
+    Ws w = wd;
+    w.Kc = Kbig; w.Vc = Vbig; w.kv_layer = kv_layer;
+    const SlotView view{spos, spool, wd.unfinished};
+    auto step = [&]() {
+        decode_step(m, w, slots, L, nullptr, cap, st, &view);
+        ArgmaxArgs g{};
+        g.logits = w.logits; g.rows = slots; g.V = c.vocab; g.ldl = c.vocab; g.eos = c.eos_token_id; g.pad = c.pad_token_id;
+        g.next_ids = w.next_ids; g.out_ids = out_ids; g.max_len = max_new_tokens; g.min_len = 0;
+        g.unfinished = w.unfinished; g.n_unfinished = sctr + 600;
+        g.n_eos_more = c.n_eos_extra;
+        for (int k = 0; k < c.n_eos_extra; ++k) g.eos_more[k] = c.eos_extra[k];
+        g.slots = tab;
+        greedy_select(g, st);
+        slot_refill(tab, w.next_ids, w.unfinished, slots, st);
+    };
+    slot_refill(tab, w.next_ids, w.unfinished, slots, st);          // the first pages take their slots
+    bool graphed = false;
+#ifndef MG_EMU
+    if (m->use_graph == 1) {
+        const mg_ocr_model::SKey key{ws, out_ids, (const void*)st, N, slots, L, max_new_tokens};
+        if (!(m->svalid && m->skey == key)) {
+            m->sreset();
+            hipGraph_t graph = nullptr;
+            if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                step();
+                if (hipStreamEndCapture(st, &graph) == hipSuccess && graph && hipGraphInstantiate(&m->sexec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                    m->skey = key; m->svalid = true;
+                }
+                if (graph) (void)hipGraphDestroy(graph);
+            }
+            (void)hipGetLastError();
+        }
+        graphed = m->svalid;
+    }
+#endif
+    m->graph_active = graphed;
+    long steps = 0;
+    int host[16] = {0};
+    const long limit = (long)N * max_new_tokens / 1 + 64;
+    while (host[1] < N) {
+        for (int g8 = 0; g8 < 8; ++g8) {
+#ifndef MG_EMU
+            if (graphed) { if (hipGraphLaunch(m->sexec, st) != hipSuccess) return failf(MG_E_HIP, "mg_ocr_generate_stream: hipGraphLaunch failed"); }
+            else
+#endif
+                step();
+            ++steps;
+        }
+        mg_memcpy_async(host, sctr, sizeof host, st);
+        mg_stream_sync(st);
+        if (steps > limit) return failf(MG_E_HIP, "mg_ocr_generate_stream: no progress (%d of %d pages after %ld steps)", host[1], N, steps);
+    }
+    int bad = 0;
+    mg_memcpy_async(&bad, err, sizeof(int), st);
+    mg_stream_sync(st);
+    rc = check("mg_ocr_generate_stream");
+    if (rc != MG_OK) return rc;
+    if (steps_host) *steps_host = steps;
+    if (bad) return failf(MG_E_INPUT, "mg_ocr_generate_stream: %d bad inputs (token id outside the vocabulary, or a sequence whose <image> count differs from n_img * %d)", bad, m->T_img);
     return MG_OK;
 }
 

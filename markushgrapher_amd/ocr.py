@@ -47,6 +47,9 @@ class OcrEngine:
                                      C.c_int, C.c_void_p]
         L.mg_ocr_generate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_int]
+        L.mg_ocr_stream_workspace_bytes.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.POINTER(C.c_size_t)]
+        L.mg_ocr_generate_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + \
+                                            [C.c_int] * 6 + [C.c_void_p, C.c_void_p, C.POINTER(C.c_long)]
         s = shape
         cfg = MgOcrConfig(s.v_hidden, s.v_inter, s.v_layers, s.v_heads, s.image_size, s.patch_size, s.t_hidden, s.t_inter, s.t_layers,
                           s.t_heads, s.t_kv_heads, s.vocab, s.scale_factor, s.image_token_id, s.eos_token_id, s.pad_token_id,
@@ -166,6 +169,29 @@ class OcrEngine:
                                           self.mem.ptr(pv) if pv is not None else None, self.mem.ptr(pos) if pos is not None else None,
                                           self.mem.ptr(msk) if msk is not None else None, B, n_img, L, self.mem.ptr(out)))
         return out
+
+    def generate_stream(self, input_ids, pixel_values=None, max_new_tokens=4096, slots=128, chunk=128, pixel_attention_mask=None):
+        """Queue form (include/mgrapher.h mg_ocr_generate_stream): N pages through `slots` decode rows -> (new ids [N, max_new_tokens]
+        padded after each page's stop token, lengths [N], decode steps).  Page n's ids equal generate()'s for that page."""
+        ids, pv, N, n_img, L = self._inputs(input_ids, pixel_values)
+        pos, msk = self.patch_inputs(pixel_attention_mask) if pv is not None else (None, None)
+        slots, chunk = min(slots, 256), min(chunk, 256, N)
+        need = C.c_size_t()
+        self._chk(self.lib.mg_ocr_stream_workspace_bytes(self.model, N, n_img, L, max_new_tokens, slots, chunk, C.byref(need)))
+        if getattr(self, "_sws_bytes", 0) < need.value:
+            self._sws = None
+            self._sws = self.mem.empty((int(need.value),), np.uint8)
+            self._sws_bytes = need.value
+        key = (N, max_new_tokens)
+        if getattr(self, "_sout_key", None) != key:        # stable output buffers: the captured step graph holds their addresses
+            self._sout = (self.mem.empty((N, max_new_tokens), np.int64), self.mem.empty((N,), np.int32))
+            self._sout_key = key
+        steps = C.c_long(0)
+        self._chk(self.lib.mg_ocr_generate_stream(self.model, self.mem.stream(), self.mem.ptr(self._sws), self._sws_bytes, self.mem.ptr(ids),
+                                                  self.mem.ptr(pv) if pv is not None else None, self.mem.ptr(pos) if pos is not None else None,
+                                                  self.mem.ptr(msk) if msk is not None else None, N, n_img, L, max_new_tokens, slots, chunk,
+                                                  self.mem.ptr(self._sout[0]), self.mem.ptr(self._sout[1]), C.byref(steps)))
+        return self.mem.copy(self._sout[0]), self.mem.copy(self._sout[1]), int(steps.value)
 
     def generate(self, input_ids, pixel_values=None, max_new_tokens=4096, capture_steps=0, pixel_attention_mask=None):
         """-> (new_ids [B][n], step_logits or None): the tokens after the prompt, as generated_ids[:, prompt_len:] of the reference."""

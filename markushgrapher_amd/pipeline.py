@@ -74,12 +74,14 @@ class Configs4Pipeline:
     block (equal length for every page: one prompt, one 512-px frame)."""
 
     def __init__(self, ocr, main, tokenizer, ocr_detok: Callable, ocr_prompt_ids, ocr_max_new_tokens: int = 4096, question: str = QUESTION,
-                 max_length: int = 512, min_length: int = 0, num_beams: int = 1, continuous: bool = False, main_batch: int = 32):
+                 max_length: int = 512, min_length: int = 0, num_beams: int = 1, continuous: bool = False, main_batch: int = 32,
+                 ocr_slots: int = 0):
         self.ocr, self.main, self.tokenizer, self.ocr_detok = ocr, main, tokenizer, ocr_detok
         self.ocr_prompt_ids = np.asarray(ocr_prompt_ids, np.int64)
         self.ocr_max_new_tokens, self.question = int(ocr_max_new_tokens), question
         self.max_length, self.min_length, self.num_beams, self.continuous = int(max_length), int(min_length), int(num_beams), bool(continuous)
         self.main_batch = int(main_batch)      # pages per VTL call (the OCR stage may take more pages per call: its model is 6x smaller)
+        self.ocr_slots = int(ocr_slots)        # > 0: the OCR stage's queue form (mg_ocr_generate_stream) with that many decode rows
         if ocr.shape.image_size != main.shape.image_size:
             raise ValueError("the two stages share the preprocessed page: equal input sizes expected (512 px in the reference)")
 
@@ -91,7 +93,12 @@ class Configs4Pipeline:
         pix = self.main.preprocess(pages_u8)                                  # [B, 3, I, I] f32 on the device, read by both stages
         B = int(pix.shape[0])
         prompt = self.ocr_prompt_ids if self.ocr_prompt_ids.ndim == 2 else np.repeat(self.ocr_prompt_ids[None], B, axis=0)
-        new, _ = self.ocr.generate(prompt[:B], pix[:, None], self.ocr_max_new_tokens)
+        if self.ocr_slots > 0:
+            new, _, ocr_steps = self.ocr.generate_stream(prompt[:B], pix[:, None], self.ocr_max_new_tokens, slots=self.ocr_slots,
+                                                         chunk=min(B, 128))
+            t["ocr_steps"] = ocr_steps
+        else:
+            new, _ = self.ocr.generate(prompt[:B], pix[:, None], self.ocr_max_new_tokens)
         new = new.cpu().numpy() if hasattr(new, "cpu") else np.asarray(new)
         t["ocr_s"] = now() - t0
         t1 = now()

@@ -450,3 +450,36 @@ def test_ocr_max_new_tokens_4096_capacity():
     assert new.shape == (3, n)
     bad = np.nonzero(new != want)
     assert len(bad[0]) == 0, (bad[0][:5], bad[1][:5])
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+@pytest.mark.parametrize("slots,chunk", [(2, 3), (3, 8), (5, 2)])
+def test_ocr_queue_form_equals_batch_form(be_name, slots, chunk):
+    """mg_ocr_generate_stream: 8 pages (the fixture's 3, repeated in a different order) through 2 / 3 / 5 decode rows: every page's new
+    ids and length equal what generate() returns for that page (rows end at different steps in the fixture: one emits EOS early)."""
+    g, s, sd, ids, pix = _setup("tiny")
+    eng = make_ocr(be_name, s, sd)
+    n = int(g["new_tokens"])
+    base, _ = eng.generate(ids, pix, n)
+    base = np.asarray(eng.mem.numpy(base)).copy()                 # [3, cols]
+    order = np.array([2, 0, 1, 1, 2, 0, 0, 2])
+    new, lens, steps = eng.generate_stream(ids[order], pix[order], n, slots=slots, chunk=chunk)
+    new, lens = np.asarray(eng.mem.numpy(new)), np.asarray(eng.mem.numpy(lens))
+    total = 0
+    for k, b in enumerate(order):
+        row = base[b]
+        e = np.nonzero(row == s.eos_token_id)[0]
+        want = int(e[0]) + 1 if len(e) else n
+        assert lens[k] == want, (k, b, lens[k], want)
+        assert np.array_equal(new[k, :want], row[:want]) and np.all(new[k, want:] == s.pad_token_id)
+        total += want - 1
+    assert steps <= -(-total // slots) + len(order) + 16
+    # a page whose FIRST token is a stop token never takes a slot: make the first token of page 0 a second stop id
+    import dataclasses
+    s2 = dataclasses.replace(s, eos_extra=(int(base[0, 0]),))
+    eng2 = make_ocr(be_name, s2, sd)
+    new2, lens2, _ = eng2.generate_stream(ids[order], pix[order], n, slots=slots, chunk=chunk)
+    new2, lens2 = np.asarray(eng2.mem.numpy(new2)), np.asarray(eng2.mem.numpy(lens2))
+    for k, b in enumerate(order):
+        if b == 0:
+            assert lens2[k] == 1 and new2[k, 0] == base[0, 0] and np.all(new2[k, 1:] == s.pad_token_id)

@@ -53,11 +53,12 @@ def _engines(be_name):
 @pytest.mark.parametrize("be_name", BACKENDS)
 @pytest.mark.parametrize("continuous", [False, True])
 def test_pages_to_ids_in_one_path(be_name, continuous):
+    # continuous: BOTH stages in their queue forms (OCR: 2 decode rows for the 4 pages; VTL: the continuous decoder)
     g = _golden()
     main, ocr, shape, s = _engines(be_name)
     id_to_piece, chains, starts = F.ocr_vocab_and_chains()
     pipe = Configs4Pipeline(ocr, main, F.make_udop_tokenizer(), lambda row: F.detokenize(id_to_piece, row, s.eos_token_id, s.pad_token_id),
-                            F.ocr_prompts(), ocr_max_new_tokens=64, max_length=16, continuous=continuous)
+                            F.ocr_prompts(), ocr_max_new_tokens=64, max_length=16, continuous=continuous, ocr_slots=2 if continuous else 0)
     pages = F.pages_u8(len(F.OCR_TEXTS))
     res = pipe(pages)
     # stage 1: the scripted OCR model walked its chains (ids), the stand-in detokeniser gives the designed strings
