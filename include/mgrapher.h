@@ -158,6 +158,12 @@ int mg_debug_bucket_table(const mg_model* m, int which, int* out_host, int n);
  * same results); enable = 2 launches the graph's device-counter form of the kernels eagerly (test hook). Default: 1.
  * Returns the previous setting. */
 int mg_set_decode_graph(mg_model* m, int enable);
+/* Trailing text padding of a batch (attention_mask with zeros at the end of a row).  0 (default): the padded slots are part of the
+ * sequence, exactly as stock HF computes a padded batch - UDOP's 1-D relative position bias then counts them between the text and
+ * the patches, so an image's result depends (slightly) on how far its batch was padded.  1: per-image semantics - every image's
+ * patches follow its own last attended text token and its result is what the reference's batch-size-1 loop computes for it
+ * (/root/reference/markushgrapher/utils/ocsr/utils_evaluation.py:140), whatever its batch mates are.  Returns the previous setting. */
+int mg_set_padding_semantics(mg_model* m, int per_image);
 /* 1 if the last mg_generate replayed a captured graph, 0 if it launched eagerly (mode 0/2, capture unavailable). */
 int mg_decode_graph_active(const mg_model* m);
 

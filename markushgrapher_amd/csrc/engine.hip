@@ -117,6 +117,9 @@ struct mg_model {
     // encoder GEMMs skip 32-row tiles without an attended position (padded text slots, slots of dropped patches); MG_ENC_ROW_TILES=0
     // computes every row (A/B; results of attended rows are bit-identical either way)
     bool row_tiles = true;
+    // trailing text padding of a batch: false = stock batched semantics (the padded slots sit between text and patches and count in the
+    // 1-D position bias), true = per-image semantics (every image as if alone and unpadded: the reference's batch size is 1)
+    bool trim_padding = false;
     bool fused_tail = true;    // MG_DECODE_FUSED_TAIL=0: separate embedding / selection launches (A/B; identical results)
     bool tied = true;          // tie_word_embeddings: lm_head = shared.weight and logits scaled by d_model^-0.5 (stock:1554-1557)
 #ifndef MG_EMU
@@ -213,18 +216,26 @@ __global__ __launch_bounds__(256) void pad_dec_inputs_kernel(const int64_t* ids,
         dst_row[i] = in ? b * T + t : -1;
     }
 }
-__global__ __launch_bounds__(256) void copy_rows_kernel(const float* src, float* dst, int B, int S, int S_cap, int d) {
+// Output position s of image b (the documented [text L | patches P] order) -> row of the workspace.  With per-image padding
+// semantics (text_len[b] = Lb < L) the workspace holds [text Lb | patches P | text padding L - Lb].
+MG_DEV size_t enc_src_row(int s, int L, int P, const int* text_len, int b) {
+    const int Lb = text_len ? text_len[b] : L;
+    if (s < Lb) return (size_t)s;
+    if (s < L) return (size_t)(Lb + P + (s - Lb));
+    return (size_t)(Lb + (s - L));
+}
+__global__ __launch_bounds__(256) void copy_rows_kernel(const float* src, float* dst, int B, int S, int S_cap, int d, int L, const int* text_len) {
     const size_t n = (size_t)B * S * (d / 4);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const size_t row = i / (d / 4), c = i - row * (d / 4);
         const size_t b = row / S, s = row - b * S;
-        ((float4*)dst)[i] = ((const float4*)src)[(b * S_cap + s) * (d / 4) + c];
+        ((float4*)dst)[i] = ((const float4*)src)[(b * S_cap + enc_src_row((int)s, L, S - L, text_len, (int)b)) * (d / 4) + c];
     }
 }
-__global__ __launch_bounds__(256) void copy_bytes_rows_kernel(const uint8_t* src, uint8_t* dst, int B, int S, int S_cap) {
+__global__ __launch_bounds__(256) void copy_bytes_rows_kernel(const uint8_t* src, uint8_t* dst, int B, int S, int S_cap, int L, const int* text_len) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * S; i += gridDim.x * blockDim.x) {
         const int b = i / S, s = i - b * S;
-        dst[i] = src[(size_t)b * S_cap + s];
+        dst[i] = src[(size_t)b * S_cap + enc_src_row(s, L, S - L, text_len, b)];
     }
 }
 
@@ -236,7 +247,7 @@ struct Ws {
     void* meta;
     double *cx, *cy;
     uint8_t* mask;
-    int *xrow, *xlen, *counters, *att_kst, *row_tiles;
+    int *xrow, *xlen, *counters, *att_kst, *row_tiles, *text_len;
     uint8_t* att_qbv;
     // OCSR-branch tokens e1, packed for the cross-K/V projections
     uint16_t* e1_pk;
@@ -306,6 +317,7 @@ void carve(const mg_model* m, char* base, int B, int L, int K, int max_len, int 
     w->counters = c.take<int>(16);
     w->att_kst = c.take<int>((size_t)B * (1 + (S_cap >> 6)));
     w->att_qbv = c.take<uint8_t>((size_t)B * ((S_cap + 127) / 128));
+    w->text_len = c.take<int>(B);
     w->row_tiles = c.take<int>(M / 32 + 1);           // [0] = count, then the live 32-row tiles (GemmArgs::row_tiles)
     w->e1_pk = c.take<uint16_t>((size_t)B * M64 * d);
     w->e1_map = c.take<int>((size_t)B * M64);
@@ -937,7 +949,7 @@ int mg_encode(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_
         e.tok_emb = m->at<uint16_t>(m->tok_emb); e.x_emb = m->at<uint16_t>(m->x_emb); e.y_emb = m->at<uint16_t>(m->y_emb);
         e.B = B; e.L = L; e.P = P; e.d = d; e.n_side = m->n_side; e.M2 = m->M2; e.V = m->V; e.S_cap = S_cap;
         e.hidden = w.hidden; e.hidden_tiled = 1; e.cx = w.cx; e.cy = w.cy; e.mask = w.mask; e.xrow = w.xrow; e.xlen = w.xlen;
-        e.err = w.counters + 3; e.x_row0 = M_e1;
+        e.err = w.counters + 3; e.x_row0 = M_e1; e.trim_padding = m->trim_padding ? 1 : 0; e.text_len = w.text_len;
         embed_assemble(e, w.meta, st);
     }
     // bucket indices of the three relative biases: shared by all layers and heads, computed once per batch
@@ -995,8 +1007,9 @@ int mg_encode(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_
         gemm(g, EPI_RESID_NORM, st);
     }
     rmsnorm_pack_tiled(w.hidden, m->at<float>(m->enc_ln), w.enc_pk, w.enc_f32, M, d, m->c.layer_norm_epsilon, st);
-    if (enc_out) MG_LAUNCH(copy_rows_kernel, dim3(1024), dim3(256), 0, st, (const float*)w.enc_f32, enc_out, B, S, S_cap, d);
-    if (enc_mask) MG_LAUNCH(copy_bytes_rows_kernel, dim3(64), dim3(256), 0, st, (const uint8_t*)w.mask, enc_mask, B, S, S_cap);
+    const int* tl = m->trim_padding ? w.text_len : nullptr;
+    if (enc_out) MG_LAUNCH(copy_rows_kernel, dim3(1024), dim3(256), 0, st, (const float*)w.enc_f32, enc_out, B, S, S_cap, d, L, tl);
+    if (enc_mask) MG_LAUNCH(copy_bytes_rows_kernel, dim3(64), dim3(256), 0, st, (const uint8_t*)w.mask, enc_mask, B, S, S_cap, L, tl);
     // e1 tokens (OCSR vision branch, precomputed by the caller): fused with the VTL states by concatenation in front of the
     // decoder (ref: README.md:212-215) - here: packed next to them for the cross-K/V projections, never normalised or mixed
     if (e1) pack_e1(e1, B, M_e1, round_up(M_e1, 64), d, w.e1_pk, w.e1_map, w.mask, S_cap, w.xmask, st);
@@ -1489,6 +1502,15 @@ int mg_profile_phases_read(mg_model* m, long* calls, double* enc_ms, double* dec
     if (enc_ms) *enc_ms = m->phase_enc_ms;
     if (dec_ms) *dec_ms = m->phase_dec_ms;
     return MG_OK;
+}
+// 0 (default): a batch's trailing text padding is part of the sequence, as stock HF computes a padded batch; 1: per-image semantics -
+// every image's patches follow ITS last attended text token, the result for an image does not depend on how far its batch was padded
+// and equals what the reference's batch-size-1 loop computes for it (utils_evaluation.py:140).  Returns the previous setting.
+int mg_set_padding_semantics(mg_model* m, int per_image) {
+    if (!m) return fail(MG_E_ARG, "mg_set_padding_semantics: null model");
+    const int prev = m->trim_padding ? 1 : 0;
+    m->trim_padding = per_image != 0;
+    return prev;
 }
 int mg_set_decode_graph(mg_model* m, int enable) {
     if (!m) return fail(MG_E_ARG, "mg_set_decode_graph: null model");

@@ -31,8 +31,30 @@ __global__ __launch_bounds__(256) void embed_index_kernel(EmbedArgs a, EmbedMeta
     const float* bb = a.bbox + (size_t)b * L * 4;
 
     for (int p = tid; p < P; p += 256) drop[p] = 0;
+    // per-image text length: index of the last attended text token + 1 (trim_padding; all of L otherwise)
+    int* lbs = cnt;
+    if (tid == 0) lbs[0] = 0;
     __syncthreads();
-    for (int i = tid; i < L; i += 256) {
+    if (a.trim_padding && a.attn_mask) {
+        int mine = 0;
+        for (int i = tid; i < L; i += 256) if (a.attn_mask[(size_t)b * L + i] != 0) mine = i + 1;
+        atomicMax(lbs, mine);
+    }
+    __syncthreads();
+    const int Lb = (a.trim_padding && a.attn_mask) ? lbs[0] : L;
+    __syncthreads();
+    if (tid == 0 && a.text_len) a.text_len[b] = Lb;
+    // padded text slots behind the image's own text (trim_padding): moved to the end of the sequence, masked, no effect on the patches
+    for (int i = Lb + tid; i < L; i += 256) {
+        const int s = Lb + P + (i - Lb);
+        EmbedMeta m;
+        m.tok = 0; m.patch = -1; m.c[0] = m.c[1] = m.c[2] = m.c[3] = 0;
+        mb[s] = m;
+        a.cx[(size_t)b * a.S_cap + s] = 0.0;
+        a.cy[(size_t)b * a.S_cap + s] = 0.0;
+        a.mask[(size_t)b * a.S_cap + s] = 0;
+    }
+    for (int i = tid; i < Lb; i += 256) {
         const float x0 = bb[i * 4 + 0], y0 = bb[i * 4 + 1], x1 = bb[i * 4 + 2], y1 = bb[i * 4 + 3];
         // stock:191-198 (float32 arithmetic, floor, clip)
         int px = (int)floorf((x0 + x1) / 2.0f * (float)n);
@@ -69,7 +91,7 @@ __global__ __launch_bounds__(256) void embed_index_kernel(EmbedArgs a, EmbedMeta
     for (int t = 0; t < 256; ++t) nsurv += cnt[t];
     for (int p = tid * per; p < P && p < (tid + 1) * per; ++p) {
         if (drop[p]) continue;
-        const int s = L + off++;
+        const int s = Lb + off++;
         // stock:135-155 visual boxes (float32 k/n, promoted to float64 by the concat at stock:248)
         const int px = p % n, py = p / n;
         const float vx0 = (float)px / (float)n, vx1 = (float)(px + 1) / (float)n;
@@ -85,7 +107,8 @@ __global__ __launch_bounds__(256) void embed_index_kernel(EmbedArgs a, EmbedMeta
         a.mask[(size_t)b * a.S_cap + s] = 1;
     }
     // zero-padded visual slots (box 0) and the internal padding up to S_cap
-    for (int s = L + nsurv + tid; s < a.S_cap; s += 256) {
+    for (int s = Lb + nsurv + tid; s < a.S_cap; s += 256) {
+        if (s >= Lb + P && s < S) continue;                    // the moved text padding (written above)
         EmbedMeta m;
         m.tok = -1; m.patch = -1;
         m.c[0] = m.c[1] = m.c[2] = m.c[3] = (s < S) ? 0 : -1;

@@ -195,6 +195,12 @@ struct EmbedArgs {
     int* xrow;                  // [B][S_cap]  compacted cross-attention row of token s, -1 if masked
     int* xlen;                  // [B]         x_row0 + number of attended tokens
     int x_row0;                 // first compacted row (rows [0, x_row0) of the cross K/V stream belong to the e1 tokens)
+    // Trailing text padding (attn_mask given): 0 = stock batched semantics - padded slots stay between the text and the patches, so
+    // UDOP's 1-D position bias counts them; 1 = per-image semantics - the patches follow the image's LAST ATTENDED text token, the
+    // padded slots move behind the visual block: every image is computed as if it were alone and unpadded (the reference's batch
+    // size is 1).  text_len [B] (nullable) receives the per-image text length either way (L in mode 0).
+    int trim_padding;
+    int* text_len;
     int* err;                   // device error word (bit 0: token id out of range)
 };
 size_t embed_meta_bytes(int B, int S_cap);

@@ -268,6 +268,12 @@ class Engine:
                                                    self.mem.ptr(frc) if frc is not None else None))
         return cap
 
+    def set_padding_semantics(self, per_image: bool):
+        """True: every image of a padded batch is computed as if it were alone and unpadded (the reference's batch size is 1);
+        False (default): stock HF batched semantics (include/mgrapher.h mg_set_padding_semantics)."""
+        self.lib.mg_set_padding_semantics.argtypes = [C.c_void_p, C.c_int]
+        return bool(self.lib.mg_set_padding_semantics(self.model, 1 if per_image else 0))
+
     def set_stream_encoder(self, mode=1, cu_mask=None):
         """Where generate_stream's encoder runs: 0 the caller's stream (serial), 1 its own low-priority stream, 2 its own stream on
         the compute units of `cu_mask` (iterable of CU bit indices)."""

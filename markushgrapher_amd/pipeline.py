@@ -75,33 +75,38 @@ class Configs4Pipeline:
 
     def __init__(self, ocr, main, tokenizer, ocr_detok: Callable, ocr_prompt_ids, ocr_max_new_tokens: int = 4096, question: str = QUESTION,
                  max_length: int = 512, min_length: int = 0, num_beams: int = 1, continuous: bool = False, main_batch: int = 32,
-                 ocr_slots: int = 0):
+                 ocr_slots: int = 0, per_image_padding: bool = True):
         self.ocr, self.main, self.tokenizer, self.ocr_detok = ocr, main, tokenizer, ocr_detok
         self.ocr_prompt_ids = np.asarray(ocr_prompt_ids, np.int64)
         self.ocr_max_new_tokens, self.question = int(ocr_max_new_tokens), question
         self.max_length, self.min_length, self.num_beams, self.continuous = int(max_length), int(min_length), int(num_beams), bool(continuous)
         self.main_batch = int(main_batch)      # pages per VTL call (the OCR stage may take more pages per call: its model is 6x smaller)
         self.ocr_slots = int(ocr_slots)        # > 0: the OCR stage's queue form (mg_ocr_generate_stream) with that many decode rows
+        # pages of one batch have different token counts; with per-image padding semantics every page is computed as the reference
+        # computes it (alone, unpadded: its batch size is 1), whatever the batch was padded to (mg_set_padding_semantics)
+        if per_image_padding:
+            self.main.set_padding_semantics(True)
         if ocr.shape.image_size != main.shape.image_size:
             raise ValueError("the two stages share the preprocessed page: equal input sizes expected (512 px in the reference)")
 
-    def __call__(self, pages_u8, timer: Optional[Callable[[], float]] = None) -> PipelineResult:
-        import torch
-        t = {}
-        now = timer or (lambda: 0.0)
-        t0 = now()
+    # ---- the three stages --------------------------------------------------------------------------------------------------
+    def stage_ocr(self, pages_u8, page0: int = 0):
+        """-> (pix [B,3,I,I] device, new ids [B,n] numpy, OCR decode steps or None).  page0: index of the first page in the caller's
+        list (per-page prompts are taken from ocr_prompt_ids[page0 : page0 + B])."""
         pix = self.main.preprocess(pages_u8)                                  # [B, 3, I, I] f32 on the device, read by both stages
         B = int(pix.shape[0])
-        prompt = self.ocr_prompt_ids if self.ocr_prompt_ids.ndim == 2 else np.repeat(self.ocr_prompt_ids[None], B, axis=0)
+        prompt = self.ocr_prompt_ids[page0:page0 + B] if self.ocr_prompt_ids.ndim == 2 else np.repeat(self.ocr_prompt_ids[None], B, axis=0)
+        steps = None
         if self.ocr_slots > 0:
-            new, _, ocr_steps = self.ocr.generate_stream(prompt[:B], pix[:, None], self.ocr_max_new_tokens, slots=self.ocr_slots,
-                                                         chunk=min(B, 128))
-            t["ocr_steps"] = ocr_steps
+            new, _, steps = self.ocr.generate_stream(prompt, pix[:, None], self.ocr_max_new_tokens, slots=self.ocr_slots, chunk=min(B, 128))
         else:
-            new, _ = self.ocr.generate(prompt[:B], pix[:, None], self.ocr_max_new_tokens)
+            new, _ = self.ocr.generate(prompt, pix[:, None], self.ocr_max_new_tokens)
         new = new.cpu().numpy() if hasattr(new, "cpu") else np.asarray(new)
-        t["ocr_s"] = now() - t0
-        t1 = now()
+        return pix, new, steps
+
+    def stage_host(self, new):
+        """OCR ids -> (texts, cells, input_ids, bbox, attention_mask): string and tokenizer work, no GPU."""
+        import torch
         texts = [self.ocr_detok(row) for row in new]
         cells = [cells_from_ocr_text(x) for x in texts]
         feats = []
@@ -110,26 +115,64 @@ class Configs4Pipeline:
             ids, bb = encode_cells(c, self.tokenizer, I, self.question)
             feats.append({"input_ids": torch.from_numpy(ids), "bbox": torch.from_numpy(bb)})
         batch = assembly.collate_for_generate(feats)
-        ids_in = batch["input_ids"].numpy().astype(np.int64)
-        bbox = batch["bbox"].numpy().astype(np.float32)
-        mask = batch["attention_mask"].numpy().astype(np.int64)
-        t["host_s"] = now() - t1
-        t2 = now()
+        return (texts, cells, batch["input_ids"].numpy().astype(np.int64), batch["bbox"].numpy().astype(np.float32),
+                batch["attention_mask"].numpy().astype(np.int64))
+
+    def stage_main(self, pix, ids_in, bbox, mask):
+        B = int(ids_in.shape[0])
         mb = min(B, self.main_batch)
         if self.continuous and self.num_beams == 1:
             out, lens, _ = self.main.generate_stream(ids_in, bbox, mask, pix, max_length=self.max_length, min_length=self.min_length,
                                                      chunk=mb, slots=mb, pool_chunks=3 if B > 2 * mb else 2)
             out = out.cpu().numpy() if hasattr(out, "cpu") else np.asarray(out)
             lens = lens.cpu().numpy() if hasattr(lens, "cpu") else np.asarray(lens)
-            out = out[:, :int(lens.max())]
-        else:
-            rows = []
-            for c0 in range(0, B, mb):
-                o, _, _ = self.main.generate(ids_in[c0:c0 + mb], bbox[c0:c0 + mb], mask[c0:c0 + mb], pix[c0:c0 + mb], num_beams=self.num_beams,
-                                             max_length=self.max_length, min_length=self.min_length)
-                rows.append(o.cpu().numpy() if hasattr(o, "cpu") else np.asarray(o))
-            width = max(r.shape[1] for r in rows)
-            pad = self.main.shape.pad_token_id
-            out = np.concatenate([np.pad(r, ((0, 0), (0, width - r.shape[1])), constant_values=pad) for r in rows], axis=0)
+            return out[:, :int(lens.max())]
+        rows = []
+        for c0 in range(0, B, mb):
+            o, _, _ = self.main.generate(ids_in[c0:c0 + mb], bbox[c0:c0 + mb], mask[c0:c0 + mb], pix[c0:c0 + mb], num_beams=self.num_beams,
+                                         max_length=self.max_length, min_length=self.min_length)
+            rows.append(o.cpu().numpy() if hasattr(o, "cpu") else np.asarray(o))
+        width = max(r.shape[1] for r in rows)
+        pad = self.main.shape.pad_token_id
+        return np.concatenate([np.pad(r, ((0, 0), (0, width - r.shape[1])), constant_values=pad) for r in rows], axis=0)
+
+    def __call__(self, pages_u8, timer: Optional[Callable[[], float]] = None) -> PipelineResult:
+        t = {}
+        now = timer or (lambda: 0.0)
+        t0 = now()
+        pix, new, steps = self.stage_ocr(pages_u8)
+        if steps is not None:
+            t["ocr_steps"] = steps
+        t["ocr_s"] = now() - t0
+        t1 = now()
+        texts, cells, ids_in, bbox, mask = self.stage_host(new)
+        t["host_s"] = now() - t1
+        t2 = now()
+        out = self.stage_main(pix, ids_in, bbox, mask)
         t["main_s"] = now() - t2
         return PipelineResult(ids=out, ocr_new_ids=new, ocr_texts=texts, cells=cells, input_ids=ids_in, bbox=bbox, attention_mask=mask, timings=t)
+
+    def run_overlapped(self, pages_u8, parts: int = 2) -> List[PipelineResult]:
+        """The same chain over `parts` slices of the pages with the HOST stage of slice i running in a worker thread underneath the GPU
+        stage that follows it (OCR of slice i + 1, then VTL of slice i - the ctypes calls release the GIL): the string / tokenizer work
+        (~2 ms per page) disappears from the wall clock.  All GPU calls stay on the calling thread.  One result per slice."""
+        from concurrent.futures import ThreadPoolExecutor
+        n = int(pages_u8.shape[0])
+        cuts = [n * i // parts for i in range(parts + 1)]
+        results = []
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            pend = None                                   # (pix, new, future of the host stage) of the previous slice
+            for i in range(parts):
+                pix, new, _ = self.stage_ocr(pages_u8[cuts[i]:cuts[i + 1]], cuts[i])
+                fut = pool.submit(self.stage_host, new)
+                if pend is not None:
+                    ppix, pnew, pfut = pend
+                    texts, cells, ids_in, bbox, mask = pfut.result()
+                    out = self.stage_main(ppix, ids_in, bbox, mask)
+                    results.append(PipelineResult(ids=out, ocr_new_ids=pnew, ocr_texts=texts, cells=cells, input_ids=ids_in, bbox=bbox, attention_mask=mask))
+                pend = (pix, new, fut)
+            ppix, pnew, pfut = pend
+            texts, cells, ids_in, bbox, mask = pfut.result()
+            out = self.stage_main(ppix, ids_in, bbox, mask)
+            results.append(PipelineResult(ids=out, ocr_new_ids=pnew, ocr_texts=texts, cells=cells, input_ids=ids_in, bbox=bbox, attention_mask=mask))
+        return results

@@ -84,3 +84,67 @@ def test_pages_to_ids_in_one_path(be_name, continuous):
     want = main.mem.numpy(want)
     assert res.ids.shape == want.shape and np.array_equal(res.ids, want)
     assert np.all(res.ids[:, 0] == shape.decoder_start_token_id) and len({tuple(r) for r in res.ids.tolist()}) > 1
+    # two slices with the host stage in a worker thread underneath the GPU stages: same OCR strings, same VTL inputs and - the pipeline
+    # runs the VTL engine with per-image padding semantics - the same ids page by page, although a slice is padded to ITS longest page
+    parts = pipe.run_overlapped(pages, parts=2)
+    assert [p.ocr_texts for p in parts] == [F.OCR_TEXTS[:2], F.OCR_TEXTS[2:]]
+    k = 0
+    for p in parts:
+        for j in range(p.input_ids.shape[0]):
+            n = len(g["pages"][k]["input_ids"])
+            assert p.input_ids[j, :n].tolist() == g["pages"][k]["input_ids"]
+            m = min(p.ids.shape[1], res.ids.shape[1])
+            assert np.array_equal(p.ids[j, :m], res.ids[k, :m]), k
+            k += 1
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+def test_per_image_padding_semantics(be_name):
+    """mg_set_padding_semantics(1): in a padded batch every image is computed as if it were alone and unpadded - what the reference's
+    batch-size-1 loop computes (ref: utils/ocsr/utils_evaluation.py:140).  Stock HF batched semantics (the default, what the golden
+    fixtures of padded batches pin) leaves the padded text slots between the text and the patches, where UDOP's 1-D position bias
+    counts them: there an image's result depends on the padding of its batch.  Here: the 4 pages of the pipeline fixture (14 - 26
+    tokens) as one padded batch against each page alone: greedy ids equal, attended encoder rows equal to accumulation-order noise."""
+    g = _golden()
+    main, _, shape, _ = _engines(be_name)
+    pages = F.pages_u8(len(F.OCR_TEXTS))
+    pix = main.mem.numpy(main.preprocess(pages)).copy()
+    feats = [(np.asarray(p["input_ids"], np.int64), np.asarray(p["bbox"], np.float32)) for p in g["pages"]]
+    L = max(len(i) for i, _ in feats)
+    ids = np.zeros((4, L), np.int64); bb = np.zeros((4, L, 4), np.float32); am = np.zeros((4, L), np.int64)
+    for b, (i, x) in enumerate(feats):
+        ids[b, :len(i)] = i; bb[b, :len(i)] = x; am[b, :len(i)] = 1
+    alone_ids, alone_enc = [], []
+    for b, (i, x) in enumerate(feats):
+        one = (i[None], x[None], np.ones((1, len(i)), np.int64), pix[b:b + 1])
+        o, _, _ = main.generate(*one, max_length=16)
+        alone_ids.append(main.mem.numpy(o)[0].copy())
+        e, _ = main.encode(*one)
+        alone_enc.append(main.mem.numpy(e)[0].copy())
+    assert main.set_padding_semantics(True) is False
+    try:
+        out, _, _ = main.generate(ids, bb, am, pix, max_length=16)
+        out = main.mem.numpy(out).copy()
+        enc, msk = main.encode(ids, bb, am, pix)
+        enc, msk = main.mem.numpy(enc).copy(), main.mem.numpy(msk).copy()
+        outs, lens, _ = main.generate_stream(ids, bb, am, pix, max_length=16, chunk=2, slots=3, pool_chunks=2)
+        outs, lens = main.mem.numpy(outs), main.mem.numpy(lens)
+    finally:
+        assert main.set_padding_semantics(False) is True
+    P = shape.num_patches
+    for b, (i, _) in enumerate(feats):
+        n = len(alone_ids[b])
+        assert np.array_equal(out[b, :n], alone_ids[b]) and np.all(out[b, n:] == shape.pad_token_id), b
+        assert np.array_equal(outs[b, :lens[b]], alone_ids[b][:lens[b]])
+        Lb = len(i)
+        # output contract [text L | patches P]: text rows, then (at offset L) the patch rows; mask of the padded text slots 0
+        assert msk[b, :Lb].all() and not msk[b, Lb:L].any()
+        a = np.concatenate([enc[b, :Lb], enc[b, L:L + P]]); r = np.concatenate([alone_enc[b][:Lb], alone_enc[b][Lb:Lb + P]])
+        keep = np.concatenate([msk[b, :Lb], msk[b, L:L + P]]).astype(bool)
+        assert np.abs(a - r)[keep].max() < 2e-3, (b, float(np.abs(a - r)[keep].max()))
+    # and the default (stock batched) semantics really is a different computation for the padded pages
+    enc0, _ = main.encode(ids, bb, am, pix)
+    enc0 = main.mem.numpy(enc0)
+    short = int(np.argmin([len(i) for i, _ in feats]))
+    Ls = len(feats[short][0])
+    assert np.abs(enc0[short, :Ls] - alone_enc[short][:Ls]).max() > 10 * 2e-3
