@@ -149,17 +149,10 @@ def configs4_run(eng, B, new_tokens, ocr_pages=128, n_scripts=32, ocr_slots=0):
     t0 = clock()
     res = pipe(pages, timer=clock)
     dt = clock() - t0
-    # the same pages with the host stage hidden under the GPU stages (two slices, worker thread for the string / tokenizer work)
-    pipe.run_overlapped(pages, parts=2)
-    t0 = clock()
-    parts = pipe.run_overlapped(pages, parts=2)
-    dt_ov = clock() - t0
-    same = np.array_equal(np.concatenate([p.ids for p in parts]), res.ids) if all(p.ids.shape[1] == res.ids.shape[1] for p in parts) else False
     ok = sum(res.ocr_texts[i] == texts[i % n_scripts] for i in range(ocr_pages))
     eng.set_padding_semantics(False)             # (the pipeline switched the engine to per-image padding semantics)
     L = res.attention_mask.sum(axis=1)
     return {"pages_per_s": round(ocr_pages / dt, 2), "pages": ocr_pages, "ms_total": round(dt * 1e3, 1),
-            "pages_per_s_host_stage_overlapped": round(ocr_pages / dt_ov, 2), "overlapped_ids_equal": bool(same),
             "ocr_s": round(res.timings["ocr_s"], 3), "host_s": round(res.timings["host_s"], 3), "main_s": round(res.timings["main_s"], 3),
             "ocr_form": (f"queue form, {ocr_slots} decode rows, {res.timings.get('ocr_steps')} steps" if ocr_slots else "batch form: every call walks to its longest page"),
             "ocr_steps_longest_page": longest, "ocr_tokens_mean": round(float(np.mean([len(c) for c in chains])), 1),

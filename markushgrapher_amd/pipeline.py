@@ -151,28 +151,3 @@ class Configs4Pipeline:
         out = self.stage_main(pix, ids_in, bbox, mask)
         t["main_s"] = now() - t2
         return PipelineResult(ids=out, ocr_new_ids=new, ocr_texts=texts, cells=cells, input_ids=ids_in, bbox=bbox, attention_mask=mask, timings=t)
-
-    def run_overlapped(self, pages_u8, parts: int = 2) -> List[PipelineResult]:
-        """The same chain over `parts` slices of the pages with the HOST stage of slice i running in a worker thread underneath the GPU
-        stage that follows it (OCR of slice i + 1, then VTL of slice i - the ctypes calls release the GIL): the string / tokenizer work
-        (~2 ms per page) disappears from the wall clock.  All GPU calls stay on the calling thread.  One result per slice."""
-        from concurrent.futures import ThreadPoolExecutor
-        n = int(pages_u8.shape[0])
-        cuts = [n * i // parts for i in range(parts + 1)]
-        results = []
-        with ThreadPoolExecutor(max_workers=1) as pool:
-            pend = None                                   # (pix, new, future of the host stage) of the previous slice
-            for i in range(parts):
-                pix, new, _ = self.stage_ocr(pages_u8[cuts[i]:cuts[i + 1]], cuts[i])
-                fut = pool.submit(self.stage_host, new)
-                if pend is not None:
-                    ppix, pnew, pfut = pend
-                    texts, cells, ids_in, bbox, mask = pfut.result()
-                    out = self.stage_main(ppix, ids_in, bbox, mask)
-                    results.append(PipelineResult(ids=out, ocr_new_ids=pnew, ocr_texts=texts, cells=cells, input_ids=ids_in, bbox=bbox, attention_mask=mask))
-                pend = (pix, new, fut)
-            ppix, pnew, pfut = pend
-            texts, cells, ids_in, bbox, mask = pfut.result()
-            out = self.stage_main(ppix, ids_in, bbox, mask)
-            results.append(PipelineResult(ids=out, ocr_new_ids=pnew, ocr_texts=texts, cells=cells, input_ids=ids_in, bbox=bbox, attention_mask=mask))
-        return results

@@ -84,18 +84,6 @@ def test_pages_to_ids_in_one_path(be_name, continuous):
     want = main.mem.numpy(want)
     assert res.ids.shape == want.shape and np.array_equal(res.ids, want)
     assert np.all(res.ids[:, 0] == shape.decoder_start_token_id) and len({tuple(r) for r in res.ids.tolist()}) > 1
-    # two slices with the host stage in a worker thread underneath the GPU stages: same OCR strings, same VTL inputs and - the pipeline
-    # runs the VTL engine with per-image padding semantics - the same ids page by page, although a slice is padded to ITS longest page
-    parts = pipe.run_overlapped(pages, parts=2)
-    assert [p.ocr_texts for p in parts] == [F.OCR_TEXTS[:2], F.OCR_TEXTS[2:]]
-    k = 0
-    for p in parts:
-        for j in range(p.input_ids.shape[0]):
-            n = len(g["pages"][k]["input_ids"])
-            assert p.input_ids[j, :n].tolist() == g["pages"][k]["input_ids"]
-            m = min(p.ids.shape[1], res.ids.shape[1])
-            assert np.array_equal(p.ids[j, :m], res.ids[k, :m]), k
-            k += 1
 
 
 @pytest.mark.parametrize("be_name", BACKENDS)
