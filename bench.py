@@ -459,8 +459,8 @@ def main():
             if not args.no_cpu_baseline:
                 extra["ocr_stage"]["cpu_baseline"] = ocr_cpu_baseline()
             extra["configs4_end_to_end_1gpu_batch_ocr"] = configs4_run(eng, B, new_tokens)
-            # the same loop with the OCR stage's queue form and a longer queue (512 pages, 128 OCR decode rows)
-            extra["configs4_end_to_end_1gpu"] = configs4_run(eng, B, new_tokens, ocr_pages=512, ocr_slots=128)
+            # the same loop with the OCR stage's queue form and a longer queue (512 pages, 256 OCR decode rows)
+            extra["configs4_end_to_end_1gpu"] = configs4_run(eng, B, new_tokens, ocr_pages=512, ocr_slots=256)
         out = {
             "metric": METRIC, "value": round(world * B * args.steps / dt, 3), "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),

@@ -447,13 +447,20 @@ __global__ __launch_bounds__(GS_THREADS) void greedy_select_kernel(ArgmaxArgs a)
 // one thread walks the slots in order: the assignment of images to slots is deterministic (it does not change any image's
 // result - rows are independent - but it keeps runs reproducible to the byte, K/V cache contents included)
 __global__ __launch_bounds__(64) void slot_refill_kernel(SlotTable s, int64_t* next_ids, int* unfinished, int rows) {
+    // the slots' state is fetched by the whole wave first (one round trip instead of one per slot for the walking thread)
+    MG_DYN_SMEM(smem);
+    int* s_unf = (int*)smem;
+    int* s_img = s_unf + 256;
+    for (int r = threadIdx.x; r < rows; r += 64) { s_unf[r] = unfinished[r]; s_img[r] = s.img[r]; }
+    __syncthreads();
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     int* c = s.ctr;
-    int head = c[4];
+    int head = c[4], done_add = 0;
     const int ready = c[5];
     int n_live = 0, oldest = 0x7fffffff;
     for (int r = 0; r < rows; ++r) {
-        while (!unfinished[r] && head < ready) {
+        int unf = s_unf[r], img = s_img[r];
+        while (!unf && head < ready) {
             const int i = head++;
             int64_t tok = (int64_t)s.start_id;
             if (s.first_tok) {
@@ -462,23 +469,25 @@ __global__ __launch_bounds__(64) void slot_refill_kernel(SlotTable s, int64_t* n
                 const int t = (int)tok;
                 bool stop = s.max_len <= 1;
                 for (int k = 0; k < s.n_stop; ++k) stop = stop || t == s.stop[k];
-                if (stop) { s.out_len[i] = 1; c[1] += 1; continue; }
+                if (stop) { s.out_len[i] = 1; ++done_add; continue; }
             }
             s.img[r] = i;
             s.pool[r] = i % s.pool_cap;
             s.pos[r] = 0;
             next_ids[r] = tok;
             unfinished[r] = 1;
+            unf = 1; img = i;
         }
-        if (unfinished[r]) { ++n_live; oldest = s.img[r] < oldest ? s.img[r] : oldest; }
+        if (unf) { ++n_live; oldest = img < oldest ? img : oldest; }
     }
     c[4] = head;
+    if (done_add) c[1] += done_add;
     c[0] = n_live;
     c[7] = n_live ? oldest : head;      // every image below this index has finished
     c[2] += 1;
 }
 void slot_refill(const SlotTable& s, int64_t* next_ids, int* unfinished, int rows, mgStream_t stream) {
-    MG_LAUNCH(slot_refill_kernel, dim3(1), dim3(64), 0, stream, s, next_ids, unfinished, rows);
+    MG_LAUNCH(slot_refill_kernel, dim3(1), dim3(64), 512 * sizeof(int), stream, s, next_ids, unfinished, rows);
 }
 
 // Fused tail of the greedy decode step: reduce the lm_head launch's per-workgroup top-2 partials (ArgmaxArgs::ptop) instead of
