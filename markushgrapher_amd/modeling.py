@@ -312,3 +312,31 @@ class MarkushgrapherForConditionalGeneration(nn.Module):
                                  max_length=max_length, min_length=int(min_length), length_penalty=float(length_penalty),
                                  early_stopping=early_stopping, e1=e1)
         return ids
+
+    @torch.no_grad()
+    def generate_queue(self, encodings, max_length=None, min_length=0, slots=32, chunk=32):
+        """The reference's evaluation loop (ref: utils/ocsr/utils_evaluation.py:140-285) as ONE call: `encodings` = the per-sample
+        dicts it builds (input_ids [1, L_n] or [L_n], bbox, pixel_values; attention_mask / labels ignored as there), greedy,
+        max_length as there.  Returns a list of 1-D id tensors - predictions[n] == self.generate(**encodings[n], num_beams=1,
+        max_length=max_length)[0] - decoded by the continuous decoder (mg_generate_stream: `slots` rows work through the queue, a row
+        that emits EOS hands its slot to the next image) with per-image padding semantics (every image computed as if alone)."""
+        from .assembly import collate_for_generate
+        self._check_e1(None)
+        eng = self._eng()
+        max_length = int(max_length or self.config.max_length)
+        feats = []
+        for e in encodings:
+            ids = torch.as_tensor(e["input_ids"]).reshape(-1).cpu()
+            feats.append({"input_ids": ids, "bbox": torch.as_tensor(e["bbox"]).reshape(-1, 4).cpu().to(torch.float32)})
+        batch = collate_for_generate(feats)
+        pix = torch.cat([torch.as_tensor(e["pixel_values"]).reshape(1, *torch.as_tensor(e["pixel_values"]).shape[-3:]) for e in encodings]).to(self.device)
+        prev = eng.set_padding_semantics(True)
+        try:
+            n = len(feats)
+            ids, lens, _ = eng.generate_stream(batch["input_ids"], batch["bbox"], batch["attention_mask"], pix, max_length=max_length,
+                                               min_length=int(min_length), chunk=min(chunk, n), slots=min(slots, n), pool_chunks=3)
+        finally:
+            eng.set_padding_semantics(prev)
+        lens = lens.cpu().tolist()
+        return [ids[i, :lens[i]] for i in range(len(lens))]
+

@@ -163,3 +163,32 @@ def test_generate_with_e1_tokens_and_opt_out_on_gpu():
     with pytest.warns(UserWarning, match="allow_missing_e1"):
         ids0 = m.generate(**kw, max_length=int(g["max_length"]))
     assert np.array_equal(ids0.cpu().numpy(), g["greedy_ids"])
+
+
+@pytest.mark.gpu
+def test_generate_queue_equals_the_per_image_loop():
+    """generate_queue(encodings) against the reference's loop `for sample: model.generate(**encoding, num_beams=1, max_length=...)`
+    (ref: utils/ocsr/utils_evaluation.py:140, 269-285) on per-sample encodings of DIFFERENT lengths: identical ids per image."""
+    import json
+    m, shape = tiny_model()
+    m = m.to("cuda")
+    dev = m.device
+    with open(os.path.join(GOLDEN, "pipeline_host.json")) as f:
+        pages = json.load(f)["pages"]
+    g = load_golden("g3_trained_tiny.npz")
+    encodings = []
+    for k in range(7):
+        p = pages[k % len(pages)]
+        encodings.append({"input_ids": torch.tensor([p["input_ids"]]), "bbox": torch.tensor([p["bbox"]], dtype=torch.float32),
+                          "pixel_values": torch.from_numpy(g["pixel_values"][k % g["pixel_values"].shape[0]][None])})
+    loop = []
+    for e in encodings:
+        enc = {k: v.to(dev) for k, v in e.items()}
+        loop.append(m.generate(**enc, num_beams=1, max_length=16)[0].cpu())
+    got = m.generate_queue(encodings, max_length=16, slots=3, chunk=2)
+    assert len(got) == len(loop)
+    for a, b in zip(got, loop):
+        b = b.tolist()
+        n = b.index(shape.eos_token_id) + 1 if shape.eos_token_id in b else len(b)
+        assert a.cpu().tolist() == b[:n]
+    assert len({tuple(x.cpu().tolist()) for x in got}) > 1
