@@ -46,6 +46,29 @@ class _Size:
         self.size = (w, h)
 
 
+class _MemoTokenizer:
+    """The word-box splitter asks the tokenizer for the pieces of every cell text and again for every piece (token budget,
+    ref: data_preprocessing.py:59-104); OCR pages repeat the same few hundred strings.  `tokenize` results are memoised per string -
+    same pieces, a dictionary lookup instead of a tokenizer call; every other attribute / call goes to the wrapped tokenizer."""
+
+    def __init__(self, tok):
+        self._tok, self._memo = tok, {}
+
+    def tokenize(self, text):
+        r = self._memo.get(text)
+        if r is None:
+            r = self._memo[text] = self._tok.tokenize(text)
+            if len(self._memo) > 200000:
+                self._memo.clear()
+        return list(r)
+
+    def __call__(self, *a, **k):
+        return self._tok(*a, **k)
+
+    def __getattr__(self, name):
+        return getattr(self._tok, name)
+
+
 def encode_cells(cells, tokenizer, image_size: int, question: str = QUESTION, normalize_bbox: bool = True):
     """One page's OCR cells -> (input_ids [L] int64, bbox [L,4] float32): `encode_item` without the pixel part (ref: utils/common.py:
     14-42): TaskCollator.collate's words / boxes, then the tokenizer call the processor makes."""
@@ -76,7 +99,7 @@ class Configs4Pipeline:
     def __init__(self, ocr, main, tokenizer, ocr_detok: Callable, ocr_prompt_ids, ocr_max_new_tokens: int = 4096, question: str = QUESTION,
                  max_length: int = 512, min_length: int = 0, num_beams: int = 1, continuous: bool = False, main_batch: int = 32,
                  ocr_slots: int = 0, per_image_padding: bool = True):
-        self.ocr, self.main, self.tokenizer, self.ocr_detok = ocr, main, tokenizer, ocr_detok
+        self.ocr, self.main, self.tokenizer, self.ocr_detok = ocr, main, _MemoTokenizer(tokenizer), ocr_detok
         self.ocr_prompt_ids = np.asarray(ocr_prompt_ids, np.int64)
         self.ocr_max_new_tokens, self.question = int(ocr_max_new_tokens), question
         self.max_length, self.min_length, self.num_beams, self.continuous = int(max_length), int(min_length), int(num_beams), bool(continuous)
@@ -109,11 +132,14 @@ class Configs4Pipeline:
         import torch
         texts = [self.ocr_detok(row) for row in new]
         cells = [cells_from_ocr_text(x) for x in texts]
-        feats = []
         I = self.main.shape.image_size
-        for c in cells:
-            ids, bb = encode_cells(c, self.tokenizer, I, self.question)
-            feats.append({"input_ids": torch.from_numpy(ids), "bbox": torch.from_numpy(bb)})
+        items = [assembly.collate_item({"image": _Size(I, I), "cells": order_cells(c), "entities": {"question": self.question, "answer": ""}},
+                                       self.tokenizer, True) for c in cells]
+        # one tokenizer call for all pages (the per-sample call of encode_item, batched: same ids and boxes per page)
+        enc = self.tokenizer(text=[it[1] for it in items], text_pair=[it[2] for it in items],
+                             boxes=[[list(map(float, b)) for b in it[3]] for it in items], padding=False, truncation=False)
+        feats = [{"input_ids": torch.tensor(enc["input_ids"][k], dtype=torch.int64), "bbox": torch.tensor(enc["bbox"][k], dtype=torch.float32)}
+                 for k in range(len(items))]
         batch = assembly.collate_for_generate(feats)
         return (texts, cells, batch["input_ids"].numpy().astype(np.int64), batch["bbox"].numpy().astype(np.float32),
                 batch["attention_mask"].numpy().astype(np.int64))
