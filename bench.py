@@ -32,6 +32,8 @@ import time
 
 # before torch loads the HIP runtime: kernel arguments in device memory (see markushgrapher_amd/__init__.py)
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+# one hardware queue per execution context of the batches in flight (same file)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np
 
@@ -41,6 +43,7 @@ sys.path.insert(0, ROOT)
 METRIC = "images/sec whole-node (greedy CXSMILES decode, 1024px crops, bs=32/GPU)"
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (same guide)
+SOLO_STEPS = 3                                      # batches of the one-batch-in-flight side measurement
 EOS_ROW_SCALES = (3.0, 4.0, 6.0, 8.0, 12.0, 16.0)   # EOS-enabled run: ladder of scales of the EOS embedding row (see extra_runs)
 
 
@@ -257,6 +260,9 @@ def main():
     ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--profile-every", type=int, default=16)
     ap.add_argument("--decode-graph", type=int, default=1, help="1: replay the captured decode-step HIP graph; 0: eager launches")
+    ap.add_argument("--inflight", type=int, default=4,
+                    help="batches in flight per GPU: execution contexts (mg_clone) with a stream and host thread each; 1 = one batch "
+                         "after the other, as the reference's loop")
     args = ap.parse_args()
     if args.pmc_child:
         return pmc_child(args)
@@ -311,8 +317,31 @@ def main():
                 ex.wait(handles.pop(0))      # the previous batch's gather has had this batch's whole step to complete
         return ids
 
-    for _ in range(args.warmup):
-        step()
+    # batches in flight: `--inflight` execution contexts on the same weights (include/mgrapher.h mg_clone), one host thread and stream
+    # each.  Every step is still one whole pass preprocess -> encoder -> 256 decode steps over one batch of 32; the decode step of one
+    # batch is latency-bound for five of its six launches per layer, the others' launches fill the machine it leaves idle.  Results
+    # per batch are identical to a call made alone (tests/test_inflight.py).
+    from markushgrapher_amd.inflight import InFlight
+    fl = InFlight(eng, max(1, args.inflight))
+
+    def job(ctx):
+        pix = ctx.preprocess(dev["pages_u8"])
+        out, _, _ = ctx.generate(dev["input_ids"], dev["bbox"], dev["attention_mask"], pix, num_beams=args.beams,
+                                 max_length=max_length, min_length=max_length)
+        return out
+
+    def run_steps(k):
+        futs = [fl.submit(job) for _ in range(k)]
+        out = None
+        for f in futs:
+            out = f.result()
+            handles.append(ex.post(out))
+            if len(handles) > 1:
+                ex.wait(handles.pop(0))      # the previous batch's gather has had this batch's whole step to complete
+        return out
+
+    torch.cuda.synchronize()
+    run_steps(max(args.warmup, 1) * len(fl) if args.warmup else 0)      # every context warms up (graph capture) `warmup` times
     while handles:
         ex.wait(handles.pop(0))
     # live timing of the dominant kernel on the launch stream (HIP events), sampled every N-th decode step; phase events
@@ -323,14 +352,27 @@ def main():
     L_.mg_profile_phases.argtypes = [C.c_void_p, C.c_int]
     L_.mg_profile_phases_read.argtypes = [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     nl = shape.num_decoder_layers
-    L_.mg_profile_cross_attention(eng.model, args.profile_every, (new_tokens // max(args.profile_every, 1) + 1) * nl)
-    L_.mg_profile_phases(eng.model, 1)
+
+    def profile_on():
+        L_.mg_profile_cross_attention(eng.model, args.profile_every, (new_tokens // max(args.profile_every, 1) + 1) * nl)
+        L_.mg_profile_phases(eng.model, 1)
+
+    def profile_read():
+        n_l, ms, keys, empty_ms = C.c_long(0), C.c_double(0), C.c_double(0), C.c_double(0)
+        L_.mg_profile_read(eng.model, C.byref(n_l), C.byref(ms), C.byref(keys))
+        L_.mg_profile_read_overhead(eng.model, C.byref(empty_ms))
+        n_ph, enc_ms, dec_ms = C.c_long(0), C.c_double(0), C.c_double(0)
+        L_.mg_profile_phases_read(eng.model, C.byref(n_ph), C.byref(enc_ms), C.byref(dec_ms))
+        L_.mg_profile_cross_attention(eng.model, 0, 0)
+        L_.mg_profile_phases(eng.model, 0)
+        return n_l, ms, keys, empty_ms, n_ph, enc_ms, dec_ms
+
+    profile_on()                       # on the first context: its launches are bracketed while the other contexts run beside it
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.time()
-    for _ in range(args.steps):
-        ids = step()
+    ids = run_steps(args.steps)
     while handles:
         all_ids, all_len = ex.wait(handles.pop(0))      # the last batch's exchange completes inside the timed region
     torch.cuda.synchronize()
@@ -341,13 +383,20 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    n_l, ms, keys, empty_ms = C.c_long(0), C.c_double(0), C.c_double(0), C.c_double(0)
-    L_.mg_profile_read(eng.model, C.byref(n_l), C.byref(ms), C.byref(keys))
-    L_.mg_profile_read_overhead(eng.model, C.byref(empty_ms))
-    n_ph, enc_ms, dec_ms = C.c_long(0), C.c_double(0), C.c_double(0)
-    L_.mg_profile_phases_read(eng.model, C.byref(n_ph), C.byref(enc_ms), C.byref(dec_ms))
-    L_.mg_profile_cross_attention(eng.model, 0, 0)
-    L_.mg_profile_phases(eng.model, 0)
+    n_l, ms, keys, empty_ms, n_ph, enc_ms, dec_ms = profile_read()
+    # the same step with ONE batch in flight (the reference's loop shape; rounds 1-2 measured this): untimed for `value`, it gives
+    # the kernel's and the phases' uncontended figures beside the in-flight ones
+    solo = None
+    if len(fl) > 1 and rank == 0:
+        step()
+        profile_on()
+        torch.cuda.synchronize(); ts = time.time()
+        for _ in range(SOLO_STEPS):
+            step()
+        while handles:
+            ex.wait(handles.pop(0))
+        torch.cuda.synchronize(); ts = time.time() - ts
+        solo = (ts,) + profile_read()
     assert ids.shape == (B, max_length), ids.shape
 
     if rank == 0:
@@ -357,47 +406,75 @@ def main():
         _, msk = eng.encode(dev["input_ids"], dev["bbox"], dev["attention_mask"], eng.preprocess(dev["pages_u8"]))
         xlen = msk.sum(dim=1).cpu().numpy().astype(np.float64)
         traffic = None if (args.no_pmc or world > 1 or args.beams != 1) else pmc_traffic(args)
-        roof = None
-        if n_l.value > 0:
+        def make_roof(n_l, ms, keys, empty_ms, with_traffic):
+            if n_l.value <= 0:
+                return None
             bytes_per_launch = keys.value / n_l.value * H * 64 * 2 * 2     # K and V rows of 64 bf16, all heads
             raw_s = ms.value / n_l.value * 1e-3            # e0 -> e1 around the launch
             empty_s = empty_ms.value / n_l.value * 1e-3    # e1 -> e2 with nothing in between: cost of the bracket itself
             # The bracket over-reads the kernel by the dispatch latency behind the first record (rocprofv3 kernel trace of
             # the same command: profiles/); the empty bracket over-corrects, so the conservative raw bracket is `achieved`.
             ach = bytes_per_launch / raw_s / 1e9
-            roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": traffic["cross_attention_bytes_per_launch"] if traffic else None, "traffic_unit": "bytes/launch",
-                    "traffic_source": traffic["source"] if traffic else None,
-                    "kernel": "attn_step_kernel<1, 8, true> (decoder cross-attention, single query per image/head)",
-                    "bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(raw_s * 1e6, 2),
-                    "empty_bracket_us": round(empty_s * 1e6, 2),
-                    "timing": "HIP events on the launch stream around the device-counter form of the launch the decode graph "
-                              "replays: (record, launch, record, record); avg_launch_us = first bracket, uncorrected; "
-                              "empty_bracket_us = second bracket (nothing in between)",
-                    "launches_timed": int(n_l.value)}
-        phases = None
-        if n_ph.value > 0 and args.beams == 1:
+            r = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)}
+            if with_traffic:
+                r.update({"traffic": traffic["cross_attention_bytes_per_launch"] if traffic else None, "traffic_unit": "bytes/launch",
+                          "traffic_source": traffic["source"] if traffic else None,
+                          "kernel": "attn_step_kernel<1, 8, true> (decoder cross-attention, single query per image/head)"})
+            r.update({"bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(raw_s * 1e6, 2),
+                      "empty_bracket_us": round(empty_s * 1e6, 2), "launches_timed": int(n_l.value)})
+            return r
+
+        # F_enc = N_enc*S*(8d^2 + 4*d*dff + 4*S*d) + 2*P*768*d;  F_xkv = N_dec*S_x*4d^2  (per image, S = attended positions)
+        f_enc = float(np.sum(n_enc * xlen * (8 * d * d + 4 * d * dff + 4 * xlen * d) + 2 * P * (shape.num_channels * shape.patch_size ** 2) * d))
+        f_xkv = float(np.sum(n_dec * xlen * 4 * d * d))
+        tbar = (new_tokens - 1) / 2.0
+        # Bytes_step = 2*(N_dec*16d^2 + d*V) + sum_b 2*N_dec*2*d*(S_x + t);  F_step = N_dec*(12d^2 + 4*d*dff) + N_dec*4*d*(S_x+t) + 2*d*V
+        bytes_step = 2.0 * (n_dec * 16 * d * d + d * V) + float(np.sum(2 * n_dec * 2 * d * (xlen + tbar)))
+        f_step = float(np.sum(n_dec * (12 * d * d + 4 * d * dff) + n_dec * 4 * d * (xlen + tbar) + 2 * d * V))
+
+        def make_phases(n_ph, enc_ms, dec_ms):
+            if n_ph.value <= 0 or args.beams != 1:
+                return None
             t_enc = enc_ms.value / n_ph.value * 1e-3
             t_step = dec_ms.value / n_ph.value * 1e-3 / new_tokens
-            # F_enc = N_enc*S*(8d^2 + 4*d*dff + 4*S*d) + 2*P*768*d;  F_xkv = N_dec*S_x*4d^2  (per image, S = attended positions)
-            f_enc = float(np.sum(n_enc * xlen * (8 * d * d + 4 * d * dff + 4 * xlen * d) + 2 * P * (shape.num_channels * shape.patch_size ** 2) * d))
-            f_xkv = float(np.sum(n_dec * xlen * 4 * d * d))
-            tbar = (new_tokens - 1) / 2.0
-            # Bytes_step = 2*(N_dec*16d^2 + d*V) + sum_b 2*N_dec*2*d*(S_x + t);  F_step = N_dec*(12d^2 + 4*d*dff) + N_dec*4*d*(S_x+t) + 2*d*V
-            bytes_step = 2.0 * (n_dec * 16 * d * d + d * V) + float(np.sum(2 * n_dec * 2 * d * (xlen + tbar)))
-            f_step = float(np.sum(n_dec * (12 * d * d + 4 * d * dff) + n_dec * 4 * d * (xlen + tbar) + 2 * d * V))
-            phases = {
-                "encoder_ms": round(t_enc * 1e3, 2), "decode_step_ms": round(t_step * 1e3, 4),
-                "enc_flops": f_enc + f_xkv, "enc_mfma_frac": round((f_enc + f_xkv) / t_enc / (MFMA_PEAK_TFLOPS * 1e12), 4),
-                "dec_bytes_step_algorithmic": int(bytes_step), "dec_hbm_frac": round(bytes_step / t_step / (HBM_PEAK_GBS * 1e9), 4),
-                "dec_bytes_step_fetched": traffic["decode_step_bytes"] if traffic else None,
-                "dec_mfma_frac": round(f_step / t_step / (MFMA_PEAK_TFLOPS * 1e12), 5),
-                "note": "phase times: HIP events in mg_generate [preprocess excluded | encoder + cross-K/V | decode loop]; formulas "
-                        "SURVEY.md §8d with S = attended positions per image (mean %.0f), t = mean decode position; the decode step "
-                        "is HBM-bound (dec_mfma_frac is reported because north_star asks for it); fetched bytes: child run of 8 steps "
-                        "(t < 8), they contain the product weights of the pair projections (+1.37x on weights, DESIGN.md) and not "
-                        "the cross-K/V projection weights the formula's 16d^2 counts" % float(xlen.mean())}
+            return {"encoder_ms": round(t_enc * 1e3, 2), "decode_step_ms": round(t_step * 1e3, 4),
+                    "enc_flops": f_enc + f_xkv, "enc_mfma_frac": round((f_enc + f_xkv) / t_enc / (MFMA_PEAK_TFLOPS * 1e12), 4),
+                    "dec_bytes_step_algorithmic": int(bytes_step), "dec_hbm_frac": round(bytes_step / t_step / (HBM_PEAK_GBS * 1e9), 4),
+                    "dec_mfma_frac": round(f_step / t_step / (MFMA_PEAK_TFLOPS * 1e12), 5)}
+
+        def whole_job(n_batches, seconds):
+            # algorithmic bytes of all decode steps and algorithmic flops of everything, over the elapsed time of the region
+            return {"hbm_frac_decode_bytes": round(n_batches * new_tokens * bytes_step / seconds / (HBM_PEAK_GBS * 1e9), 4),
+                    "mfma_frac_all_flops": round(n_batches * (f_enc + f_xkv + new_tokens * f_step) / seconds / (MFMA_PEAK_TFLOPS * 1e12), 4)}
+
+        roof = make_roof(n_l, ms, keys, empty_ms, True)
+        if roof is not None:
+            roof["timing"] = ("HIP events on the launch stream around the device-counter form of the launch the decode graph "
+                              "replays: (record, launch, record, record); avg_launch_us = first bracket, uncorrected; "
+                              "empty_bracket_us = second bracket (nothing in between); taken on the first execution context during "
+                              "the timed region, i.e. with the other %d batches' kernels sharing the GPU" % (len(fl) - 1))
+            roof["batches_in_flight"] = len(fl)
+        phases = make_phases(n_ph, enc_ms, dec_ms)
+        if phases is not None:
+            phases["dec_bytes_step_fetched"] = traffic["decode_step_bytes"] if traffic else None
+            phases["batches_in_flight"] = len(fl)
+            phases["whole_job"] = whole_job(args.steps, dt)
+            phases["note"] = ("phase times: HIP events in mg_generate on the first execution context [preprocess excluded | encoder + "
+                              "cross-K/V | decode loop] = one batch's latency while %d batches share the GPU (per-context fractions "
+                              "are of the whole GPU's peak); whole_job = algorithmic decode bytes / all algorithmic flops of the K "
+                              "batches over the timed region; formulas SURVEY.md §8d with S = attended positions per image (mean "
+                              "%.0f), t = mean decode position; the decode step is HBM-bound (dec_mfma_frac is reported because "
+                              "north_star asks for it); fetched bytes: child run of 8 steps (t < 8), they contain the product "
+                              "weights of the pair projections (+1.37x on weights, DESIGN.md) and not the cross-K/V projection "
+                              "weights the formula's 16d^2 counts" % (len(fl), float(xlen.mean())))
+        single = None
+        if solo is not None:
+            ts = solo[0]
+            single = {"images_per_s": round(B * SOLO_STEPS / ts, 2), "ms_per_batch": round(ts / SOLO_STEPS * 1e3, 2), "steps": SOLO_STEPS,
+                      "roofline": make_roof(*solo[1:5], False), "phases": make_phases(*solo[5:8]),
+                      "whole_job": whole_job(SOLO_STEPS, ts),
+                      "note": "the same step with one batch in flight (one context, one stream): the loop shape of the reference and of "
+                              "rounds 1-2; kernel and phase figures without other batches' kernels beside them"}
         extra = None
         if not args.no_extra_runs and world == 1 and args.beams == 1:
             extra = {}
@@ -407,7 +484,22 @@ def main():
             step(beams=5, max_len=129, min_len=129)
             torch.cuda.synchronize(); tb = time.time() - tb
             extra["beam5"] = {"images_per_s": round(B / tb, 2), "ms_per_batch": round(tb * 1e3, 1), "new_tokens": 128,
-                              "config": "configs[2]: batch 32, num_beams 5 (160 live rows), EOS suppressed"}
+                              "config": "configs[2]: batch 32, num_beams 5 (160 live rows), EOS suppressed; one batch in flight"}
+            if len(fl) > 1:
+                def job_beam(ctx):
+                    out, _, _ = ctx.generate(dev["input_ids"], dev["bbox"], dev["attention_mask"], ctx.preprocess(dev["pages_u8"]),
+                                             num_beams=5, max_length=129, min_length=129)
+                    return out
+                for f in [fl.submit(job_beam) for _ in range(len(fl))]:
+                    f.result()
+                nb5 = 2 * len(fl)
+                torch.cuda.synchronize(); tb = time.time()
+                for f in [fl.submit(job_beam) for _ in range(nb5)]:
+                    f.result()
+                torch.cuda.synchronize(); tb = time.time() - tb
+                extra["beam5_in_flight"] = {"images_per_s": round(B * nb5 / tb, 2), "ms_per_batch": round(tb / nb5 * 1e3, 1), "new_tokens": 128,
+                                            "batches": nb5, "batches_in_flight": len(fl),
+                                            "config": "configs[2] with %d batches in flight (execution contexts as in the headline run)" % len(fl)}
             # EOS enabled (max_length 512): random-init weights never emit EOS on their own, so the EOS row of the tied embedding
             # is scaled up the ladder until at least three quarters of the rows end by themselves; rows then end at different
             # steps, finished rows emit pad and the batch stops when all have ended or at max_length (gen:2927-2937 bookkeeping)
@@ -469,9 +561,12 @@ def main():
                                    f"decode, {new_tokens} forced new tokens (EOS suppressed), UDOP-large-shaped "
                                    "MarkushGrapher-2 VTL encoder + CXSMILES decoder, recipe weights = tests/golden/g4_bench.npz",
                        "shape": args.shape, "batch_per_gpu": B, "text_len_padded": int(L), "new_tokens": new_tokens,
-                       "num_beams": args.beams, "decode_graph": args.decode_graph,
+                       "num_beams": args.beams, "decode_graph": args.decode_graph, "batches_in_flight": len(fl),
+                       "in_flight": "execution contexts on one set of weights (mg_clone), a stream + host thread + workspace each; every "
+                                    "step is one whole batch start to end; ids identical to one-at-a-time calls; warm-up = `warmup` "
+                                    "batches per context",
                        "parallelism": f"dp{world} (independent image shards; one RCCL all-gather of [32,512] int32 ids + lengths per batch)"},
-            "roofline": roof, "phases": phases, "extra_runs": extra,
+            "roofline": roof, "phases": phases, "one_batch_in_flight": single, "extra_runs": extra,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(shape, sd)

@@ -64,6 +64,15 @@ int mg_load_tensor(mg_model* m, void* stream, const char* hf_key, const void* sr
                    int ndim);
 int mg_finalize(mg_model* m, void* stream);
 
+/* A further execution context on the weights of a finalized model: the clone reads the same arena (no copy; the arena must
+ * outlive it) and owns everything a call mutates - captured decode graph, events, run-ahead stream, profiling state, last-error
+ * text is per host thread - so calls on different contexts may run at the same time from different host threads, each on its
+ * own stream with its own workspace.  That is how several batches are kept in flight on one GPU: five of the six launches of
+ * a decoder layer are latency-sized, a second and third batch's launches fill the machine they leave idle, and every batch's
+ * ids are exactly what it gets alone (rows never meet).  Calls on ONE context stay serial.  Tensors loaded later through any
+ * of the contexts land in the shared arena; run mg_finalize on the context that loaded them before the next call of any. */
+int mg_clone(const mg_model* src, mg_model** out);
+
 /* Workspace for a batch of B images with L text tokens, num_beams beams, decoder length max_length, (for
  * mg_decoder_forward) T teacher-forced positions (0 if unused) and M_e1 OCSR-branch tokens per image (0 if unused). */
 int mg_workspace_bytes(const mg_model* m, int B, int L, int num_beams, int max_length, int T, int M_e1, size_t* out_bytes);

@@ -6,3 +6,8 @@ import os as _os
 # ~150 latency-sized launches, and host-resident arguments cost it ~1-2 % (eager launches: 62 -> 72 images/s).
 # Import this package before torch for it to take effect; a value already set by the caller is respected.
 _os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+# Hardware queues the HIP runtime spreads its streams over (default 4, one of them taken by the null stream): with the batches
+# in flight of markushgrapher_amd/inflight.py every execution context needs a queue of its own - two contexts sharing one run
+# back to back (4 contexts: 102 images/s on 4 queues, 116 on 8; profiles/r03_inflight_ab.txt).  More than 4 busy queues
+# oversubscribe the chip's compute pipes and collapse (5 contexts: 80 images/s), which is why InFlight caps at 4.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")

@@ -708,6 +708,29 @@ int mg_create(const mg_config* cfg, mg_model** out) {
 
 void mg_destroy(mg_model* m) { delete m; }
 
+int mg_clone(const mg_model* src, mg_model** out) {
+    if (!src || !out) return fail(MG_E_ARG, "mg_clone: null argument");
+    if (!src->arena || !src->finalized) return fail(MG_E_STATE, "mg_clone: the source model has no finalized weights");
+    mg_model* m = new mg_model();
+    // geometry, arena layout and switches are copied; everything a call mutates (graphs, events, streams, profiling) starts fresh
+    m->c = src->c;
+    m->d = src->d; m->H = src->H; m->inner = src->inner; m->dff = src->dff; m->V = src->V; m->P = src->P; m->n_side = src->n_side;
+    m->Kpatch = src->Kpatch; m->M2 = src->M2; m->T_cap = src->T_cap;
+    m->arena = src->arena; m->arena_bytes = src->arena_bytes;
+    m->tok_emb = src->tok_emb; m->lm_head = src->lm_head; m->patch_w = src->patch_w; m->patch_b = src->patch_b;
+    m->x_emb = src->x_emb; m->y_emb = src->y_emb;
+    for (int i = 0; i < 3; ++i) m->rb_raw[i] = src->rb_raw[i];
+    m->rb_dec_raw = src->rb_dec_raw; m->dec_tab = src->dec_tab;
+    m->bk1 = src->bk1; m->bkhv = src->bkhv; m->bkdec = src->bkdec; m->enc_ln = src->enc_ln; m->dec_ln = src->dec_ln;
+    m->enc = src->enc; m->dec = src->dec; m->loaded = src->loaded; m->lm_head_loaded = src->lm_head_loaded; m->finalized = true;
+    m->h_bk1 = src->h_bk1; m->h_bkhv = src->h_bkhv; m->h_bkdec = src->h_bkdec;
+    m->fin_a = src->fin_a; m->fin_b = src->fin_b; m->fin_c = src->fin_c;
+    m->use_graph = src->use_graph; m->enc_mode = src->enc_mode; m->enc_mask = src->enc_mask;
+    m->row_tiles = src->row_tiles; m->trim_padding = src->trim_padding; m->fused_tail = src->fused_tail; m->tied = src->tied;
+    *out = m;
+    return MG_OK;
+}
+
 size_t mg_weights_bytes(const mg_model* m) { return m ? m->arena_bytes : 0; }
 
 int mg_bind_weights(mg_model* m, void* arena) {

@@ -9,6 +9,7 @@
 
 #include <math.h>
 #include <map>
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -30,6 +31,8 @@ double lanczos3(double x) {
 // Resample.c precompute_coeffs + normalize_coeffs_8bpc for the full source range
 const CoefTable& coef_table(int in_size, int out_size) {
     static std::map<std::pair<int, int>, CoefTable> cache;    // host tables persist: async uploads may still read them
+    static std::mutex mu;                                     // callers on several host threads (one execution context each)
+    std::lock_guard<std::mutex> lock(mu);                     // map nodes keep their address across later inserts
     auto key = std::make_pair(in_size, out_size);
     auto it = cache.find(key);
     if (it != cache.end()) return it->second;

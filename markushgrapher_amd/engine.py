@@ -111,6 +111,7 @@ class Engine:
         L.mg_weights_bytes.restype = C.c_size_t
         L.mg_weights_bytes.argtypes = [C.c_void_p]
         L.mg_destroy.argtypes = [C.c_void_p]
+        L.mg_clone.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.mg_bind_weights.argtypes = [C.c_void_p, C.c_void_p]
         L.mg_finalize.argtypes = [C.c_void_p, C.c_void_p]
         L.mg_load_tensor.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]
@@ -142,6 +143,19 @@ class Engine:
 
     def decode_graph_active(self):
         return bool(self.lib.mg_decode_graph_active(self.model))
+
+    def clone(self):
+        """A further execution context on this engine's weights (include/mgrapher.h mg_clone): same arena, own workspace, decode
+        graph and output buffers.  Calls on different contexts may overlap in time when made from different host threads, each under
+        its own stream (`with torch.cuda.stream(s): ctx.generate(...)`); ids per batch are those of a call made alone."""
+        other = object.__new__(Engine)
+        other.lib, other.mem, other.shape = self.lib, self.mem, self.shape
+        other.max_decode_len = self.max_decode_len
+        other.arena = self.arena            # shared, kept alive by every context
+        other.model = C.c_void_p()
+        self._chk(self.lib.mg_clone(self.model, C.byref(other.model)))
+        other._ws, other._ws_bytes, other._gen_out, other.ignored_keys = None, 0, {}, list(self.ignored_keys)
+        return other
 
     def close(self):
         if self.model:

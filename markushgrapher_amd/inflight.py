@@ -1,0 +1,76 @@
+"""Several batches in flight on one GPU.
+
+The reference's evaluation loop (utils_evaluation.py:269-285) hands the model one batch after the other.  On MI355X one batch
+cannot fill the machine while it decodes: five of the six launches of a decoder layer are latency-sized (a few MB of weights on
+32 rows), only the cross-attention K/V stream is bandwidth-sized.  `InFlight` keeps `n` batches going at once, each on its own
+execution context (`Engine.clone()`: shared weights; own workspace, decode graph, stream and host thread), so one batch's small
+launches run in the gaps of another's.  Rows of different batches never meet, so every batch's result is exactly what a call made
+alone returns (tests/test_inflight.py); what changes is throughput (profiles/r03_inflight_ab.txt).
+"""
+import queue
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
+
+class InFlight:
+    """`submit(fn, *args)` runs `fn(ctx, *args)` on the next free context and returns a future; `map(fn, items)` keeps the order.
+
+    `fn` runs on a worker thread with the context's stream current; whatever it returns must be complete on the host's clock
+    (Engine.generate ends with a synchronisation of its stream) and must not alias the context's reusable output buffers if it is
+    read after the context's next call - copy inside `fn` (`ids.clone()`).
+    """
+
+    MAX = 4      # busy hardware queues beyond four are time-sliced by the chip's scheduler: throughput drops below one batch at a time
+
+    def __init__(self, engine, n=4, streams=None):
+        if n < 1 or n > self.MAX:
+            raise ValueError("InFlight: n must be in [1, %d] (more contexts than compute pipes collapse: profiles/r03_inflight_ab.txt)" % self.MAX)
+        self.contexts = [engine] + [engine.clone() for _ in range(n - 1)]
+        torch = getattr(engine.mem, "torch", None)
+        if streams is not None:
+            self.streams = list(streams)
+        elif torch is not None and torch.cuda.is_available():
+            self.streams = [torch.cuda.Stream(device=engine.mem.device) for _ in range(n)]
+        else:
+            self.streams = [None] * n          # emulator backend: no streams, the worker threads still interleave on the host
+        self._torch = torch
+        self._free = queue.SimpleQueue()
+        for i in range(n):
+            self._free.put(i)
+        self._pool = ThreadPoolExecutor(max_workers=n, thread_name_prefix="mg-inflight")
+        self._lock = threading.Lock()
+
+    def __len__(self):
+        return len(self.contexts)
+
+    def _run(self, fn, args):
+        i = self._free.get()
+        try:
+            st = self.streams[i]
+            if st is None:
+                return fn(self.contexts[i], *args)
+            with self._torch.cuda.stream(st):
+                out = fn(self.contexts[i], *args)
+                st.synchronize()
+                return out
+        finally:
+            self._free.put(i)
+
+    def submit(self, fn, *args):
+        return self._pool.submit(self._run, fn, args)
+
+    def map(self, fn, items):
+        futures = [self.submit(fn, it) for it in items]
+        return [f.result() for f in futures]
+
+    def close(self):
+        self._pool.shutdown(wait=True)
+        for c in self.contexts[1:]:
+            c.close()
+        self.contexts = self.contexts[:1]
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

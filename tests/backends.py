@@ -124,5 +124,6 @@ def make_engine(be_name, shape, sd, max_decode_len=64):
         eng = Engine(shape, lib=be.lib, mem=NumpyMem(), max_decode_len=max_decode_len)
     else:
         eng = Engine(shape, max_decode_len=max_decode_len)
-    eng.load_state_dict(sd)
+    if sd is not None:
+        eng.load_state_dict(sd)
     return eng

@@ -1,0 +1,112 @@
+"""Several batches in flight (C ABI mg_clone; markushgrapher_amd/inflight.py): further execution contexts on one set of weights,
+each with its own workspace / decode graph / stream / host thread.  What must hold: a context's results are exactly those of the
+context it was cloned from, whether the calls run one after the other (`emu`: the CPU SIMT emulator is single-threaded test
+infrastructure) or overlap in time on the GPU (`hip`), greedy and beam, and weights loaded later through the source are seen by
+every context.  The reference has no counterpart: it runs one batch at a time (utils_evaluation.py:269-285)."""
+import numpy as np
+import pytest
+
+from tests.backends import make_engine
+from tests.conftest import load_golden
+from tests.test_oracle_golden import _weights, _inputs
+
+BACKENDS = [pytest.param("emu"), pytest.param("hip", marks=pytest.mark.gpu)]
+
+
+def _gen(eng, inp, **kw):
+    ids, _, _ = eng.generate(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"], **kw)
+    return eng.mem.numpy(ids).copy()
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+def test_clone_matches_source_and_golden(be_name):
+    g = load_golden("g3_trained_tiny.npz")
+    shape, sd = _weights(g)
+    inp = _inputs(g, shape)
+    T = int(g["max_length"])
+    eng = make_engine(be_name, shape, sd)
+    ctx = eng.clone()
+    a = _gen(eng, inp, max_length=T)
+    b = _gen(ctx, inp, max_length=T)
+    assert np.array_equal(a, b)
+    assert np.array_equal(b, g["greedy_ids"][:, :b.shape[1]])
+    # beam search on the clone, greedy on the source in between (each context has its own captured step)
+    bb = _gen(ctx, inp, max_length=T, num_beams=5)
+    a2 = _gen(eng, inp, max_length=T)
+    ba = _gen(eng, inp, max_length=T, num_beams=5)
+    assert np.array_equal(a2, a) and np.array_equal(ba, bb)
+    assert np.array_equal(bb, g["beam_ids"][:, :bb.shape[1]])
+    # encoder output through the clone
+    ea, _ = eng.encode(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"])
+    eb, _ = ctx.encode(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"])
+    assert np.array_equal(eng.mem.numpy(ea), ctx.mem.numpy(eb))
+    ctx.close()
+    assert np.array_equal(_gen(eng, inp, max_length=T), a)          # the source outlives its clones
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+def test_clone_sees_later_weights(be_name):
+    g = load_golden("g3_trained_tiny.npz")
+    shape, sd = _weights(g)
+    inp = _inputs(g, shape)
+    eng = make_engine(be_name, shape, sd)
+    ctx = eng.clone()
+    T = 10
+    base = _gen(ctx, inp, max_length=T, min_length=T)
+    emb = np.array(sd["shared.weight"], dtype=np.float32).copy()
+    emb[5] *= 6.0                                                       # makes token 5 the arg-max of most steps
+    eng.load_state_dict({"shared.weight": emb})
+    a = _gen(eng, inp, max_length=T, min_length=T)
+    b = _gen(ctx, inp, max_length=T, min_length=T)
+    assert np.array_equal(a, b) and not np.array_equal(b, base)
+
+
+def test_clone_refuses_unfinalized():
+    g = load_golden("g3_trained_tiny.npz")
+    shape, sd = _weights(g)
+    eng = make_engine("emu", shape, None)
+    with pytest.raises(Exception, match="finalized"):
+        eng.clone()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 3])
+def test_batches_in_flight_equal_serial_calls(n):
+    """n worker threads, one context + stream each, overlapping on the GPU; different inputs per job so a mix-up would show."""
+    import torch
+    from markushgrapher_amd.inflight import InFlight
+    g = load_golden("g3_trained_tiny.npz")
+    shape, sd = _weights(g)
+    inp = _inputs(g, shape)
+    B = inp["input_ids"].shape[0]
+    T = 24
+    eng = make_engine("hip", shape, sd)
+    jobs = []
+    rng = np.random.default_rng(5)
+    for j in range(4 * n + 1):
+        order = rng.permutation(B)[: 2 + j % (B - 1)]
+        jobs.append({k: np.ascontiguousarray(v[order]) for k, v in inp.items()})
+    want = [_gen(eng, jb, max_length=T, min_length=T) for jb in jobs]
+    want_beam = [_gen(eng, jb, max_length=T, num_beams=3) for jb in jobs[:n + 1]]
+
+    def greedy(ctx, jb):
+        return _gen(ctx, jb, max_length=T, min_length=T)
+
+    def beam(ctx, jb):
+        return _gen(ctx, jb, max_length=T, num_beams=3)
+
+    with InFlight(eng, n) as fl:
+        assert len(fl) == n
+        for _ in range(2):                                   # second pass: replayed graphs on every context
+            got = fl.map(greedy, jobs)
+            for w, o in zip(want, got):
+                assert np.array_equal(w, o)
+        gb = fl.map(beam, jobs[:n + 1])
+        for w, o in zip(want_beam, gb):
+            assert np.array_equal(w, o)
+        # mixed: greedy and beam calls overlapping
+        futs = [fl.submit(beam if i % 2 else greedy, jobs[i % (n + 1)]) for i in range(2 * n)]
+        for i, f in enumerate(futs):
+            assert np.array_equal(f.result(), (want_beam if i % 2 else want)[i % (n + 1)])
+    torch.cuda.synchronize()
+    assert np.array_equal(_gen(eng, jobs[0], max_length=T, min_length=T), want[0])
