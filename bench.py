@@ -111,14 +111,40 @@ def ocr_stage_run(B=32, new_tokens=256):
     wbytes = 2 * (s.t_layers * ((s.t_heads + 2 * s.t_kv_heads) * 64 * s.t_hidden + s.t_hidden * s.t_hidden + 3 * s.t_inter * s.t_hidden) + s.vocab * s.t_hidden)
     L = int(ids.shape[1])
     kvbytes = B * s.t_layers * 2 * s.t_kv_heads * 64 * 2 * (L + new_tokens / 2)   # caches hold the key/value heads once (grouped-query attention)
+    # four batches in flight: execution contexts of the OCR model (mg_ocr_clone), a host thread + stream each
+    import threading
+    from markushgrapher_amd.inflight import shared_streams
+    sts = shared_streams(torch, eng.mem.device, 4)
+    ctxs = [(eng, sts[0])] + [(eng.clone(), sts[i]) for i in range(1, 4)]
+
+    def work(c, st, reps):
+        with torch.cuda.stream(st):
+            for _ in range(reps):
+                c.generate(ids, pix, new_tokens)
+            st.synchronize()
+
+    def run_all(reps):
+        torch.cuda.synchronize(); t0 = time.time()
+        th = [threading.Thread(target=work, args=(c, st, reps)) for c, st in ctxs]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        torch.cuda.synchronize()
+        return time.time() - t0
+    run_all(1)
+    t4 = run_all(2)
+    for c, _ in ctxs[1:]:
+        c.close()
     return {"pages_per_s": round(B / tn, 2), "ms_per_batch": round(tn * 1e3, 1), "new_tokens": new_tokens, "batch": B, "prompt_len": L,
+            "pages_per_s_4_in_flight": round(8 * B / t4, 2),
             "vision_plus_prefill_ms": round(t1 * 1e3, 2), "decode_step_ms": round(step_ms, 4),
             "dec_hbm_frac": round((wbytes + kvbytes) / (step_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
             "config": "ChemicalOCR stage alone: SmolDocling-256M geometry (INFERRED), recipe weights, one 512-px page per sequence, "
                       "greedy, EOS impossible; vision tower / prefill: one kernel per operation with fp32 intermediates; decode step: 4 launches per layer at one row tile (rotary grouped-query attention + cache append, o_proj + norm, gate/up + SwiGLU, [down_proj + norm | next QKV]), replayed as a HIP graph"}
 
 
-def configs4_run(eng, B, new_tokens, ocr_pages=128, n_scripts=32, ocr_slots=0):
+def configs4_run(eng, B, new_tokens, ocr_pages=128, n_scripts=32, ocr_slots=0, overlapped=0, slab=128, main_inflight=1, ocr_inflight=1):
     """BASELINE configs[4] measured as ONE loop on one GPU (markushgrapher_amd/pipeline.py): 128 IP5-M-shaped pages (1024 px u8 crops,
     resident) -> device LANCZOS -> ChemicalOCR (SmolDocling-256M geometry, 128 pages per call) -> text -> cells -> tokens -> VTL encoder +
     256-token greedy decode (continuous decoder, 32 slots).  No OCR checkpoint / tokenizer model exists offline: the OCR model's lm_head
@@ -141,22 +167,41 @@ def configs4_run(eng, B, new_tokens, ocr_pages=128, n_scripts=32, ocr_slots=0):
     longest = max(len(c) for c in chains)
     pipe = Configs4Pipeline(ocr, eng, make_udop_tokenizer(), lambda row: detokenize(id_to_piece, row, s.eos_token_id, s.pad_token_id), prompts,
                             ocr_max_new_tokens=longest + 8, max_length=new_tokens + 1, min_length=new_tokens + 1, continuous=True, main_batch=B,
-                            ocr_slots=ocr_slots)
+                            ocr_slots=ocr_slots, main_inflight=main_inflight, ocr_inflight=ocr_inflight)
+    if main_inflight > 1:
+        pipe.continuous = False          # forced-length decode: one mg_generate per 32 pages and context
     pages = torch.from_numpy(synth.synth_pages_u8(32, 1024, synth.BENCH_SEED)).cuda()
     pages = torch.cat([pages] * (ocr_pages // 32), dim=0)
 
     def clock():
         torch.cuda.synchronize()
         return time.time()
-    pipe(pages)
-    t0 = clock()
-    res = pipe(pages, timer=clock)
-    dt = clock() - t0
+    if overlapped:
+        # the three stages beside each other (pipeline.run_overlapped): OCR slabs of `slab` pages on their own stream + thread, host stage
+        # on this thread, the VTL batches on `overlapped` execution contexts (forced-length decode: one mg_generate per 32 pages)
+        pipe.continuous = False
+        pipe.run_overlapped(pages, ocr_pages=slab, inflight=overlapped)
+        t0 = clock()
+        res = pipe.run_overlapped(pages, ocr_pages=slab, inflight=overlapped)
+        dt = clock() - t0
+        pipe.close()
+        res.timings["main_s"] = float("nan")
+    else:
+        pipe(pages)
+        t0 = clock()
+        res = pipe(pages, timer=clock)
+        dt = clock() - t0
+        pipe.close()
     ok = sum(res.ocr_texts[i] == texts[i % n_scripts] for i in range(ocr_pages))
     eng.set_padding_semantics(False)             # (the pipeline switched the engine to per-image padding semantics)
     L = res.attention_mask.sum(axis=1)
     return {"pages_per_s": round(ocr_pages / dt, 2), "pages": ocr_pages, "ms_total": round(dt * 1e3, 1),
-            "ocr_s": round(res.timings["ocr_s"], 3), "host_s": round(res.timings["host_s"], 3), "main_s": round(res.timings["main_s"], 3),
+            "ocr_s": round(res.timings["ocr_s"], 3), "host_s": round(res.timings["host_s"], 3),
+            "main_s": None if overlapped else round(res.timings["main_s"], 3),
+            "stages": (f"overlapped: OCR slabs of {slab} pages on their own stream, host stage on the calling thread, {overlapped} VTL execution "
+                       "contexts; ocr_s / host_s = busy time of those threads (they overlap)" if overlapped else
+                       f"one after the other; OCR stage on {ocr_inflight} execution context(s), VTL stage on {main_inflight}"
+                       + (" (host stage pipelined with it: main_s contains host_s)" if main_inflight > 1 else "")),
             "ocr_form": (f"queue form, {ocr_slots} decode rows, {res.timings.get('ocr_steps')} steps" if ocr_slots else "batch form: every call walks to its longest page"),
             "ocr_steps_longest_page": longest, "ocr_tokens_mean": round(float(np.mean([len(c) for c in chains])), 1),
             "cells_per_page": [int(n_cells.min()), int(n_cells.max())], "vtl_text_tokens_mean": round(float(L.mean()), 1),
@@ -248,7 +293,7 @@ def pmc_traffic(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--shape", default="large")
     ap.add_argument("--batch", type=int, default=32)
@@ -546,13 +591,42 @@ def main():
                 "ids_equal_batch_calls": bool(same),
                 "config": "mg_generate_stream: continuous decoding of a queue of images on 32 slots (finished rows free their slot; encoder + "
                           "cross-K/V of the next 32 images on a second stream), device preprocessing of all pages inside the timed region"}
+            if len(fl) > 1:
+                # the queue split over the execution contexts, each its own continuous decoder (32 slots; encoder on the context's own
+                # stream - the contexts overlap one another, a run-ahead stream per context would only take hardware queues)
+                for c in fl.contexts:
+                    c.set_stream_encoder(0)
+                per = QB * B // len(fl)
+
+                def job_stream(ctx, i):
+                    sl = slice(i * per, (i + 1) * per)
+                    pix = torch.cat([ctx.preprocess(dev["pages_u8"]) for _ in range(per // B)], dim=0)
+                    o, l, st = ctx.generate_stream(qd["input_ids"][sl], qd["bbox"][sl], qd["attention_mask"][sl], pix, max_length=512,
+                                                   min_length=0, chunk=B, slots=B, pool_chunks=3)
+                    return o.cpu().numpy(), l.cpu().numpy(), st
+                fl.map(job_stream, range(len(fl)))
+                torch.cuda.synchronize(); tq = time.time()
+                res_q = fl.map(job_stream, range(len(fl)))
+                torch.cuda.synchronize(); tq = time.time() - tq
+                ids_q = np.concatenate([r[0] for r in res_q]); len_q = np.concatenate([r[1] for r in res_q])
+                same_q = all(np.array_equal(ids_q[n, :len_q[n]], ie[n % B, :len_q[n]]) for n in range(QB * B))
+                extra["eos_enabled_continuous_in_flight"] = {
+                    "images_per_s": round(QB * B / tq, 2), "queue_images": QB * B, "contexts": len(fl), "slots_per_context": B,
+                    "decode_steps_run_per_context": [int(r[2]) for r in res_q], "speedup_vs_batch_calls": round(QB * B / tq / (B / te), 2),
+                    "ids_equal_batch_calls": bool(same_q),
+                    "config": "the same queue split over the execution contexts of the headline run, one continuous decoder each"}
+                for c in fl.contexts:
+                    c.set_stream_encoder(1)
             eng.load_state_dict({"shared.weight": sd["shared.weight"]})
             extra["ocr_stage"] = ocr_stage_run()
             if not args.no_cpu_baseline:
                 extra["ocr_stage"]["cpu_baseline"] = ocr_cpu_baseline()
             extra["configs4_end_to_end_1gpu_batch_ocr"] = configs4_run(eng, B, new_tokens)
             # the same loop with the OCR stage's queue form and a longer queue (512 pages, 256 OCR decode rows)
-            extra["configs4_end_to_end_1gpu"] = configs4_run(eng, B, new_tokens, ocr_pages=512, ocr_slots=256)
+            extra["configs4_end_to_end_1gpu_one_context"] = configs4_run(eng, B, new_tokens, ocr_pages=512, ocr_slots=256)
+            # the same 512 pages with several batches in flight inside each stage: the OCR stage's pages over 4 execution contexts of the
+            # OCR model (128 decode rows each), the VTL stage's batches of 32 over 4 contexts, host stage pipelined with the VTL stage
+            extra["configs4_end_to_end_1gpu"] = configs4_run(eng, B, new_tokens, ocr_pages=512, ocr_slots=128, main_inflight=4, ocr_inflight=4)
         out = {
             "metric": METRIC, "value": round(world * B * args.steps / dt, 3), "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),

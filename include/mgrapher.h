@@ -287,6 +287,9 @@ typedef struct mg_ocr_config {
 
 int mg_ocr_create(const mg_ocr_config* cfg, mg_ocr_model** out);
 void mg_ocr_destroy(mg_ocr_model* m);
+/* a further execution context on a finalized model's weights (see mg_clone): own captured graphs, calls may overlap in time with the
+ * source's when made from another host thread on another stream with another workspace */
+int mg_ocr_clone(const mg_ocr_model* src, mg_ocr_model** out);
 size_t mg_ocr_weights_bytes(const mg_ocr_model* m);
 int mg_ocr_bind_weights(mg_ocr_model* m, void* arena);
 /* hf_key: a state-dict key of stock Idefics3ForConditionalGeneration ("model.vision_model....", "model.connector....",

@@ -393,6 +393,23 @@ int mg_ocr_create(const mg_ocr_config* cfg, mg_ocr_model** out) {
 }
 
 void mg_ocr_destroy(mg_ocr_model* m) { delete m; }
+
+// A further execution context on a finalized model's weights (as mg_clone, engine.hip): same arena, own captured graphs.
+int mg_ocr_clone(const mg_ocr_model* src, mg_ocr_model** out) {
+    if (!src || !out) return fail_msg(MG_E_ARG, "mg_ocr_clone: null argument");
+    if (!src->arena || !src->finalized) return fail_msg(MG_E_STATE, "mg_ocr_clone: the source model has no finalized weights");
+    mg_ocr_model* m = new mg_ocr_model();
+    m->c = src->c;
+    m->P = src->P; m->g = src->g; m->P_cap = src->P_cap; m->T_img = src->T_img; m->vka = src->vka; m->kvd = src->kvd; m->qkvn = src->qkvn;
+    m->arena = src->arena; m->arena_bytes = src->arena_bytes;
+    m->raw = src->raw; m->vl = src->vl; m->tl = src->tl; m->wqkv2 = src->wqkv2;
+    m->fin_a = src->fin_a; m->fin_c = src->fin_c;
+    m->patch_w = src->patch_w; m->pos_emb = src->pos_emb; m->conn = src->conn; m->tok_emb = src->tok_emb; m->lm_head = src->lm_head;
+    m->zero_tab = src->zero_tab; m->rope_cs = src->rope_cs;
+    m->finalized = true; m->use_graph = src->use_graph;
+    *out = m;
+    return MG_OK;
+}
 size_t mg_ocr_weights_bytes(const mg_ocr_model* m) { return m ? m->arena_bytes : 0; }
 int mg_ocr_bind_weights(mg_ocr_model* m, void* arena) {
     if (!m || !arena) return failf(MG_E_ARG, "mg_ocr_bind_weights: null argument");

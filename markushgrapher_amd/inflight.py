@@ -12,6 +12,20 @@ import threading
 from concurrent.futures import ThreadPoolExecutor
 
 
+_STREAMS = {}
+
+
+def shared_streams(torch, device, n):
+    """The process-wide streams of the batches in flight, `n` of at most InFlight.MAX.  The HIP runtime spreads streams over its
+    hardware queues as they are created, and two busy streams that land on one queue run back to back: every user of several
+    contexts in a process (InFlight, the pipeline's OCR contexts) takes its streams from this one list instead of creating more."""
+    key = str(device)
+    lst = _STREAMS.setdefault(key, [])
+    while len(lst) < n:
+        lst.append(torch.cuda.Stream(device=device))
+    return lst[:n]
+
+
 class InFlight:
     """`submit(fn, *args)` runs `fn(ctx, *args)` on the next free context and returns a future; `map(fn, items)` keeps the order.
 
@@ -22,23 +36,26 @@ class InFlight:
 
     MAX = 4      # busy hardware queues beyond four are time-sliced by the chip's scheduler: throughput drops below one batch at a time
 
-    def __init__(self, engine, n=4, streams=None):
+    def __init__(self, engine, n=4, streams=None, include_source=True, lock=None):
+        """include_source=False: every context is a clone (the source engine stays free for its owner's other calls);
+        lock: shared with other users of the same single-threaded backend (CPU emulator in the tests)."""
         if n < 1 or n > self.MAX:
             raise ValueError("InFlight: n must be in [1, %d] (more contexts than compute pipes collapse: profiles/r03_inflight_ab.txt)" % self.MAX)
-        self.contexts = [engine] + [engine.clone() for _ in range(n - 1)]
+        self._owned_from = 1 if include_source else 0
+        self.contexts = ([engine] if include_source else []) + [engine.clone() for _ in range(n - (1 if include_source else 0))]
         torch = getattr(engine.mem, "torch", None)
         if streams is not None:
             self.streams = list(streams)
         elif torch is not None and torch.cuda.is_available():
-            self.streams = [torch.cuda.Stream(device=engine.mem.device) for _ in range(n)]
+            self.streams = shared_streams(torch, engine.mem.device, n)
         else:
-            self.streams = [None] * n          # emulator backend: no streams, the worker threads still interleave on the host
+            self.streams = [None] * n          # CPU emulator backend (tests): no streams; jobs run one at a time
         self._torch = torch
         self._free = queue.SimpleQueue()
         for i in range(n):
             self._free.put(i)
         self._pool = ThreadPoolExecutor(max_workers=n, thread_name_prefix="mg-inflight")
-        self._lock = threading.Lock()
+        self._lock = lock if lock is not None else threading.Lock()
 
     def __len__(self):
         return len(self.contexts)
@@ -48,7 +65,8 @@ class InFlight:
         try:
             st = self.streams[i]
             if st is None:
-                return fn(self.contexts[i], *args)
+                with self._lock:                # the emulator is single-threaded test infrastructure
+                    return fn(self.contexts[i], *args)
             with self._torch.cuda.stream(st):
                 out = fn(self.contexts[i], *args)
                 st.synchronize()
@@ -65,9 +83,9 @@ class InFlight:
 
     def close(self):
         self._pool.shutdown(wait=True)
-        for c in self.contexts[1:]:
+        for c in self.contexts[self._owned_from:]:
             c.close()
-        self.contexts = self.contexts[:1]
+        self.contexts = self.contexts[:self._owned_from]
 
     def __enter__(self):
         return self

@@ -67,6 +67,22 @@ class OcrEngine:
         self._ws = None
         self._ws_bytes = 0
 
+    def clone(self):
+        """A further execution context on this engine's weights (include/mgrapher.h mg_ocr_clone): own workspace and graphs; calls on
+        different contexts may overlap when made from different host threads under different streams."""
+        other = object.__new__(OcrEngine)
+        other.lib, other.mem, other.shape, other.arena = self.lib, self.mem, self.shape, self.arena
+        other.model = C.c_void_p()
+        self.lib.mg_ocr_clone.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        self._chk(self.lib.mg_ocr_clone(self.model, C.byref(other.model)))
+        other._ws, other._ws_bytes = None, 0
+        return other
+
+    def close(self):
+        if getattr(self, "model", None):
+            self.lib.mg_ocr_destroy(self.model)
+            self.model = None
+
     def __del__(self):
         try:
             if getattr(self, "model", None):

@@ -98,13 +98,19 @@ class Configs4Pipeline:
 
     def __init__(self, ocr, main, tokenizer, ocr_detok: Callable, ocr_prompt_ids, ocr_max_new_tokens: int = 4096, question: str = QUESTION,
                  max_length: int = 512, min_length: int = 0, num_beams: int = 1, continuous: bool = False, main_batch: int = 32,
-                 ocr_slots: int = 0, per_image_padding: bool = True):
+                 ocr_slots: int = 0, per_image_padding: bool = True, main_inflight: int = 1, ocr_inflight: int = 1):
         self.ocr, self.main, self.tokenizer, self.ocr_detok = ocr, main, _MemoTokenizer(tokenizer), ocr_detok
         self.ocr_prompt_ids = np.asarray(ocr_prompt_ids, np.int64)
         self.ocr_max_new_tokens, self.question = int(ocr_max_new_tokens), question
         self.max_length, self.min_length, self.num_beams, self.continuous = int(max_length), int(min_length), int(num_beams), bool(continuous)
         self.main_batch = int(main_batch)      # pages per VTL call (the OCR stage may take more pages per call: its model is 6x smaller)
         self.ocr_slots = int(ocr_slots)        # > 0: the OCR stage's queue form (mg_ocr_generate_stream) with that many decode rows
+        # > 1: the VTL stage keeps that many batches of `main_batch` pages in flight (execution contexts, markushgrapher_amd/inflight.py)
+        self.main_inflight = int(main_inflight)
+        self._fl = None
+        # > 1: the OCR stage splits its pages over that many execution contexts of the OCR model (mg_ocr_clone), a thread + stream each
+        self.ocr_inflight = int(ocr_inflight)
+        self._ocr_ctx = []
         # pages of one batch have different token counts; with per-image padding semantics every page is computed as the reference
         # computes it (alone, unpadded: its batch size is 1), whatever the batch was padded to (mg_set_padding_semantics)
         if per_image_padding:
@@ -113,19 +119,53 @@ class Configs4Pipeline:
             raise ValueError("the two stages share the preprocessed page: equal input sizes expected (512 px in the reference)")
 
     # ---- the three stages --------------------------------------------------------------------------------------------------
+    def _ocr_part(self, ocr, pix, prompt):
+        B = int(pix.shape[0])
+        if self.ocr_slots > 0:
+            new, _, steps = ocr.generate_stream(prompt, pix[:, None], self.ocr_max_new_tokens, slots=min(self.ocr_slots, B), chunk=min(B, 128))
+        else:
+            (new, _), steps = ocr.generate(prompt, pix[:, None], self.ocr_max_new_tokens), None
+        return (new.cpu().numpy() if hasattr(new, "cpu") else np.asarray(new)), steps
+
     def stage_ocr(self, pages_u8, page0: int = 0):
         """-> (pix [B,3,I,I] device, new ids [B,n] numpy, OCR decode steps or None).  page0: index of the first page in the caller's
         list (per-page prompts are taken from ocr_prompt_ids[page0 : page0 + B])."""
         pix = self.main.preprocess(pages_u8)                                  # [B, 3, I, I] f32 on the device, read by both stages
         B = int(pix.shape[0])
         prompt = self.ocr_prompt_ids[page0:page0 + B] if self.ocr_prompt_ids.ndim == 2 else np.repeat(self.ocr_prompt_ids[None], B, axis=0)
-        steps = None
-        if self.ocr_slots > 0:
-            new, _, steps = self.ocr.generate_stream(prompt, pix[:, None], self.ocr_max_new_tokens, slots=self.ocr_slots, chunk=min(B, 128))
-        else:
-            new, _ = self.ocr.generate(prompt, pix[:, None], self.ocr_max_new_tokens)
-        new = new.cpu().numpy() if hasattr(new, "cpu") else np.asarray(new)
-        return pix, new, steps
+        n = min(self.ocr_inflight, B)
+        torch = getattr(self.main.mem, "torch", None)
+        if n <= 1 or torch is None or not torch.cuda.is_available():          # (the CPU emulator of the tests runs one context)
+            new, steps = self._ocr_part(self.ocr, pix, prompt)
+            return pix, new, steps
+        import threading
+        from .inflight import shared_streams
+        streams = shared_streams(torch, self.main.mem.device, n)             # the VTL contexts' streams (the stages alternate)
+        while len(self._ocr_ctx) < n:
+            self._ocr_ctx.append((self.ocr if not self._ocr_ctx else self.ocr.clone(), streams[len(self._ocr_ctx)]))
+        torch.cuda.current_stream().synchronize()                             # pix is complete before the other streams read it
+        per = -(-B // n)
+        parts, errs = [None] * n, []
+
+        def work(i):
+            try:
+                ctx, st = self._ocr_ctx[i]
+                with torch.cuda.stream(st):
+                    parts[i] = self._ocr_part(ctx, pix[i * per:(i + 1) * per], prompt[i * per:(i + 1) * per])
+                    st.synchronize()
+            except BaseException as e:
+                errs.append(e)
+        th = [threading.Thread(target=work, args=(i,)) for i in range(n) if i * per < B]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errs:
+            raise errs[0]
+        parts = [p for p in parts if p is not None]
+        width = max(p[0].shape[1] for p in parts)
+        new = np.concatenate([np.pad(p[0], ((0, 0), (0, width - p[0].shape[1])), constant_values=self.ocr.shape.pad_token_id) for p in parts], axis=0)
+        return pix, new, max(p[1] or 0 for p in parts) or None
 
     def stage_host(self, new):
         """OCR ids -> (texts, cells, input_ids, bbox, attention_mask): string and tokenizer work, no GPU."""
@@ -144,20 +184,42 @@ class Configs4Pipeline:
         return (texts, cells, batch["input_ids"].numpy().astype(np.int64), batch["bbox"].numpy().astype(np.float32),
                 batch["attention_mask"].numpy().astype(np.int64))
 
-    def stage_main(self, pix, ids_in, bbox, mask):
+    def _contexts(self, n):
+        import threading
+        from .inflight import InFlight
+        if self._fl is None or len(self._fl) != n:
+            if self._fl is not None:
+                self._fl.close()
+            self._emu_lock = threading.Lock()
+            self._fl = InFlight(self.main, n, include_source=False, lock=self._emu_lock)
+            for c in self._fl.contexts:
+                c.set_stream_encoder(0)       # the contexts overlap one another: no run-ahead stream (and hardware queue) per context
+        return self._fl
+
+    def stage_main(self, pix, ids_in, bbox, mask, engine=None):
+        main = engine if engine is not None else self.main
         B = int(ids_in.shape[0])
         mb = min(B, self.main_batch)
+        if engine is None and self.main_inflight > 1 and B > mb:
+            fl = self._contexts(self.main_inflight)
+            # slabs of whole batches per context: the continuous decoder works through its slab, the batch form takes one batch per job
+            per = mb * (-(-B // (mb * len(fl))) if (self.continuous and self.num_beams == 1) else 1)
+            jobs = [(pix[c0:c0 + per], ids_in[c0:c0 + per], bbox[c0:c0 + per], mask[c0:c0 + per]) for c0 in range(0, B, per)]
+            return self._stack_rows(fl.map(lambda ctx, a: self.stage_main(*a, engine=ctx), jobs))
         if self.continuous and self.num_beams == 1:
-            out, lens, _ = self.main.generate_stream(ids_in, bbox, mask, pix, max_length=self.max_length, min_length=self.min_length,
+            out, lens, _ = main.generate_stream(ids_in, bbox, mask, pix, max_length=self.max_length, min_length=self.min_length,
                                                      chunk=mb, slots=mb, pool_chunks=3 if B > 2 * mb else 2)
             out = out.cpu().numpy() if hasattr(out, "cpu") else np.asarray(out)
             lens = lens.cpu().numpy() if hasattr(lens, "cpu") else np.asarray(lens)
             return out[:, :int(lens.max())]
         rows = []
         for c0 in range(0, B, mb):
-            o, _, _ = self.main.generate(ids_in[c0:c0 + mb], bbox[c0:c0 + mb], mask[c0:c0 + mb], pix[c0:c0 + mb], num_beams=self.num_beams,
+            o, _, _ = main.generate(ids_in[c0:c0 + mb], bbox[c0:c0 + mb], mask[c0:c0 + mb], pix[c0:c0 + mb], num_beams=self.num_beams,
                                          max_length=self.max_length, min_length=self.min_length)
             rows.append(o.cpu().numpy() if hasattr(o, "cpu") else np.asarray(o))
+        return self._stack_rows(rows)
+
+    def _stack_rows(self, rows):
         width = max(r.shape[1] for r in rows)
         pad = self.main.shape.pad_token_id
         return np.concatenate([np.pad(r, ((0, 0), (0, width - r.shape[1])), constant_values=pad) for r in rows], axis=0)
@@ -170,6 +232,27 @@ class Configs4Pipeline:
         if steps is not None:
             t["ocr_steps"] = steps
         t["ocr_s"] = now() - t0
+        B, mb = int(new.shape[0]), self.main_batch
+        if self.main_inflight > 1 and B > mb:
+            # host stage and VTL stage pipelined: the pages go through the host stage a group at a time, the group's batches are handed to
+            # the VTL contexts at once and decode while the next group is tokenised (continuous decoder: 4 batches' worth per context)
+            import time as _time
+            fl = self._contexts(self.main_inflight)
+            per = mb * (4 if (self.continuous and self.num_beams == 1) else 1)
+            group = per * len(fl)
+            t1, host_busy, parts, futures = now(), 0.0, [], []
+            for g0 in range(0, B, group):
+                h0 = _time.perf_counter()
+                part = self.stage_host(new[g0:g0 + group])
+                host_busy += _time.perf_counter() - h0
+                parts.append((new[g0:g0 + group],) + part)
+                ids_in, bbox, mask = part[2:]
+                for c0 in range(0, int(ids_in.shape[0]), per):
+                    futures.append(fl.submit(lambda ctx, a: self.stage_main(*a, engine=ctx),
+                                             (pix[g0 + c0:g0 + c0 + per], ids_in[c0:c0 + per], bbox[c0:c0 + per], mask[c0:c0 + per])))
+            out = self._stack_rows([f.result() for f in futures])
+            t["host_s"], t["main_s"] = host_busy, now() - t1
+            return self._assemble(parts, out, t)
         t1 = now()
         texts, cells, ids_in, bbox, mask = self.stage_host(new)
         t["host_s"] = now() - t1
@@ -177,3 +260,87 @@ class Configs4Pipeline:
         out = self.stage_main(pix, ids_in, bbox, mask)
         t["main_s"] = now() - t2
         return PipelineResult(ids=out, ocr_new_ids=new, ocr_texts=texts, cells=cells, input_ids=ids_in, bbox=bbox, attention_mask=mask, timings=t)
+
+    def _assemble(self, parts, out, timings):
+        """parts: per group (ocr new ids, texts, cells, input_ids, bbox, attention_mask), each padded to its own widths."""
+        width = max(p[3].shape[1] for p in parts)
+        wnew = max(p[0].shape[1] for p in parts)
+        padw = lambda a, v: np.pad(a, ((0, 0), (0, width - a.shape[1])) + ((0, 0),) * (a.ndim - 2), constant_values=v)
+        return PipelineResult(
+            ids=out, ocr_new_ids=np.concatenate([np.pad(p[0], ((0, 0), (0, wnew - p[0].shape[1])), constant_values=self.ocr.shape.pad_token_id)
+                                                 for p in parts], axis=0),
+            ocr_texts=[t for p in parts for t in p[1]], cells=[c for p in parts for c in p[2]],
+            input_ids=np.concatenate([padw(p[3], self.main.shape.pad_token_id) for p in parts], axis=0),
+            bbox=np.concatenate([padw(p[4], 0.0) for p in parts], axis=0), attention_mask=np.concatenate([padw(p[5], 0) for p in parts], axis=0),
+            timings=timings)
+
+    # ---- the same three stages, overlapped ---------------------------------------------------------------------------------
+    def run_overlapped(self, pages_u8, ocr_pages: int = 128, inflight: int = 3, timer: Optional[Callable[[], float]] = None) -> PipelineResult:
+        """Same result as __call__, the stages running beside each other on one GPU: the OCR stage works through the pages `ocr_pages`
+        at a time on its own stream and host thread; the calling thread turns each finished slab into VTL inputs; `inflight` execution
+        contexts of the VTL model (markushgrapher_amd/inflight.py) decode `main_batch` pages each.  Both decoders are chains of
+        latency-sized launches, so they fill each other's idle time instead of queueing (OCR + 3 VTL contexts = the chip's four
+        compute pipes).  Per-image padding semantics make a page's result independent of the slab it was padded with."""
+        import queue
+        import threading
+        torch = getattr(self.main.mem, "torch", None)
+        on_gpu = torch is not None and torch.cuda.is_available()
+        self._contexts(inflight)
+        if getattr(self, "_ocr_stream", None) is None and on_gpu:
+            from .inflight import shared_streams
+            self._ocr_stream = shared_streams(torch, self.main.mem.device, inflight + 1)[inflight]      # the one the VTL contexts leave free
+        fl, now = self._fl, (timer or (lambda: 0.0))
+        n_pages = int(pages_u8.shape[0])
+        slabs = queue.SimpleQueue()
+        busy = {"ocr_s": 0.0, "host_s": 0.0, "ocr_steps": 0}
+
+        def ocr_worker():
+            import contextlib
+            import time as _time
+            try:
+                with (torch.cuda.stream(self._ocr_stream) if on_gpu else contextlib.nullcontext()):
+                    for p0 in range(0, n_pages, ocr_pages):
+                        t0 = _time.perf_counter()
+                        with (contextlib.nullcontext() if on_gpu else self._emu_lock):
+                            pix, new, steps = self.stage_ocr(pages_u8[p0:p0 + ocr_pages], page0=p0)
+                        if on_gpu:
+                            self._ocr_stream.synchronize()
+                        busy["ocr_s"] += _time.perf_counter() - t0
+                        busy["ocr_steps"] += steps or 0
+                        slabs.put((p0, pix, new))
+                slabs.put(None)
+            except BaseException as e:          # surfaces in the calling thread
+                slabs.put(e)
+
+        def main_job(ctx, pix, ids_in, bbox, mask):
+            return self.stage_main(pix, ids_in, bbox, mask, engine=ctx)
+
+        import time as _time
+        th = threading.Thread(target=ocr_worker, name="mg-ocr-stage", daemon=True)
+        th.start()
+        parts, futures = [], []
+        while True:
+            item = slabs.get()
+            if item is None:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            p0, pix, new = item
+            t1 = _time.perf_counter()
+            texts, cells, ids_in, bbox, mask = self.stage_host(new)
+            busy["host_s"] += _time.perf_counter() - t1
+            parts.append((new, texts, cells, ids_in, bbox, mask))
+            mb = self.main_batch
+            for c0 in range(0, int(ids_in.shape[0]), mb):
+                futures.append(fl.submit(main_job, pix[c0:c0 + mb], ids_in[c0:c0 + mb], bbox[c0:c0 + mb], mask[c0:c0 + mb]))
+        th.join()
+        out = self._stack_rows([f.result() for f in futures])
+        return self._assemble(parts, out, {"ocr_s": busy["ocr_s"], "host_s": busy["host_s"], "ocr_steps": busy["ocr_steps"] or None, "overlapped": True})
+
+    def close(self):
+        for ctx, _ in self._ocr_ctx[1:]:
+            ctx.close()
+        self._ocr_ctx = []
+        if self._fl is not None:
+            self._fl.close()
+            self._fl = None

@@ -110,3 +110,26 @@ def test_batches_in_flight_equal_serial_calls(n):
             assert np.array_equal(f.result(), (want_beam if i % 2 else want)[i % (n + 1)])
     torch.cuda.synchronize()
     assert np.array_equal(_gen(eng, jobs[0], max_length=T, min_length=T), want[0])
+
+
+def test_inflight_helper_on_emulator_keeps_order_and_contexts():
+    """Host logic of InFlight without a GPU: jobs are spread over the contexts, results come back in submission order."""
+    from markushgrapher_amd.inflight import InFlight
+    g = load_golden("g3_trained_tiny.npz")
+    shape, sd = _weights(g)
+    inp = _inputs(g, shape)
+    eng = make_engine("emu", shape, sd)
+    jobs = [{k: np.ascontiguousarray(v[i:i + 2]) for k, v in inp.items()} for i in range(4)]
+    want = [_gen(eng, jb, max_length=8, min_length=8) for jb in jobs]
+    seen = set()
+
+    def fn(ctx, jb):
+        seen.add(id(ctx))
+        return _gen(ctx, jb, max_length=8, min_length=8)
+
+    with InFlight(eng, 2) as fl:
+        got = fl.map(fn, jobs)
+    assert all(np.array_equal(w, o) for w, o in zip(want, got))
+    assert 1 <= len(seen) <= 2
+    with pytest.raises(ValueError):
+        InFlight(eng, 5)

@@ -136,3 +136,48 @@ def test_per_image_padding_semantics(be_name):
     short = int(np.argmin([len(i) for i, _ in feats]))
     Ls = len(feats[short][0])
     assert np.abs(enc0[short, :Ls] - alone_enc[short][:Ls]).max() > 10 * 2e-3
+
+
+@pytest.mark.parametrize("be_name,continuous,ocr_pages,inflight,reps", [
+    ("emu", False, 5, 2, 2),
+    pytest.param("hip", False, 5, 2, 3, marks=pytest.mark.gpu), pytest.param("hip", True, 4, 3, 3, marks=pytest.mark.gpu)])
+def test_overlapped_stages_equal_the_serial_path(be_name, continuous, ocr_pages, inflight, reps):
+    """run_overlapped: OCR slabs on their own stream/thread, host stage on the caller's, VTL batches on `inflight` execution contexts -
+    page for page the serial call's strings, VTL inputs and ids (slabs that cut the page list unevenly, a VTL batch size that does
+    not divide a slab; `emu` runs the threads' device work one at a time)."""
+    main, ocr, shape, s = _engines(be_name)
+    id_to_piece, chains, starts = F.ocr_vocab_and_chains()
+    n = len(F.OCR_TEXTS)
+    prompts = np.concatenate([F.ocr_prompts()] * reps, axis=0)
+    pipe = Configs4Pipeline(ocr, main, F.make_udop_tokenizer(), lambda row: F.detokenize(id_to_piece, row, s.eos_token_id, s.pad_token_id),
+                            prompts, ocr_max_new_tokens=64, max_length=16, continuous=continuous, ocr_slots=2 if continuous else 0, main_batch=3)
+    pages = np.concatenate([F.pages_u8(n)] * reps, axis=0)
+    if be_name == "hip":
+        import torch
+        pages = torch.from_numpy(pages).cuda()
+    try:
+        want = pipe(pages)
+        pipe.main_inflight = 2                   # serial stages, the VTL stage with two batches in flight
+        mid = pipe(pages)
+        pipe.main_inflight = 1
+        assert mid.ocr_texts == want.ocr_texts and mid.ids.shape == want.ids.shape and np.array_equal(mid.ids, want.ids)
+        if be_name == "hip":
+            pipe.ocr_inflight = 3                # the OCR stage's pages over three contexts of the OCR model (uneven split)
+            mid = pipe(pages)
+            pipe.ocr_inflight = 1
+            assert mid.ocr_texts == want.ocr_texts and np.array_equal(mid.ids, want.ids)
+            n_new = min(mid.ocr_new_ids.shape[1], want.ocr_new_ids.shape[1])
+            assert np.array_equal(mid.ocr_new_ids[:, :n_new], want.ocr_new_ids[:, :n_new])
+        for _ in range(1 if be_name == "emu" else 2):      # second call: warm contexts (replayed graphs)
+            got = pipe.run_overlapped(pages, ocr_pages=ocr_pages, inflight=inflight)
+            assert got.ocr_texts == want.ocr_texts == F.OCR_TEXTS * reps
+            assert got.cells == want.cells
+            L = min(got.input_ids.shape[1], want.input_ids.shape[1])
+            assert np.array_equal(got.input_ids[:, :L], want.input_ids[:, :L]) and np.array_equal(got.attention_mask[:, :L], want.attention_mask[:, :L])
+            assert np.array_equal(got.bbox[:, :L], want.bbox[:, :L])
+            W = min(got.ids.shape[1], want.ids.shape[1])
+            assert np.array_equal(got.ids[:, :W], want.ids[:, :W])
+            assert np.all(got.ids[:, W:] == shape.pad_token_id) and np.all(want.ids[:, W:] == shape.pad_token_id)
+    finally:
+        pipe.close()
+        main.set_padding_semantics(False)

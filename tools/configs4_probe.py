@@ -1,0 +1,26 @@
+"""Probe: configs[4] loop with the stages overlapped, sweep of slab size / VTL contexts / OCR form.
+    python tools/configs4_probe.py"""
+import json
+import os
+import sys
+
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    import bench
+    from markushgrapher_amd import synth
+    from markushgrapher_amd.engine import Engine
+    shape = synth.SHAPES["large"]
+    eng = Engine(shape, max_decode_len=512)
+    eng.load_state_dict(synth.recipe_state_dict(shape, **synth.BENCH_RECIPE))
+    keep = ("pages_per_s", "ocr_s", "host_s", "main_s", "ocr_form")
+    for kw in (dict(ocr_slots=256), dict(ocr_slots=128, main_inflight=4, ocr_inflight=4), dict(ocr_slots=256, overlapped=3, slab=256)):
+        r = bench.configs4_run(eng, 32, 256, ocr_pages=512, **kw)
+        print(kw, {k: r[k] for k in keep}, r["ocr_strings_as_scripted"], flush=True)
+
+
+if __name__ == "__main__":
+    main()
