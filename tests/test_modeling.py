@@ -192,3 +192,10 @@ def test_generate_queue_equals_the_per_image_loop():
         n = b.index(shape.eos_token_id) + 1 if shape.eos_token_id in b else len(b)
         assert a.cpu().tolist() == b[:n]
     assert len({tuple(x.cpu().tolist()) for x in got}) > 1
+    # the same queue cut over two execution contexts decoding at the same time (7 images, 3 slots each)
+    for _ in range(2):
+        got2 = m.generate_queue(encodings, max_length=16, slots=3, chunk=2, contexts=2)
+        assert [x.cpu().tolist() for x in got2] == [x.cpu().tolist() for x in got]
+    # and the per-image loop is unaffected afterwards (padding semantics restored)
+    e0 = {k: v.to(dev) for k, v in encodings[0].items()}
+    assert m.generate(**e0, num_beams=1, max_length=16)[0].cpu().tolist() == loop[0].tolist()
