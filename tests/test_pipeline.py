@@ -157,11 +157,11 @@ def test_overlapped_stages_equal_the_serial_path(be_name, continuous, ocr_pages,
         pages = torch.from_numpy(pages).cuda()
     try:
         want = pipe(pages)
-        pipe.main_inflight = 2                   # serial stages, the VTL stage with two batches in flight
-        mid = pipe(pages)
-        pipe.main_inflight = 1
-        assert mid.ocr_texts == want.ocr_texts and mid.ids.shape == want.ids.shape and np.array_equal(mid.ids, want.ids)
         if be_name == "hip":
+            pipe.main_inflight = 2               # serial stages, the VTL stage with two batches in flight
+            mid = pipe(pages)
+            pipe.main_inflight = 1
+            assert mid.ocr_texts == want.ocr_texts and mid.ids.shape == want.ids.shape and np.array_equal(mid.ids, want.ids)
             pipe.ocr_inflight = 3                # the OCR stage's pages over three contexts of the OCR model (uneven split)
             mid = pipe(pages)
             pipe.ocr_inflight = 1
