@@ -118,7 +118,7 @@ def ocr_stage_run(B=32, new_tokens=256):
     ctxs = [(eng, sts[0])] + [(eng.clone(), sts[i]) for i in range(1, 4)]
 
     def work(c, st, reps):
-        with torch.cuda.stream(st):
+        with torch.cuda.device(st.device), torch.cuda.stream(st):
             for _ in range(reps):
                 c.generate(ids, pix, new_tokens)
             st.synchronize()

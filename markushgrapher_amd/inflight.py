@@ -67,7 +67,8 @@ class InFlight:
             if st is None:
                 with self._lock:                # the emulator is single-threaded test infrastructure
                     return fn(self.contexts[i], *args)
-            with self._torch.cuda.stream(st):
+            # a new host thread starts on device 0: make the context's GPU current for the raw HIP calls of the library too
+            with self._torch.cuda.device(st.device), self._torch.cuda.stream(st):
                 out = fn(self.contexts[i], *args)
                 st.synchronize()
                 return out

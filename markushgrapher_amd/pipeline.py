@@ -150,7 +150,7 @@ class Configs4Pipeline:
         def work(i):
             try:
                 ctx, st = self._ocr_ctx[i]
-                with torch.cuda.stream(st):
+                with torch.cuda.device(st.device), torch.cuda.stream(st):
                     parts[i] = self._ocr_part(ctx, pix[i * per:(i + 1) * per], prompt[i * per:(i + 1) * per])
                     st.synchronize()
             except BaseException as e:
@@ -298,7 +298,8 @@ class Configs4Pipeline:
             import contextlib
             import time as _time
             try:
-                with (torch.cuda.stream(self._ocr_stream) if on_gpu else contextlib.nullcontext()):
+                with (torch.cuda.device(self._ocr_stream.device) if on_gpu else contextlib.nullcontext()), \
+                        (torch.cuda.stream(self._ocr_stream) if on_gpu else contextlib.nullcontext()):
                     for p0 in range(0, n_pages, ocr_pages):
                         t0 = _time.perf_counter()
                         with (contextlib.nullcontext() if on_gpu else self._emu_lock):
