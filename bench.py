@@ -305,10 +305,10 @@ def main():
     ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--profile-every", type=int, default=16)
     ap.add_argument("--decode-graph", type=int, default=1, help="1: replay the captured decode-step HIP graph; 0: eager launches")
-    ap.add_argument("--inflight", type=int, default=0,
+    ap.add_argument("--inflight", type=int, default=4,
                     help="batches in flight per GPU: execution contexts (mg_clone) with a stream and host thread each; 1 = one batch "
-                         "after the other, as the reference's loop; 0 (default) = 4 on one GPU, 3 per rank with --gpus > 1 (RCCL's "
-                         "all-gather stream then has the chip's fourth compute pipe to itself: a fifth busy queue is time-sliced)")
+                         "after the other, as the reference's loop.  (The id exchange - a few small kernels per batch on the null "
+                         "stream / RCCL's stream - is a fifth queue in use for microseconds at a time; measured harmless at one GPU.)")
     args = ap.parse_args()
     if args.pmc_child:
         return pmc_child(args)
@@ -368,7 +368,7 @@ def main():
     # batch is latency-bound for five of its six launches per layer, the others' launches fill the machine it leaves idle.  Results
     # per batch are identical to a call made alone (tests/test_inflight.py).
     from markushgrapher_amd.inflight import InFlight
-    fl = InFlight(eng, args.inflight if args.inflight > 0 else (4 if world == 1 else 3))
+    fl = InFlight(eng, max(1, args.inflight))
 
     def job(ctx):
         pix = ctx.preprocess(dev["pages_u8"])
