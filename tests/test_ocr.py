@@ -483,3 +483,43 @@ def test_ocr_queue_form_equals_batch_form(be_name, slots, chunk):
     for k, b in enumerate(order):
         if b == 0:
             assert lens2[k] == 1 and new2[k, 0] == base[0, 0] and np.all(new2[k, 1:] == s.pad_token_id)
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+def test_ocr_clone_is_a_second_context_on_the_same_weights(be_name):
+    """mg_ocr_clone: batch and queue form through a clone equal the source's (own workspace and captured graphs); on the GPU the two
+    contexts also run at the same time from two host threads on two streams."""
+    g, s, sd, ids, pix = _setup("tiny")
+    eng = make_ocr(be_name, s, sd)
+    ctx = eng.clone()
+    n = int(g["new_tokens"])
+    base = np.asarray(eng.mem.numpy(eng.generate(ids, pix, n)[0])).copy()
+    got = np.asarray(ctx.mem.numpy(ctx.generate(ids, pix, n)[0])).copy()
+    assert np.array_equal(base, got)
+    order = np.array([2, 0, 1, 1, 0])
+    q0 = eng.generate_stream(ids[order], pix[order], n, slots=2, chunk=3)
+    q1 = ctx.generate_stream(ids[order], pix[order], n, slots=2, chunk=3)
+    assert np.array_equal(eng.mem.numpy(q0[0]), ctx.mem.numpy(q1[0])) and np.array_equal(eng.mem.numpy(q0[1]), ctx.mem.numpy(q1[1]))
+    if be_name == "hip":
+        import threading
+        import torch
+        from markushgrapher_amd.inflight import shared_streams
+        sts = shared_streams(torch, eng.mem.device, 2)
+        ids_d, pix_d = torch.from_numpy(np.ascontiguousarray(ids)).cuda(), torch.from_numpy(np.ascontiguousarray(pix)).cuda()
+        torch.cuda.synchronize()
+        outs = [None, None]
+
+        def work(i, e):
+            with torch.cuda.device(sts[i].device), torch.cuda.stream(sts[i]):
+                for _ in range(6):
+                    o = e.generate(ids_d, pix_d, n)[0]
+                sts[i].synchronize()
+                outs[i] = o.cpu().numpy()
+        th = [threading.Thread(target=work, args=(i, e)) for i, e in enumerate((eng, ctx))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert np.array_equal(outs[0], base) and np.array_equal(outs[1], base)
+    ctx.close()
+    assert np.array_equal(np.asarray(eng.mem.numpy(eng.generate(ids, pix, n)[0])), base)

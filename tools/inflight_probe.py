@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--batches", type=int, default=4, help="batches per handle")
     ap.add_argument("--new-tokens", type=int, default=256)
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--only", action="store_true", help="measure the full in-flight count only (plus the one-at-a-time reference)")
     args = ap.parse_args()
     import torch
     from markushgrapher_amd import synth
@@ -63,7 +64,7 @@ def main():
     t1 = run(1, args.batches)
     print("1 in flight: %.1f ms/batch  %.2f images/s" % (t1 / args.batches * 1e3, B * args.batches / t1), flush=True)
     ref = results[0].cpu().numpy()
-    for k in range(2, len(engs) + 1):
+    for k in range(len(engs) if args.only else 2, len(engs) + 1):
         tk = run(k, args.batches)
         same = all(np.array_equal(results[i].cpu().numpy(), ref) for i in range(k))
         print("%d in flight: %.1f ms/batch  %.2f images/s  (x%.2f)  ids equal: %s" %
