@@ -104,6 +104,39 @@ def releasers(db_path):
     print("other queues' kernels running at the middle of a 16-128 us gap:")
     for k, c in sorted(combos.items(), key=lambda kv: -kv[1])[:14]:
         print(f"  {c:>7}  {k}")
+    # does a gap close right after ANOTHER queue's kernel starts (a shared dispatcher working through its queues in turn)?
+    near_start = defaultdict(int)
+    tot = 0
+    for q, ks in per.items():
+        if len(ks) < 50000:
+            continue
+        for (s0, e0, n0), (s1, e1, n1) in zip(ks, ks[1:]):
+            g = (s1 - e0) / 1e3
+            if not (16 <= g < 128):
+                continue
+            tot += 1
+            i = bisect.bisect_right(start_t, s1) - 1
+            best = None
+            j = i
+            while j >= 0 and s1 - start_t[j] < 8000:
+                if starts[j][2] != q:
+                    best = (s1 - start_t[j]) / 1e3
+                    break
+                j -= 1
+            k = i + 1
+            nxt = None
+            while k < len(starts) and start_t[k] - s1 < 8000:
+                if starts[k][2] != q:
+                    nxt = (start_t[k] - s1) / 1e3
+                    break
+                k += 1
+            near_start["other start within 1 us before" if best is not None and best < 1 else
+                       ("other start within 3 us before" if best is not None and best < 3 else
+                        ("other start within 8 us before" if best is not None else "none within 8 us before"))] += 1
+            near_start["other start within 1 us after" if nxt is not None and nxt < 1 else ("other start 1-8 us after" if nxt is not None else "none within 8 us after")] += 1
+    print(f"gap closes relative to other queues' kernel STARTS ({tot} gaps):")
+    for k, c in sorted(near_start.items(), key=lambda kv: -kv[1]):
+        print(f"  {c:>7}  {k}")
     print("kernel on another queue that ended within 3 us before a 16-128 us gap closed (count, its mean duration):")
     for k, (c, t) in sorted(hist.items(), key=lambda kv: -kv[1][0])[:12]:
         print(f"  {c:>7} x {t/c:8.1f} us  {k}")
