@@ -314,6 +314,14 @@ class MarkushgrapherForConditionalGeneration(nn.Module):
         return ids
 
     @torch.no_grad()
+    def in_flight(self, n: int = 4):
+        """`inflight.InFlight` over this model's engine: n execution contexts (the engine + n - 1 clones on the same weights), a host
+        thread and stream each, for keeping several batches going at once: `with model.in_flight(4) as fl: fl.map(job, batches)`
+        where `job(ctx, batch)` calls `ctx.preprocess` / `ctx.generate` (engine level: arrays in, ids out).  DESIGN.md section 8f."""
+        from .inflight import InFlight
+        self._check_e1(None)
+        return InFlight(self._eng(), n)
+
     def generate_queue(self, encodings, max_length=None, min_length=0, slots=32, chunk=32, contexts=1):
         """The reference's evaluation loop (ref: utils/ocsr/utils_evaluation.py:140-285) as ONE call: `encodings` = the per-sample
         dicts it builds (input_ids [1, L_n] or [L_n], bbox, pixel_values; attention_mask / labels ignored as there), greedy,

@@ -199,3 +199,26 @@ def test_generate_queue_equals_the_per_image_loop():
     # and the per-image loop is unaffected afterwards (padding semantics restored)
     e0 = {k: v.to(dev) for k, v in encodings[0].items()}
     assert m.generate(**e0, num_beams=1, max_length=16)[0].cpu().tolist() == loop[0].tolist()
+
+
+@pytest.mark.gpu
+def test_in_flight_contexts_from_the_model():
+    """model.in_flight(n): batches decoded at the same time on n contexts equal model.generate's ids."""
+    m, shape = tiny_model()
+    m = m.to("cuda")
+    g = load_golden("g3_trained_tiny.npz")
+    kw = {k: torch.from_numpy(g[k]).to(m.device) for k in ("input_ids", "bbox", "attention_mask", "pixel_values")}
+    T = int(g["max_length"])
+    want = m.generate(**kw, max_length=T).cpu().numpy()
+    batches = [{k: v[i:i + 3] for k, v in kw.items()} for i in (0, 3, 1, 2)]
+
+    def job(ctx, b):
+        ids, _, _ = ctx.generate(b["input_ids"], b["bbox"], b["attention_mask"], b["pixel_values"], max_length=T)
+        return ids.cpu().numpy()
+    with m.in_flight(3) as fl:
+        got = fl.map(job, batches)
+    for b, o in zip((0, 3, 1, 2), got):
+        w = want[b:b + 3]
+        n = min(o.shape[1], w.shape[1])
+        assert np.array_equal(o[:, :n], w[:, :n]) and np.all(w[:, n:] == shape.pad_token_id)
+    assert np.array_equal(m.generate(**kw, max_length=T).cpu().numpy(), want)
