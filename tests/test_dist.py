@@ -85,3 +85,76 @@ def test_sharded_generate_world2_gloo():
             for r in range(2):
                 want = (np.arange(32 * t, dtype=np.int64).reshape(32, t) % 33201) + 1000 * r + step
                 assert np.array_equal(a[32 * r:32 * r + 32, :t], want) and np.all(a[32 * r:32 * r + 32, t:] == 0)
+
+
+class _FakeMem:
+    pass
+
+
+class _FakeEngine:
+    """engine stand-in for the host logic of the batches in flight: clone() gives a further context, generate() is fake_generate"""
+    made = 0
+
+    def __init__(self):
+        self.mem = _FakeMem()
+        _FakeEngine.made += 1
+        self.closed = False
+
+    def clone(self):
+        return _FakeEngine()
+
+    def close(self):
+        self.closed = True
+
+    def generate(self, ids):
+        return fake_generate(ids)
+
+
+def _worker_inflight(rank, world, port, q):
+    """bench.py's loop shape at world 2: K batches over n contexts in flight per rank, every batch's ids posted to the exchange by the
+    main thread in submission order (double-buffered), results identical on both ranks."""
+    from markushgrapher_amd.inflight import InFlight
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    fl = InFlight(_FakeEngine(), 3)
+    ex = IdExchange(4, torch.device("cpu"))
+    K = 7
+    batches = [torch.full((4, 6), 10 * rank + k, dtype=torch.int64) + torch.arange(6)[None] for k in range(K)]
+    futs = [fl.submit(lambda ctx, b: ctx.generate(b), b) for b in batches]
+    handles, gathered = [], []
+    for f in futs:
+        handles.append(ex.post(f.result()))
+        if len(handles) > 1:
+            a, l = ex.wait(handles.pop(0))
+            gathered.append((a.numpy().copy(), l.numpy().copy()))
+    while handles:
+        a, l = ex.wait(handles.pop(0))
+        gathered.append((a.numpy().copy(), l.numpy().copy()))
+    n_ctx = len(fl)
+    fl.close()
+    q.put((rank, gathered, n_ctx))
+    dist.destroy_process_group()
+
+
+def test_batches_in_flight_with_the_exchange_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 77) % 1000
+    procs = [ctx.Process(target=_worker_inflight, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {r: (g, n) for r, g, n in [q.get(timeout=120) for _ in range(2)]}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][1] == got[1][1] == 3
+    assert len(got[0][0]) == len(got[1][0]) == 7
+    for k in range(7):
+        (a0, l0), (a1, l1) = got[0][0][k], got[1][0][k]
+        assert np.array_equal(a0, a1) and np.array_equal(l0, l1)            # every rank holds the same gathered block
+        for r in range(2):
+            want = fake_generate(torch.full((4, 6), 10 * r + k, dtype=torch.int64) + torch.arange(6)[None]).numpy()
+            t = want.shape[1]
+            assert np.all(l0[4 * r:4 * r + 4] == t)
+            assert np.array_equal(a0[4 * r:4 * r + 4, :t], want)           # batch k of rank r, in submission order
