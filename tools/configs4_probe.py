@@ -17,11 +17,14 @@ def main():
     eng = Engine(shape, max_decode_len=512)
     eng.load_state_dict(synth.recipe_state_dict(shape, **synth.BENCH_RECIPE))
     keep = ("pages_per_s", "ocr_s", "host_s", "main_s", "ocr_form")
-    cases = (dict(ocr_slots=256), dict(ocr_slots=128, main_inflight=4, ocr_inflight=4), dict(ocr_slots=256, overlapped=3, slab=256))
+    cases = (dict(ocr_slots=256), dict(ocr_slots=128, main_inflight=4, ocr_inflight=4), dict(ocr_slots=256, overlapped=3, slab=256),
+             dict(ocr_pages=2048, ocr_slots=128, main_inflight=4, ocr_inflight=4), dict(ocr_pages=2048, ocr_slots=256, main_inflight=4, ocr_inflight=4),
+             dict(ocr_pages=1024, ocr_slots=128, main_inflight=4, ocr_inflight=4))
     if len(sys.argv) > 1:
         cases = cases[int(sys.argv[1]):int(sys.argv[1]) + 1]
     for kw in cases:
-        r = bench.configs4_run(eng, 32, 256, ocr_pages=512, **kw)
+        kw = dict(kw)
+        r = bench.configs4_run(eng, 32, 256, ocr_pages=kw.pop("ocr_pages", 512), **kw)
         print(kw, {k: r[k] for k in keep}, r["ocr_strings_as_scripted"], flush=True)
 
 
