@@ -144,7 +144,7 @@ def ocr_stage_run(B=32, new_tokens=256):
                       "greedy, EOS impossible; vision tower / prefill: one kernel per operation with fp32 intermediates; decode step: 4 launches per layer at one row tile (rotary grouped-query attention + cache append, o_proj + norm, gate/up + SwiGLU, [down_proj + norm | next QKV]), replayed as a HIP graph"}
 
 
-def configs4_run(eng, B, new_tokens, ocr_pages=128, n_scripts=32, ocr_slots=0, overlapped=0, slab=128, main_inflight=1, ocr_inflight=1):
+def configs4_run(eng, B, new_tokens, ocr_pages=128, n_scripts=32, ocr_slots=0, main_inflight=1, ocr_inflight=1):
     """BASELINE configs[4] measured as ONE loop on one GPU (markushgrapher_amd/pipeline.py): 128 IP5-M-shaped pages (1024 px u8 crops,
     resident) -> device LANCZOS -> ChemicalOCR (SmolDocling-256M geometry, 128 pages per call) -> text -> cells -> tokens -> VTL encoder +
     256-token greedy decode (continuous decoder, 32 slots).  No OCR checkpoint / tokenizer model exists offline: the OCR model's lm_head
@@ -176,31 +176,18 @@ def configs4_run(eng, B, new_tokens, ocr_pages=128, n_scripts=32, ocr_slots=0, o
     def clock():
         torch.cuda.synchronize()
         return time.time()
-    if overlapped:
-        # the three stages beside each other (pipeline.run_overlapped): OCR slabs of `slab` pages on their own stream + thread, host stage
-        # on this thread, the VTL batches on `overlapped` execution contexts (forced-length decode: one mg_generate per 32 pages)
-        pipe.continuous = False
-        pipe.run_overlapped(pages, ocr_pages=slab, inflight=overlapped)
-        t0 = clock()
-        res = pipe.run_overlapped(pages, ocr_pages=slab, inflight=overlapped)
-        dt = clock() - t0
-        pipe.close()
-        res.timings["main_s"] = float("nan")
-    else:
-        pipe(pages)
-        t0 = clock()
-        res = pipe(pages, timer=clock)
-        dt = clock() - t0
-        pipe.close()
+    pipe(pages)
+    t0 = clock()
+    res = pipe(pages, timer=clock)
+    dt = clock() - t0
+    pipe.close()
     ok = sum(res.ocr_texts[i] == texts[i % n_scripts] for i in range(ocr_pages))
     eng.set_padding_semantics(False)             # (the pipeline switched the engine to per-image padding semantics)
     L = res.attention_mask.sum(axis=1)
     return {"pages_per_s": round(ocr_pages / dt, 2), "pages": ocr_pages, "ms_total": round(dt * 1e3, 1),
             "ocr_s": round(res.timings["ocr_s"], 3), "host_s": round(res.timings["host_s"], 3),
-            "main_s": None if overlapped else round(res.timings["main_s"], 3),
-            "stages": (f"overlapped: OCR slabs of {slab} pages on their own stream, host stage on the calling thread, {overlapped} VTL execution "
-                       "contexts; ocr_s / host_s = busy time of those threads (they overlap)" if overlapped else
-                       f"one after the other; OCR stage on {ocr_inflight} execution context(s), VTL stage on {main_inflight}"
+            "main_s": round(res.timings["main_s"], 3),
+            "stages": (f"one after the other; OCR stage on {ocr_inflight} execution context(s), VTL stage on {main_inflight}"
                        + (" (host stage pipelined with it: main_s contains host_s)" if main_inflight > 1 else "")),
             "ocr_form": (f"queue form, {ocr_slots} decode rows, {res.timings.get('ocr_steps')} steps" if ocr_slots else "batch form: every call walks to its longest page"),
             "ocr_steps_longest_page": longest, "ocr_tokens_mean": round(float(np.mean([len(c) for c in chains])), 1),

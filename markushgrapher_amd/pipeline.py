@@ -274,70 +274,6 @@ class Configs4Pipeline:
             bbox=np.concatenate([padw(p[4], 0.0) for p in parts], axis=0), attention_mask=np.concatenate([padw(p[5], 0) for p in parts], axis=0),
             timings=timings)
 
-    # ---- the same three stages, overlapped ---------------------------------------------------------------------------------
-    def run_overlapped(self, pages_u8, ocr_pages: int = 128, inflight: int = 3, timer: Optional[Callable[[], float]] = None) -> PipelineResult:
-        """Same result as __call__, the stages running beside each other on one GPU: the OCR stage works through the pages `ocr_pages`
-        at a time on its own stream and host thread; the calling thread turns each finished slab into VTL inputs; `inflight` execution
-        contexts of the VTL model (markushgrapher_amd/inflight.py) decode `main_batch` pages each.  Both decoders are chains of
-        latency-sized launches, so they fill each other's idle time instead of queueing (OCR + 3 VTL contexts = the chip's four
-        compute pipes).  Per-image padding semantics make a page's result independent of the slab it was padded with."""
-        import queue
-        import threading
-        torch = getattr(self.main.mem, "torch", None)
-        on_gpu = torch is not None and torch.cuda.is_available()
-        self._contexts(inflight)
-        if getattr(self, "_ocr_stream", None) is None and on_gpu:
-            from .inflight import shared_streams
-            self._ocr_stream = shared_streams(torch, self.main.mem.device, inflight + 1)[inflight]      # the one the VTL contexts leave free
-        fl, now = self._fl, (timer or (lambda: 0.0))
-        n_pages = int(pages_u8.shape[0])
-        slabs = queue.SimpleQueue()
-        busy = {"ocr_s": 0.0, "host_s": 0.0, "ocr_steps": 0}
-
-        def ocr_worker():
-            import contextlib
-            import time as _time
-            try:
-                with (torch.cuda.device(self._ocr_stream.device) if on_gpu else contextlib.nullcontext()), \
-                        (torch.cuda.stream(self._ocr_stream) if on_gpu else contextlib.nullcontext()):
-                    for p0 in range(0, n_pages, ocr_pages):
-                        t0 = _time.perf_counter()
-                        with (contextlib.nullcontext() if on_gpu else self._emu_lock):
-                            pix, new, steps = self.stage_ocr(pages_u8[p0:p0 + ocr_pages], page0=p0)
-                        if on_gpu:
-                            self._ocr_stream.synchronize()
-                        busy["ocr_s"] += _time.perf_counter() - t0
-                        busy["ocr_steps"] += steps or 0
-                        slabs.put((p0, pix, new))
-                slabs.put(None)
-            except BaseException as e:          # surfaces in the calling thread
-                slabs.put(e)
-
-        def main_job(ctx, pix, ids_in, bbox, mask):
-            return self.stage_main(pix, ids_in, bbox, mask, engine=ctx)
-
-        import time as _time
-        th = threading.Thread(target=ocr_worker, name="mg-ocr-stage", daemon=True)
-        th.start()
-        parts, futures = [], []
-        while True:
-            item = slabs.get()
-            if item is None:
-                break
-            if isinstance(item, BaseException):
-                raise item
-            p0, pix, new = item
-            t1 = _time.perf_counter()
-            texts, cells, ids_in, bbox, mask = self.stage_host(new)
-            busy["host_s"] += _time.perf_counter() - t1
-            parts.append((new, texts, cells, ids_in, bbox, mask))
-            mb = self.main_batch
-            for c0 in range(0, int(ids_in.shape[0]), mb):
-                futures.append(fl.submit(main_job, pix[c0:c0 + mb], ids_in[c0:c0 + mb], bbox[c0:c0 + mb], mask[c0:c0 + mb]))
-        th.join()
-        out = self._stack_rows([f.result() for f in futures])
-        return self._assemble(parts, out, {"ocr_s": busy["ocr_s"], "host_s": busy["host_s"], "ocr_steps": busy["ocr_steps"] or None, "overlapped": True})
-
     def close(self):
         for ctx, _ in self._ocr_ctx[1:]:
             ctx.close()

@@ -1,4 +1,4 @@
-"""Probe: configs[4] loop with the stages overlapped, sweep of slab size / VTL contexts / OCR form.
+"""Probe: configs[4] loop, sweep of contexts in flight inside the stages / OCR form / queue length.
     python tools/configs4_probe.py"""
 import json
 import os
@@ -17,7 +17,7 @@ def main():
     eng = Engine(shape, max_decode_len=512)
     eng.load_state_dict(synth.recipe_state_dict(shape, **synth.BENCH_RECIPE))
     keep = ("pages_per_s", "ocr_s", "host_s", "main_s", "ocr_form")
-    cases = (dict(ocr_slots=256), dict(ocr_slots=128, main_inflight=4, ocr_inflight=4), dict(ocr_slots=256, overlapped=3, slab=256),
+    cases = (dict(ocr_slots=256), dict(ocr_slots=128, main_inflight=4, ocr_inflight=4),
              dict(ocr_pages=2048, ocr_slots=128, main_inflight=4, ocr_inflight=4), dict(ocr_pages=2048, ocr_slots=256, main_inflight=4, ocr_inflight=4),
              dict(ocr_pages=1024, ocr_slots=128, main_inflight=4, ocr_inflight=4))
     if len(sys.argv) > 1:
