@@ -452,8 +452,19 @@ __global__ __launch_bounds__(64) void stream_ready_kernel(int n, int* ctr) {
 
 int check_launch(const char* what) {
     const int e = mg_peek_error();
-    if (e != 0) return fail(MG_E_HIP, "%s: HIP error %d (%s)", what, e, mg_error_string(e));
+    if (e != 0) {
+        const MgErrSite site = mg_err_site();
+        mg_err_site() = MgErrSite{0, nullptr};
+        return fail(MG_E_HIP, "%s: HIP error %d (%s)%s%s", what, e, mg_error_string(e), site.what ? ", first failing call: " : "",
+                    site.what ? site.what : "");
+    }
     return MG_OK;
+}
+// Start of a compute entry point: the runtime's last-error slot is per host thread and shared with every other library in the process -
+// whatever is pending there was not caused by this call.
+void entry_drain() {
+    (void)mg_peek_error();
+    mg_err_site() = MgErrSite{0, nullptr};
 }
 
 GemmArgs gemm_args(const uint16_t* X, const uint16_t* W, int M, int N, int K) {
@@ -948,6 +959,7 @@ int mg_workspace_bytes(const mg_model* m, int B, int L, int num_beams, int max_l
 int mg_encode(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* input_ids, const float* bbox,
               const uint8_t* attention_mask, const float* pixel_values, const float* e1, int M_e1, int B, int L, float* enc_out,
               uint8_t* enc_mask) {
+    entry_drain();
     if (!m || !ws || !input_ids || !bbox || !pixel_values) return fail(MG_E_ARG, "mg_encode: null argument");
     if (!m->finalized) return fail(MG_E_STATE, "mg_encode: call mg_finalize first");
     if (B < 1 || L < 1) return fail(MG_E_SHAPE, "mg_encode: B and L must be >= 1");
@@ -1042,6 +1054,7 @@ int mg_encode(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_
 
 int mg_decoder_forward(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* decoder_input_ids,
                        const uint8_t* decoder_attention_mask, int B, int T, float* logits) {
+    entry_drain();
     if (!m || !ws || !decoder_input_ids || !logits) return fail(MG_E_ARG, "mg_decoder_forward: null argument");
     if (m->st_ws != ws || m->st_B != B) return fail(MG_E_STATE, "mg_decoder_forward: run mg_encode on this workspace/batch first");
     if (T < 1 || T > m->T_cap) return fail(MG_E_SHAPE, "mg_decoder_forward: T must be in [1, %d]", m->T_cap);
@@ -1114,6 +1127,7 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
                 const uint8_t* attention_mask, const float* pixel_values, const float* e1, int M_e1, int B, int L, int num_beams, int max_length,
                 int min_length, float length_penalty, int early_stopping, int64_t* out_ids, int* out_cols_host,
                 float* out_scores, float* step_top2) {
+    entry_drain();
     if (!m || !out_ids || !out_cols_host) return fail(MG_E_ARG, "mg_generate: null argument");
     if (max_length < 2 || max_length > m->T_cap) return fail(MG_E_SHAPE, "mg_generate: max_length must be in [2, %d]", m->T_cap);
     if (num_beams < 1 || num_beams > 8) return fail(MG_E_UNSUPPORTED, "mg_generate: num_beams must be in [1, 8]");
@@ -1204,6 +1218,7 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
         const StepGraph::Key key{ws, out_ids, step_top2, (const void*)st, B, L, K, max_length, min_length, early_stopping, M_e1, length_penalty};
         StepGraph& sg = m->step_graph;
         if (!(sg.valid && sg.key == key)) {
+            std::lock_guard<std::mutex> capture_lock(mg_capture_mutex());
             sg.reset();
             hipGraph_t graph = nullptr;
             hipError_t e1 = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal), e2 = hipSuccess, e3 = hipSuccess;
@@ -1313,6 +1328,7 @@ int mg_stream_encoder_mode(mg_model* m, int mode, const uint32_t* cu_mask, int n
 int mg_generate_stream(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* input_ids, const float* bbox,
                        const uint8_t* attention_mask, const float* pixel_values, int N, int L, int chunk, int slots, int pool_chunks,
                        int max_length, int min_length, int64_t* out_ids, int32_t* out_len, long* steps_host) {
+    entry_drain();
     if (!m || !ws || !input_ids || !bbox || !pixel_values || !out_ids || !out_len) return fail(MG_E_ARG, "mg_generate_stream: null argument");
     if (!m->finalized) return fail(MG_E_STATE, "mg_generate_stream: call mg_finalize first");
     if (N < 1 || L < 1 || chunk < 1 || pool_chunks < 2) return fail(MG_E_SHAPE, "mg_generate_stream: N, L, chunk must be >= 1, pool_chunks >= 2");
@@ -1372,6 +1388,7 @@ int mg_generate_stream(mg_model* m, void* stream, void* ws, size_t ws_bytes, con
         const StepGraph::Key key{ws, out_ids, out_len, (const void*)st, slots, L, chunk * 1000 + pool_chunks, max_length, min_length, N, 0, 0.0f};
         StepGraph& sg = m->stream_graph;
         if (!(sg.valid && sg.key == key)) {
+            std::lock_guard<std::mutex> capture_lock(mg_capture_mutex());
             sg.reset();
             hipGraph_t graph = nullptr;
             if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {

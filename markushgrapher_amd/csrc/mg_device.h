@@ -58,16 +58,17 @@ static inline int mg_event_sync(mgEvent_t) { return 0; }
 static inline void* mg_host_alloc(size_t n) { return malloc(n); }
 static inline void mg_host_free(void* p) { free(p); }
 #else
-static inline int mg_memset_async(void* p, int v, size_t n, mgStream_t st) { return (int)hipMemsetAsync(p, v, n, st); }
+static inline int mg_track(int rc, const char* what);
+static inline int mg_memset_async(void* p, int v, size_t n, mgStream_t st) { return mg_track((int)hipMemsetAsync(p, v, n, st), "hipMemsetAsync"); }
 static inline int mg_memcpy_async(void* d, const void* s, size_t n, mgStream_t st) {
-    return (int)hipMemcpyAsync(d, s, n, hipMemcpyDefault, st);
+    return mg_track((int)hipMemcpyAsync(d, s, n, hipMemcpyDefault, st), "hipMemcpyAsync");
 }
-static inline int mg_stream_sync(mgStream_t st) { return (int)hipStreamSynchronize(st); }
+static inline int mg_stream_sync(mgStream_t st) { return mg_track((int)hipStreamSynchronize(st), "hipStreamSynchronize"); }
 static inline int mg_peek_error() { return (int)hipGetLastError(); }
 static inline const char* mg_error_string(int e) { return hipGetErrorString((hipError_t)e); }
 typedef hipEvent_t mgEvent_t;
 static inline int mg_event_create(mgEvent_t* e) { return (int)hipEventCreate(e); }
-static inline int mg_event_record(mgEvent_t e, mgStream_t st) { return (int)hipEventRecord(e, st); }
+static inline int mg_event_record(mgEvent_t e, mgStream_t st) { return mg_track((int)hipEventRecord(e, st), "hipEventRecord"); }
 static inline float mg_event_elapsed_ms(mgEvent_t a, mgEvent_t b) { float ms = 0.f; (void)hipEventElapsedTime(&ms, a, b); return ms; }
 static inline void mg_event_destroy(mgEvent_t e) { (void)hipEventDestroy(e); }
 // A second stream for work that overlaps the caller's stream.  low_priority: lowest stream priority (the dispatcher prefers the
@@ -81,9 +82,9 @@ static inline int mg_stream_create(mgStream_t* s, int low_priority, const uint32
 }
 static inline void mg_stream_destroy(mgStream_t s) { (void)hipStreamDestroy(s); }
 static inline int mg_event_create_notiming(mgEvent_t* e) { return (int)hipEventCreateWithFlags(e, hipEventDisableTiming); }
-static inline int mg_stream_wait_event(mgStream_t s, mgEvent_t e) { return (int)hipStreamWaitEvent(s, e, 0); }
+static inline int mg_stream_wait_event(mgStream_t s, mgEvent_t e) { return mg_track((int)hipStreamWaitEvent(s, e, 0), "hipStreamWaitEvent"); }
 static inline int mg_event_done(mgEvent_t e) { const hipError_t r = hipEventQuery(e); if (r == hipErrorNotReady) { (void)hipGetLastError(); return 0; } return 1; }
-static inline int mg_event_sync(mgEvent_t e) { return (int)hipEventSynchronize(e); }
+static inline int mg_event_sync(mgEvent_t e) { return mg_track((int)hipEventSynchronize(e), "hipEventSynchronize"); }
 static inline void* mg_host_alloc(size_t n) { void* p = nullptr; return hipHostMalloc(&p, n, hipHostMallocDefault) == hipSuccess ? p : nullptr; }
 static inline void mg_host_free(void* p) { (void)hipHostFree(p); }
 #endif
@@ -104,6 +105,17 @@ static inline void mg_host_free(void* p) { (void)hipHostFree(p); }
 #define MG_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define MG_SET_MAX_SMEM(kern, bytes) (void)hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))
 #endif
+
+// Stream capture is serialised across host threads (execution contexts of the batches in flight capture their decode step on first
+// use, possibly at the same moment): one capture + instantiate at a time, process-wide.  Captures are thread-local
+// (hipStreamCaptureModeThreadLocal), so other threads keep launching on their own streams meanwhile.
+#include <mutex>
+inline std::mutex& mg_capture_mutex() { static std::mutex mu; return mu; }
+// First failing runtime call of the current entry point on this thread (the runtime's own "last error" is per thread and sticky across
+// callers: an error some other library left behind is drained at entry, MG_ENTRY, and is not ours to report).
+struct MgErrSite { int code; const char* what; };
+inline MgErrSite& mg_err_site() { static thread_local MgErrSite s{0, nullptr}; return s; }
+static inline int mg_track(int rc, const char* what) { if (rc != 0 && mg_err_site().code == 0) mg_err_site() = MgErrSite{rc, what}; return rc; }
 
 #define MG_DEV __device__ __forceinline__
 #define MG_HD __host__ __device__ __forceinline__

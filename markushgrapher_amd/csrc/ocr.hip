@@ -34,7 +34,11 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 int round_up(int x, int a) { return (x + a - 1) / a * a; }
 int check(const char* what) {
     const int e = mg_peek_error();
-    if (e != 0) return failf(MG_E_HIP, "%s: HIP error %d (%s)", what, e, mg_error_string(e));
+    if (e != 0) {
+        const MgErrSite site = mg_err_site();
+        mg_err_site() = MgErrSite{0, nullptr};
+        return failf(MG_E_HIP, "%s: HIP error %d (%s)%s%s", what, e, mg_error_string(e), site.what ? ", first failing call: " : "", site.what ? site.what : "");
+    }
     return MG_OK;
 }
 GemmArgs ga(const uint16_t* X, const uint16_t* W, int M, int N, int K) {
@@ -155,6 +159,9 @@ void carve(const mg_ocr_model* m, char* base, int B, int n_img, int L, int max_n
 }
 
 int check_args(const mg_ocr_model* m, int B, int n_img, int L, const char* who) {
+    // (every compute entry starts here) whatever is pending in the runtime's per-thread last-error slot was not caused by this call
+    (void)mg_peek_error();
+    mg_err_site() = MgErrSite{0, nullptr};
     if (!m) return failf(MG_E_ARG, "%s: null model", who);
     if (!m->finalized) return failf(MG_E_STATE, "%s: mg_ocr_finalize has not run", who);
     if (B < 1 || B > 256 || n_img < 0 || L < 1 || L > 2048) return failf(MG_E_SHAPE, "%s: B=%d n_img=%d L=%d out of range", who, B, n_img, L);
@@ -593,6 +600,7 @@ int mg_ocr_generate(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, co
     if (m->use_graph == 1 && !step_logits && max_new_tokens > 1) {
         const mg_ocr_model::Key key{ws, out_ids, (const void*)st, B, n_img, L, max_new_tokens};
         if (!(m->gvalid && m->gkey == key)) {
+            std::lock_guard<std::mutex> capture_lock(mg_capture_mutex());
             m->greset();
             hipGraph_t graph = nullptr;
             if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
@@ -763,6 +771,7 @@ int mg_ocr_generate_stream(mg_ocr_model* m, void* stream, void* ws, size_t ws_by
     if (m->use_graph == 1) {
         const mg_ocr_model::SKey key{ws, out_ids, (const void*)st, N, slots, L, max_new_tokens};
         if (!(m->svalid && m->skey == key)) {
+            std::lock_guard<std::mutex> capture_lock(mg_capture_mutex());
             m->sreset();
             hipGraph_t graph = nullptr;
             if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {

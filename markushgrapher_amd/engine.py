@@ -74,7 +74,9 @@ class TorchMem:
         return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
 
     def sync(self):
-        self.torch.cuda.synchronize(self.device)
+        # the calling thread's current stream only: a device-wide synchronisation is refused by the runtime ("operation not permitted
+        # when stream is capturing") whenever ANOTHER execution context is capturing its decode step at that moment
+        self.torch.cuda.current_stream(self.device).synchronize()
 
     def numpy(self, h):
         self.sync()

@@ -353,7 +353,7 @@ class MarkushgrapherForConditionalGeneration(nn.Module):
                     for c in self._inflight.contexts:
                         c.set_stream_encoder(0)                                         # the contexts overlap one another instead
                 per = -(-n // contexts)
-                torch.cuda.synchronize(self.device)          # the inputs are complete before the contexts' streams read them
+                torch.cuda.current_stream(self.device).synchronize()      # the inputs are complete before the contexts' streams read them
 
                 def part(ctx, i):
                     sl = slice(i * per, min(n, (i + 1) * per))
