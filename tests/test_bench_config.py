@@ -209,3 +209,26 @@ def test_g4_long_256_forced_steps_top8():
             if margin[b, t - 1] < MARGIN_TOL:
                 break
             assert ids_free[b, t] == gl["greedy_ids"][b, t], (b, t)
+
+
+def test_g4_four_batches_in_flight_equal_the_call_made_alone():
+    """bench.py's own loop shape at production dimensions: the benchmark batch (B = 32, large shape) on four execution contexts at the
+    same time, two rounds (capture, then replay): every context's ids and per-step top-2 logits are bit-identical to the one-at-a-time
+    call - which the tests above pin on stock UDOP - and so is a different batch (images in reverse order) decoded beside them."""
+    from markushgrapher_amd.inflight import InFlight
+    g, shape, eng, args = _setup()
+    new = int(g["new_tokens"])
+    ids, bbox, mask, pix = args
+    pix_np = eng.mem.numpy(pix).copy()
+    batches = [(ids, bbox, mask, pix_np), (ids[::-1].copy(), bbox[::-1].copy(), mask[::-1].copy(), pix_np[::-1].copy())]
+
+    def run(ctx, k):
+        o, _, top2 = ctx.generate(*batches[k], max_length=new + 1, min_length=new + 1, return_top2=True)
+        return ctx.mem.numpy(o).copy(), ctx.mem.numpy(top2).copy()
+    want = [run(eng, 0), run(eng, 1)]
+    assert np.array_equal(want[0][0], want[1][0][::-1])                  # rows do not depend on their place in the batch
+    with InFlight(eng, 4) as fl:
+        for _ in range(2):
+            got = fl.map(run, [0, 1, 0, 0, 1, 0, 1, 1])
+            for k, (o, t2) in zip([0, 1, 0, 0, 1, 0, 1, 1], got):
+                assert np.array_equal(o, want[k][0]) and np.array_equal(t2, want[k][1])
