@@ -69,9 +69,10 @@ class InFlight:
                     return fn(self.contexts[i], *args)
             # a new host thread starts on device 0: make the context's GPU current for the raw HIP calls of the library too
             with self._torch.cuda.device(st.device), self._torch.cuda.stream(st):
-                out = fn(self.contexts[i], *args)
-                st.synchronize()
-                return out
+                try:
+                    return fn(self.contexts[i], *args)
+                finally:
+                    st.synchronize()        # also after an exception: the context's buffers are free for its next job
         finally:
             self._free.put(i)
 
