@@ -7,14 +7,19 @@ decode steps (EOS suppressed: min_length = max_length = 257, SURVEY.md §8d Cfg-
 MarkushGrapher-2 model with the recipe weights of tests/golden/g4_bench.npz (synth.BENCH_RECIPE: the configuration the
 parity tests pin on stock UDOP).  Inputs are resident in HBM when the timed region starts.  With --gpus N every rank
 runs its own 32-image shard (weak scaling) and the decoded ids are all-gathered over RCCL inside the timed region.
+Every rank keeps --inflight (default 4) such steps going at once, each on its own execution context (mg_clone: same weights,
+own workspace / decode graph / stream / host thread): all K timed steps start and end inside the timed region, ids per batch
+are bit-identical to one-at-a-time calls (tests/test_bench_config.py), `one_batch_in_flight` repeats the step the old way.
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0:
   roofline       dominant kernel (single-query cross-attention over the per-image K/V stream), algorithmic bytes / average
-                 launch duration from HIP events on the launch stream; `traffic` = HBM bytes per launch from a FETCH_SIZE pass
-                 (rocprofv3 --pmc, run by this script as a child on a short copy of the workload when rocprofv3 is present)
+                 launch duration from HIP events on the launch stream of the first context during the timed region (i.e. beside
+                 the other batches' kernels); `traffic` = HBM bytes per launch from a FETCH_SIZE pass (rocprofv3 --pmc, run by this
+                 script as a child on a short copy of the workload when rocprofv3 is present)
+  one_batch_in_flight   the same step with one context: images/s, the kernel's and the phases' uncontended figures
   phases         encoder (MFMA-bound) and decode step (HBM-bound) against their own rooflines: enc_mfma_frac, dec_hbm_frac,
                  dec_mfma_frac (SURVEY.md §8d formulas), phase times from HIP events inside mg_generate
   extra_runs     EOS-enabled greedy run (max_length 512) and beam-5 (BASELINE configs[2]) on the same inputs
