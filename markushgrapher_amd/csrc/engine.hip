@@ -670,6 +670,9 @@ int mg_create(const mg_config* cfg, mg_model** out) {
     m->M2 = c.max_2d_position_embeddings;
     m->T_cap = round_up(c.max_decode_len > 0 ? c.max_decode_len : 512, 64);
     m->tied = c.tie_word_embeddings != 0;
+    // The runtime's queue-thread mode (AMD_DIRECT_DISPATCH=0, a debugging switch) replays captured decode steps wrongly on this ROCm
+    // (all-pad ids, tests/test_engine.py graph-mode test under that switch): launch eagerly there.
+    { const char* e = getenv("AMD_DIRECT_DISPATCH"); if (e && e[0] == '0') m->use_graph = 0; }
     { const char* e = getenv("MG_ENC_ROW_TILES"); if (e && e[0] == '0') m->row_tiles = false; }
     { const char* e = getenv("MG_DECODE_FUSED_TAIL"); if (e && e[0] == '0') m->fused_tail = false; }
     // arena layout

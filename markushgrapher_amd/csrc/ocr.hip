@@ -395,6 +395,7 @@ int mg_ocr_create(const mg_ocr_config* cfg, mg_ocr_model** out) {
     off = align_up(off, 256); m->rope_cs = off; off += (size_t)mg_ocr_model::MAX_POS * 64 * sizeof(float);
     m->arena_bytes = align_up(off, 256);
     { const char* e = getenv("MG_OCR_GRAPH"); if (e && e[0] == '0') m->use_graph = 0; }
+    { const char* e = getenv("AMD_DIRECT_DISPATCH"); if (e && e[0] == '0') m->use_graph = 0; }     // (see mg_create)
     *out = m;
     return MG_OK;
 }

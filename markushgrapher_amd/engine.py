@@ -62,7 +62,9 @@ class TorchMem:
         want = self._dt(dtype)
         if x.dtype == t.bfloat16 and np.dtype(dtype) == np.uint16:
             x = x.view(t.int16)
-        return x.to(device=self.device, dtype=want, non_blocking=True).contiguous()
+        # host sources are copied synchronously: a non-blocking copy from pageable memory may read the (temporary) source after this
+        # function has returned and released it (the runtime's queue-thread mode, AMD_DIRECT_DISPATCH=0, does exactly that)
+        return x.to(device=self.device, dtype=want, non_blocking=x.is_cuda).contiguous()
 
     def copy(self, h):
         return h.clone()

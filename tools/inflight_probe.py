@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--batches", type=int, default=4, help="batches per handle")
     ap.add_argument("--new-tokens", type=int, default=256)
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--clones", action="store_true", help="contexts = clones of one engine (shared weights) instead of separately loaded engines")
     ap.add_argument("--only", action="store_true", help="measure the full in-flight count only (plus the one-at-a-time reference)")
     args = ap.parse_args()
     import torch
@@ -32,6 +33,9 @@ def main():
     B, max_length = args.batch, args.new_tokens + 1
     engs = []
     for i in range(args.inflight):
+        if args.clones and engs:
+            engs.append(engs[0].clone())
+            continue
         e = Engine(shape, max_decode_len=512)
         e.load_state_dict(sd)
         engs.append(e)
@@ -64,9 +68,17 @@ def main():
     t1 = run(1, args.batches)
     print("1 in flight: %.1f ms/batch  %.2f images/s" % (t1 / args.batches * 1e3, B * args.batches / t1), flush=True)
     ref = results[0].cpu().numpy()
+    print("   one at a time, rows 0-1, first 8 ids:", ref[:2, :8].tolist(), flush=True)
     for k in range(len(engs) if args.only else 2, len(engs) + 1):
         tk = run(k, args.batches)
         same = all(np.array_equal(results[i].cpu().numpy(), ref) for i in range(k))
+        if not same:
+            for i in range(k):
+                r = results[i].cpu().numpy()
+                print("   context %d rows 0-1:" % i, r[:2, :8].tolist(), flush=True)
+                bad = r != ref
+                first = int(np.argmax(bad.any(axis=0))) if bad.any() else -1
+                print("   context %d: %d of %d rows differ, first differing step %d" % (i, int(bad.any(axis=1).sum()), r.shape[0], first), flush=True)
         print("%d in flight: %.1f ms/batch  %.2f images/s  (x%.2f)  ids equal: %s" %
               (k, tk / (k * args.batches) * 1e3, B * k * args.batches / tk, t1 * k / tk, same), flush=True)
 
