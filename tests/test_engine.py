@@ -524,11 +524,13 @@ def test_long_positions_forced_decode(be_name, ids_kind):
     below the standard one).  Argmax must agree wherever the fp32 margin exceeds twice the tolerance."""
     from oracle.udop_oracle import Oracle
     import torch
+    if be_name == "emu" and ids_kind == "random":
+        pytest.skip("one id sequence is enough on the emulator (CPU suite time); the GPU runs both at 511 positions")
     g = load_golden("g3_trained_tiny.npz")
     shape, sd = _weights(g)
     B = 2 if be_name == "emu" else 6
     inp = {k: v[:B] for k, v in _inputs(g, shape).items()}
-    T = (261 if ids_kind == "golden-cycle" else 151) if be_name == "emu" else 512
+    T = 261 if be_name == "emu" else 512
     if ids_kind == "random":
         forced = synth.randint("forced.long", B * T, 2, shape.vocab_size - 1, 1).reshape(B, T)
     else:
