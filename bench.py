@@ -122,11 +122,15 @@ def ocr_stage_run(B=32, new_tokens=256):
     sts = shared_streams(torch, eng.mem.device, 4)
     ctxs = [(eng, sts[0])] + [(eng.clone(), sts[i]) for i in range(1, 4)]
 
+    solo_ids = eng.generate(ids, pix, new_tokens)[0].cpu().numpy()
+    last = {}
+
     def work(c, st, reps):
         with torch.cuda.device(st.device), torch.cuda.stream(st):
             for _ in range(reps):
-                c.generate(ids, pix, new_tokens)
+                o = c.generate(ids, pix, new_tokens)[0]
             st.synchronize()
+            last[id(c)] = o.cpu().numpy()
 
     def run_all(reps):
         torch.cuda.synchronize(); t0 = time.time()
@@ -139,10 +143,11 @@ def ocr_stage_run(B=32, new_tokens=256):
         return time.time() - t0
     run_all(1)
     t4 = run_all(2)
+    same4 = all(np.array_equal(v, solo_ids) for v in last.values()) and len(last) == 4
     for c, _ in ctxs[1:]:
         c.close()
     return {"pages_per_s": round(B / tn, 2), "ms_per_batch": round(tn * 1e3, 1), "new_tokens": new_tokens, "batch": B, "prompt_len": L,
-            "pages_per_s_4_in_flight": round(8 * B / t4, 2),
+            "pages_per_s_4_in_flight": round(8 * B / t4, 2), "ids_4_in_flight_equal_one_context": bool(same4),
             "vision_plus_prefill_ms": round(t1 * 1e3, 2), "decode_step_ms": round(step_ms, 4),
             "dec_hbm_frac": round((wbytes + kvbytes) / (step_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
             "config": "ChemicalOCR stage alone: SmolDocling-256M geometry (INFERRED), recipe weights, one 512-px page per sequence, "
