@@ -617,6 +617,23 @@ def main():
                     "config": "a queue of 1024 images cut over the execution contexts of the headline run, one continuous decoder each"}
                 for c in fl.contexts:
                     c.set_stream_encoder(1)
+            if len(fl) > 1:
+                # the reference's shipped decode settings (config/predict.yaml: beam_search True -> num_beams 5; generate(max_length=512), EOS
+                # live): one mg_generate per 32 images and context - a batch walks until all of its beams are done (no queue form for beams yet)
+                def job_beam_eos(ctx):
+                    out, _, _ = ctx.generate(dev["input_ids"], dev["bbox"], dev["attention_mask"], ctx.preprocess(dev["pages_u8"]),
+                                             num_beams=5, max_length=512, min_length=0)
+                    return out.cpu().numpy()
+                for f in [fl.submit(job_beam_eos) for _ in range(len(fl))]:
+                    f.result()
+                nbe = 2 * len(fl)
+                torch.cuda.synchronize(); tbe = time.time()
+                outs = [f.result() for f in [fl.submit(job_beam_eos) for _ in range(nbe)]]
+                torch.cuda.synchronize(); tbe = time.time() - tbe
+                extra["beam5_eos_enabled_in_flight"] = {
+                    "images_per_s": round(B * nbe / tbe, 2), "ms_per_batch": round(tbe / nbe * 1e3, 1), "batches": nbe, "batches_in_flight": len(fl),
+                    "columns_returned": int(outs[0].shape[1]), "all_batches_equal": bool(all(np.array_equal(o, outs[0]) for o in outs)),
+                    "config": "num_beams 5, max_length 512, EOS enabled (EOS row scaled as in eos_enabled): the reference's default decode mode"}
             eng.load_state_dict({"shared.weight": sd["shared.weight"]})
             extra["ocr_stage"] = ocr_stage_run()
             if not args.no_cpu_baseline:
