@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -121,6 +122,8 @@ struct mg_model {
     // 1-D position bias), true = per-image semantics (every image as if alone and unpadded: the reference's batch size is 1)
     bool trim_padding = false;
     bool fused_tail = true;    // MG_DECODE_FUSED_TAIL=0: separate embedding / selection launches (A/B; identical results)
+    // one call at a time per execution context (mg_clone gives further contexts); recursive: mg_generate runs mg_encode
+    std::recursive_mutex call_mu;
     bool tied = true;          // tie_word_embeddings: lm_head = shared.weight and logits scaled by d_model^-0.5 (stock:1554-1557)
 #ifndef MG_EMU
     hipStream_t own_stream = nullptr;
@@ -460,6 +463,11 @@ int check_launch(const char* what) {
     }
     return MG_OK;
 }
+// One call at a time per execution context: a second thread entering the same context gets MG_E_STATE instead of racing on its buffers.
+#define MG_ONE_CALL(m, who)                                                                                         \
+    std::unique_lock<std::recursive_mutex> call_lock((m)->call_mu, std::try_to_lock);                               \
+    if (!call_lock.owns_lock())                                                                                    \
+        return fail(MG_E_STATE, who ": this execution context is inside another call (one call at a time per context; mg_clone gives further contexts)")
 // Start of a compute entry point: the runtime's last-error slot is per host thread and shared with every other library in the process -
 // whatever is pending there was not caused by this call.
 void entry_drain() {
@@ -964,6 +972,7 @@ int mg_encode(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_
               uint8_t* enc_mask) {
     entry_drain();
     if (!m || !ws || !input_ids || !bbox || !pixel_values) return fail(MG_E_ARG, "mg_encode: null argument");
+    MG_ONE_CALL(m, "mg_encode");
     if (!m->finalized) return fail(MG_E_STATE, "mg_encode: call mg_finalize first");
     if (B < 1 || L < 1) return fail(MG_E_SHAPE, "mg_encode: B and L must be >= 1");
     if ((e1 == nullptr) != (M_e1 == 0) || M_e1 < 0) return fail(MG_E_ARG, "mg_encode: e1 and M_e1 must be given together");
@@ -1059,6 +1068,7 @@ int mg_decoder_forward(mg_model* m, void* stream, void* ws, size_t ws_bytes, con
                        const uint8_t* decoder_attention_mask, int B, int T, float* logits) {
     entry_drain();
     if (!m || !ws || !decoder_input_ids || !logits) return fail(MG_E_ARG, "mg_decoder_forward: null argument");
+    MG_ONE_CALL(m, "mg_decoder_forward");
     if (m->st_ws != ws || m->st_B != B) return fail(MG_E_STATE, "mg_decoder_forward: run mg_encode on this workspace/batch first");
     if (T < 1 || T > m->T_cap) return fail(MG_E_SHAPE, "mg_decoder_forward: T must be in [1, %d]", m->T_cap);
     mgStream_t st = (mgStream_t)stream;
@@ -1132,6 +1142,7 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
                 float* out_scores, float* step_top2) {
     entry_drain();
     if (!m || !out_ids || !out_cols_host) return fail(MG_E_ARG, "mg_generate: null argument");
+    MG_ONE_CALL(m, "mg_generate");
     if (max_length < 2 || max_length > m->T_cap) return fail(MG_E_SHAPE, "mg_generate: max_length must be in [2, %d]", m->T_cap);
     if (num_beams < 1 || num_beams > 8) return fail(MG_E_UNSUPPORTED, "mg_generate: num_beams must be in [1, 8]");
     // the decode-step projections keep all live rows of a workgroup's feature slice in registers: at most 8 row tiles
@@ -1333,6 +1344,7 @@ int mg_generate_stream(mg_model* m, void* stream, void* ws, size_t ws_bytes, con
                        int max_length, int min_length, int64_t* out_ids, int32_t* out_len, long* steps_host) {
     entry_drain();
     if (!m || !ws || !input_ids || !bbox || !pixel_values || !out_ids || !out_len) return fail(MG_E_ARG, "mg_generate_stream: null argument");
+    MG_ONE_CALL(m, "mg_generate_stream");
     if (!m->finalized) return fail(MG_E_STATE, "mg_generate_stream: call mg_finalize first");
     if (N < 1 || L < 1 || chunk < 1 || pool_chunks < 2) return fail(MG_E_SHAPE, "mg_generate_stream: N, L, chunk must be >= 1, pool_chunks >= 2");
     if (slots < 1 || slots > 256) return fail(MG_E_UNSUPPORTED, "mg_generate_stream: slots must be in [1, 256]");

@@ -15,6 +15,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -78,6 +79,7 @@ struct mg_ocr_model {
     size_t patch_w, pos_emb, conn, tok_emb, lm_head, zero_tab, rope_cs;
     static constexpr int MAX_POS = 8192;     // positions of the rotation table (prompt + new tokens)
     bool finalized = false;
+    mutable std::recursive_mutex call_mu;      // one call at a time per execution context (mg_ocr_clone gives further contexts)
     // one decode step (30 layers x 9 launches + lm_head + selection) captured as a HIP graph whose kernels read the position from the
     // device step counter; replayed while the call's buffers and sizes match (MG_OCR_GRAPH=0: eager launches, same kernels)
     int use_graph = 1;
@@ -514,6 +516,11 @@ int mg_ocr_image_features(mg_ocr_model* m, void* stream, void* ws, size_t ws_byt
                           const uint8_t* patch_mask, int N, float* out) {
     int rc = check_args(m, N, 1, 1, "mg_ocr_image_features");
     if (rc != MG_OK) return rc;
+    std::unique_lock<std::recursive_mutex> call_lock;
+    if (m) {
+        call_lock = std::unique_lock<std::recursive_mutex>(m->call_mu, std::try_to_lock);
+        if (!call_lock.owns_lock()) return failf(MG_E_STATE, "mg_ocr_image_features: this execution context is inside another call (one call at a time per context; mg_ocr_clone gives further contexts)");
+    }
     Ws w;
     carve(m, (char*)ws, N, 1, 1, 0, false, &w);
     if (!ws || ws_bytes < w.total) return failf(MG_E_WORKSPACE, "mg_ocr_image_features: workspace %zu < %zu bytes", ws_bytes, w.total);
@@ -529,6 +536,11 @@ int mg_ocr_forward(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, con
                    const int32_t* patch_pos, const uint8_t* patch_mask, int B, int n_img, int L, float* logits) {
     int rc = check_args(m, B, n_img, L, "mg_ocr_forward");
     if (rc != MG_OK) return rc;
+    std::unique_lock<std::recursive_mutex> call_lock;
+    if (m) {
+        call_lock = std::unique_lock<std::recursive_mutex>(m->call_mu, std::try_to_lock);
+        if (!call_lock.owns_lock()) return failf(MG_E_STATE, "mg_ocr_forward: this execution context is inside another call (one call at a time per context; mg_ocr_clone gives further contexts)");
+    }
     Ws w;
     carve(m, (char*)ws, B, n_img, L, 0, true, &w);
     if (!ws || ws_bytes < w.total) return failf(MG_E_WORKSPACE, "mg_ocr_forward: workspace %zu < %zu bytes", ws_bytes, w.total);
@@ -557,6 +569,11 @@ int mg_ocr_generate(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, co
                     int* out_cols_host, float* step_logits, int capture_steps) {
     int rc = check_args(m, B, n_img, L, "mg_ocr_generate");
     if (rc != MG_OK) return rc;
+    std::unique_lock<std::recursive_mutex> call_lock;
+    if (m) {
+        call_lock = std::unique_lock<std::recursive_mutex>(m->call_mu, std::try_to_lock);
+        if (!call_lock.owns_lock()) return failf(MG_E_STATE, "mg_ocr_generate: this execution context is inside another call (one call at a time per context; mg_ocr_clone gives further contexts)");
+    }
     if (max_new_tokens < 1 || !out_ids || !out_cols_host) return failf(MG_E_ARG, "mg_ocr_generate: bad output arguments");
     if (L + max_new_tokens > mg_ocr_model::MAX_POS) return failf(MG_E_SHAPE, "mg_ocr_generate: %d + %d positions exceed %d", L, max_new_tokens, mg_ocr_model::MAX_POS);
     Ws w;
@@ -673,6 +690,11 @@ int mg_ocr_generate_stream(mg_ocr_model* m, void* stream, void* ws, size_t ws_by
                            int64_t* out_ids, int32_t* out_len, long* steps_host) {
     int rc = check_args(m, chunk < N ? chunk : N, n_img, L, "mg_ocr_generate_stream");
     if (rc != MG_OK) return rc;
+    std::unique_lock<std::recursive_mutex> call_lock;
+    if (m) {
+        call_lock = std::unique_lock<std::recursive_mutex>(m->call_mu, std::try_to_lock);
+        if (!call_lock.owns_lock()) return failf(MG_E_STATE, "mg_ocr_generate_stream: this execution context is inside another call (one call at a time per context; mg_ocr_clone gives further contexts)");
+    }
     if (N < 1 || slots < 1 || slots > 256 || chunk < 1 || chunk > 256) return failf(MG_E_SHAPE, "mg_ocr_generate_stream: N >= 1, slots and chunk in [1, 256]");
     if (max_new_tokens < 1 || !out_ids || !out_len) return failf(MG_E_ARG, "mg_ocr_generate_stream: bad output arguments");
     if (L + max_new_tokens > mg_ocr_model::MAX_POS) return failf(MG_E_SHAPE, "mg_ocr_generate_stream: %d + %d positions exceed %d", L, max_new_tokens, mg_ocr_model::MAX_POS);

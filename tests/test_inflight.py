@@ -134,3 +134,28 @@ def test_inflight_helper_on_emulator_keeps_order_and_contexts():
     assert 1 <= len(seen) <= 2
     with pytest.raises(ValueError):
         InFlight(eng, 5)
+
+
+def test_one_call_at_a_time_per_context():
+    """A context refuses a second call while it is inside one (two host threads on ONE context): MG_E_STATE, the first call's result intact.
+    (The emulator backend: a generate call takes seconds and ctypes releases the GIL, so the overlap is certain.)"""
+    import threading
+    import time
+    from markushgrapher_amd.engine import MgError
+    g = load_golden("g3_trained_tiny.npz")
+    shape, sd = _weights(g)
+    inp = _inputs(g, shape)
+    eng = make_engine("emu", shape, sd)
+    want = _gen(eng, inp, max_length=10, min_length=10)
+    out = {}
+
+    def first():
+        out["ids"] = _gen(eng, inp, max_length=10, min_length=10)
+    t = threading.Thread(target=first)
+    t.start()
+    time.sleep(0.3)
+    with pytest.raises(MgError, match="one call at a time"):
+        eng.encode(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"])
+    t.join()
+    assert np.array_equal(out["ids"], want)
+    assert np.array_equal(_gen(eng, inp, max_length=10, min_length=10), want)       # and the context is usable afterwards
