@@ -38,7 +38,7 @@ import time
 # before torch loads the HIP runtime: kernel arguments in device memory (see markushgrapher_amd/__init__.py)
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 # one hardware queue per execution context of the batches in flight (same file)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np
 
@@ -321,9 +321,13 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # MG_BENCH_FORCE_DIST=1: a process group of ONE rank over RCCL, the id exchange issued as a real all-gather - the multi-GPU code path
+    # (group set-up, asynchronous collectives beside the contexts in flight, barrier) on a single GPU
+    force_dist = os.environ.get("MG_BENCH_FORCE_DIST", "0") in ("1", "2")          # 2: the group only, the exchange stays a copy
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
 
     shape = synth.SHAPES[args.shape]
@@ -345,7 +349,7 @@ def main():
     # (at world == 1 the exchange degenerates to its single-rank copy path, which runs all the same: the packing of the static
     #  [32, 512] int32 block + lengths is part of the step on every node size)
     from markushgrapher_amd.dist import IdExchange
-    ex = IdExchange(B, torch.device("cuda", local_rank), pad_token_id=shape.pad_token_id)
+    ex = IdExchange(B, torch.device("cuda", local_rank), pad_token_id=shape.pad_token_id, always_collective=os.environ.get("MG_BENCH_FORCE_DIST") == "1")
     handles = []
 
     def step(beams=args.beams, max_len=max_length, min_len=max_length):
@@ -411,7 +415,7 @@ def main():
         return n_l, ms, keys, empty_ms, n_ph, enc_ms, dec_ms
 
     profile_on()                       # on the first context: its launches are bracketed while the other contexts run beside it
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.time()
@@ -419,10 +423,10 @@ def main():
     while handles:
         all_ids, all_len = ex.wait(handles.pop(0))      # the last batch's exchange completes inside the timed region
     torch.cuda.synchronize()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     dt = time.time() - t0
-    if world > 1:
+    if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -653,6 +657,7 @@ def main():
                                    "MarkushGrapher-2 VTL encoder + CXSMILES decoder, recipe weights = tests/golden/g4_bench.npz",
                        "shape": args.shape, "batch_per_gpu": B, "text_len_padded": int(L), "new_tokens": new_tokens,
                        "num_beams": args.beams, "decode_graph": args.decode_graph, "batches_in_flight": len(fl),
+                       "single_rank_rccl_group": bool(force_dist),
                        "in_flight": "execution contexts on one set of weights (mg_clone), a stream + host thread + workspace each; every "
                                     "step is one whole batch start to end; ids identical to one-at-a-time calls; warm-up = `warmup` "
                                     "batches per context",
@@ -665,7 +670,7 @@ def main():
             out["cpu_baseline"] = None
         out["setup_s"] = {"recipe_weights": round(t_weights, 1)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

@@ -8,6 +8,8 @@ import os as _os
 _os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 # Hardware queues the HIP runtime spreads its streams over (default 4, one of them taken by the null stream): with the batches
 # in flight of markushgrapher_amd/inflight.py every execution context needs a queue of its own - two contexts sharing one run
-# back to back (4 contexts: 102 images/s on 4 queues, 116 on 8; profiles/r03_inflight_ab.txt).  More than 4 busy queues
+# back to back (4 contexts: 102 images/s on 4 queues, 116 on 8 or 16; profiles/r03_inflight_ab.txt).  16 rather than 8: a process
+# that also runs RCCL collectives needs queues for RCCL's streams too - with 8, the all-gather of the ids landed on a context's queue
+# (115 -> 98 images/s with a one-rank group on one GPU, back to 115 with 16).  More than 4 busy queues
 # oversubscribe the chip's compute pipes and collapse (5 contexts: 80 images/s), which is why InFlight caps at 4.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")

@@ -37,9 +37,12 @@ class IdExchange:
                                         # views of the slot's receive blocks: valid until the slot is posted again
     """
 
-    def __init__(self, rows: int, device, pad_token_id: int = 0, group: Optional[dist.ProcessGroup] = None, cols: int = ID_COLS):
+    def __init__(self, rows: int, device, pad_token_id: int = 0, group: Optional[dist.ProcessGroup] = None, cols: int = ID_COLS,
+                 always_collective: bool = False):
+        """always_collective: issue the all-gather even in a group of one rank (exercises the RCCL path on a single GPU)."""
         self.rows, self.cols, self.pad, self.group = rows, cols, pad_token_id, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.collective = self.world > 1 or (always_collective and dist.is_initialized())
         mk = lambda *shape: torch.empty(shape, dtype=torch.int32, device=device)
         self.send = [mk(rows, cols), mk(rows, cols)]
         self.slen = [mk(rows), mk(rows)]
@@ -61,7 +64,7 @@ class IdExchange:
         s[:n, :t] = ids.to(torch.int32)
         sl.zero_()
         sl[:n] = t if lengths is None else lengths.to(torch.int32)
-        if self.world == 1:
+        if not self.collective:
             self.recv[slot].copy_(s)
             self.rlen[slot].copy_(sl)
             self.pending[slot] = ()

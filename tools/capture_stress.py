@@ -6,7 +6,7 @@ import threading
 import time
 
 os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import numpy as np
