@@ -158,3 +158,37 @@ def test_batches_in_flight_with_the_exchange_world2_gloo():
             t = want.shape[1]
             assert np.all(l0[4 * r:4 * r + 4] == t)
             assert np.array_equal(a0[4 * r:4 * r + 4, :t], want)           # batch k of rank r, in submission order
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_id_exchange_over_rccl_single_rank_group():
+    """The exchange's collective path on real hardware: a process group of one rank over RCCL (backend "nccl"), the ids of three batches
+    posted asynchronously (double-buffered) as all-gathers while a second stream keeps the GPU busy - what every rank of `bench.py --gpus N`
+    runs, minus the peers."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(29500 + (os.getpid() + 311) % 1000)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        ex = IdExchange(32, dev, pad_token_id=0, always_collective=True)
+        assert ex.collective and ex.world == 1
+        side = torch.cuda.Stream()
+        busy = torch.randn(2048, 2048, device=dev)
+        mk = lambda step: ((torch.arange(32 * (257 - step), dtype=torch.int64).reshape(32, 257 - step) % 33201) + step).to(dev)
+        with torch.cuda.stream(side):
+            for _ in range(20):
+                busy = busy @ busy * 1e-3
+        h0, h1 = ex.post(mk(0)), ex.post(mk(1))
+        r0 = [x.cpu().numpy().copy() for x in ex.wait(h0)]
+        r1 = [x.cpu().numpy().copy() for x in ex.wait(h1)]
+        r2 = [x.cpu().numpy().copy() for x in ex.wait(ex.post(mk(2)))]
+        for step, (a, l) in enumerate((r0, r1, r2)):
+            t = 257 - step
+            assert a.shape == (32, ID_COLS) and a.dtype == np.int32 and np.all(l == t)
+            assert np.array_equal(a[:, :t], mk(step).cpu().numpy()) and np.all(a[:, t:] == 0)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
