@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--new-tokens", type=int, default=256)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--clones", action="store_true", help="contexts = clones of one engine (shared weights) instead of separately loaded engines")
+    ap.add_argument("--stagger-ms", type=float, default=0.0, help="start context i that many ms x i late")
     ap.add_argument("--only", action="store_true", help="measure the full in-flight count only (plus the one-at-a-time reference)")
     args = ap.parse_args()
     import torch
@@ -46,6 +47,8 @@ def main():
     results = [None] * len(engs)
 
     def worker(i, n):
+        if args.stagger_ms > 0:
+            time.sleep(i * args.stagger_ms * 1e-3)
         with torch.cuda.stream(streams[i]):
             for _ in range(n):
                 pix = engs[i].preprocess(dev["pages_u8"])
