@@ -79,6 +79,7 @@ struct mg_model {
     std::vector<int> h_bk1, h_bkhv, h_bkdec;
     // encoder state left in the workspace by the last mg_encode
     int st_B = 0, st_L = 0, st_S = 0, st_Scap = 0, st_M = 0;
+    bool st_row_tiles = false;          // the last mg_encode on this context ran its GEMMs on the live row-tile list (w.row_tiles is valid)
     void* st_ws = nullptr;
     // optional live timing of the dominant decode kernel (cross-attention K/V stream), HIP events on the caller's stream
     int prof_every = 0;
@@ -426,7 +427,7 @@ void carve_stream(const mg_model* m, char* base, int chunk, int L, int slots, in
     w->total = align_up(c.off, 256);
 }
 __global__ __launch_bounds__(256) void stream_init_kernel(int64_t* out_ids, int* out_len, int N, int max_len, int64_t start, int64_t pad,
-                                                     int* unfinished, int* pos, int* img, int* pool, int64_t* next_ids, int slots, int* ctr) {
+                                                     int* unfinished, int* pos, int* img, int* pool, int64_t* next_ids, int slots, int* ctr, int* err) {
     const size_t n = (size_t)N * max_len;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         out_ids[i] = (i % max_len) == 0 ? start : pad;
@@ -434,7 +435,7 @@ __global__ __launch_bounds__(256) void stream_init_kernel(int64_t* out_ids, int*
         for (int i = threadIdx.x; i < N; i += blockDim.x) out_len[i] = 0;
         for (int r = threadIdx.x; r < slots; r += blockDim.x) { unfinished[r] = 0; pos[r] = 0; img[r] = -1; pool[r] = 0; next_ids[r] = start; }
         if (threadIdx.x < 16) ctr[threadIdx.x] = threadIdx.x == 8 ? N : 0;
-        if (threadIdx.x < 2) ctr[64 + threadIdx.x] = 0;          // the accumulators `err` are carved right behind the 64 counters
+        if (threadIdx.x < 2) err[threadIdx.x] = 0;
     }
 }
 // a chunk's cross K/V are in the pool: publish its key counts and make its images available to the slots
@@ -470,7 +471,12 @@ int check_launch(const char* what) {
         return fail(MG_E_STATE, who ": this execution context is inside another call (one call at a time per context; mg_clone gives further contexts)")
 // Start of a compute entry point: the runtime's last-error slot is per host thread and shared with every other library in the process -
 // whatever is pending there was not caused by this call.
+// (not inside a nested call: mg_generate_stream runs mg_encode per chunk in the middle of its decode loop, and a launch failure of
+// the steps enqueued before it must survive until the outer call's check_launch)
+static thread_local int g_nested_entry = 0;
+struct NestedEntry { NestedEntry() { ++g_nested_entry; } ~NestedEntry() { --g_nested_entry; } };
 void entry_drain() {
+    if (g_nested_entry > 0) return;
     (void)mg_peek_error();
     mg_err_site() = MgErrSite{0, nullptr};
 }
@@ -1008,7 +1014,14 @@ int mg_encode(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_
     // holds finite values (its keys are masked by the -1e30 table entry, which a NaN would survive).
     const int* tiles = nullptr;
     const int* n_tiles = nullptr;
-    if (m->row_tiles) {
+    // The list is honoured by the large-tile kernel only: it is used when EVERY encoder GEMM of this geometry runs on that kernel
+    // (otherwise a GEMM on another kernel would compute dead rows from the uninitialised outputs of one that skipped them).
+    int n_min = 3 * inner < d ? 3 * inner : d;
+    n_min = n_min < m->dff ? n_min : m->dff;
+    n_min = n_min < 2 * inner ? n_min : 2 * inner;
+    const bool use_tiles = m->row_tiles && gemm_has_gelu_epilogue(M, n_min);
+    m->st_row_tiles = use_tiles;
+    if (use_tiles) {
         row_tile_list(w.mask, M, w.row_tiles + 1, w.row_tiles, st);
         tiles = w.row_tiles + 1; n_tiles = w.row_tiles;
         mg_memset_async(w.q_pk, 0, (size_t)M * inner * 2, st);
@@ -1176,7 +1189,7 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
         GemmArgs kv = gemm_args(w.enc_pk, m->at<uint16_t>(m->dec[li].xkv), M, 2 * inner, d);
         set_heads(kv, H, S_cap, Sx_cap, w.xk + li * xkv_stride, HF_NATURAL, w.xv + li * xkv_stride, HF_NATURAL, nullptr, HF_NONE);
         kv.heads.row_map = w.xrow;
-        if (m->row_tiles) { kv.row_tiles = w.row_tiles + 1; kv.n_row_tiles = w.row_tiles; }      // left by mg_encode
+        if (m->st_row_tiles) { kv.row_tiles = w.row_tiles + 1; kv.n_row_tiles = w.row_tiles; }      // left by mg_encode
         gemm(kv, EPI_HEADS, st);
     }
     if (m->phase_on) mg_event_record(m->phase_ev[1], st);
@@ -1332,6 +1345,7 @@ int mg_stream_workspace_bytes(const mg_model* m, int chunk, int L, int slots, in
 // priority; 2: own stream restricted to the compute units of cu_mask (nwords x 32 bits).  Takes effect at the next call.
 int mg_stream_encoder_mode(mg_model* m, int mode, const uint32_t* cu_mask, int nwords) {
     if (!m || mode < 0 || mode > 2 || (mode == 2 && (!cu_mask || nwords < 1))) return fail(MG_E_ARG, "mg_stream_encoder_mode: bad argument");
+    MG_ONE_CALL(m, "mg_stream_encoder_mode");          // (a call on this context may be using the stream that is destroyed below)
     if (m->enc_stream_ready && m->enc_stream) { mg_stream_sync(m->enc_stream); mg_stream_destroy(m->enc_stream); }
     m->enc_stream = nullptr; m->enc_stream_ready = false;
     m->enc_mode = mode;
@@ -1384,7 +1398,7 @@ int mg_generate_stream(mg_model* m, void* stream, void* ws, size_t ws_bytes, con
     // slot table, outputs
     const int64_t start = m->c.decoder_start_token_id, pad = m->c.pad_token_id;
     MG_LAUNCH(stream_init_kernel, dim3(64), dim3(256), 0, st, out_ids, out_len, N, max_length, start, pad, w.unfinished, w.pos, w.img, w.pool,
-              w.next_ids, slots, w.ctr);
+              w.next_ids, slots, w.ctr, w.err);
     mg_event_record(m->start_ev, st);
     if (es != st) mg_stream_wait_event(es, m->start_ev);      // inputs / workspace are ordered behind the caller's earlier work
     DecodeCtx dc{};
@@ -1400,7 +1414,7 @@ int mg_generate_stream(mg_model* m, void* stream, void* ws, size_t ws_bytes, con
     bool graphed = false;
 #ifndef MG_EMU
     if (m->use_graph == 1) {
-        const StepGraph::Key key{ws, out_ids, out_len, (const void*)st, slots, L, chunk * 1000 + pool_chunks, max_length, min_length, N, 0, 0.0f};
+        const StepGraph::Key key{ws, out_ids, out_len, (const void*)st, slots, L, chunk, max_length, min_length, N, pool_chunks, 0.0f};     // (K = chunk, M_e1 = pool_chunks)
         StepGraph& sg = m->stream_graph;
         if (!(sg.valid && sg.key == key)) {
             std::lock_guard<std::mutex> capture_lock(mg_capture_mutex());
@@ -1428,6 +1442,7 @@ int mg_generate_stream(mg_model* m, void* stream, void* ws, size_t ws_bytes, con
         const int entry0 = (submitted % pool_chunks) * chunk;
         mgEvent_t e0 = m->chunk_ev[2 * (submitted % pool_chunks)], e1 = m->chunk_ev[2 * (submitted % pool_chunks) + 1];
         mg_event_record(e0, es);
+        NestedEntry nested;                    // keeps the pending runtime error / first failing site of this call's earlier launches
         int rc = mg_encode(m, es, ws, ws_bytes, input_ids + (size_t)c0 * L, bbox + (size_t)c0 * L * 4, attention_mask ? attention_mask + (size_t)c0 * L : nullptr,
                            pixel_values + (size_t)c0 * img_in, nullptr, 0, n, L, nullptr, nullptr);
         if (rc != MG_OK) return rc;
@@ -1438,7 +1453,7 @@ int mg_generate_stream(mg_model* m, void* stream, void* ws, size_t ws_bytes, con
             GemmArgs kv = gemm_args(we.enc_pk, m->at<uint16_t>(m->dec[li].xkv), n * S_cap, 2 * inner, d);
             set_heads(kv, H, S_cap, Sx_cap, w.xk + li * w.pool_stride + ent_off, HF_NATURAL, w.xv + li * w.pool_stride + ent_off, HF_NATURAL, nullptr, HF_NONE);
             kv.heads.row_map = we.xrow;
-            if (m->row_tiles) { kv.row_tiles = we.row_tiles + 1; kv.n_row_tiles = we.row_tiles; }
+            if (m->st_row_tiles) { kv.row_tiles = we.row_tiles + 1; kv.n_row_tiles = we.row_tiles; }
             gemm(kv, EPI_HEADS, es);
         }
         MG_LAUNCH(stream_chunk_done_kernel, dim3(1), dim3(64), 0, es, (const int*)we.xlen, w.xlen_pool, entry0, n, (const int*)we.counters, w.err);
@@ -1458,12 +1473,14 @@ int mg_generate_stream(mg_model* m, void* stream, void* ws, size_t ws_bytes, con
         return true;
     };
     int rc = MG_OK;
+    // error returns from the loop: nothing enqueued by this call may still be writing ws / out_ids / out_len when it returns
+    auto quiesce = [&]() { if (es != st) mg_stream_sync(es); mg_stream_sync(st); };
     while (done_host < N) {
         // feed the encoder stream: chunk c overwrites the pool entries of chunk c - pool_chunks, whose images must all have
         // finished (oldest live image known to the host, a few steps late: conservative)
         while (submitted < n_chunks && (submitted < pool_chunks || oldest_host >= (submitted - pool_chunks + 1) * chunk) &&
                (es != st || submitted == announced)) {
-            if ((rc = submit_chunk()) != MG_OK) return rc;
+            if ((rc = submit_chunk()) != MG_OK) { quiesce(); return rc; }
             if (es == st) break;              // serial mode: one chunk, then decode until the slots run dry
         }
         // hand finished chunks to the slots; when no slot is live and the queue is empty the decode stream has to wait for one
@@ -1474,7 +1491,7 @@ int mg_generate_stream(mg_model* m, void* stream, void* ws, size_t ws_bytes, con
             const bool timed_step = m->prof_every > 0 && (steps % m->prof_every) == 0;
 #ifndef MG_EMU
             if (graphed && !timed_step) {
-                if (hipGraphLaunch(m->stream_graph.exec, st) != hipSuccess) return fail(MG_E_HIP, "mg_generate_stream: hipGraphLaunch failed");
+                if (hipGraphLaunch(m->stream_graph.exec, st) != hipSuccess) { quiesce(); return fail(MG_E_HIP, "mg_generate_stream: hipGraphLaunch failed"); }
             } else
 #endif
                 decode_step(m, dc, 0, nullptr, timed_step, st);
@@ -1491,7 +1508,7 @@ int mg_generate_stream(mg_model* m, void* stream, void* ws, size_t ws_bytes, con
             live_host = h[0]; done_host = h[1]; head_host = h[4]; oldest_host = h[7];
             ++rb_seen;
         }
-        if (steps > (long)N * max_length + 64L * n_chunks + 1024) return fail(MG_E_HIP, "mg_generate_stream: no progress (%d of %d images after %ld steps)", done_host, N, steps);
+        if (steps > (long)N * max_length + 64L * n_chunks + 1024) { quiesce(); return fail(MG_E_HIP, "mg_generate_stream: no progress (%d of %d images after %ld steps)", done_host, N, steps); }
     }
     int err2[2] = {0, 0};
     int& err_host = err2[0];

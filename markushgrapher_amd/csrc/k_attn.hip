@@ -285,6 +285,9 @@ MG_DEV float fast_exp2(float x) {
 // (4 x 1 KiB of index words, 2 fragments; waves without an attended query issue only the 2 fragments).  Inside the stage
 // loop there must be NO compiler-tracked vector-memory access: a compiler-inserted vmcnt(0) would drain the pipeline
 // (the stage list therefore lives in LDS, and the loads of the prologue are retired by hand before the loop).
+// XP != 0: timing experiments of the tools build only (MG_ATT_EXP, WRONG results): 1 = no index-word copies (stale LDS is read),
+// 2 = no table lookup (bias 0), 4 = no exp2 (weights = shifted scores), 8 = K / V^T copies of the first two stages only
+template <int XP = 0>
 __global__ __launch_bounds__(512) void attention_enc_kernel(AttnArgs a) {
     MG_DYN_SMEM(smem);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(512) void attention_enc_kernel(AttnArgs a) {
     // fragments into ring slot i % AE_RING (fragments 0..7 = K: key-tile f/4, dk-tile f%4; 8..15 = V^T: d-tile, key-k-tile)
     auto issue = [&](int i) {
         const int st = sid(i);
-        if (act) {
+        if (act && !(XP & 1)) {
             char* ix = ix_base + (i % AE_DEPTH) * AE_IDX_BYTES;
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2) {
@@ -394,9 +397,10 @@ __global__ __launch_bounds__(512) void attention_enc_kernel(AttnArgs a) {
                 vkt = vkt < vkt_max ? vkt : vkt_max;
                 src = (const char*)(Vb + ((size_t)dt * (size_t)(a.Sk_cap >> 4) + (size_t)vkt) * TILE_ELEMS);
             }
-            glds16_async(src + lane * 16, dst + f * TILE_BYTES);
+            if (!(XP & 8) || i < 2) glds16_async(src + lane * 16, dst + f * TILE_BYTES);
         }
     };
+    constexpr int XW_ACT = ((XP & 1) ? 0 : 4) + ((XP & 8) ? 0 : 2), XW_IDLE = (XP & 8) ? 0 : 2;      // copies per wave and stage
 
     f32x16 o[2] = {acc_zero(), acc_zero()};
     float lsum = 0.f, m_run = AT_NEG;
@@ -405,8 +409,15 @@ __global__ __launch_bounds__(512) void attention_enc_kernel(AttnArgs a) {
     if (1 < nst) issue(1);
     for (int sti = 0; sti < nst; ++sti) {
         // own copies of stage sti have landed when at most those of the one later stage in flight are outstanding
-        if (sti + 1 < nst && !(a.dbg & 1)) { if (act) MG_WAIT_VMCNT(6); else MG_WAIT_VMCNT(2); }
-        else MG_WAIT_VMCNT(0);
+        if constexpr (XP == 0) {
+            if (sti + 1 < nst && !(a.dbg & 1)) { if (act) MG_WAIT_VMCNT(6); else MG_WAIT_VMCNT(2); }
+            else MG_WAIT_VMCNT(0);
+        } else {                       // (experiments: same structure with the variant's copy counts)
+            if (sti + 1 < nst && sti >= 2) {
+                if (act) { if constexpr (XW_ACT == 6) MG_WAIT_VMCNT(6); else if constexpr (XW_ACT == 4) MG_WAIT_VMCNT(4); else if constexpr (XW_ACT == 2) MG_WAIT_VMCNT(2); else MG_WAIT_VMCNT(0); }
+                else { if constexpr (XW_IDLE == 2) MG_WAIT_VMCNT(2); else MG_WAIT_VMCNT(0); }
+            } else MG_WAIT_VMCNT(0);
+        }
         MG_BARRIER_RAW();            // everybody's copies of stage sti have landed; the K / V^T slot of stage sti - 1 is free
         const int st = sid(sti);
         if (!act) {
@@ -442,7 +453,7 @@ __global__ __launch_bounds__(512) void attention_enc_kernel(AttnArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const uint32_t e = (r & 1) ? (bw[r >> 1] >> 16) : (bw[r >> 1] & 0xFFFFu);
-                    const float bias = *(const float*)((const char*)hv + e) + *(const float*)(tl + ((r & 3) + 8 * (r >> 2)) * 4);
+                    const float bias = ((XP & 2) ? __uint_as_float(e) : *(const float*)((const char*)hv + e)) + *(const float*)(tl + ((r & 3) + 8 * (r >> 2)) * 4);
                     const float v = fmaf(s[t2][r], AE_LOG2E, bias);
                     s[t2][r] = v;
                     tm = fmaxf(tm, v);
@@ -452,7 +463,7 @@ __global__ __launch_bounds__(512) void attention_enc_kernel(AttnArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const uint32_t e = (r & 1) ? (bw[r >> 1] >> 16) : (bw[r >> 1] & 0xFFFFu);
-                    const float v = fmaf(s[t2][r], AE_LOG2E, *(const float*)((const char*)hv + e));
+                    const float v = fmaf(s[t2][r], AE_LOG2E, (XP & 2) ? __uint_as_float(e) : *(const float*)((const char*)hv + e));
                     s[t2][r] = v;
                     tm = fmaxf(tm, v);
                 }
@@ -481,7 +492,7 @@ __global__ __launch_bounds__(512) void attention_enc_kernel(AttnArgs a) {
             for (int r = 0; r < 16; r += 2) {                      // packed subtract: half an instruction per score
                 const mg_f32x2 sv = {s[t2][r], s[t2][r + 1]};
                 const mg_f32x2 d = sv - mt2;
-                p[r] = fast_exp2(d.x); p[r + 1] = fast_exp2(d.y);
+                if constexpr (XP & 4) { p[r] = d.x; p[r + 1] = d.y; } else { p[r] = fast_exp2(d.x); p[r + 1] = fast_exp2(d.y); }
             }
 #endif
             const PackedAcc pa = acc_pack(p);
@@ -650,8 +661,19 @@ void attention(const AttnArgs& a_in, mgStream_t stream) {
     if (a.mode == ATT_ENC) {
         const int nqe = (a.Sq_cap + AE_QB - 1) / AE_QB;
         static bool once = false;
-        if (!once) { MG_SET_MAX_SMEM(&attention_enc_kernel, AE_SMEM); once = true; }
-        MG_LAUNCH(attention_enc_kernel, dim3(a.B * a.H * nqe), dim3(512), (size_t)AE_SMEM, stream, a);
+        if (!once) { MG_SET_MAX_SMEM(&attention_enc_kernel<0>, AE_SMEM); once = true; }
+#ifdef MG_TOOLS      // what-if variants with WRONG results: tools builds only
+        static int xp = -1;
+        if (xp < 0) { const char* e = getenv("MG_ATT_EXP"); xp = e ? atoi(e) : 0; }
+        if (xp) {
+#define MG_AX(N) case N: { static bool o = false; if (!o) { MG_SET_MAX_SMEM(&attention_enc_kernel<N>, AE_SMEM); o = true; } \
+                           MG_LAUNCH(attention_enc_kernel<N>, dim3(a.B * a.H * nqe), dim3(512), (size_t)AE_SMEM, stream, a); } break;
+            switch (xp) { MG_AX(1) MG_AX(2) MG_AX(3) MG_AX(4) MG_AX(7) MG_AX(8) MG_AX(9) MG_AX(15) default: MG_AX(11) }
+#undef MG_AX
+            return;
+        }
+#endif
+        MG_LAUNCH(attention_enc_kernel<0>, dim3(a.B * a.H * nqe), dim3(512), (size_t)AE_SMEM, stream, a);
     } else if (a.mode == ATT_DEC_SELF) MG_LAUNCH((attention_kernel<ATT_DEC_SELF>), grid, block, sh, stream, a);
     else MG_LAUNCH((attention_kernel<ATT_CROSS>), grid, block, sh, stream, a);
 }

@@ -708,6 +708,250 @@ static void launch_xl(const GemmArgs& a, mgStream_t stream) {
     MG_LAUNCH((gemm_xl_kernel<EPI, TI>), dim3(nblk), dim3(512), sh, stream, a);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// large-M GEMM, third form: PERSISTENT workgroups with a PING-PONG wave schedule (round 4).
+//
+// What the two-stage kernel above leaves on the table (measured, profiles/r02_gemm_whatif.txt, r04 notes in DESIGN.md): its 8 waves
+// run in lockstep - both waves of a SIMD read fragments at the same time and want the matrix pipe at the same time - and a
+// workgroup's HBM-heavy epilogue, its first-stage latency and the next workgroup's start are all paid with the matrix pipe idle.
+// Here:
+//   * same block tile (64*TI x 256, 8 waves as 2 x 4, 32*TI x 64 per wave) and the same operand format, so the same epilogues;
+//   * the two wave rows are two GROUPS (waves 0-3 / 4-7: one wave of each group per SIMD) that run the same phase program one
+//     barrier apart: a phase = [LOAD: ds_read the 16-wide k-tile's TI + 2 fragments, issue this wave's copies of a later k-tile,
+//     counted vmcnt] barrier [lgkmcnt(0); 2*TI MFMAs at raised priority] barrier.  While group A multiplies, group B loads, and
+//     vice versa: the matrix pipe of every SIMD always has one wave feeding it (cdna_hip_programming.md, "8-phase" schedule);
+//   * operands travel in a ring of 8 k-tile slots ((2 TI + 8) KiB each = the two 64-deep stages of the kernel above, cut in
+//     four): the slot of k-tile g is refilled with k-tile g + 8 as soon as both groups have read it, i.e. the copies of k-tile
+//     g + 6 are issued in phase g - 1.5 K-steps (about 3000 cycles) of lead instead of one, with the same LDS footprint;
+//   * the workgroup is persistent (one per CU, tiles dealt round-robin inside XCD-contiguous ranges) and the k-tile stream runs
+//     ACROSS tiles: the first six k-tiles of the next tile are in flight during the epilogue, and nothing is re-launched.
+// Hazards (barrier numbers: group A runs phase g between barriers 2g and 2g+2, group B between 2g+1 and 2g+3):
+//   RAW  a wave waits for ITS copies of k-tile g+1 before its first barrier of phase g (A: 2g+1, B: 2g+2); the reads of k-tile g+1
+//        start after barrier 2g+2 (A) / 2g+3 (B): every copy has landed and a barrier lies in between;
+//   WAR  the reads of k-tile h are complete before barrier 2h+2 (A) / 2h+3 (B); the slot is refilled with k-tile h+8 in phase h+2
+//        = after barrier 2h+4 (A) / 2h+5 (B).
+// Sums are accumulated in the same order as in gemm_xl_kernel (k ascending per accumulator): results are bit-identical.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int GP_RING = 8, GP_AHEAD = 6, GP_MAXT = 16;          // ring slots, copy lead (k-tiles), tiles per workgroup at most
+
+template <int N>
+MG_DEV void wait_vmcnt_n() {
+#ifndef MG_EMU
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+MG_DEV void set_prio_hi() {
+#ifndef MG_EMU
+    __builtin_amdgcn_s_setprio(1);
+#endif
+}
+MG_DEV void set_prio_lo() {
+#ifndef MG_EMU
+    __builtin_amdgcn_s_setprio(0);
+#endif
+}
+
+template <int EPI, int TI>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs a) {
+    MG_DYN_SMEM(smem);
+    constexpr int XT = 2 * TI, FR = XT + 8;                     // fragments per k-tile slot: X row tiles, then 8 W row tiles
+    constexpr int KT_BYTES = FR * TILE_BYTES;
+    constexpr int NHI = FR - 16;                                // waves 0 .. NHI-1 copy three fragments per k-tile, the others two
+    constexpr int BM = 64 * TI;
+    static_assert(FR >= 16 && FR <= 24, "two or three copies per wave and k-tile");
+    const int tid = threadIdx.x, lane = tid & 63;
+#ifdef MG_EMU
+    const int w = tid >> 6;
+#else
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+    const int wr = w >> 2, wc = w & 3;
+    const int nbn = (a.N + GX_N - 1) / GX_N;
+    const int n_list = a.row_tiles ? *a.n_row_tiles : 0;
+    const int M_run = a.row_tiles ? n_list * 32 : a.M;
+    const int nbm = (M_run + BM - 1) / BM;
+    const int nblk = nbm * nbn;
+    const int mt32 = (a.M + 31) >> 5, nt32 = (a.N + 31) >> 5;
+    const int KT = a.K >> 4;                                    // 16-wide k-tiles per output tile (a multiple of GP_RING)
+    // tiles of this workgroup: t_first, t_first + t_step, ... < t_end  (XCD-contiguous ranges: block b runs on XCD b % 8)
+    const int G = gridDim.x, b = blockIdx.x;
+    int t_first, t_step, t_end;
+    if ((G & 7) == 0) {
+        const int T8 = (nblk + 7) >> 3, xcd = b & 7;
+        t_first = xcd * T8 + (b >> 3); t_step = G >> 3;
+        t_end = (xcd + 1) * T8 < nblk ? (xcd + 1) * T8 : nblk;
+    } else {
+        t_first = b; t_step = G; t_end = nblk;
+    }
+    int n_my = t_first < t_end ? (t_end - t_first + t_step - 1) / t_step : 0;
+    if (n_my > GP_MAXT) n_my = GP_MAXT;                         // (the launcher keeps tiles / workgroup <= GP_MAXT)
+    if (n_my == 0) return;
+
+    // row tiles of my output tiles: rtab[i][r] = 32-row tile id (>= 0) or -1 - (a live tile to read instead) past the end
+    int* rtab = (int*)(smem + GP_RING * KT_BYTES);
+    for (int e = tid; e < n_my * XT; e += 512) {
+        const int i = e / XT, r = e - i * XT;
+        const int bm = (t_first + i * t_step) / nbn;
+        int rt = bm * XT + r, live;
+        if (a.row_tiles) { live = rt < n_list; rt = a.row_tiles[live ? rt : n_list - 1]; }
+        else { live = rt < mt32; rt = live ? rt : mt32 - 1; }
+        rtab[e] = live ? rt : -1 - rt;
+    }
+    __syncthreads();
+
+    const mg_lds_t sm0 = mg_lds_addr(smem);
+    // this wave's copies of a k-tile: fragments w, w + 8 and (w < NHI) 16 + w
+    auto frag_src = [&](int i, int k) -> const char* {
+        const int f = k < 2 ? w + 8 * k : 16 + w;
+        const int tile = t_first + i * t_step, bm = tile / nbn, bn = tile - bm * nbn;
+        (void)bm;
+        if (f < XT) {
+            const int v = rtab[i * XT + f], rt = v >= 0 ? v : -1 - v;
+            return (const char*)(a.X + pk_tile_off(rt, 0, a.K)) + lane * 16;
+        }
+        int rt = bn * 8 + (f - XT);
+        rt = rt < nt32 - 1 ? rt : nt32 - 1;
+        return (const char*)(a.W + pk_tile_off(rt, 0, a.K)) + lane * 16;
+    };
+    const char* pc[3];
+    const char* pn[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { pc[k] = frag_src(0, k < 2 || w < NHI ? k : 0); pn[k] = n_my > 1 ? frag_src(1, k < 2 || w < NHI ? k : 0) : pc[k]; }
+    const bool three = NHI > 0 && w < NHI;
+    auto issue = [&](const char* const (&ptr)[3], int kk, int slot) {
+        const mg_lds_t dst = sm0 + slot * KT_BYTES;
+        glds16_async_lds(ptr[0] + (size_t)kk * TILE_BYTES, dst + w * TILE_BYTES);
+        glds16_async_lds(ptr[1] + (size_t)kk * TILE_BYTES, dst + (w + 8) * TILE_BYTES);
+        if (NHI > 0 && three) glds16_async_lds(ptr[2] + (size_t)kk * TILE_BYTES, dst + (16 + w) * TILE_BYTES);
+    };
+    // own copies of everything but the `ahead` most recent k-tiles have landed
+    auto wait_groups5 = [&]() { if (three) wait_vmcnt_n<15>(); else wait_vmcnt_n<10>(); };
+
+    struct Frags { mg_raw16 x[TI], w[2]; };
+    const mg_lds_t lx0 = sm0 + lane * 16 + wr * (TI * TILE_BYTES);
+    const mg_lds_t lw0 = sm0 + lane * 16 + (XT + wc * 2) * TILE_BYTES;
+    auto rd = [&](int slot, Frags& f) {
+        const mg_lds_t lx = lx0 + slot * KT_BYTES, lw = lw0 + slot * KT_BYTES;
+        lds_rd16_async<0>(f.w[0], lw);
+        lds_rd16_async<TILE_BYTES>(f.w[1], lw);
+        lds_rd16_async<0 * TILE_BYTES>(f.x[0], lx);
+        lds_rd16_async<1 * TILE_BYTES>(f.x[1], lx);
+        lds_rd16_async<2 * TILE_BYTES>(f.x[2], lx);
+        lds_rd16_async<3 * TILE_BYTES>(f.x[3], lx);
+        if constexpr (TI > 4) lds_rd16_async<4 * TILE_BYTES>(f.x[TI - 1], lx);
+    };
+    auto landed = [&](Frags& f) {
+        MG_WAIT_LGKM_TIE(0, f.w[0]);
+        MG_TIE(f.w[1]);
+#pragma unroll
+        for (int i = 0; i < TI; ++i) MG_TIE(f.x[i]);
+    };
+
+    // prologue: k-tiles 0 .. AHEAD-1 of the first tile
+#pragma unroll
+    for (int j = 0; j < GP_AHEAD; ++j) issue(pc, j, j);
+    wait_groups5();                                            // k-tile 0
+    MG_BARRIER_RAW();
+
+    for (int i = 0; i < n_my; ++i) {
+        const bool has_next = i + 1 < n_my;
+        const int tile = t_first + i * t_step, bm = tile / nbn, bn = tile - bm * nbn;
+        (void)bm;
+        const int n0w = bn * GX_N + wc * 64;
+        bool tor;
+        if (EPI == EPI_F32_STORE || EPI == EPI_F32_RESID) tor = false;
+        else if (EPI == EPI_HEADS) tor = !heads_region_is_T(a.heads, n0w < a.N ? n0w : 0);
+        else tor = true;
+        f32x16 acc[TI][2];
+#pragma unroll
+        for (int ii = 0; ii < TI; ++ii)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[ii][j] = acc_zero();
+        if (wr == 1) MG_BARRIER_RAW();                         // group B runs one barrier behind group A
+        for (int kb = 0; kb < KT; kb += GP_RING) {
+#pragma unroll
+            for (int p = 0; p < GP_RING; ++p) {
+                Frags f;
+                rd(p, f);
+                const int kk = kb + p + GP_AHEAD;
+                bool issued = true;
+                if (kk < KT) issue(pc, kk, (p + GP_AHEAD) & (GP_RING - 1));
+                else if (has_next) issue(pn, kk - KT, (p + GP_AHEAD) & (GP_RING - 1));
+                else issued = false;
+                if (issued) wait_groups5(); else wait_vmcnt_n<0>();      // own copies of the NEXT k-tile have landed
+                MG_BARRIER_RAW();
+                landed(f);
+                MG_SCHED_FENCE();
+                set_prio_hi();
+                {
+                    uint4 xw[2], xx[TI];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) xw[j] = raw16_get(f.w[j]);
+#pragma unroll
+                    for (int ii = 0; ii < TI; ++ii) xx[ii] = raw16_get(f.x[ii]);
+                    if (tor) {
+#pragma unroll
+                        for (int ii = 0; ii < TI; ++ii)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) acc[ii][j] = mfma32(xw[j], xx[ii], acc[ii][j]);
+                    } else {
+#pragma unroll
+                        for (int ii = 0; ii < TI; ++ii)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) acc[ii][j] = mfma32(xx[ii], xw[j], acc[ii][j]);
+                    }
+                }
+                set_prio_lo();
+                MG_SCHED_FENCE();
+                MG_BARRIER_RAW();
+            }
+        }
+        if (wr == 0) MG_BARRIER_RAW();                         // group A waits for group B's last phase: both groups store together
+        int mrow[TI];
+#pragma unroll
+        for (int ii = 0; ii < TI; ++ii) {
+            const int v = rtab[i * XT + wr * TI + ii];
+            mrow[ii] = v >= 0 ? v * 32 : a.M;                  // past the end: row index M, every store is guarded by m < M
+        }
+        // the copy sources of the tile after the next one (LDS table: no vector-memory wait in the way of the copies in flight)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { pc[k] = pn[k]; if (i + 2 < n_my) pn[k] = frag_src(i + 2, k < 2 || w < NHI ? k : 0); }
+        xl_epilogue<EPI, TI>(a, acc, mrow, n0w, tor, lane);
+        wait_vmcnt_n<0>();            // stores and loads retire out of order with respect to each other: the counted waits of the next tile start from an empty queue
+    }
+}
+template <int EPI, int TI>
+static bool launch_pp(const GemmArgs& a, mgStream_t stream) {
+    constexpr int BM = 64 * TI;
+    const int nblk = ((a.M + BM - 1) / BM) * ((a.N + GX_N - 1) / GX_N);
+    static int ncu = 0;
+#ifndef MG_EMU
+    if (!ncu) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1) ncu = 256; }
+#else
+    ncu = 8;
+#endif
+    int G = nblk < ncu ? nblk : ncu;
+    if (G >= 8) G &= ~7;
+    if ((a.K & 127) != 0 || nblk > GP_MAXT * G) return false;                   // (K/16 must be a multiple of the ring)
+    const size_t sh = (size_t)GP_RING * (2 * TI + 8) * TILE_BYTES + (size_t)GP_MAXT * 2 * TI * sizeof(int);
+    static bool once = false;
+    if (!once) { MG_SET_MAX_SMEM((&gemm_pp_kernel<EPI, TI>), sh); once = true; }
+    MG_LAUNCH((gemm_pp_kernel<EPI, TI>), dim3(G), dim3(512), sh, stream, a);
+    return true;
+}
+template <int TI>
+static bool launch_pp_epi(const GemmArgs& a, int epi, mgStream_t stream) {
+    switch (epi) {
+        case EPI_F32_STORE: return launch_pp<EPI_F32_STORE, TI>(a, stream);
+        case EPI_F32_RESID: return launch_pp<EPI_F32_RESID, TI>(a, stream);
+        case EPI_PK_RELU: return launch_pp<EPI_PK_RELU, TI>(a, stream);
+        case EPI_PK_GELU: return launch_pp<EPI_PK_GELU, TI>(a, stream);
+        case EPI_PK: return launch_pp<EPI_PK, TI>(a, stream);
+        case EPI_RESID_NORM: return launch_pp<EPI_RESID_NORM, TI>(a, stream);
+        default: return launch_pp<EPI_HEADS, TI>(a, stream);
+    }
+}
+
 template <int EPI>
 static void launch_wide(const GemmArgs& a, mgStream_t stream) {
     const int nblk = ((a.M + GW_M - 1) / GW_M) * ((a.N + GW_N - 1) / GW_N);
@@ -727,10 +971,13 @@ bool gemm_has_gelu_epilogue(int M, int N) { return g_gemm_variant >= 2 && M >= 3
 void gemm(const GemmArgs& a, int epi, mgStream_t stream) {
     static bool env_read = false;
     if (!env_read) { env_read = true; if (const char* e = getenv("MG_GEMM_VARIANT")) g_gemm_variant = atoi(e); }   // A/B runs
+    if ((g_gemm_variant == 5 || g_gemm_variant == 6) && a.M >= 320 && a.N >= GX_N) {        // ping-pong persistent kernel, TI = 4 / 5
+        if (g_gemm_variant == 5 ? launch_pp_epi<4>(a, epi, stream) : launch_pp_epi<5>(a, epi, stream)) return;
+    }
     if (g_gemm_variant >= 2 && a.M >= 320 && a.N >= GX_N) {
         // measured at M = 40960 (PFLOP/s, 256x128 / 256x256 / 320x256): QKV 0.72 / 0.92 / 1.01, O 0.47 / 0.45 / 0.53,
         // wi 0.78 / 0.99 / 1.04, wo 0.73 / 0.69 / 0.80, cross-KV 0.97 / 1.10 / 1.09 -> the 320-row tile by default
-        const bool five = g_gemm_variant == 4 || g_gemm_variant == 3;
+        const bool five = g_gemm_variant >= 3;
         const bool four = g_gemm_variant == 2;
         if (five) {
             switch (epi) {

@@ -86,7 +86,7 @@ struct mg_ocr_model {
     bool graph_active = false;
     struct Key { const void *ws, *out, *stream; int B, n_img, L, max_new; bool operator==(const Key& o) const { return ws == o.ws && out == o.out && stream == o.stream && B == o.B && n_img == o.n_img && L == o.L && max_new == o.max_new; } } gkey{};   // n_img: the text-side buffers are carved behind the vision buffers
     bool gvalid = false;
-    struct SKey { const void *ws, *out, *stream; int N, slots, L, max_new; bool operator==(const SKey& o) const { return ws == o.ws && out == o.out && stream == o.stream && N == o.N && slots == o.slots && L == o.L && max_new == o.max_new; } } skey{};
+    struct SKey { const void *ws, *out, *out_len, *stream; int N, slots, L, max_new, chunk, n_img; bool operator==(const SKey& o) const { return ws == o.ws && out == o.out && out_len == o.out_len && stream == o.stream && N == o.N && slots == o.slots && L == o.L && max_new == o.max_new && chunk == o.chunk && n_img == o.n_img; } } skey{};   // chunk, n_img: the decode rows, K/V pages and slot table are carved behind the prefill region they size
     bool svalid = false;
 #ifndef MG_EMU
     hipGraphExec_t sexec = nullptr;
@@ -792,7 +792,7 @@ int mg_ocr_generate_stream(mg_ocr_model* m, void* stream, void* ws, size_t ws_by
     bool graphed = false;
 #ifndef MG_EMU
     if (m->use_graph == 1) {
-        const mg_ocr_model::SKey key{ws, out_ids, (const void*)st, N, slots, L, max_new_tokens};
+        const mg_ocr_model::SKey key{ws, out_ids, out_len, (const void*)st, N, slots, L, max_new_tokens, chunk, n_img};
         if (!(m->svalid && m->skey == key)) {
             std::lock_guard<std::mutex> capture_lock(mg_capture_mutex());
             m->sreset();

@@ -113,8 +113,8 @@ class Configs4Pipeline:
         self._ocr_ctx = []
         # pages of one batch have different token counts; with per-image padding semantics every page is computed as the reference
         # computes it (alone, unpadded: its batch size is 1), whatever the batch was padded to (mg_set_padding_semantics)
-        if per_image_padding:
-            self.main.set_padding_semantics(True)
+        # (the engine's previous setting is put back by close(): other users of `main` keep stock batched semantics)
+        self._prev_padding = self.main.set_padding_semantics(True) if per_image_padding else None
         if ocr.shape.image_size != main.shape.image_size:
             raise ValueError("the two stages share the preprocessed page: equal input sizes expected (512 px in the reference)")
 
@@ -281,3 +281,6 @@ class Configs4Pipeline:
         if self._fl is not None:
             self._fl.close()
             self._fl = None
+        if self._prev_padding is not None:
+            self.main.set_padding_semantics(self._prev_padding)
+            self._prev_padding = None

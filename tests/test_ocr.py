@@ -464,7 +464,7 @@ def test_ocr_queue_form_equals_batch_form(be_name, slots, chunk):
     base = np.asarray(eng.mem.numpy(base)).copy()                 # [3, cols]
     order = np.array([2, 0, 1, 1, 2, 0, 0, 2])
     new, lens, steps = eng.generate_stream(ids[order], pix[order], n, slots=slots, chunk=chunk)
-    new, lens = np.asarray(eng.mem.numpy(new)), np.asarray(eng.mem.numpy(lens))
+    new, lens = np.asarray(eng.mem.numpy(new)).copy(), np.asarray(eng.mem.numpy(lens)).copy()
     total = 0
     for k, b in enumerate(order):
         row = base[b]
@@ -474,6 +474,12 @@ def test_ocr_queue_form_equals_batch_form(be_name, slots, chunk):
         assert np.array_equal(new[k, :want], row[:want]) and np.all(new[k, want:] == s.pad_token_id)
         total += want - 1
     assert steps <= -(-total // slots) + len(order) + 16
+    # the same engine (same workspace, same captured step graph key but for `chunk`) with another chunk: the decode rows, K/V pages
+    # and slot table are carved behind the prefill region `chunk` sizes, so the captured graph must not be replayed
+    new_b, lens_b, _ = eng.generate_stream(ids[order], pix[order], n, slots=slots, chunk=chunk + 3)
+    assert np.array_equal(np.asarray(eng.mem.numpy(new_b)), new) and np.array_equal(np.asarray(eng.mem.numpy(lens_b)), lens)
+    new_c, lens_c, _ = eng.generate_stream(ids[order], pix[order], n, slots=slots, chunk=chunk)
+    assert np.array_equal(np.asarray(eng.mem.numpy(new_c)), new) and np.array_equal(np.asarray(eng.mem.numpy(lens_c)), lens)
     # a page whose FIRST token is a stop token never takes a slot: make the first token of page 0 a second stop id
     import dataclasses
     s2 = dataclasses.replace(s, eos_extra=(int(base[0, 0]),))

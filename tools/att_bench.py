@@ -8,7 +8,12 @@ os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 from markushgrapher_amd import synth
 from markushgrapher_amd.engine import Engine
 shape = synth.SHAPES["large"]
-eng = Engine(shape, max_decode_len=64)
+_tools = os.environ.get("MG_ATT_EXP") or os.environ.get("MG_GEMM_EXP") or os.environ.get("MG_TOOLS_LIB")
+if _tools:                                   # what-if variants (WRONG results, timing only) live in the tools build
+    from tools import _toolslib
+    eng = Engine(shape, lib=_toolslib.load(), max_decode_len=64)
+else:
+    eng = Engine(shape, max_decode_len=64)
 eng.load_state_dict(synth.recipe_state_dict(shape, **synth.BENCH_RECIPE))
 inp = synth.synth_batch(shape, 32, seed=synth.BENCH_SEED, return_pages=True)
 pix = eng.preprocess(inp["pages_u8"])
@@ -20,4 +25,5 @@ e0.record()
 for _ in range(5):
     eng.encode(inp["input_ids"], inp["bbox"], inp["attention_mask"], pix, want_out=False)
 e1.record(); torch.cuda.synchronize()
-print("MG_ATT_DEPTH", os.environ.get("MG_ATT_DEPTH", "default"), "encoder ms per batch: %.2f" % (e0.elapsed_time(e1) / 5))
+print("MG_ATT_EXP", os.environ.get("MG_ATT_EXP", "0"), "MG_GEMM_EXP", os.environ.get("MG_GEMM_EXP", "0"),
+      "encoder ms per batch: %.2f" % (e0.elapsed_time(e1) / 5))
