@@ -5,264 +5,9 @@
 //   * every ds_read_b128 of a fragment is base + 16*lane: conflict-free without swizzling,
 //   * swapping the two MFMA operands transposes the accumulator for free, which lets each epilogue store
 //     16-byte chunks in the layout its consumer wants (packed rows, packed transposed, or row-major fp32).
-#include "mg_kernels.h"
-#include <type_traits>
+#include "k_gemm_epi.h"
 
 namespace mg {
-
-// Deferred RMSNorm scales r(m) = rsqrt(sum_i part[m][i] * inv_d + eps) for rows [0, nrows) into LDS, computed by the
-// whole workgroup: 8 threads per row, each summing nparts/8 partials with independent 16-byte loads (one L2 round
-// trip, issued before the weight stream), combined by a fixed DPP tree.  Callers read `out` after their next barrier.
-MG_DEV void block_row_scales(const RowScale& rs, int M, int nrows, float* out, int tid, int nthreads) {
-    for (int base = 0; base < nrows; base += nthreads >> 3) {
-        const int row = base + (tid >> 3), j = tid & 7;
-        float s = 0.f;
-        if (rs.part && row < nrows) {
-            const int mr = row < M ? row : M - 1;
-            const int per = rs.nparts >> 3;                               // floats per thread
-            const float* p = rs.part + (size_t)mr * rs.nparts + j * per;
-            if ((per & 3) == 0) {
-                for (int i = 0; i < per; i += 4) { const float4 a = *(const float4*)(p + i); s += (a.x + a.y) + (a.z + a.w); }
-            } else {
-                for (int i = 0; i < per; ++i) s += p[i];
-            }
-        }
-        s = sum8(s);
-        if (j == 0 && row < nrows) out[row] = rs.part ? rsqrtf(s * rs.inv_d + rs.eps) : 1.0f;
-    }
-}
-
-// Split form of block_row_scales for the common decode shape (all rows in one pass, <= 16 partials per thread): the
-// partial sums are FETCHED first of all (rs_issue), the weight and activation streams are issued behind them, and the
-// reduction (rs_finish) then waits only for these earliest loads - a wait on a later load would drain the whole in-order
-// vector-memory queue, i.e. serialise the row scales behind the HBM round trip of the weights.
-struct RsRegs { float4 v[4]; bool fast; };
-MG_DEV void rs_issue(const RowScale& rs, int M, int nrows, int tid, int nthreads, RsRegs& r) {
-    const int per = rs.nparts >> 3;
-    r.fast = rs.part && nrows <= (nthreads >> 3) && per <= 16 && (per & 3) == 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) r.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r.fast) {
-        const int row = tid >> 3, j = tid & 7;
-        if (row < nrows) {
-            const int mr = row < M ? row : M - 1;
-            const float* p = rs.part + (size_t)mr * rs.nparts + j * per;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (4 * i < per) r.v[i] = *(const float4*)(p + 4 * i);
-        }
-    }
-}
-MG_DEV void rs_finish(const RowScale& rs, int M, int nrows, float* out, int tid, int nthreads, const RsRegs& r) {
-    if (!r.fast) { block_row_scales(rs, M, nrows, out, tid, nthreads); return; }
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) s += (r.v[i].x + r.v[i].y) + (r.v[i].z + r.v[i].w);
-    s = sum8(s);
-    const int row = tid >> 3;
-    if ((tid & 7) == 0 && row < nrows) out[row] = rsqrtf(s * rs.inv_d + rs.eps);
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// epilogue helpers
-// ---------------------------------------------------------------------------------------------------------
-// One 16-byte chunk of a per-head projection.  `tok0..` semantics depend on the format:
-//  token-major formats (PK_ROWS / NATURAL / STEP_*): chunk = token m, head dims [dim0, dim0+8)
-//  HF_PK_T: chunk = head dim `dim0`, tokens [m, m+8)
-MG_DEV void heads_store(const HeadsOut& ho, int ri, int h, int m, int dim0, const uint4& c) {
-    const int fmt = ho.fmt[ri];
-    uint16_t* base = ho.ptr[ri];
-    if (fmt == HF_PK_ROWS) {
-        const int b = m / ho.S_in, s = m - b * ho.S_in + ho.s_off;
-        size_t off = (((size_t)b * ho.H + h) * (size_t)(ho.S_cap >> 5) + (size_t)(s >> 5)) * (4 * TILE_ELEMS) +
-                     (size_t)(dim0 >> 4) * TILE_ELEMS + (size_t)(((dim0 >> 3) & 1) * 256 + (s & 31) * 8);
-        st16(base + off, c);
-    } else if (fmt == HF_PK_T) {
-        const int b = m / ho.S_in, s = m - b * ho.S_in + ho.s_off;
-        size_t off = ((((size_t)b * ho.H + h) * 2 + (size_t)(dim0 >> 5)) * (size_t)(ho.S_cap >> 4) + (size_t)(s >> 4)) *
-                         TILE_ELEMS +
-                     (size_t)(((s >> 3) & 1) * 256 + (dim0 & 31) * 8);
-        st16(base + off, c);
-    } else if (fmt == HF_NATURAL) {
-        const int b = m / ho.S_in, s = m - b * ho.S_in;
-        const int row = ho.row_map ? ho.row_map[m] : s;
-        if (row >= 0) st16(base + (((size_t)b * ho.H + h) * (size_t)ho.S_cap + (size_t)row) * 64 + dim0, c);
-    } else if (fmt == HF_STEP_Q) {
-        st16(base + ((size_t)m * ho.H + h) * 64 + dim0, c);
-    } else if (fmt == HF_STEP_KV) {
-        const int row = ho.row_map ? ho.row_map[m] : m;
-        const int pos = ho.pos_rows ? ho.pos_rows[m] : (ho.pos_dev ? *ho.pos_dev : ho.pos);
-        st16(base + (((size_t)row * ho.H + h) * (size_t)ho.S_cap + (size_t)pos) * 64 + dim0, c);
-    }
-}
-
-// Epilogue of one 32x32 accumulator tile.
-//  TOR (operands swapped, D = W·X^T): lane owns token m = m0 + lane%32, rows of D are output features n0 + i.
-//  !TOR (D = X·W^T):                  lane owns feature n = n0 + lane%32, rows of D are tokens m0 + i.
-// deferred RMSNorm scale of token row m from the partial sums of squares left by EPI_RESID_NORM (1 when rs.part is null)
-MG_DEV float row_scale_of(const RowScale& rs, int m, int M) {
-    if (!rs.part) return 1.0f;
-    const int mr = m < M ? m : M - 1;
-    const float* p = rs.part + (size_t)mr * rs.nparts;
-    float s = 0.f;
-    for (int i = 0; i < rs.nparts; i += 4) { const float4 v = *(const float4*)(p + i); s += (v.x + v.y) + (v.z + v.w); }
-    return rsqrtf(s * rs.inv_d + rs.eps);
-}
-
-// the scales of NT consecutive 32-token row tiles for this lane's token (m0 + 32 i + lane%32): the partial-sum loads of a
-// group of 16 partials are unconditional and issued together for all NT tiles (one L2 round trip at the start of the epilogue
-// for d_model <= 1024; one more per further 1024 columns); nparts is a multiple of 4 (groups past nparts re-read the last one
-// with weight 0)
-template <int NT>
-MG_DEV void row_scales_tiles(const RowScale& rs, const int (&mrow)[NT], int M, int lane, float (&out)[NT]) {
-#pragma unroll
-    for (int i = 0; i < NT; ++i) out[i] = 1.0f;
-    if (!rs.part) return;
-    float s[NT];
-#pragma unroll
-    for (int i = 0; i < NT; ++i) s[i] = 0.f;
-    for (int g0 = 0; g0 < rs.nparts; g0 += 16) {
-        float4 v[NT][4];
-#pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            int m = mrow[i] + (lane & 31);
-            m = m < M ? m : M - 1;
-            const float* p = rs.part + (size_t)m * rs.nparts;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[i][k] = *(const float4*)(p + (g0 + 4 * k < rs.nparts ? g0 + 4 * k : rs.nparts - 4));
-        }
-#pragma unroll
-        for (int i = 0; i < NT; ++i) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) s[i] += (g0 + 4 * k < rs.nparts) ? (v[i][k].x + v[i][k].y) + (v[i][k].z + v[i][k].w) : 0.f;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < NT; ++i) out[i] = rsqrtf(s[i] * rs.inv_d + rs.eps);
-}
-
-// APPLY_RS (tiled large-M kernels only; the decode-step kernels scale their sums themselves): multiply the rows of the
-// packed / per-head outputs by the deferred RMSNorm scale a.rs of their token.
-template <int EPI, bool TOR, bool APPLY_RS = false>
-MG_DEV void tile_epilogue(const GemmArgs& a, const f32x16& acc_in, int m0, int n0, int lane, int qmask = 3, float rsl = 1.0f) {
-    const int half = lane >> 5, l32 = lane & 31;
-    f32x16 acc = acc_in;
-    if constexpr (APPLY_RS && (EPI == EPI_PK || EPI == EPI_PK_RELU || EPI == EPI_PK_GELU || EPI == EPI_HEADS)) {
-        if (a.rs.part) {                                              // rsl: the scale of token m0 + lane%32 (both half-waves)
-            if (TOR) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] *= rsl;
-            } else {                                                   // rows of D are tokens m0 + acc_row(r, half)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] *= __shfl(rsl, acc_row(r, half));
-            }
-        }
-    }
-    if constexpr (EPI == EPI_F32_STORE || EPI == EPI_F32_RESID) {
-        static_assert(!TOR, "fp32 epilogues use D = X·W^T");
-        const int n = n0 + l32;
-        if (n >= a.N) return;
-        const float bv = (EPI == EPI_F32_STORE && a.bias) ? a.bias[n] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + acc_row(r, half);
-            if (m < a.M) {
-                float* p = a.out_f32 + (size_t)m * a.ldo + n;
-                if (EPI == EPI_F32_RESID) *p = *p + acc[r];
-                else *p = acc[r] + bv;
-            }
-        }
-    } else if constexpr (EPI == EPI_PK || EPI == EPI_PK_RELU || EPI == EPI_PK_GELU) {
-        f32x16 v = acc;
-        if (EPI == EPI_PK_RELU) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
-        }
-        if (EPI == EPI_PK_GELU) {        // torch gelu(approximate="tanh"): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))) = x sigmoid(2 u)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float x = v[r], u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-                v[r] = x / (1.0f + fast_exp(-2.0f * u));
-            }
-        }
-        uint4 ch[2];
-        acc_to_chunks(v, half, ch);
-        const int m = m0 + l32;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int n = n0 + 16 * q + 8 * half;
-            if (m < a.M && n < a.N && ((qmask >> q) & 1)) st16(a.out_pk + pk_off(m, n, a.N), ch[q]);
-        }
-    } else {  // EPI_HEADS
-        const HeadsOut& ho = a.heads;
-        uint4 ch[2];
-        acc_to_chunks(acc, half, ch);
-        if (TOR) {
-            const int m = m0 + l32;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int n = n0 + 16 * q + 8 * half;
-                if (m < a.M && n < a.N && ((qmask >> q) & 1)) {
-                    const int ri = n / ho.inner, nn = n - ri * ho.inner;
-                    heads_store(ho, ri, nn >> 6, m, nn & 63, ch[q]);
-                }
-            }
-        } else {
-            const int n = n0 + l32;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int m = m0 + 16 * q + 8 * half;
-                if (m < a.M && n < a.N) {
-                    const int ri = n / ho.inner, nn = n - ri * ho.inner;
-                    heads_store(ho, ri, nn >> 6, m, nn & 63, ch[q]);
-                }
-            }
-        }
-    }
-}
-
-// EPI_RESID_NORM for one 32-token row tile and a wave's two 32-feature column tiles (D = W·X^T: a lane owns token
-// m0 + lane%32 and, per accumulator group g, the 4 consecutive features n0 + 8g + 4*half ..: one float4 of the tiled h).
-MG_DEV void resid_norm_epilogue(const GemmArgs& a, const f32x16& acc0, const f32x16& acc1, int m0, int n0, int lane) {
-    const int half = lane >> 5, l32 = lane & 31, m = m0 + l32;
-    const bool row_ok = m < a.M;
-    float ss = 0.f;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const f32x16& acc = j ? acc1 : acc0;
-        const int nj = n0 + 32 * j;
-        if (nj >= a.N) continue;                       // (N is a multiple of 32 here: whole tiles only)
-        f32x16 xg;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int n = nj + 8 * g + 4 * half;
-            float* p = a.out_f32 + ht_off(row_ok ? m : 0, n, a.N);
-            float4 hv = *(const float4*)p;
-            hv.x += acc[4 * g]; hv.y += acc[4 * g + 1]; hv.z += acc[4 * g + 2]; hv.w += acc[4 * g + 3];
-            if (row_ok) { *(float4*)p = hv; ss += (hv.x * hv.x + hv.y * hv.y) + (hv.z * hv.z + hv.w * hv.w); }
-            if (a.gain) {
-                const float4 gn = *(const float4*)(a.gain + n);
-                xg[4 * g] = hv.x * gn.x; xg[4 * g + 1] = hv.y * gn.y; xg[4 * g + 2] = hv.z * gn.z; xg[4 * g + 3] = hv.w * gn.w;
-            }
-        }
-        if (a.gain) {
-            uint4 ch[2];
-            acc_to_chunks(xg, half, ch);
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-                if (row_ok) st16(a.out_pk + pk_off(m, nj + 16 * q + 8 * half, a.N), ch[q]);
-        }
-    }
-    if (a.part) {
-        ss += __shfl_xor(ss, 32);
-        if (half == 0 && row_ok && n0 < a.N) a.part[(size_t)m * a.ldo + (n0 >> 6)] = ss;      // ldo = partial sums per row
-    }
-}
-
-MG_DEV bool heads_region_is_T(const HeadsOut& ho, int n) {
-    const int ri = n / ho.inner;
-    return ho.fmt[ri] == HF_PK_T;
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // large-M GEMM: 128x128x64 block tile, 4 waves (2x2), wave tile 64x64 = 2x2 MFMA 32x32x16 accumulators,
@@ -480,43 +225,6 @@ __global__ __launch_bounds__(512) void gemm_wide_kernel(GemmArgs a) {
         }
 }
 
-// epilogue of a wave's TI x 2 accumulator tiles (token rows mrow[i] .. mrow[i] + 31, feature columns n0w + 32 j) of the large-M kernels
-template <int EPI, int TI, int XP = 0>
-MG_DEV void xl_epilogue(const GemmArgs& a, f32x16 (&acc)[TI][2], const int (&mrow)[TI], int n0w, bool tor, int lane) {
-    if constexpr (EPI == EPI_RESID_NORM) {
-#pragma unroll
-        for (int i = 0; i < TI; ++i) resid_norm_epilogue(a, acc[i][0], acc[i][1], mrow[i], n0w, lane);
-        return;
-    }
-    float rsv[TI];
-    row_scales_tiles<TI>(a.rs, mrow, a.M, lane, rsv);
-    if constexpr (EPI == EPI_HEADS) {          // (the operand order is a property of the whole tile: one branch around the loops)
-        if (tor) {
-#pragma unroll
-            for (int i = 0; i < TI; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) tile_epilogue<EPI_HEADS, true, true>(a, acc[i][j], mrow[i], n0w + 32 * j, lane, 3, rsv[i]);
-        } else {
-#pragma unroll
-            for (int i = 0; i < TI; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) tile_epilogue<EPI_HEADS, false, true>(a, acc[i][j], mrow[i], n0w + 32 * j, lane, 3, rsv[i]);
-        }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int m0 = mrow[i], n0 = n0w + 32 * j;
-            if constexpr ((XP & 4) != 0) { if ((i || j) && acc[i][j][0] != 123456.789f) continue; }
-            if constexpr (EPI == EPI_F32_STORE || EPI == EPI_F32_RESID) {
-                tile_epilogue<EPI, false>(a, acc[i][j], m0, n0, lane);
-            } else if constexpr (EPI != EPI_RESID_NORM && EPI != EPI_HEADS) {
-                tile_epilogue<EPI, true, true>(a, acc[i][j], m0, n0, lane, 3, rsv[i]);
-            }
-        }
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // large-M GEMM, 256x256x64 block tile, 8 waves as 2 (M) x 4 (N), 128x64 per wave (4x2 MFMA tiles, 128 accumulator
@@ -525,7 +233,6 @@ MG_DEV void xl_epilogue(const GemmArgs& a, f32x16 (&acc)[TI][2], const int (&mro
 // 128 B/clk LDS port against 1024 cycles of MFMA per SIMD).  Two LDS stages of 64 KiB; the copies of K-step ks+1 are
 // issued right after the barrier of step ks and have a whole compute phase (~2048 MFMA cycles) to land.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int GX_N = 256, GX_K = 64;
 
 // TI = row tiles (of 32) per wave: TI = 4 -> 256x256 block tile; TI = 5 -> 320x256 (0.7 LDS reads per MFMA, 160
 // accumulator registers, two 72 KiB stages), used where it makes the tile count a whole number of rounds over the 256 CUs
@@ -708,250 +415,6 @@ static void launch_xl(const GemmArgs& a, mgStream_t stream) {
     MG_LAUNCH((gemm_xl_kernel<EPI, TI>), dim3(nblk), dim3(512), sh, stream, a);
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// large-M GEMM, third form: PERSISTENT workgroups with a PING-PONG wave schedule (round 4).
-//
-// What the two-stage kernel above leaves on the table (measured, profiles/r02_gemm_whatif.txt, r04 notes in DESIGN.md): its 8 waves
-// run in lockstep - both waves of a SIMD read fragments at the same time and want the matrix pipe at the same time - and a
-// workgroup's HBM-heavy epilogue, its first-stage latency and the next workgroup's start are all paid with the matrix pipe idle.
-// Here:
-//   * same block tile (64*TI x 256, 8 waves as 2 x 4, 32*TI x 64 per wave) and the same operand format, so the same epilogues;
-//   * the two wave rows are two GROUPS (waves 0-3 / 4-7: one wave of each group per SIMD) that run the same phase program one
-//     barrier apart: a phase = [LOAD: ds_read the 16-wide k-tile's TI + 2 fragments, issue this wave's copies of a later k-tile,
-//     counted vmcnt] barrier [lgkmcnt(0); 2*TI MFMAs at raised priority] barrier.  While group A multiplies, group B loads, and
-//     vice versa: the matrix pipe of every SIMD always has one wave feeding it (cdna_hip_programming.md, "8-phase" schedule);
-//   * operands travel in a ring of 8 k-tile slots ((2 TI + 8) KiB each = the two 64-deep stages of the kernel above, cut in
-//     four): the slot of k-tile g is refilled with k-tile g + 8 as soon as both groups have read it, i.e. the copies of k-tile
-//     g + 6 are issued in phase g - 1.5 K-steps (about 3000 cycles) of lead instead of one, with the same LDS footprint;
-//   * the workgroup is persistent (one per CU, tiles dealt round-robin inside XCD-contiguous ranges) and the k-tile stream runs
-//     ACROSS tiles: the first six k-tiles of the next tile are in flight during the epilogue, and nothing is re-launched.
-// Hazards (barrier numbers: group A runs phase g between barriers 2g and 2g+2, group B between 2g+1 and 2g+3):
-//   RAW  a wave waits for ITS copies of k-tile g+1 before its first barrier of phase g (A: 2g+1, B: 2g+2); the reads of k-tile g+1
-//        start after barrier 2g+2 (A) / 2g+3 (B): every copy has landed and a barrier lies in between;
-//   WAR  the reads of k-tile h are complete before barrier 2h+2 (A) / 2h+3 (B); the slot is refilled with k-tile h+8 in phase h+2
-//        = after barrier 2h+4 (A) / 2h+5 (B).
-// Sums are accumulated in the same order as in gemm_xl_kernel (k ascending per accumulator): results are bit-identical.
-// ---------------------------------------------------------------------------------------------------------
-constexpr int GP_RING = 8, GP_AHEAD = 6, GP_MAXT = 16;          // ring slots, copy lead (k-tiles), tiles per workgroup at most
-
-template <int N>
-MG_DEV void wait_vmcnt_n() {
-#ifndef MG_EMU
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-#endif
-}
-MG_DEV void set_prio_hi() {
-#ifndef MG_EMU
-    __builtin_amdgcn_s_setprio(1);
-#endif
-}
-MG_DEV void set_prio_lo() {
-#ifndef MG_EMU
-    __builtin_amdgcn_s_setprio(0);
-#endif
-}
-
-template <int EPI, int TI>
-__global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs a) {
-    MG_DYN_SMEM(smem);
-    constexpr int XT = 2 * TI, FR = XT + 8;                     // fragments per k-tile slot: X row tiles, then 8 W row tiles
-    constexpr int KT_BYTES = FR * TILE_BYTES;
-    constexpr int NHI = FR - 16;                                // waves 0 .. NHI-1 copy three fragments per k-tile, the others two
-    constexpr int BM = 64 * TI;
-    static_assert(FR >= 16 && FR <= 24, "two or three copies per wave and k-tile");
-    const int tid = threadIdx.x, lane = tid & 63;
-#ifdef MG_EMU
-    const int w = tid >> 6;
-#else
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-#endif
-    const int wr = w >> 2, wc = w & 3;
-    const int nbn = (a.N + GX_N - 1) / GX_N;
-    const int n_list = a.row_tiles ? *a.n_row_tiles : 0;
-    const int M_run = a.row_tiles ? n_list * 32 : a.M;
-    const int nbm = (M_run + BM - 1) / BM;
-    const int nblk = nbm * nbn;
-    const int mt32 = (a.M + 31) >> 5, nt32 = (a.N + 31) >> 5;
-    const int KT = a.K >> 4;                                    // 16-wide k-tiles per output tile (a multiple of GP_RING)
-    // tiles of this workgroup: t_first, t_first + t_step, ... < t_end  (XCD-contiguous ranges: block b runs on XCD b % 8)
-    const int G = gridDim.x, b = blockIdx.x;
-    int t_first, t_step, t_end;
-    if ((G & 7) == 0) {
-        const int T8 = (nblk + 7) >> 3, xcd = b & 7;
-        t_first = xcd * T8 + (b >> 3); t_step = G >> 3;
-        t_end = (xcd + 1) * T8 < nblk ? (xcd + 1) * T8 : nblk;
-    } else {
-        t_first = b; t_step = G; t_end = nblk;
-    }
-    int n_my = t_first < t_end ? (t_end - t_first + t_step - 1) / t_step : 0;
-    if (n_my > GP_MAXT) n_my = GP_MAXT;                         // (the launcher keeps tiles / workgroup <= GP_MAXT)
-    if (n_my == 0) return;
-
-    // row tiles of my output tiles: rtab[i][r] = 32-row tile id (>= 0) or -1 - (a live tile to read instead) past the end
-    int* rtab = (int*)(smem + GP_RING * KT_BYTES);
-    for (int e = tid; e < n_my * XT; e += 512) {
-        const int i = e / XT, r = e - i * XT;
-        const int bm = (t_first + i * t_step) / nbn;
-        int rt = bm * XT + r, live;
-        if (a.row_tiles) { live = rt < n_list; rt = a.row_tiles[live ? rt : n_list - 1]; }
-        else { live = rt < mt32; rt = live ? rt : mt32 - 1; }
-        rtab[e] = live ? rt : -1 - rt;
-    }
-    __syncthreads();
-
-    const mg_lds_t sm0 = mg_lds_addr(smem);
-    // this wave's copies of a k-tile: fragments w, w + 8 and (w < NHI) 16 + w
-    auto frag_src = [&](int i, int k) -> const char* {
-        const int f = k < 2 ? w + 8 * k : 16 + w;
-        const int tile = t_first + i * t_step, bm = tile / nbn, bn = tile - bm * nbn;
-        (void)bm;
-        if (f < XT) {
-            const int v = rtab[i * XT + f], rt = v >= 0 ? v : -1 - v;
-            return (const char*)(a.X + pk_tile_off(rt, 0, a.K)) + lane * 16;
-        }
-        int rt = bn * 8 + (f - XT);
-        rt = rt < nt32 - 1 ? rt : nt32 - 1;
-        return (const char*)(a.W + pk_tile_off(rt, 0, a.K)) + lane * 16;
-    };
-    const char* pc[3];
-    const char* pn[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { pc[k] = frag_src(0, k < 2 || w < NHI ? k : 0); pn[k] = n_my > 1 ? frag_src(1, k < 2 || w < NHI ? k : 0) : pc[k]; }
-    const bool three = NHI > 0 && w < NHI;
-    auto issue = [&](const char* const (&ptr)[3], int kk, int slot) {
-        const mg_lds_t dst = sm0 + slot * KT_BYTES;
-        glds16_async_lds(ptr[0] + (size_t)kk * TILE_BYTES, dst + w * TILE_BYTES);
-        glds16_async_lds(ptr[1] + (size_t)kk * TILE_BYTES, dst + (w + 8) * TILE_BYTES);
-        if (NHI > 0 && three) glds16_async_lds(ptr[2] + (size_t)kk * TILE_BYTES, dst + (16 + w) * TILE_BYTES);
-    };
-    // own copies of everything but the `ahead` most recent k-tiles have landed
-    auto wait_groups5 = [&]() { if (three) wait_vmcnt_n<15>(); else wait_vmcnt_n<10>(); };
-
-    struct Frags { mg_raw16 x[TI], w[2]; };
-    const mg_lds_t lx0 = sm0 + lane * 16 + wr * (TI * TILE_BYTES);
-    const mg_lds_t lw0 = sm0 + lane * 16 + (XT + wc * 2) * TILE_BYTES;
-    auto rd = [&](int slot, Frags& f) {
-        const mg_lds_t lx = lx0 + slot * KT_BYTES, lw = lw0 + slot * KT_BYTES;
-        lds_rd16_async<0>(f.w[0], lw);
-        lds_rd16_async<TILE_BYTES>(f.w[1], lw);
-        lds_rd16_async<0 * TILE_BYTES>(f.x[0], lx);
-        lds_rd16_async<1 * TILE_BYTES>(f.x[1], lx);
-        lds_rd16_async<2 * TILE_BYTES>(f.x[2], lx);
-        lds_rd16_async<3 * TILE_BYTES>(f.x[3], lx);
-        if constexpr (TI > 4) lds_rd16_async<4 * TILE_BYTES>(f.x[TI - 1], lx);
-    };
-    auto landed = [&](Frags& f) {
-        MG_WAIT_LGKM_TIE(0, f.w[0]);
-        MG_TIE(f.w[1]);
-#pragma unroll
-        for (int i = 0; i < TI; ++i) MG_TIE(f.x[i]);
-    };
-
-    // prologue: k-tiles 0 .. AHEAD-1 of the first tile
-#pragma unroll
-    for (int j = 0; j < GP_AHEAD; ++j) issue(pc, j, j);
-    wait_groups5();                                            // k-tile 0
-    MG_BARRIER_RAW();
-
-    for (int i = 0; i < n_my; ++i) {
-        const bool has_next = i + 1 < n_my;
-        const int tile = t_first + i * t_step, bm = tile / nbn, bn = tile - bm * nbn;
-        (void)bm;
-        const int n0w = bn * GX_N + wc * 64;
-        bool tor;
-        if (EPI == EPI_F32_STORE || EPI == EPI_F32_RESID) tor = false;
-        else if (EPI == EPI_HEADS) tor = !heads_region_is_T(a.heads, n0w < a.N ? n0w : 0);
-        else tor = true;
-        f32x16 acc[TI][2];
-#pragma unroll
-        for (int ii = 0; ii < TI; ++ii)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[ii][j] = acc_zero();
-        if (wr == 1) MG_BARRIER_RAW();                         // group B runs one barrier behind group A
-        for (int kb = 0; kb < KT; kb += GP_RING) {
-#pragma unroll
-            for (int p = 0; p < GP_RING; ++p) {
-                Frags f;
-                rd(p, f);
-                const int kk = kb + p + GP_AHEAD;
-                bool issued = true;
-                if (kk < KT) issue(pc, kk, (p + GP_AHEAD) & (GP_RING - 1));
-                else if (has_next) issue(pn, kk - KT, (p + GP_AHEAD) & (GP_RING - 1));
-                else issued = false;
-                if (issued) wait_groups5(); else wait_vmcnt_n<0>();      // own copies of the NEXT k-tile have landed
-                MG_BARRIER_RAW();
-                landed(f);
-                MG_SCHED_FENCE();
-                set_prio_hi();
-                {
-                    uint4 xw[2], xx[TI];
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) xw[j] = raw16_get(f.w[j]);
-#pragma unroll
-                    for (int ii = 0; ii < TI; ++ii) xx[ii] = raw16_get(f.x[ii]);
-                    if (tor) {
-#pragma unroll
-                        for (int ii = 0; ii < TI; ++ii)
-#pragma unroll
-                            for (int j = 0; j < 2; ++j) acc[ii][j] = mfma32(xw[j], xx[ii], acc[ii][j]);
-                    } else {
-#pragma unroll
-                        for (int ii = 0; ii < TI; ++ii)
-#pragma unroll
-                            for (int j = 0; j < 2; ++j) acc[ii][j] = mfma32(xx[ii], xw[j], acc[ii][j]);
-                    }
-                }
-                set_prio_lo();
-                MG_SCHED_FENCE();
-                MG_BARRIER_RAW();
-            }
-        }
-        if (wr == 0) MG_BARRIER_RAW();                         // group A waits for group B's last phase: both groups store together
-        int mrow[TI];
-#pragma unroll
-        for (int ii = 0; ii < TI; ++ii) {
-            const int v = rtab[i * XT + wr * TI + ii];
-            mrow[ii] = v >= 0 ? v * 32 : a.M;                  // past the end: row index M, every store is guarded by m < M
-        }
-        // the copy sources of the tile after the next one (LDS table: no vector-memory wait in the way of the copies in flight)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { pc[k] = pn[k]; if (i + 2 < n_my) pn[k] = frag_src(i + 2, k < 2 || w < NHI ? k : 0); }
-        xl_epilogue<EPI, TI>(a, acc, mrow, n0w, tor, lane);
-        wait_vmcnt_n<0>();            // stores and loads retire out of order with respect to each other: the counted waits of the next tile start from an empty queue
-    }
-}
-template <int EPI, int TI>
-static bool launch_pp(const GemmArgs& a, mgStream_t stream) {
-    constexpr int BM = 64 * TI;
-    const int nblk = ((a.M + BM - 1) / BM) * ((a.N + GX_N - 1) / GX_N);
-    static int ncu = 0;
-#ifndef MG_EMU
-    if (!ncu) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1) ncu = 256; }
-#else
-    ncu = 8;
-#endif
-    int G = nblk < ncu ? nblk : ncu;
-    if (G >= 8) G &= ~7;
-    if ((a.K & 127) != 0 || nblk > GP_MAXT * G) return false;                   // (K/16 must be a multiple of the ring)
-    const size_t sh = (size_t)GP_RING * (2 * TI + 8) * TILE_BYTES + (size_t)GP_MAXT * 2 * TI * sizeof(int);
-    static bool once = false;
-    if (!once) { MG_SET_MAX_SMEM((&gemm_pp_kernel<EPI, TI>), sh); once = true; }
-    MG_LAUNCH((gemm_pp_kernel<EPI, TI>), dim3(G), dim3(512), sh, stream, a);
-    return true;
-}
-template <int TI>
-static bool launch_pp_epi(const GemmArgs& a, int epi, mgStream_t stream) {
-    switch (epi) {
-        case EPI_F32_STORE: return launch_pp<EPI_F32_STORE, TI>(a, stream);
-        case EPI_F32_RESID: return launch_pp<EPI_F32_RESID, TI>(a, stream);
-        case EPI_PK_RELU: return launch_pp<EPI_PK_RELU, TI>(a, stream);
-        case EPI_PK_GELU: return launch_pp<EPI_PK_GELU, TI>(a, stream);
-        case EPI_PK: return launch_pp<EPI_PK, TI>(a, stream);
-        case EPI_RESID_NORM: return launch_pp<EPI_RESID_NORM, TI>(a, stream);
-        default: return launch_pp<EPI_HEADS, TI>(a, stream);
-    }
-}
-
 template <int EPI>
 static void launch_wide(const GemmArgs& a, mgStream_t stream) {
     const int nblk = ((a.M + GW_M - 1) / GW_M) * ((a.N + GW_N - 1) / GW_N);
@@ -962,7 +425,8 @@ static void launch_wide(const GemmArgs& a, mgStream_t stream) {
 }
 
 // 0: 128x128 two-stage kernel only; 1: + 256x128 three-stage kernel for M >= 256; 2: + 256x256 kernel wherever it fits;
-// 4: + 320x256; 3 (default): by shape (currently = 4)
+// 4: + 320x256; 5 / 6: persistent ping-pong kernel with 256- / 320-row tiles (k_gemm_pp.hip);
+// 3 (default): by shape = 6 where the ping-pong kernel applies, else 4
 static int g_gemm_variant = 3;
 void gemm_set_variant(int v) { g_gemm_variant = v; }
 
@@ -971,8 +435,10 @@ bool gemm_has_gelu_epilogue(int M, int N) { return g_gemm_variant >= 2 && M >= 3
 void gemm(const GemmArgs& a, int epi, mgStream_t stream) {
     static bool env_read = false;
     if (!env_read) { env_read = true; if (const char* e = getenv("MG_GEMM_VARIANT")) g_gemm_variant = atoi(e); }   // A/B runs
-    if ((g_gemm_variant == 5 || g_gemm_variant == 6) && a.M >= 320 && a.N >= GX_N) {        // ping-pong persistent kernel, TI = 4 / 5
-        if (g_gemm_variant == 5 ? launch_pp_epi<4>(a, epi, stream) : launch_pp_epi<5>(a, epi, stream)) return;
+    // default (3): the persistent ping-pong kernel with 320-row tiles where its shape rules hold (K % 128 == 0), measured against the
+    // two-stage kernel at M = 40960 (us): QKV 292 -> 245, O 166 -> 156, wi 356 -> 301, wo 434 -> 396, cross-KV 154 -> 146 (profiles/r04_b_*)
+    if ((g_gemm_variant == 3 || g_gemm_variant == 5 || g_gemm_variant == 6) && a.M >= 320 && a.N >= GX_N) {        // ping-pong persistent kernel, TI = 4 (variant 5) / 5
+        if (gemm_pp(a, epi, g_gemm_variant == 5 ? 4 : 5, stream)) return;
     }
     if (g_gemm_variant >= 2 && a.M >= 320 && a.N >= GX_N) {
         // measured at M = 40960 (PFLOP/s, 256x128 / 256x256 / 320x256): QKV 0.72 / 0.92 / 1.01, O 0.47 / 0.45 / 0.53,

@@ -1,0 +1,304 @@
+// Epilogues of the bf16 MFMA GEMM kernels (k_gemm.hip, k_gemm_pp.hip): row scales of the deferred RMSNorm, per-head stores, the
+// tiled fp32 residual update, packed outputs.  Device code only; included by the GEMM translation units.
+#pragma once
+#include "mg_kernels.h"
+#include <type_traits>
+
+namespace mg {
+
+// Deferred RMSNorm scales r(m) = rsqrt(sum_i part[m][i] * inv_d + eps) for rows [0, nrows) into LDS, computed by the
+// whole workgroup: 8 threads per row, each summing nparts/8 partials with independent 16-byte loads (one L2 round
+// trip, issued before the weight stream), combined by a fixed DPP tree.  Callers read `out` after their next barrier.
+MG_DEV void block_row_scales(const RowScale& rs, int M, int nrows, float* out, int tid, int nthreads) {
+    for (int base = 0; base < nrows; base += nthreads >> 3) {
+        const int row = base + (tid >> 3), j = tid & 7;
+        float s = 0.f;
+        if (rs.part && row < nrows) {
+            const int mr = row < M ? row : M - 1;
+            const int per = rs.nparts >> 3;                               // floats per thread
+            const float* p = rs.part + (size_t)mr * rs.nparts + j * per;
+            if ((per & 3) == 0) {
+                for (int i = 0; i < per; i += 4) { const float4 a = *(const float4*)(p + i); s += (a.x + a.y) + (a.z + a.w); }
+            } else {
+                for (int i = 0; i < per; ++i) s += p[i];
+            }
+        }
+        s = sum8(s);
+        if (j == 0 && row < nrows) out[row] = rs.part ? rsqrtf(s * rs.inv_d + rs.eps) : 1.0f;
+    }
+}
+
+// Split form of block_row_scales for the common decode shape (all rows in one pass, <= 16 partials per thread): the
+// partial sums are FETCHED first of all (rs_issue), the weight and activation streams are issued behind them, and the
+// reduction (rs_finish) then waits only for these earliest loads - a wait on a later load would drain the whole in-order
+// vector-memory queue, i.e. serialise the row scales behind the HBM round trip of the weights.
+struct RsRegs { float4 v[4]; bool fast; };
+MG_DEV void rs_issue(const RowScale& rs, int M, int nrows, int tid, int nthreads, RsRegs& r) {
+    const int per = rs.nparts >> 3;
+    r.fast = rs.part && nrows <= (nthreads >> 3) && per <= 16 && (per & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r.fast) {
+        const int row = tid >> 3, j = tid & 7;
+        if (row < nrows) {
+            const int mr = row < M ? row : M - 1;
+            const float* p = rs.part + (size_t)mr * rs.nparts + j * per;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (4 * i < per) r.v[i] = *(const float4*)(p + 4 * i);
+        }
+    }
+}
+MG_DEV void rs_finish(const RowScale& rs, int M, int nrows, float* out, int tid, int nthreads, const RsRegs& r) {
+    if (!r.fast) { block_row_scales(rs, M, nrows, out, tid, nthreads); return; }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += (r.v[i].x + r.v[i].y) + (r.v[i].z + r.v[i].w);
+    s = sum8(s);
+    const int row = tid >> 3;
+    if ((tid & 7) == 0 && row < nrows) out[row] = rsqrtf(s * rs.inv_d + rs.eps);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// epilogue helpers
+// ---------------------------------------------------------------------------------------------------------
+// One 16-byte chunk of a per-head projection.  `tok0..` semantics depend on the format:
+//  token-major formats (PK_ROWS / NATURAL / STEP_*): chunk = token m, head dims [dim0, dim0+8)
+//  HF_PK_T: chunk = head dim `dim0`, tokens [m, m+8)
+MG_DEV void heads_store(const HeadsOut& ho, int ri, int h, int m, int dim0, const uint4& c) {
+    const int fmt = ho.fmt[ri];
+    uint16_t* base = ho.ptr[ri];
+    if (fmt == HF_PK_ROWS) {
+        const int b = m / ho.S_in, s = m - b * ho.S_in + ho.s_off;
+        size_t off = (((size_t)b * ho.H + h) * (size_t)(ho.S_cap >> 5) + (size_t)(s >> 5)) * (4 * TILE_ELEMS) +
+                     (size_t)(dim0 >> 4) * TILE_ELEMS + (size_t)(((dim0 >> 3) & 1) * 256 + (s & 31) * 8);
+        st16(base + off, c);
+    } else if (fmt == HF_PK_T) {
+        const int b = m / ho.S_in, s = m - b * ho.S_in + ho.s_off;
+        size_t off = ((((size_t)b * ho.H + h) * 2 + (size_t)(dim0 >> 5)) * (size_t)(ho.S_cap >> 4) + (size_t)(s >> 4)) *
+                         TILE_ELEMS +
+                     (size_t)(((s >> 3) & 1) * 256 + (dim0 & 31) * 8);
+        st16(base + off, c);
+    } else if (fmt == HF_NATURAL) {
+        const int b = m / ho.S_in, s = m - b * ho.S_in;
+        const int row = ho.row_map ? ho.row_map[m] : s;
+        if (row >= 0) st16(base + (((size_t)b * ho.H + h) * (size_t)ho.S_cap + (size_t)row) * 64 + dim0, c);
+    } else if (fmt == HF_STEP_Q) {
+        st16(base + ((size_t)m * ho.H + h) * 64 + dim0, c);
+    } else if (fmt == HF_STEP_KV) {
+        const int row = ho.row_map ? ho.row_map[m] : m;
+        const int pos = ho.pos_rows ? ho.pos_rows[m] : (ho.pos_dev ? *ho.pos_dev : ho.pos);
+        st16(base + (((size_t)row * ho.H + h) * (size_t)ho.S_cap + (size_t)pos) * 64 + dim0, c);
+    }
+}
+
+// Epilogue of one 32x32 accumulator tile.
+//  TOR (operands swapped, D = W·X^T): lane owns token m = m0 + lane%32, rows of D are output features n0 + i.
+//  !TOR (D = X·W^T):                  lane owns feature n = n0 + lane%32, rows of D are tokens m0 + i.
+// deferred RMSNorm scale of token row m from the partial sums of squares left by EPI_RESID_NORM (1 when rs.part is null)
+MG_DEV float row_scale_of(const RowScale& rs, int m, int M) {
+    if (!rs.part) return 1.0f;
+    const int mr = m < M ? m : M - 1;
+    const float* p = rs.part + (size_t)mr * rs.nparts;
+    float s = 0.f;
+    for (int i = 0; i < rs.nparts; i += 4) { const float4 v = *(const float4*)(p + i); s += (v.x + v.y) + (v.z + v.w); }
+    return rsqrtf(s * rs.inv_d + rs.eps);
+}
+
+// the scales of NT consecutive 32-token row tiles for this lane's token (m0 + 32 i + lane%32): the partial-sum loads of a
+// group of 16 partials are unconditional and issued together for all NT tiles (one L2 round trip at the start of the epilogue
+// for d_model <= 1024; one more per further 1024 columns); nparts is a multiple of 4 (groups past nparts re-read the last one
+// with weight 0)
+template <int NT>
+MG_DEV void row_scales_tiles(const RowScale& rs, const int (&mrow)[NT], int M, int lane, float (&out)[NT]) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) out[i] = 1.0f;
+    if (!rs.part) return;
+    float s[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) s[i] = 0.f;
+    for (int g0 = 0; g0 < rs.nparts; g0 += 16) {
+        float4 v[NT][4];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            int m = mrow[i] + (lane & 31);
+            m = m < M ? m : M - 1;
+            const float* p = rs.part + (size_t)m * rs.nparts;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[i][k] = *(const float4*)(p + (g0 + 4 * k < rs.nparts ? g0 + 4 * k : rs.nparts - 4));
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s[i] += (g0 + 4 * k < rs.nparts) ? (v[i][k].x + v[i][k].y) + (v[i][k].z + v[i][k].w) : 0.f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) out[i] = rsqrtf(s[i] * rs.inv_d + rs.eps);
+}
+
+// APPLY_RS (tiled large-M kernels only; the decode-step kernels scale their sums themselves): multiply the rows of the
+// packed / per-head outputs by the deferred RMSNorm scale a.rs of their token.
+template <int EPI, bool TOR, bool APPLY_RS = false>
+MG_DEV void tile_epilogue(const GemmArgs& a, const f32x16& acc_in, int m0, int n0, int lane, int qmask = 3, float rsl = 1.0f) {
+    const int half = lane >> 5, l32 = lane & 31;
+    f32x16 acc = acc_in;
+    if constexpr (APPLY_RS && (EPI == EPI_PK || EPI == EPI_PK_RELU || EPI == EPI_PK_GELU || EPI == EPI_HEADS)) {
+        if (a.rs.part) {                                              // rsl: the scale of token m0 + lane%32 (both half-waves)
+            if (TOR) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] *= rsl;
+            } else {                                                   // rows of D are tokens m0 + acc_row(r, half)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] *= __shfl(rsl, acc_row(r, half));
+            }
+        }
+    }
+    if constexpr (EPI == EPI_F32_STORE || EPI == EPI_F32_RESID) {
+        static_assert(!TOR, "fp32 epilogues use D = X·W^T");
+        const int n = n0 + l32;
+        if (n >= a.N) return;
+        const float bv = (EPI == EPI_F32_STORE && a.bias) ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + acc_row(r, half);
+            if (m < a.M) {
+                float* p = a.out_f32 + (size_t)m * a.ldo + n;
+                if (EPI == EPI_F32_RESID) *p = *p + acc[r];
+                else *p = acc[r] + bv;
+            }
+        }
+    } else if constexpr (EPI == EPI_PK || EPI == EPI_PK_RELU || EPI == EPI_PK_GELU) {
+        f32x16 v = acc;
+        if (EPI == EPI_PK_RELU) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (EPI == EPI_PK_GELU) {        // torch gelu(approximate="tanh"): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))) = x sigmoid(2 u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float x = v[r], u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+                v[r] = x / (1.0f + fast_exp(-2.0f * u));
+            }
+        }
+        uint4 ch[2];
+        acc_to_chunks(v, half, ch);
+        const int m = m0 + l32;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int n = n0 + 16 * q + 8 * half;
+            if (m < a.M && n < a.N && ((qmask >> q) & 1)) st16(a.out_pk + pk_off(m, n, a.N), ch[q]);
+        }
+    } else {  // EPI_HEADS
+        const HeadsOut& ho = a.heads;
+        uint4 ch[2];
+        acc_to_chunks(acc, half, ch);
+        if (TOR) {
+            const int m = m0 + l32;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int n = n0 + 16 * q + 8 * half;
+                if (m < a.M && n < a.N && ((qmask >> q) & 1)) {
+                    const int ri = n / ho.inner, nn = n - ri * ho.inner;
+                    heads_store(ho, ri, nn >> 6, m, nn & 63, ch[q]);
+                }
+            }
+        } else {
+            const int n = n0 + l32;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int m = m0 + 16 * q + 8 * half;
+                if (m < a.M && n < a.N) {
+                    const int ri = n / ho.inner, nn = n - ri * ho.inner;
+                    heads_store(ho, ri, nn >> 6, m, nn & 63, ch[q]);
+                }
+            }
+        }
+    }
+}
+
+// EPI_RESID_NORM for one 32-token row tile and a wave's two 32-feature column tiles (D = W·X^T: a lane owns token
+// m0 + lane%32 and, per accumulator group g, the 4 consecutive features n0 + 8g + 4*half ..: one float4 of the tiled h).
+MG_DEV void resid_norm_epilogue(const GemmArgs& a, const f32x16& acc0, const f32x16& acc1, int m0, int n0, int lane) {
+    const int half = lane >> 5, l32 = lane & 31, m = m0 + l32;
+    const bool row_ok = m < a.M;
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const f32x16& acc = j ? acc1 : acc0;
+        const int nj = n0 + 32 * j;
+        if (nj >= a.N) continue;                       // (N is a multiple of 32 here: whole tiles only)
+        f32x16 xg;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = nj + 8 * g + 4 * half;
+            float* p = a.out_f32 + ht_off(row_ok ? m : 0, n, a.N);
+            float4 hv = *(const float4*)p;
+            hv.x += acc[4 * g]; hv.y += acc[4 * g + 1]; hv.z += acc[4 * g + 2]; hv.w += acc[4 * g + 3];
+            if (row_ok) { *(float4*)p = hv; ss += (hv.x * hv.x + hv.y * hv.y) + (hv.z * hv.z + hv.w * hv.w); }
+            if (a.gain) {
+                const float4 gn = *(const float4*)(a.gain + n);
+                xg[4 * g] = hv.x * gn.x; xg[4 * g + 1] = hv.y * gn.y; xg[4 * g + 2] = hv.z * gn.z; xg[4 * g + 3] = hv.w * gn.w;
+            }
+        }
+        if (a.gain) {
+            uint4 ch[2];
+            acc_to_chunks(xg, half, ch);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (row_ok) st16(a.out_pk + pk_off(m, nj + 16 * q + 8 * half, a.N), ch[q]);
+        }
+    }
+    if (a.part) {
+        ss += __shfl_xor(ss, 32);
+        if (half == 0 && row_ok && n0 < a.N) a.part[(size_t)m * a.ldo + (n0 >> 6)] = ss;      // ldo = partial sums per row
+    }
+}
+
+MG_DEV bool heads_region_is_T(const HeadsOut& ho, int n) {
+    const int ri = n / ho.inner;
+    return ho.fmt[ri] == HF_PK_T;
+}
+
+
+// epilogue of a wave's TI x 2 accumulator tiles (token rows mrow[i] .. mrow[i] + 31, feature columns n0w + 32 j) of the large-M kernels
+template <int EPI, int TI, int XP = 0>
+MG_DEV void xl_epilogue(const GemmArgs& a, f32x16 (&acc)[TI][2], const int (&mrow)[TI], int n0w, bool tor, int lane) {
+    if constexpr (EPI == EPI_RESID_NORM) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i) resid_norm_epilogue(a, acc[i][0], acc[i][1], mrow[i], n0w, lane);
+        return;
+    }
+    float rsv[TI];
+    row_scales_tiles<TI>(a.rs, mrow, a.M, lane, rsv);
+    if constexpr (EPI == EPI_HEADS) {          // (the operand order is a property of the whole tile: one branch around the loops)
+        if (tor) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) tile_epilogue<EPI_HEADS, true, true>(a, acc[i][j], mrow[i], n0w + 32 * j, lane, 3, rsv[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) tile_epilogue<EPI_HEADS, false, true>(a, acc[i][j], mrow[i], n0w + 32 * j, lane, 3, rsv[i]);
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m0 = mrow[i], n0 = n0w + 32 * j;
+            if constexpr ((XP & 4) != 0) { if ((i || j) && acc[i][j][0] != 123456.789f) continue; }
+            if constexpr (EPI == EPI_F32_STORE || EPI == EPI_F32_RESID) {
+                tile_epilogue<EPI, false>(a, acc[i][j], m0, n0, lane);
+            } else if constexpr (EPI != EPI_RESID_NORM && EPI != EPI_HEADS) {
+                tile_epilogue<EPI, true, true>(a, acc[i][j], m0, n0, lane, 3, rsv[i]);
+            }
+        }
+}
+
+constexpr int GX_N = 256, GX_K = 64;          // column tile / K-step of the large-M tile kernels
+
+}  // namespace mg

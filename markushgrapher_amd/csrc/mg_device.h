@@ -259,6 +259,19 @@ MG_DEV void glds16_async_lds(const void* gsrc_lane, mg_lds_t lds_wave_base) {
 #endif
 }
 
+// the same copy with a wave-uniform 64-bit source base (scalar registers) + a 32-bit per-lane byte offset: no per-lane 64-bit
+// pointers to keep (global_load_lds_dwordx4 vaddr32, saddr64)
+MG_DEV void glds16_async_sv(const char* src_uniform, unsigned lane_off, mg_lds_t lds_wave_base) {
+#ifdef MG_EMU
+    emu::glds16(src_uniform + lane_off, (void*)lds_wave_base);
+#else
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_wave_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane_off), "s"(src_uniform), "s"(dst) : "memory");
+#endif
+}
+
 // 16-byte global load into registers that the compiler does not track (no s_waitcnt inserted on its behalf, it does not
 // count against the vmcnt the compiler computes for its own loads): for hand-pipelined prefetch several stages ahead.
 // The destination must not be read, copied or moved before MG_WAIT_VMCNT_TIE(N, regs...) has covered the load.

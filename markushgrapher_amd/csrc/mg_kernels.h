@@ -81,6 +81,7 @@ struct GemmArgs {
 };
 void gemm(const GemmArgs& a, int epi, mgStream_t stream);
 bool gemm_has_gelu_epilogue(int M, int N);     // EPI_PK_GELU exists in the 320x256 / 256x256 tile kernels only
+bool gemm_pp(const GemmArgs& a, int epi, int ti, mgStream_t stream);   // k_gemm_pp.hip: persistent ping-pong tile kernel (ti = 4, 5); false = shape not supported
 void gemm_set_variant(int v);   // 0: 128x128 kernel only; 1: + 256x128 three-stage; 2: + 256x256; 4: + 320x256 wherever it fits; 3 (default): by shape
 
 // small-M (decode step) GEMM: M <= 32*MT rows of live sequences, weights streamed once.

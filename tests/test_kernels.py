@@ -10,6 +10,16 @@ from tests import pkutil as pk
 from tests.backends import get_backend
 
 BACKENDS = [pytest.param("emu"), pytest.param("hip", marks=pytest.mark.gpu)]
+
+
+@pytest.fixture(autouse=True)
+def _default_gemm_variant():
+    """Tests that select a GEMM tile-kernel variant leave the library on its default afterwards, whatever happened in between."""
+    yield
+    from tests import backends as _b
+    for be in _b._cache.values():
+        be.lib.mgk_gemm_set_variant(3)
+
 EPI_F32_STORE, EPI_F32_RESID, EPI_PK_RELU, EPI_PK = 0, 1, 2, 3
 HF_PK_ROWS, HF_PK_T, HF_NATURAL, HF_STEP_Q, HF_STEP_KV = 1, 2, 3, 4, 5
 
@@ -74,11 +84,14 @@ def test_gemm_packed_relu(be_name, mode, M, N, K):
 
 
 @pytest.mark.parametrize("be_name", BACKENDS)
-@pytest.mark.parametrize("variant", [2, 4])
-@pytest.mark.parametrize("M,N,K", [(320, 256, 64), (300, 520, 128), (512, 384, 192), (700, 256, 128)])
+@pytest.mark.parametrize("variant", [2, 4, 5, 6])
+@pytest.mark.parametrize("M,N,K", [(320, 256, 64), (300, 520, 128), (512, 384, 192), (700, 256, 128), (1100, 768, 256)])
 def test_gemm_256x256_tile_kernel(be_name, M, N, K, variant):
     """variants 2 / 4: the 256x256x64 and 320x256x64 two-stage kernels (ragged edges in M and N, several K-steps), all
-    epilogue families."""
+    epilogue families.  Variants 5 / 6: the persistent ping-pong kernel (k_gemm_pp.hip) with 256- / 320-row tiles for K % 128 == 0
+    (other K fall back to the two-stage kernel); (1100, 768, 256) gives every workgroup of the emulator's 8 several tiles."""
+    if be_name == "emu" and M > 1000 and variant in (2, 4):
+        pytest.skip("large case: persistent kernel only on the emulator")
     be = get_backend(be_name)
     be.lib.mgk_gemm_set_variant(variant)
     try:
@@ -698,12 +711,14 @@ def test_gemm_encoder_deferred_norm(be_name, M, d, K, N2):
 
 
 @pytest.mark.parametrize("be_name", BACKENDS)
+@pytest.mark.parametrize("variant", [3, 4, 5])
 @pytest.mark.parametrize("M,N,K", [(640, 256, 64), (1280, 512, 128)])
-def test_gemm_row_tile_list(be_name, M, N, K):
+def test_gemm_row_tile_list(be_name, M, N, K, variant):
     """The encoder's row-tile list (GemmArgs::row_tiles): only 32-row tiles with an attended position are computed.  Live tiles must
     equal the full GEMM bit for bit (same kernel, same K order), dead tiles must be left untouched - for the fp32 store, the packed
     relu output with deferred row scales, and the tiled residual + packed + partial-sum epilogue."""
     be = get_backend(be_name)
+    be.lib.mgk_gemm_set_variant(variant)          # (put back by the autouse fixture _default_gemm_variant)
     be.lib.mgk_gemm_row_tiles.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 2 + [C.c_int] * 3 + [C.c_void_p] * 4 + \
                                          [C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
     be.lib.mgk_gemm_norm.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 2 + [C.c_int] * 3 + [C.c_void_p] * 4 + \

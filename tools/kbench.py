@@ -60,6 +60,25 @@ def bench_gemm():
                   f"{us:7.2f} us  {wbytes / us / 1e3:7.1f} GB/s")
 
 
+def bench_ppexp():
+    """What-if variants of the ping-pong GEMM (MG_PP_EXP, tools build, wrong results): where the tile time goes."""
+    M = 40960
+    xp = os.environ.get("MG_PP_EXP", "0")
+    for name, N, K, epi in [("qkv", 3072, 1024, 3), ("o", 1024, 1024, 1), ("wo", 1024, 4096, 1)]:
+        X = torch.randint(-3000, 3000, (M * K,), dtype=torch.int16, device=dev)
+        W = torch.randint(-3000, 3000, (N * K,), dtype=torch.int16, device=dev)
+        out_pk = torch.empty((M * N,), dtype=torch.int16, device=dev)
+        out_f = torch.zeros((M, N), dtype=torch.float32, device=dev) if epi == 1 else None
+        for variant in (5, 6):
+            lib.mgk_gemm_set_variant(variant)
+
+            def f(i):
+                lib.mgk_gemm(stream(), 0, epi, P(X), P(W), M, N, K, P(out_f), N, None, P(out_pk))
+            us = timeit(f, iters=20, warm=3)
+            print(f"pp exp {xp:>2s} {name:4s} variant {variant}: {us:8.1f} us  {2.0 * M * N * K / us / 1e9:7.3f} PFLOP/s", flush=True)
+    lib.mgk_gemm_set_variant(3)
+
+
 def bench_encgemm():
     """Encoder-sized GEMMs (M = 32 images x 1280 positions): 256x128 three-stage kernel (variant 1) vs 256x256 (variant 2)."""
     M = 40960
@@ -68,13 +87,28 @@ def bench_encgemm():
         W = torch.randint(-3000, 3000, (N * K,), dtype=torch.int16, device=dev)
         out_pk = torch.empty((M * N,), dtype=torch.int16, device=dev)
         out_f = torch.zeros((M, N), dtype=torch.float32, device=dev) if epi == 1 else None
-        for variant in (2, 4):
+        ref = None
+        for variant in (4, 5, 6):
             lib.mgk_gemm_set_variant(variant)
 
             def f(i):
                 lib.mgk_gemm(stream(), 0, epi, P(X), P(W), M, N, K, P(out_f), N, None, P(out_pk))
             us = timeit(f, iters=20, warm=3)
-            print(f"enc gemm {name:4s} M={M} N={N:5d} K={K:4d} variant {variant}: {us:8.1f} us  {2.0 * M * N * K / us / 1e9:7.3f} PFLOP/s")
+            # same bits as the two-stage kernel (same K order per accumulator): one run from a zeroed output each, repeated 3x (race screen)
+            same = []
+            for rep in range(3 if variant != 4 else 1):
+                out_pk.zero_()
+                if out_f is not None:
+                    out_f.zero_()
+                f(0)
+                torch.cuda.synchronize()
+                got = (out_f.view(torch.int32) if epi == 1 else out_pk).clone()          # bit patterns (random operands overflow to inf / nan)
+                if variant == 4:
+                    ref = got
+                else:
+                    same.append(bool(torch.equal(got, ref)))
+            print(f"enc gemm {name:4s} M={M} N={N:5d} K={K:4d} variant {variant}: {us:8.1f} us  {2.0 * M * N * K / us / 1e9:7.3f} PFLOP/s"
+                  + ("" if variant == 4 else f"  bits equal to variant 4: {same}"), flush=True)
     lib.mgk_gemm_set_variant(3)
 
 
@@ -127,6 +161,8 @@ if __name__ == "__main__":
         bench_gemm()
     if "encgemm" in sys.argv:
         bench_encgemm()
+    if "ppexp" in sys.argv:
+        bench_ppexp()
     if "attn" in what:
         bench_attn()
     if "norm" in what:
