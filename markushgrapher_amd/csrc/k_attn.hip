@@ -543,6 +543,13 @@ __global__ __launch_bounds__(512) void attention_enc_kernel(AttnArgs a) {
     }
 }
 
+// Measured and rejected in round 4 (kernels in this file's history, numbers under profiles/r04_e_*): (1) the same arithmetic on a
+// PING-PONG schedule - a stage cut into an M phase (P.V of stage j-1, K.Q^T of stage j; fragments prefetched into registers, index
+// words straight from global memory into registers) and a V phase (the softmax arithmetic), the two wave groups one barrier apart:
+// bit-identical, encoder 37.1 against 36.5 ms; phase stamps show ~2000 cycles per stage in the V phase against ~900 in the M phase;
+// (2) 12 waves = 384 queries per workgroup (three waves per SIMD at 146 registers): bit-identical, 37.5 ms.  Neither more waves nor
+// complementary phases move it: the stage is a chain of dependent LDS / matrix / transcendental latencies, not a busy pipe.
+
 static size_t attn_smem(const AttnArgs& a) {
     const int Sk_pad = (a.Sk + AT_KEYS - 1) / AT_KEYS * AT_KEYS;
     const int t1n = (a.mode == ATT_CROSS) ? 0 : (a.mode == ATT_ENC ? 64 : a.tab1_len);
