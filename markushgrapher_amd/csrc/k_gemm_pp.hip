@@ -66,13 +66,27 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs a) {
     const int wr = w >> 2, wc = w & 3;
     const int nbn = (a.N + GX_N - 1) / GX_N;
     const int n_list = a.row_tiles ? *a.n_row_tiles : 0;
-    const int M_run = a.row_tiles ? n_list * 32 : a.M;
-    const int nbm = (M_run + BM - 1) / BM;
-    const int nblk = nbm * nbn;
     const int mt32 = (a.M + 31) >> 5, nt32 = (a.N + 31) >> 5;
+    const int nrt = a.row_tiles ? n_list : mt32;                // 32-row tiles to compute
     const int KT = a.K >> 4;                                    // 16-wide k-tiles per output tile (a multiple of GP_RING)
-    // tiles of this workgroup: t_first, t_first + t_step, ... < t_end  (XCD-contiguous ranges: block b runs on XCD b % 8)
     const int G = gridDim.x, b = blockIdx.x;
+    // Row blocks of BALANCED height: a persistent workgroup runs whole tiles, so the launch takes ceil(tiles / G) tile times whatever
+    // the remainder (QKV at the benchmark's lengths: 1332 tiles of 10 row tiles on 256 workgroups = 5.2 -> 6 rounds).  The row tiles
+    // are therefore cut into nbm blocks of floor / ceil(nrt / nbm) <= 2 TI row tiles with nbm the next count that makes nbm * nbn a
+    // multiple of G (if that costs at most 30 % more blocks): 1536 tiles of 8.7 row tiles = 6 rounds of 0.87 the height.  A wave whose
+    // share of a block is short of TI tiles skips the missing tiles' MFMAs and stores (their fragment slots are filled from a live tile).
+    const int need = (nrt + XT - 1) / XT;
+    int nbm = need;
+    {
+        int g = G, r = nbn;                                     // gcd(G, nbn)
+        while (r) { const int t = g % r; g = r; r = t; }
+        const int step = G / g;
+        const int bal = (need + step - 1) / step * step;
+        if (a.pp_balance && bal * 10 <= need * 13 && bal <= nrt) nbm = bal;
+    }
+    (void)BM;
+    const int nblk = nbm * nbn;
+    // tiles of this workgroup: t_first, t_first + t_step, ... < t_end  (XCD-contiguous ranges: block b runs on XCD b % 8)
     int t_first, t_step, t_end;
     if ((G & 7) == 0) {
         const int T8 = (nblk + 7) >> 3, xcd = b & 7;
@@ -85,15 +99,23 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs a) {
     if (n_my > GP_MAXT) n_my = GP_MAXT;                         // (the launcher keeps tiles / workgroup <= GP_MAXT)
     if (n_my == 0) return;
 
-    // row tiles of my output tiles: rtab[i][r] = 32-row tile id (>= 0) or -1 - (a live tile to read instead) past the end
+    // row tiles of my output tiles: rtab[i][wr * TI + ii] = 32-row tile id (>= 0) of wave row wr's ii-th tile, or -1 - (a live tile to
+    // read instead) where the block is short; rcnt[i][wr] = tiles of wave row wr.  Block bm = list entries [bm nrt / nbm, (bm+1) nrt / nbm),
+    // the first half (rounded up) for wave row 0
     int* rtab = (int*)(smem + GP_RING * KT_BYTES);
+    int* rcnt = rtab + GP_MAXT * XT;
     for (int e = tid; e < n_my * XT; e += 512) {
         const int i = e / XT, r = e - i * XT;
         const int bm = (t_first + i * t_step) / nbn;
-        int rt = bm * XT + r, live;
-        if (a.row_tiles) { live = rt < n_list; rt = a.row_tiles[live ? rt : n_list - 1]; }
-        else { live = rt < mt32; rt = live ? rt : mt32 - 1; }
+        const int e0 = (int)((long long)bm * nrt / nbm), e1 = (int)((long long)(bm + 1) * nrt / nbm);
+        const int h = e1 - e0, c0 = (h + 1) >> 1;
+        const int wrow = r / TI, ii = r - wrow * TI;
+        const int cnt = wrow == 0 ? c0 : h - c0;
+        const bool live = ii < cnt;
+        const int idx = e0 + (live ? (wrow == 0 ? ii : c0 + ii) : 0);
+        const int rt = a.row_tiles ? a.row_tiles[idx] : idx;
         rtab[e] = live ? rt : -1 - rt;
+        if (ii == 0) rcnt[i * 2 + wrow] = cnt;
     }
     __syncthreads();
 
@@ -173,6 +195,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs a) {
         for (int ii = 0; ii < TI; ++ii)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[ii][j] = acc_zero();
+#ifdef MG_EMU
+        const int cnt = rcnt[i * 2 + wr];
+#else
+        const int cnt = __builtin_amdgcn_readfirstlane(rcnt[i * 2 + wr]);      // live row tiles of this wave (TI, or fewer in a short block)
+#endif
         if (wr == 1) MG_BARRIER_RAW();                         // group B runs one barrier behind group A
         // the K loop exists once per operand order (tor is a property of the whole tile): one branch around the loop, not 64 inside it
         auto kloop = [&](auto tor_c) {
@@ -206,8 +233,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs a) {
                         for (int ii = 0; ii < TI; ++ii) xx[ii] = raw16_get(f.x[ii]);
 #pragma unroll
                         for (int ii = 0; ii < TI; ++ii) {
+                            if (ii < cnt || ii < TI - 2) {         // (blocks are at least 2 TI - 3 tiles high wherever they are balanced: only the last two tiles of a wave can be missing)
 #pragma unroll
-                            for (int j = 0; j < 2; ++j) acc[ii][j] = TOR ? mfma32(xw[j], xx[ii], acc[ii][j]) : mfma32(xx[ii], xw[j], acc[ii][j]);
+                                for (int j = 0; j < 2; ++j) acc[ii][j] = TOR ? mfma32(xw[j], xx[ii], acc[ii][j]) : mfma32(xx[ii], xw[j], acc[ii][j]);
+                            }
                             // the copies ride in the shadow of the matrix pipe: one after every second pair of MFMAs
                             if (ii < 3 && any && !(XP & 1)) {
                                 MG_SCHED_FENCE();
@@ -245,7 +274,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs a) {
     }
 }
 template <int EPI, int TI>
-static bool launch_pp(const GemmArgs& a, mgStream_t stream) {
+static bool launch_pp(const GemmArgs& a_in, mgStream_t stream) {
+    GemmArgs a = a_in;
+    static int balance = -1;
+    if (balance < 0) { const char* e = getenv("MG_PP_BALANCE"); balance = e ? atoi(e) : 1; }      // (A/B runs)
+    a.pp_balance = balance;
     constexpr int BM = 64 * TI;
     const int nblk = ((a.M + BM - 1) / BM) * ((a.N + GX_N - 1) / GX_N);
     static int ncu = 0;
@@ -256,8 +289,8 @@ static bool launch_pp(const GemmArgs& a, mgStream_t stream) {
 #endif
     int G = nblk < ncu ? nblk : ncu;
     if (G >= 8) G &= ~7;
-    if ((a.K & 127) != 0 || nblk > GP_MAXT * G) return false;                   // (K/16 must be a multiple of the ring)
-    const size_t sh = (size_t)GP_RING * (2 * TI + 8) * TILE_BYTES + (size_t)GP_MAXT * 2 * TI * sizeof(int);
+    if ((a.K & 127) != 0 || (nblk + nblk / 3 + G) > GP_MAXT * G) return false;   // (K/16 a multiple of the ring; balanced blocks are up to 30 % more)
+    const size_t sh = (size_t)GP_RING * (2 * TI + 8) * TILE_BYTES + (size_t)GP_MAXT * (2 * TI + 2) * sizeof(int);
     static bool once = false;
     if (!once) { MG_SET_MAX_SMEM((&gemm_pp_kernel<EPI, TI>), sh); once = true; }
 #ifdef MG_TOOLS      // what-if variants with WRONG results: tools builds only
