@@ -322,6 +322,10 @@ static bool launch_pp_epi(const GemmArgs& a, int epi, mgStream_t stream) {
     }
 }
 
+// Measured and rejected (profiles/r04_h_gemm_coresident_rejected.txt): the TI = 4 form compiled to <= 192 registers per lane
+// (__attribute__((amdgpu_num_vgpr(96))): the attribute counts half of gfx950's unified register file) so that two of its waves leave a
+// quarter of a SIMD's registers and 31 KiB of LDS to the decode kernels of the other batches in flight - 116.0-116.1 images/s against
+// 116.2-116.5 for the forms that own their CU: the dispatcher does not turn the free room into throughput.
 // Measured and rejected (profiles/r04_c_gemm_duo_rejected.txt; the kernel is in the history of this file): TWO persistent 4-wave
 // workgroups per CU with (32 TI) x 256 tiles, meant to put one workgroup's epilogue under the other's K loop.  Bit-identical, but its
 // smaller tiles move 1.44 x the operand bytes from L2 (the copies cost 86 us of the QKV projection's 283 against 46 of 239 here:

@@ -9,7 +9,9 @@ from markushgrapher_amd import synth
 from markushgrapher_amd.engine import Engine
 shape = synth.SHAPES["large"]
 _tools = os.environ.get("MG_ATT_EXP") or os.environ.get("MG_GEMM_EXP") or os.environ.get("MG_TOOLS_LIB")
-if _tools:                                   # what-if variants (WRONG results, timing only) live in the tools build
+if os.environ.get("MG_LIB_PATH"):            # A/B against another build of the library (e.g. tools/_build/libmgrapher_prev.so)
+    eng = Engine(shape, lib=C.CDLL(os.path.join(ROOT, os.environ["MG_LIB_PATH"])), max_decode_len=64)
+elif _tools:                                 # what-if variants (WRONG results, timing only) live in the tools build
     from tools import _toolslib
     eng = Engine(shape, lib=_toolslib.load(), max_decode_len=64)
 else:
