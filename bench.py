@@ -638,6 +638,38 @@ def main():
                     "images_per_s": round(B * nbe / tbe, 2), "ms_per_batch": round(tbe / nbe * 1e3, 1), "batches": nbe, "batches_in_flight": len(fl),
                     "columns_returned": int(outs[0].shape[1]), "all_batches_equal": bool(all(np.array_equal(o, outs[0]) for o in outs)),
                     "config": "num_beams 5, max_length 512, EOS enabled (EOS row scaled as in eos_enabled): the reference's default decode mode"}
+                # the same mode through the beam QUEUE (mg_generate_stream_beam): image slots of 5 rows; an image whose search stops is
+                # written out and its slot handed to the next image of the queue - no slot walks to the longest image of a batch
+                for c in fl.contexts:
+                    c.set_stream_encoder(0)
+                QBq = 8                                        # a queue of 8 batches' worth of images per context
+                SLOTS_B = 32                                   # 32 image slots x 5 beams = 160 rows, the batch form's row count
+                qb = {k: torch.cat([dev[k]] * QBq, dim=0) for k in ("input_ids", "bbox", "attention_mask")}
+
+                def job_beam_queue(ctx, i):
+                    pix = torch.cat([ctx.preprocess(dev["pages_u8"]) for _ in range(QBq)], dim=0)
+                    o, l, sc, st = ctx.generate_stream_beam(qb["input_ids"], qb["bbox"], qb["attention_mask"], pix, num_beams=5, max_length=512,
+                                                            min_length=0, chunk=B, slots=SLOTS_B, pool_chunks=3)
+                    return o.cpu().numpy(), l.cpu().numpy(), st
+                job_beam_queue(eng, 0)
+                torch.cuda.synchronize(); t1q = time.time()
+                o1, l1, st1 = job_beam_queue(eng, 0)
+                torch.cuda.synchronize(); t1q = time.time() - t1q
+                ref_b = outs[0]
+                same_b = all(np.array_equal(o1[n, :min(int(l1[n]), ref_b.shape[1])], ref_b[n % B, :min(int(l1[n]), ref_b.shape[1])]) for n in range(QBq * B))
+                fl.map(job_beam_queue, range(len(fl)))
+                torch.cuda.synchronize(); tbq = time.time()
+                res_bq = fl.map(job_beam_queue, range(len(fl)))
+                torch.cuda.synchronize(); tbq = time.time() - tbq
+                extra["beam5_eos_enabled_queue"] = {
+                    "images_per_s_one_context": round(QBq * B / t1q, 2), "images_per_s": round(len(fl) * QBq * B / tbq, 2), "contexts": len(fl),
+                    "queue_images_per_context": QBq * B, "image_slots": SLOTS_B, "decode_steps_run": int(st1),
+                    "decode_steps_run_per_context": [int(r[2]) for r in res_bq], "mean_hypothesis_length": round(float(l1.mean()), 1),
+                    "speedup_vs_batch_calls": round(len(fl) * QBq * B / tbq / (B * nbe / tbe), 2), "hypotheses_equal_batch_calls": bool(same_b),
+                    "config": "mg_generate_stream_beam: num_beams 5, max_length 512, EOS enabled, 32 image slots of 5 rows working through a "
+                              "queue of 256 images per context (finished images free their slot; device preprocessing inside the timed region)"}
+                for c in fl.contexts:
+                    c.set_stream_encoder(1)
             eng.load_state_dict({"shared.weight": sd["shared.weight"]})
             extra["ocr_stage"] = ocr_stage_run()
             if not args.no_cpu_baseline:

@@ -128,6 +128,18 @@ int mg_stream_workspace_bytes(const mg_model* m, int chunk, int L, int slots, in
 int mg_generate_stream(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* input_ids, const float* bbox,
                        const uint8_t* attention_mask, const float* pixel_values, int N, int L, int chunk, int slots, int pool_chunks,
                        int max_length, int min_length, int64_t* out_ids, int32_t* out_len, long* steps_host);
+/* The same queue with BEAM SEARCH - the reference's shipped decode mode (/root/reference/config/predict.yaml:12-13 beam_search: True;
+ * utils_evaluation.py:269-285 generate(num_beams=5, max_length=512)): `slots` IMAGE slots of num_beams rows each (slots * num_beams <= 256)
+ * work through the queue; an image whose own stopping condition holds (stock 5.15 generation/utils.py:3055-3075 for that image alone - in a
+ * batch call such an image is frozen until the whole batch stops) is written out and its slot handed to the next image.
+ *   outputs  out_ids [N][max_length] i64 = best hypothesis (unfinished tails filled as stock does), out_len [N] = its columns,
+ *            out_scores [N] f32 (nullable) = its length-penalised score
+ * Every image's hypothesis and score equal mg_generate(num_beams)'s for that image.  SYNCHRONISES before returning. */
+int mg_stream_beam_workspace_bytes(const mg_model* m, int chunk, int L, int slots, int pool_chunks, int num_beams, int max_length, size_t* out_bytes);
+int mg_generate_stream_beam(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* input_ids, const float* bbox,
+                            const uint8_t* attention_mask, const float* pixel_values, int N, int L, int chunk, int slots, int pool_chunks,
+                            int num_beams, int max_length, int min_length, float length_penalty, int early_stopping, int64_t* out_ids,
+                            int32_t* out_len, float* out_scores, long* steps_host);
 /* Where the encoder of mg_generate_stream runs: 0 = on the caller's stream (serial), 1 = own stream at the lowest priority
  * (default), 2 = own stream restricted to the compute units of cu_mask (nwords x 32 bits, hipExtStreamCreateWithCUMask). */
 int mg_stream_encoder_mode(mg_model* m, int mode, const uint32_t* cu_mask, int nwords);

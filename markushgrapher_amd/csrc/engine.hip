@@ -392,13 +392,19 @@ struct StreamWs {
     float *dh, *logits, *rs_part, *rs_part1, *rs_part2;
     int64_t* next_ids;
     int *unfinished, *pos, *img, *pool, *ctr, *err;
+    // beam queue form (K > 1): `slots` image slots of K rows each; per-slot K/V owner, slot -> image assignment of the step, ancestor
+    // table, beam bookkeeping of the slots
+    int *bpool, *assign, *anc, *beam_idx;
+    float* beam_div;
+    void* beam_state;
     size_t total;
 };
-void carve_stream(const mg_model* m, char* base, int chunk, int L, int slots, int pool_chunks, StreamWs* w) {
+void carve_stream(const mg_model* m, char* base, int chunk, int L, int slots_img, int pool_chunks, StreamWs* w, int K = 1, int max_len = 0) {
     carve(m, base, chunk, L, 1, 0, 0, 0, &w->enc);
     Carver c{base};
     c.off = w->enc.total;
     const int d = m->d, inner = m->inner, H = m->H;
+    const int slots = slots_img * K;                        // decode rows
     const int Sx_cap = round_up(L + m->P, 64), Rp = round_up(slots, 32);
     const size_t nl = m->dec.size(), entries = (size_t)pool_chunks * chunk;
     w->pool_stride = entries * H * Sx_cap * 64;
@@ -424,6 +430,16 @@ void carve_stream(const mg_model* m, char* base, int chunk, int L, int slots, in
     w->pool = c.take<int>(Rp);
     w->ctr = c.take<int>(64);
     w->err = c.take<int>(64);
+    w->bpool = c.take<int>(round_up(slots_img, 32));
+    w->assign = c.take<int>(round_up(slots_img, 32));
+    if (K > 1) {
+        w->anc = c.take<int>((size_t)m->T_cap * slots);
+        w->beam_idx = c.take<int>(Rp);
+        w->beam_div = c.take<float>((size_t)m->T_cap + 1);
+        w->beam_state = c.take<char>(beam_state_bytes(slots_img, K, max_len));
+    } else {
+        w->anc = nullptr; w->beam_idx = nullptr; w->beam_div = nullptr; w->beam_state = nullptr;
+    }
     w->total = align_up(c.off, 256);
 }
 __global__ __launch_bounds__(256) void stream_init_kernel(int64_t* out_ids, int* out_len, int N, int max_len, int64_t start, int64_t pad,
@@ -531,6 +547,11 @@ struct DecodeCtx {
     float* step_top2;
     const int* live;          // rows skipped by the attention launches (finished / idle), nullable
     SlotTable slots;          // continuous decoding
+    // continuous BEAM decoding (slots.pos non-null and K > 1): B image slots of K rows; per-slot K/V owner, this step's slot -> image
+    // assignment, outputs of the images that stop
+    int *bpool, *assign;
+    int32_t* out_len;
+    float* out_scores;
 };
 
 // Decode step, 6 launches per layer: QKV -> self-attention -> [O residual | cross-Q] -> cross-attention ->
@@ -599,7 +620,7 @@ static void decode_step(mg_model* m, const DecodeCtx& c, int t, const int* tdev,
         AttnStepArgs x{};
         x.q = c.dq; x.qrs = rs1; x.Kc = c.xk + li * xkv_stride; x.Vc = c.xv + li * xkv_stride; x.ctx = c.xb; x.ctx_ld = K2;
         x.ctx_col0 = d; x.rows = R; x.H = H; x.group = K; x.cap = Sx_cap; x.len = c.xlen;
-        x.live = live; x.kv_owner = c.slots.pool;
+        x.live = live; x.kv_owner = (K > 1 && stream) ? c.bpool : c.slots.pool;       // (beams: one owner per image slot = group of K rows)
         const bool timed = time_cross && m->prof_used + 3 <= m->prof_ev.size();
         if (timed) mg_event_record(m->prof_ev[m->prof_used], st);
         attention_step(x, st);
@@ -655,12 +676,21 @@ static void decode_step(mg_model* m, const DecodeCtx& c, int t, const int* tdev,
         if (stream) slot_refill(c.slots, c.next_ids, c.unfinished, R, st);
         if (m->dbg_forced && t + 1 < max_length)
             MG_LAUNCH(force_ids_kernel, dim3((R + 63) / 64), dim3(64), 0, st, c.next_ids, m->dbg_forced, R, max_length, t + 1);
+    } else if (stream) {
+        // queue form: every slot at its own length; stopped images are written out and their slots handed to the next images
+        const BeamSlots bs{c.slots.pos, c.unfinished};
+        beam_step(c.beam_state, c.logits, ldl, m->V, B, K, max_length, 0, nullptr, c.beam_div, m->c.eos_token_id, min_length,
+                  length_penalty, early_stopping, c.next_ids, c.beam_idx, counters, st, &bs);
+        beam_reorder_anc(c.anc, c.beam_idx, R, max_length - 1, nullptr, counters, st, &bs);
+        beam_slots_step(c.beam_state, B, K, max_length, (int)pad, m->c.eos_token_id, c.slots.start_id, early_stopping, c.slots.pos, c.slots.img,
+                        c.slots.pool, c.bpool, c.unfinished, c.assign, c.next_ids, c.anc, T_cap, c.slots.pool_cap, out_ids, c.out_len,
+                        c.out_scores, c.slots.ctr, true, st);
     } else {
         beam_step(c.beam_state, c.logits, ldl, m->V, B, K, max_length, t + 1, tdev, c.beam_div, m->c.eos_token_id, min_length,
                   length_penalty, early_stopping, c.next_ids, c.beam_idx, counters, st);
         beam_reorder_anc(c.anc, c.beam_idx, R, tdev ? max_length - 1 : t + 1, tdev, counters, st);
     }
-    if (K > 1) MG_LAUNCH(step_end_kernel, dim3(1), dim3(64), 0, st, counters, 0);
+    if (K > 1 && !stream) MG_LAUNCH(step_end_kernel, dim3(1), dim3(64), 0, st, counters, 0);
 }
 
 extern "C" {
@@ -1353,20 +1383,26 @@ int mg_stream_encoder_mode(mg_model* m, int mode, const uint32_t* cu_mask, int n
     return MG_OK;
 }
 
-int mg_generate_stream(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* input_ids, const float* bbox,
-                       const uint8_t* attention_mask, const float* pixel_values, int N, int L, int chunk, int slots, int pool_chunks,
-                       int max_length, int min_length, int64_t* out_ids, int32_t* out_len, long* steps_host) {
+}   // extern "C"
+
+// Continuous decoding of a queue of images: greedy (K = 1: `slots` decode rows) or beam search (K > 1: `slots` IMAGE slots of K rows).
+static int generate_stream_impl(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* input_ids, const float* bbox,
+                                const uint8_t* attention_mask, const float* pixel_values, int N, int L, int chunk, int slots, int pool_chunks,
+                                int K, int max_length, int min_length, float length_penalty, int early_stopping, int64_t* out_ids,
+                                int32_t* out_len, float* out_scores, long* steps_host) {
     entry_drain();
     if (!m || !ws || !input_ids || !bbox || !pixel_values || !out_ids || !out_len) return fail(MG_E_ARG, "mg_generate_stream: null argument");
     MG_ONE_CALL(m, "mg_generate_stream");
     if (!m->finalized) return fail(MG_E_STATE, "mg_generate_stream: call mg_finalize first");
     if (N < 1 || L < 1 || chunk < 1 || pool_chunks < 2) return fail(MG_E_SHAPE, "mg_generate_stream: N, L, chunk must be >= 1, pool_chunks >= 2");
-    if (slots < 1 || slots > 256) return fail(MG_E_UNSUPPORTED, "mg_generate_stream: slots must be in [1, 256]");
+    if (K < 1 || K > 8) return fail(MG_E_UNSUPPORTED, "mg_generate_stream: num_beams must be in [1, 8]");
+    if (slots < 1 || (long)slots * K > 256) return fail(MG_E_UNSUPPORTED, "mg_generate_stream: slots * num_beams must be in [1, 256]");
     if (slots > pool_chunks * chunk) return fail(MG_E_SHAPE, "mg_generate_stream: slots (%d) exceed the %d pool entries", slots, pool_chunks * chunk);
     if (max_length < 2 || max_length > m->T_cap) return fail(MG_E_SHAPE, "mg_generate_stream: max_length must be in [2, %d]", m->T_cap);
     if (m->dbg_logits || m->dbg_forced) return fail(MG_E_STATE, "mg_generate_stream: the decode-capture instrumentation is for mg_generate");
+    const int R = slots * K;                         // decode rows
     StreamWs w;
-    carve_stream(m, (char*)ws, chunk, L, slots, pool_chunks, &w);
+    carve_stream(m, (char*)ws, chunk, L, slots, pool_chunks, &w, K, max_length);
     if (w.total > ws_bytes) return fail(MG_E_WORKSPACE, "mg_generate_stream: workspace too small (%zu < %zu)", ws_bytes, w.total);
     mgStream_t st = (mgStream_t)stream;
     const int d = m->d, H = m->H, inner = m->inner, P = m->P;
@@ -1398,23 +1434,36 @@ int mg_generate_stream(mg_model* m, void* stream, void* ws, size_t ws_bytes, con
     // slot table, outputs
     const int64_t start = m->c.decoder_start_token_id, pad = m->c.pad_token_id;
     MG_LAUNCH(stream_init_kernel, dim3(64), dim3(256), 0, st, out_ids, out_len, N, max_length, start, pad, w.unfinished, w.pos, w.img, w.pool,
-              w.next_ids, slots, w.ctr, w.err);
+              w.next_ids, R, w.ctr, w.err);
+    mg_memset_async(w.bpool, 0, (size_t)round_up(slots, 32) * sizeof(int), st);
+    mg_memset_async(w.assign, 0xFF, (size_t)round_up(slots, 32) * sizeof(int), st);
+    mg_memset_async(w.xlen_pool, 0, (size_t)entries * sizeof(int), st);           // (idle slots' cross-attention is skipped; belt and braces)
+    if (K > 1) {
+        m->beam_div_host.resize((size_t)max_length + 1);
+        for (int c = 0; c <= max_length; ++c) m->beam_div_host[c] = beam_length_divisor(c, length_penalty);
+        mg_memcpy_async(w.beam_div, m->beam_div_host.data(), m->beam_div_host.size() * sizeof(float), st);
+        mg_stream_sync(st);        // (the host vector may be resized by the context's next call)
+    }
     mg_event_record(m->start_ev, st);
     if (es != st) mg_stream_wait_event(es, m->start_ev);      // inputs / workspace are ordered behind the caller's earlier work
     DecodeCtx dc{};
     dc.xk = w.xk; dc.xv = w.xv; dc.xkv_stride = w.pool_stride; dc.Sx_cap = Sx_cap; dc.xlen = w.xlen_pool;
-    dc.sk = w.sk; dc.sv = w.sv; dc.skv_stride = (size_t)slots * H * m->T_cap * 64;
+    dc.sk = w.sk; dc.sv = w.sv; dc.skv_stride = (size_t)R * H * m->T_cap * 64;
     dc.dq = w.dq; dc.dx_pk = w.dx_pk; dc.dy_pk = w.dy_pk; dc.xa = w.xa; dc.xb = w.xb;
     dc.dh = w.dh; dc.logits = w.logits; dc.rs_part = w.rs_part; dc.rs_part1 = w.rs_part1; dc.rs_part2 = w.rs_part2;
     dc.next_ids = w.next_ids; dc.unfinished = w.unfinished; dc.counters = w.ctr;
-    dc.B = slots; dc.K = 1; dc.R = slots; dc.max_length = max_length; dc.min_length = min_length; dc.length_penalty = 1.0f;
+    dc.B = slots; dc.K = K; dc.R = R; dc.max_length = max_length; dc.min_length = min_length; dc.length_penalty = length_penalty;
+    dc.early_stopping = early_stopping;
     dc.out_ids = out_ids; dc.live = w.unfinished;
+    dc.anc = w.anc; dc.beam_idx = w.beam_idx; dc.beam_div = w.beam_div; dc.beam_state = w.beam_state;
+    dc.bpool = w.bpool; dc.assign = w.assign; dc.out_len = out_len; dc.out_scores = out_scores;
     dc.slots = SlotTable{w.pos, w.img, w.pool, w.ctr, out_len, entries, (int)start};
     // the step as a graph (every step-dependent value lives in the slot table)
     bool graphed = false;
 #ifndef MG_EMU
     if (m->use_graph == 1) {
-        const StepGraph::Key key{ws, out_ids, out_len, (const void*)st, slots, L, chunk, max_length, min_length, N, pool_chunks, 0.0f};     // (K = chunk, M_e1 = pool_chunks)
+        const StepGraph::Key key{ws, out_ids, out_len, (const void*)st, slots * 16 + K, L, chunk, max_length, min_length, N * 2 + (early_stopping ? 1 : 0),
+                                 pool_chunks, length_penalty};     // (B = slots and beams, K = chunk, early_stopping = N and the flag, M_e1 = pool_chunks)
         StepGraph& sg = m->stream_graph;
         if (!(sg.valid && sg.key == key)) {
             std::lock_guard<std::mutex> capture_lock(mg_capture_mutex());
@@ -1532,6 +1581,30 @@ int mg_generate_stream(mg_model* m, void* stream, void* ws, size_t ws_bytes, con
     if (steps_host) *steps_host = steps;
     if (err_host != 0) return fail(MG_E_INPUT, "mg_generate_stream: %d token ids outside [0, vocab)", err_host);
     return MG_OK;
+}
+
+extern "C" {
+
+int mg_generate_stream(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* input_ids, const float* bbox,
+                       const uint8_t* attention_mask, const float* pixel_values, int N, int L, int chunk, int slots, int pool_chunks,
+                       int max_length, int min_length, int64_t* out_ids, int32_t* out_len, long* steps_host) {
+    return generate_stream_impl(m, stream, ws, ws_bytes, input_ids, bbox, attention_mask, pixel_values, N, L, chunk, slots, pool_chunks, 1,
+                                max_length, min_length, 1.0f, 0, out_ids, out_len, nullptr, steps_host);
+}
+int mg_stream_beam_workspace_bytes(const mg_model* m, int chunk, int L, int slots, int pool_chunks, int num_beams, int max_length, size_t* out_bytes) {
+    if (!m || !out_bytes || chunk < 1 || L < 1 || slots < 1 || pool_chunks < 2 || num_beams < 1 || num_beams > 8 || max_length < 2)
+        return fail(MG_E_ARG, "mg_stream_beam_workspace_bytes: bad argument");
+    StreamWs w;
+    carve_stream(m, nullptr, chunk, L, slots, pool_chunks, &w, num_beams, max_length);
+    *out_bytes = w.total;
+    return MG_OK;
+}
+int mg_generate_stream_beam(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* input_ids, const float* bbox,
+                            const uint8_t* attention_mask, const float* pixel_values, int N, int L, int chunk, int slots, int pool_chunks,
+                            int num_beams, int max_length, int min_length, float length_penalty, int early_stopping, int64_t* out_ids,
+                            int32_t* out_len, float* out_scores, long* steps_host) {
+    return generate_stream_impl(m, stream, ws, ws_bytes, input_ids, bbox, attention_mask, pixel_values, N, L, chunk, slots, pool_chunks,
+                                num_beams, max_length, min_length, length_penalty, early_stopping, out_ids, out_len, out_scores, steps_host);
 }
 
 // Live timing of the dominant decode kernel (single-query cross-attention over the image K/V stream): when enabled,

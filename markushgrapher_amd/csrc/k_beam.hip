@@ -125,9 +125,11 @@ MG_DEV float block_sum16(float v, float* red, int tid) {
     return r;
 }
 __global__ __launch_bounds__(BT_THREADS) void beam_row_topk_kernel(BeamPtrs p, const float* logits, int ldl, int V, int K, int cur_len_arg,
-                                                              int eos, int min_len, const int* counters, const int* tdev) {
-    if (counters[0] == 0) return;
-    const int cur_len = tdev ? *tdev + 1 : cur_len_arg;
+                                                              int eos, int min_len, const int* counters, const int* tdev, BeamSlots bs) {
+    // queue form (bs.pos): every image slot is at its own length, idle slots are skipped; batch form: one length, the batch's
+    // continue flag
+    if (bs.pos ? bs.live[blockIdx.x] == 0 : counters[0] == 0) return;
+    const int cur_len = bs.pos ? bs.pos[blockIdx.x] + 1 : (tdev ? *tdev + 1 : cur_len_arg);
     MG_DYN_SMEM(smem);
     float* red = (float*)smem;            // [16]
     float* selv = red + 16;               // [16]
@@ -205,8 +207,8 @@ __global__ __launch_bounds__(BT_THREADS) void beam_row_topk_kernel(BeamPtrs p, c
     }
 }
 // rank of every row candidate among the image's K*2K; ranks < 2K are the image's top-2K in order
-__global__ __launch_bounds__(128) void beam_merge_topk_kernel(BeamPtrs p, int K, const int* counters) {
-    if (counters[0] == 0) return;
+__global__ __launch_bounds__(128) void beam_merge_topk_kernel(BeamPtrs p, int K, const int* counters, BeamSlots bs) {
+    if (bs.pos ? bs.live[blockIdx.x * K] == 0 : counters[0] == 0) return;
     MG_DYN_SMEM(smem);
     const int b = blockIdx.x, tid = threadIdx.x, keep = 2 * K, n = K * keep;
     float* cv = (float*)smem;             // [128]
@@ -223,9 +225,9 @@ __global__ __launch_bounds__(128) void beam_merge_topk_kernel(BeamPtrs p, int K,
 // c.-g. bookkeeping for one image (K <= 8, 2K <= 16 candidates)
 __global__ __launch_bounds__(256) void beam_update_kernel(BeamPtrs p, int B, int K, int V, int max_len, int cur_len_arg, int eos,
                                                      float div_arg, const float* div_table, int early_stopping, int64_t* next_ids,
-                                                     int* beam_idx, const int* counters, const int* tdev) {
-    if (counters[0] == 0) return;
-    const int cur_len = tdev ? *tdev + 1 : cur_len_arg;
+                                                     int* beam_idx, const int* counters, const int* tdev, BeamSlots bs) {
+    if (bs.pos ? bs.live[blockIdx.x * K] == 0 : counters[0] == 0) return;
+    const int cur_len = bs.pos ? bs.pos[blockIdx.x * K] + 1 : (tdev ? *tdev + 1 : cur_len_arg);
     // (cur_len + 1 - prompt_len)^length_penalty with prompt_len = 1: the divisor of the finished-beam score
     // (utils.py:3182) and, after the increment of cur_len, of the early-stop heuristic (utils.py:3047-3052)
     const float fin_div = div_table ? div_table[cur_len] : div_arg;
@@ -371,14 +373,15 @@ float beam_length_divisor(int cur_len, float length_penalty) { return (float)pow
 // filled on the host with beam_length_divisor so both forms use bit-identical values)
 void beam_step(void* state, const float* logits, int ldl, int V, int B, int K, int max_len, int cur_len, const int* tdev,
                const float* div_table, int eos, int min_len, float length_penalty, int early_stopping, int64_t* next_ids,
-               int* beam_idx, int* counters, mgStream_t stream) {
+               int* beam_idx, int* counters, mgStream_t stream, const BeamSlots* slots) {
     const BeamPtrs p = beam_ptrs(state, B, K, max_len);
-    MG_LAUNCH(beam_row_topk_kernel, dim3(B * K), dim3(BT_THREADS), 256, stream, p, logits, ldl, V, K, cur_len, eos, min_len, (const int*)counters, tdev);
-    MG_LAUNCH(beam_merge_topk_kernel, dim3(B), dim3(128), 1024, stream, p, K, (const int*)counters);
+    const BeamSlots bs = slots ? *slots : BeamSlots{nullptr, nullptr};
+    MG_LAUNCH(beam_row_topk_kernel, dim3(B * K), dim3(BT_THREADS), 256, stream, p, logits, ldl, V, K, cur_len, eos, min_len, (const int*)counters, tdev, bs);
+    MG_LAUNCH(beam_merge_topk_kernel, dim3(B), dim3(128), 1024, stream, p, K, (const int*)counters, bs);
     const float div = beam_length_divisor(cur_len, length_penalty);
-    MG_LAUNCH(beam_update_kernel, dim3(B), dim3(256), 1024, stream, p, B, K, V, max_len, cur_len, eos, div, tdev ? div_table : nullptr,
-              early_stopping, next_ids, beam_idx, (const int*)counters, tdev);
-    MG_LAUNCH(beam_flags_kernel, dim3(1), dim3(64), 0, stream, p, B, early_stopping, counters);
+    MG_LAUNCH(beam_update_kernel, dim3(B), dim3(256), 1024, stream, p, B, K, V, max_len, cur_len, eos, div, (tdev || bs.pos) ? div_table : nullptr,
+              early_stopping, next_ids, beam_idx, (const int*)counters, tdev, bs);
+    if (!bs.pos) MG_LAUNCH(beam_flags_kernel, dim3(1), dim3(64), 0, stream, p, B, early_stopping, counters);
 }
 
 // utils.py:3510-3523: best beam per image, generated length from its beam-index history
@@ -408,19 +411,126 @@ void beam_finalize(void* state, int B, int K, int max_len, int64_t* out_ids, int
 
 // ancestor-table reorder: one workgroup per cached position j < t_written, in place
 __global__ __launch_bounds__(256) void beam_reorder_anc_kernel(int* anc, const int* beam_idx, int rows, const int* counters,
-                                                          const int* tdev) {
-    if (counters[0] == 0) return;
+                                                          const int* tdev, BeamSlots bs) {
     const int j = blockIdx.x;
-    if (tdev && j > *tdev) return;      // graph form: launched over every position, only the written ones are permuted
+    if (!bs.pos) {
+        if (counters[0] == 0) return;
+        if (tdev && j > *tdev) return;      // graph form: launched over every position, only the written ones are permuted
+    }
     int v[4];
     int n = 0;
-    for (int r = threadIdx.x; r < rows; r += 256) v[n++] = anc[(size_t)j * rows + beam_idx[r]];
+    // queue form: a row is permuted at position j when its slot is live and has written that position (rows of other slots keep theirs)
+    for (int r = threadIdx.x; r < rows; r += 256) {
+        const bool on = !bs.pos || (bs.live[r] != 0 && j <= bs.pos[r]);
+        v[n++] = anc[(size_t)j * rows + (on ? beam_idx[r] : r)];
+    }
     __syncthreads();
     n = 0;
     for (int r = threadIdx.x; r < rows; r += 256) anc[(size_t)j * rows + r] = v[n++];
 }
-void beam_reorder_anc(int* anc, const int* beam_idx, int rows, int t_written, const int* tdev, const int* counters, mgStream_t stream) {
-    MG_LAUNCH(beam_reorder_anc_kernel, dim3(t_written), dim3(256), 0, stream, anc, beam_idx, rows, counters, tdev);
+void beam_reorder_anc(int* anc, const int* beam_idx, int rows, int t_written, const int* tdev, const int* counters, mgStream_t stream,
+                      const BeamSlots* slots) {
+    const BeamSlots bs = slots ? *slots : BeamSlots{nullptr, nullptr};
+    MG_LAUNCH(beam_reorder_anc_kernel, dim3(t_written), dim3(256), 0, stream, anc, beam_idx, rows, counters, tdev, bs);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Queue form (mg_generate_stream_beam): the image slots of a continuous beam decoder.  A slot = the K rows of one image; every slot
+// runs the batch form's per-image arithmetic at its own length (BeamSlots), so an image's hypotheses are what a batch call returns
+// for it: in the batch form an image whose own stopping condition holds is frozen (its heuristic flag gates every new finished
+// candidate with -1e9, utils.py:3187) until the last image of the batch stops.
+//   end    per live slot: the image's own loop condition (utils.py:3055-3075 without the reduction over the batch); a stopped image
+//          is written out (best hypothesis, its length from the beam-index history, its score) and the slot becomes idle,
+//          otherwise the slot's rows advance one position
+//   assign one thread walks the slots in order and hands idle ones the next queued images whose cross K/V are in the pool
+//   init   per newly assigned slot: the batch form's initial values (beam_init_kernel), identity ancestors, start tokens
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void beam_slot_end_kernel(BeamPtrs p, int K, int max_len, int early_stopping, int* pos, int* img, int* live,
+                                                       int64_t* out_ids, int* out_len, float* out_scores, int* ctr) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (live[b * K] == 0) return;
+    const bool cont = p.flags[b * 4 + 0] && !(p.flags[b * 4 + 1] && early_stopping) && !p.flags[b * 4 + 2];
+    if (cont) {
+        if (tid < K) pos[b * K + tid] += 1;
+        return;
+    }
+    const int i = img[b * K];
+    const int ml = max_len, il = max_len - 1;
+    for (int j = tid; j < ml; j += 256) out_ids[(size_t)i * ml + j] = p.sequences[(size_t)b * K * ml + j];
+    int c = 0;
+    for (int j = tid; j < il; j += 256) c += p.beam_idx_out[(size_t)b * K * il + j] != -1;
+    MG_DYN_SMEM(smem);
+    int* tot = (int*)smem;
+    if (tid == 0) *tot = 0;
+    __syncthreads();
+    if (c) atomicAdd(tot, c);
+    __syncthreads();
+    if (tid == 0) {
+        out_len[i] = 1 + *tot;
+        if (out_scores) out_scores[i] = p.beam_scores[b * K];
+        atomicAdd(ctr + 1, 1);
+    }
+    __syncthreads();
+    if (tid < K) { live[b * K + tid] = 0; img[b * K + tid] = -1; }
+}
+__global__ __launch_bounds__(64) void beam_slot_assign_kernel(int slots, int K, const int* live, const int* img, int* assign, int* ctr) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int head = ctr[4];
+    const int ready = ctr[5];
+    int n_live = 0, oldest = 0x7fffffff;
+    for (int b = 0; b < slots; ++b) {
+        int a = -1, im = img[b * K];
+        if (live[b * K] == 0 && head < ready) { a = head++; im = a; }
+        assign[b] = a;
+        if (live[b * K] != 0 || a >= 0) { ++n_live; oldest = im < oldest ? im : oldest; }
+    }
+    ctr[4] = head;
+    ctr[0] = n_live;
+    ctr[7] = n_live ? oldest : head;      // every image below this index has finished
+    ctr[2] += 1;
+}
+__global__ __launch_bounds__(256) void beam_slot_init_kernel(BeamPtrs p, int slots, int K, int max_len, int fill, int start, const int* assign,
+                                                        int* pos, int* img, int* pool, int* bpool, int* live, int64_t* next_ids, int* anc,
+                                                        int T_cap, int pool_cap) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int a = assign[b];
+    if (a < 0) return;
+    const int R = slots * K;
+    for (int i = tid; i < K * max_len; i += 256) {
+        const int64_t v = (i % max_len == 0) ? start : fill;
+        p.running_seq[(size_t)b * K * max_len + i] = v;
+        p.sequences[(size_t)b * K * max_len + i] = v;
+    }
+    for (int i = tid; i < K * (max_len - 1); i += 256) {
+        p.run_idx[(size_t)b * K * (max_len - 1) + i] = -1;
+        p.beam_idx_out[(size_t)b * K * (max_len - 1) + i] = -1;
+    }
+    for (int i = tid; i < K; i += 256) {
+        p.running_scores[b * K + i] = i == 0 ? 0.f : -1.0e9f;
+        p.beam_scores[b * K + i] = -1.0e9f;
+        p.is_fin[b * K + i] = 0;
+        next_ids[b * K + i] = start;
+        pos[b * K + i] = 0; img[b * K + i] = a; pool[b * K + i] = a % pool_cap; live[b * K + i] = 1;
+    }
+    for (int i = tid; i < T_cap * K; i += 256) {   // identity ancestor table for this slot's rows
+        const int j = i / K, k = i - j * K;
+        anc[(size_t)j * R + b * K + k] = b * K + k;
+    }
+    if (tid == 0) {
+        p.heur[b] = 1;
+        bpool[b] = a % pool_cap;
+        p.flags[b * 4 + 0] = 1; p.flags[b * 4 + 1] = 0; p.flags[b * 4 + 2] = 0;
+    }
+}
+void beam_slots_step(void* state, int slots, int K, int max_len, int pad, int eos, int start, int early_stopping, int* pos, int* img, int* pool,
+                     int* bpool, int* live, int* assign, int64_t* next_ids, int* anc, int T_cap, int pool_cap, int64_t* out_ids, int* out_len,
+                     float* out_scores, int* ctr, bool end_first, mgStream_t stream) {
+    const BeamPtrs p = beam_ptrs(state, slots, K, max_len);
+    if (end_first)
+        MG_LAUNCH(beam_slot_end_kernel, dim3(slots), dim3(256), 16, stream, p, K, max_len, early_stopping, pos, img, live, out_ids, out_len, out_scores, ctr);
+    MG_LAUNCH(beam_slot_assign_kernel, dim3(1), dim3(64), 0, stream, slots, K, (const int*)live, (const int*)img, assign, ctr);
+    MG_LAUNCH(beam_slot_init_kernel, dim3(slots), dim3(256), 0, stream, p, slots, K, max_len, pad ? pad : eos, start, (const int*)assign, pos, img,
+              pool, bpool, live, next_ids, anc, T_cap, pool_cap);
 }
 
 // physical reorder (cache_utils.py:100-104): dst[lk][r] = src[lk][beam_idx[r]], 16-byte copies, HBM-bound

@@ -34,6 +34,7 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a, long
     const int sub = lane & 7, ks = lane >> 3;
     const int owner = blockIdx.x / a.H, h = blockIdx.x - owner * a.H;
     if constexpr (G == 1 || ROPE) { if (a.live && a.live[owner] == 0) return; }       // finished / idle row (whole workgroup: uniform)
+    else { if (a.live && a.kv_owner && a.live[owner * G] == 0) return; }              // beam queue form: idle image slot (its G rows share the flag)
     const int tcur = a.pos_rows ? a.pos_rows[owner] + a.t_off : (a.t_dev ? *a.t_dev + a.t_off : a.t);
     // the K/V stream this row reads (and, for self-attention, appends to): a pool entry of the continuous decoders (cross form: the
     // image's encoder K/V; rotary form: the page's own cache), else the row itself

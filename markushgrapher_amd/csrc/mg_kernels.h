@@ -350,16 +350,27 @@ void greedy_select_fused(const ArgmaxArgs& a, mgStream_t stream);
 void slot_refill(const SlotTable& s, int64_t* next_ids, int* unfinished, int rows, mgStream_t stream);
 
 // beam search on the device (k_beam.hip; restates stock generation/utils.py:3208-3525)
+// queue form (continuous beam decoder): per ROW position of the token fed to the step and live flag - the K rows of an image slot
+// hold the same values; pos == null: batch form (one position for all images, the batch's continue flag in counters[0])
+struct BeamSlots { const int* pos; const int* live; };
 size_t beam_state_bytes(int B, int K, int max_len);
 void beam_init(void* state, int B, int K, int max_len, int pad, int eos, int start, int64_t* next_ids, int* anc, int T_cap,
                int* counters, mgStream_t stream);
 float beam_length_divisor(int cur_len, float length_penalty);
 void beam_step(void* state, const float* logits, int ldl, int V, int B, int K, int max_len, int cur_len, const int* tdev,
                const float* div_table, int eos, int min_len, float length_penalty, int early_stopping, int64_t* next_ids,
-               int* beam_idx, int* counters, mgStream_t stream);
+               int* beam_idx, int* counters, mgStream_t stream, const BeamSlots* slots = nullptr);
 void beam_finalize(void* state, int B, int K, int max_len, int64_t* out_ids, int* out_cols, float* out_scores, mgStream_t stream);
 // ancestor-table form of the KV-cache reorder (cache_utils.py:100-104): anc[j][row] <- anc[j][beam_idx[row]], j < t_written
-void beam_reorder_anc(int* anc, const int* beam_idx, int rows, int t_written, const int* tdev, const int* counters, mgStream_t stream);
+void beam_reorder_anc(int* anc, const int* beam_idx, int rows, int t_written, const int* tdev, const int* counters, mgStream_t stream,
+                      const BeamSlots* slots = nullptr);
+// queue form, after the step of every slot: [end_first: stopped images are written out (out_ids [N][max_len], out_len, out_scores) and
+// their slots freed, the others advance] -> idle slots are handed the next ready images of the queue (assign[slot] = image or -1) ->
+// newly assigned slots get the batch form's initial state.  Counters as the greedy queue's (ctr[0] live, [1] done, [2] steps,
+// [4] queue head, [5] ready, [7] oldest live image)
+void beam_slots_step(void* state, int slots, int K, int max_len, int pad, int eos, int start, int early_stopping, int* pos, int* img, int* pool,
+                     int* bpool, int* live, int* assign, int64_t* next_ids, int* anc, int T_cap, int pool_cap, int64_t* out_ids, int* out_len,
+                     float* out_scores, int* ctr, bool end_first, mgStream_t stream);
 // physical form: dst[lk][row] = src[lk][beam_idx[row]] for nlk = layers*2 K/V planes of [rows][H][t_cap][64] bf16
 void beam_reorder_copy(const uint16_t* src, uint16_t* dst, const int* beam_idx, int nlk, int rows, int H, int t_cap, int t_used,
                        mgStream_t stream);

@@ -132,6 +132,9 @@ class Engine:
         L.mg_stream_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
         L.mg_generate_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + \
                                         [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.POINTER(C.c_long)]
+        L.mg_stream_beam_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
+        L.mg_generate_stream_beam.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + \
+                                             [C.c_int] * 8 + [C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_long)]
         L.mg_stream_encoder_mode.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.mg_debug_bucket_table.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int]
         L.mg_debug_decode_capture.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
@@ -325,6 +328,33 @@ class Engine:
                                               self.mem.ptr(bb), self.mem.ptr(am) if am is not None else None, self.mem.ptr(pv), N, L, chunk, slots,
                                               pool_chunks, max_length, min_length, self.mem.ptr(out[0]), self.mem.ptr(out[1]), C.byref(steps)))
         return self.mem.copy(out[0]), self.mem.copy(out[1]), int(steps.value)
+
+    def generate_stream_beam(self, input_ids, bbox, attention_mask, pixel_values, num_beams=5, max_length=512, min_length=0,
+                             length_penalty=1.0, early_stopping=False, chunk=32, slots=32, pool_chunks=3):
+        """Continuous BEAM-SEARCH decoding of N images (include/mgrapher.h mg_generate_stream_beam): `slots` image slots of num_beams
+        rows -> (ids [N, max_length] = best hypothesis per image, lengths [N], scores [N], decode steps run).  Row n equals
+        generate(num_beams=...)'s result for image n."""
+        ids, bb, am, pv, N, L = self._inputs(input_ids, bbox, attention_mask, pixel_values)
+        if slots * num_beams > self.MAX_LIVE_ROWS:
+            raise MgError(f"generate_stream_beam: slots * num_beams = {slots * num_beams} rows exceed the supported {self.MAX_LIVE_ROWS}")
+        need = C.c_size_t()
+        self._chk(self.lib.mg_stream_beam_workspace_bytes(self.model, chunk, L, slots, pool_chunks, num_beams, max_length, C.byref(need)))
+        if getattr(self, "_sws_bytes", 0) < need.value:
+            self._sws = None
+            self._sws = self.mem.empty((need.value,), np.uint8)
+            self._sws_bytes = need.value
+        okey = ("stream-beam", N, max_length)
+        out = self._gen_out.get(okey)
+        if out is None:
+            out = self._gen_out[okey] = (self.mem.empty((N, max_length), np.int64), self.mem.empty((N,), np.int32),
+                                         self.mem.empty((N,), np.float32))
+        steps = C.c_long(0)
+        self._chk(self.lib.mg_generate_stream_beam(self.model, self.mem.stream(), self.mem.ptr(self._sws), self._sws_bytes, self.mem.ptr(ids),
+                                                   self.mem.ptr(bb), self.mem.ptr(am) if am is not None else None, self.mem.ptr(pv), N, L, chunk,
+                                                   slots, pool_chunks, num_beams, max_length, min_length, C.c_float(length_penalty),
+                                                   1 if early_stopping else 0, self.mem.ptr(out[0]), self.mem.ptr(out[1]),
+                                                   self.mem.ptr(out[2]), C.byref(steps)))
+        return self.mem.copy(out[0]), self.mem.copy(out[1]), self.mem.copy(out[2]), int(steps.value)
 
     def generate(self, input_ids, bbox, attention_mask, pixel_values, num_beams=1, max_length=512, min_length=0,
                  length_penalty=1.0, early_stopping=False, return_top2=False, e1=None):

@@ -139,3 +139,34 @@ def test_stream_large_shape_matches_batch_generate(mode):
         assert lens[n] == wlen[n], (n, lens[n], wlen[n])
         assert np.array_equal(ids[n, :wlen[n]], want[n][:wlen[n]]), n
     eng.set_stream_encoder(1)
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+@pytest.mark.parametrize("chunk,slots,pool_chunks,early", [(4, 3, 2, False), (3, 2, 3, True), (6, 5, 2, False)])
+def test_beam_stream_equals_per_image_beam_search(be_name, chunk, slots, pool_chunks, early):
+    """mg_generate_stream_beam: image slots of K = 3 beams work through a queue of 11 images (the trained fixture's 6, repeated in another
+    order: their searches stop at different steps).  Every image's best hypothesis, its length and its score equal what
+    generate(num_beams=3) returns for that image alone - the reference's call (batch size 1, utils_evaluation.py:140, 269-285)."""
+    g = load_golden("g3_trained_tiny.npz")
+    shape, sd = _weights(g)
+    inp = _inputs(g, shape)
+    K, T = 3, int(g["max_length"])
+    eng = make_engine(be_name, shape, sd)
+    want = []
+    for b in range(inp["input_ids"].shape[0]):
+        one = {k: v[b:b + 1] for k, v in inp.items()}
+        ids, scores, _ = eng.generate(one["input_ids"], one["bbox"], one["attention_mask"], one["pixel_values"], num_beams=K, max_length=T,
+                                      early_stopping=early)
+        ids = _np(eng, ids)
+        want.append((ids[0].copy(), float(_np(eng, scores)[0]), int(ids.shape[1])))
+    order = np.array([0, 3, 5, 1, 2, 4, 4, 0, 1, 5, 2])
+    q = _queue(inp, order)
+    ids, lens, scores, steps = eng.generate_stream_beam(q["input_ids"], q["bbox"], q["attention_mask"], q["pixel_values"], num_beams=K,
+                                                         max_length=T, early_stopping=early, chunk=chunk, slots=slots, pool_chunks=pool_chunks)
+    ids, lens, scores = _np(eng, ids), _np(eng, lens), _np(eng, scores)
+    for n, b in enumerate(order):
+        row, sc, cols = want[b]
+        assert lens[n] == cols, (n, b, lens[n], cols)
+        assert np.array_equal(ids[n, :cols], row[:cols]), (n, b, ids[n].tolist(), row.tolist())
+        assert scores[n] == np.float32(sc), (n, b, scores[n], sc)
+    assert steps <= int(sum(lens)) // slots + len(order) + 48
