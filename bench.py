@@ -651,9 +651,9 @@ def main():
                     o, l, sc, st = ctx.generate_stream_beam(qb["input_ids"], qb["bbox"], qb["attention_mask"], pix, num_beams=5, max_length=512,
                                                             min_length=0, chunk=B, slots=SLOTS_B, pool_chunks=3)
                     return o.cpu().numpy(), l.cpu().numpy(), st
-                job_beam_queue(eng, 0)
+                fl.map(job_beam_queue, range(1))               # (one context: the queue of 256 images alone on the GPU)
                 torch.cuda.synchronize(); t1q = time.time()
-                o1, l1, st1 = job_beam_queue(eng, 0)
+                (o1, l1, st1), = fl.map(job_beam_queue, range(1))
                 torch.cuda.synchronize(); t1q = time.time() - t1q
                 ref_b = outs[0]
                 same_b = all(np.array_equal(o1[n, :min(int(l1[n]), ref_b.shape[1])], ref_b[n % B, :min(int(l1[n]), ref_b.shape[1])]) for n in range(QBq * B))

@@ -322,14 +322,18 @@ class MarkushgrapherForConditionalGeneration(nn.Module):
         self._check_e1(None)
         return InFlight(self._eng(), n)
 
-    def generate_queue(self, encodings, max_length=None, min_length=0, slots=32, chunk=32, contexts=1):
+    def generate_queue(self, encodings, max_length=None, min_length=0, slots=32, chunk=32, contexts=1, num_beams=1, length_penalty=1.0,
+                       early_stopping=False):
         """The reference's evaluation loop (ref: utils/ocsr/utils_evaluation.py:140-285) as ONE call: `encodings` = the per-sample
         dicts it builds (input_ids [1, L_n] or [L_n], bbox, pixel_values; attention_mask / labels ignored as there), greedy,
         max_length as there.  Returns a list of 1-D id tensors - predictions[n] == self.generate(**encodings[n], num_beams=1,
         max_length=max_length)[0] - decoded by the continuous decoder (mg_generate_stream: `slots` rows work through the queue, a row
         that emits EOS hands its slot to the next image) with per-image padding semantics (every image computed as if alone).
         contexts > 1: the queue is cut into that many contiguous parts, each decoded by its own execution context (inflight.InFlight,
-        at most 4) at the same time - same ids, 1.4 x the images/s at 4."""
+        at most 4) at the same time - same ids, 1.4 x the images/s at 4.
+        num_beams > 1 (the reference's shipped setting, config/predict.yaml beam_search: True -> 5): the beam queue (mg_generate_stream_beam,
+        `slots` image slots of num_beams rows, slots * num_beams <= 256); predictions[n] == self.generate(**encodings[n],
+        num_beams=num_beams, ...)[0]."""
         from .assembly import collate_for_generate
         self._check_e1(None)
         eng = self._eng()
@@ -341,6 +345,22 @@ class MarkushgrapherForConditionalGeneration(nn.Module):
         batch = collate_for_generate(feats)
         pix = torch.cat([torch.as_tensor(e["pixel_values"]).reshape(1, *torch.as_tensor(e["pixel_values"]).shape[-3:]) for e in encodings]).to(self.device)
         n = len(feats)
+        num_beams = int(num_beams)
+        if num_beams > 1:
+            slots = max(1, min(int(slots), 256 // num_beams))
+
+        def run(ctx, sl):
+            m = sl.stop - sl.start
+            if num_beams > 1:
+                o, l, _, _ = ctx.generate_stream_beam(batch["input_ids"][sl], batch["bbox"][sl], batch["attention_mask"][sl], pix[sl],
+                                                      num_beams=num_beams, max_length=max_length, min_length=int(min_length),
+                                                      length_penalty=float(length_penalty), early_stopping=bool(early_stopping),
+                                                      chunk=min(chunk, m), slots=min(slots, m), pool_chunks=3)
+            else:
+                o, l, _ = ctx.generate_stream(batch["input_ids"][sl], batch["bbox"][sl], batch["attention_mask"][sl], pix[sl],
+                                              max_length=max_length, min_length=int(min_length), chunk=min(chunk, m), slots=min(slots, m),
+                                              pool_chunks=3)
+            return o, l
         contexts = max(1, min(int(contexts), 4, n // max(1, min(slots, n))))
         prev = eng.set_padding_semantics(True)
         try:
@@ -356,20 +376,14 @@ class MarkushgrapherForConditionalGeneration(nn.Module):
                 torch.cuda.current_stream(self.device).synchronize()      # the inputs are complete before the contexts' streams read them
 
                 def part(ctx, i):
-                    sl = slice(i * per, min(n, (i + 1) * per))
-                    m = sl.stop - sl.start
-                    o, l, _ = ctx.generate_stream(batch["input_ids"][sl], batch["bbox"][sl], batch["attention_mask"][sl], pix[sl],
-                                                  max_length=max_length, min_length=int(min_length), chunk=min(chunk, m), slots=min(slots, m),
-                                                  pool_chunks=3)
-                    return o, l
+                    return run(ctx, slice(i * per, min(n, (i + 1) * per)))
                 outs = self._inflight.map(part, range(-(-n // per)))
                 rows = []
                 for o, l in outs:
                     l = l.cpu().tolist()
                     rows += [o[i, :l[i]] for i in range(len(l))]
                 return rows
-            ids, lens, _ = eng.generate_stream(batch["input_ids"], batch["bbox"], batch["attention_mask"], pix, max_length=max_length,
-                                               min_length=int(min_length), chunk=min(chunk, n), slots=min(slots, n), pool_chunks=3)
+            ids, lens = run(eng, slice(0, n))
         finally:
             eng.set_padding_semantics(prev)
         lens = lens.cpu().tolist()

@@ -196,6 +196,17 @@ def test_generate_queue_equals_the_per_image_loop():
     for _ in range(2):
         got2 = m.generate_queue(encodings, max_length=16, slots=3, chunk=2, contexts=2)
         assert [x.cpu().tolist() for x in got2] == [x.cpu().tolist() for x in got]
+    # the reference's shipped decode mode (config/predict.yaml beam_search: True): the same queue with beam search against the loop
+    # `model.generate(**encoding, num_beams=3, max_length=...)` - the beam queue (image slots of 3 rows), one context and two
+    loop_b = []
+    for e in encodings:
+        enc = {k: v.to(dev) for k, v in e.items()}
+        loop_b.append(m.generate(**enc, num_beams=3, max_length=16)[0].cpu().tolist())
+    for ctxs in (1, 2):
+        got_b = m.generate_queue(encodings, max_length=16, slots=3, chunk=2, num_beams=3, contexts=ctxs)
+        for a, b in zip(got_b, loop_b):
+            a = a.cpu().tolist()
+            assert a == b[:len(a)] and len(a) >= 2, (a, b)
     # and the per-image loop is unaffected afterwards (padding semantics restored)
     e0 = {k: v.to(dev) for k, v in encodings[0].items()}
     assert m.generate(**e0, num_beams=1, max_length=16)[0].cpu().tolist() == loop[0].tolist()
