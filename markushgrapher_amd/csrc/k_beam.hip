@@ -235,6 +235,10 @@ __global__ __launch_bounds__(256) void beam_update_kernel(BeamPtrs p, int B, int
     MG_DYN_SMEM(smem);
     const int b = blockIdx.x, tid = threadIdx.x;
     const int keep = 2 * K, ml = max_len, il = max_len - 1;
+    // Only columns <= cur_len are live: every row of the sequence arrays holds the fill value (the index histories -1) beyond the
+    // column written by the latest step, in every slot, so the gathers below move columns [0, cur_len] ([0, cur_len) for the
+    // histories) and leave the tails as they are - the same arrays as a copy of whole rows, at cur_len / max_len of the traffic.
+    const int mle = cur_len + 1 < ml ? cur_len + 1 : ml, ile = cur_len < il ? cur_len : il;
     int* src = (int*)smem;                  // [16] source beam of candidate c
     int* hit = src + 16;                    // [16]
     int* nxt = hit + 16;                    // [8] candidate chosen as running beam k
@@ -259,17 +263,17 @@ __global__ __launch_bounds__(256) void beam_update_kernel(BeamPtrs p, int B, int
     }
     __syncthreads();
     // top-2K sequences / beam-index histories (utils.py:3115-3127)
-    for (int i = tid; i < keep * ml; i += 256) {
-        const int c = i / ml, j = i - c * ml;
+    for (int i = tid; i < keep * mle; i += 256) {
+        const int c = i / mle, j = i - c * mle;
         int64_t v = rs[(size_t)src[c] * ml + j];
         if (j == cur_len) v = p.topi[b * keep + c] - src[c] * V;
-        ts[i] = v;
+        ts[(size_t)c * ml + j] = v;
     }
-    for (int i = tid; i < keep * il; i += 256) {
-        const int c = i / il, j = i - c * il;
+    for (int i = tid; i < keep * ile; i += 256) {
+        const int c = i / ile, j = i - c * ile;
         int v = ri[(size_t)src[c] * il + j];
         if (j == cur_len - 1) v = src[c] + b * K;
-        tr[i] = v;
+        tr[(size_t)c * il + j] = v;
     }
     if (tid < keep) {
         const float tv = p.topv[b * keep + tid];
@@ -312,19 +316,19 @@ __global__ __launch_bounds__(256) void beam_update_kernel(BeamPtrs p, int B, int
     // new finished set: gathered from the OLD sequences / candidates into temporaries, then copied back
     int64_t* tq = p.tmp_seq + (size_t)b * K * ml;
     int* ti = p.tmp_idx + (size_t)b * K * ml;
-    for (int i = tid; i < K * ml; i += 256) {
-        const int k = i / ml, j = i - k * ml, s2 = sel[k];
-        tq[i] = s2 < K ? sq[(size_t)s2 * ml + j] : ts[(size_t)(s2 - K) * ml + j];
+    for (int i = tid; i < K * mle; i += 256) {
+        const int k = i / mle, j = i - k * mle, s2 = sel[k];
+        tq[(size_t)k * ml + j] = s2 < K ? sq[(size_t)s2 * ml + j] : ts[(size_t)(s2 - K) * ml + j];
     }
-    for (int i = tid; i < K * il; i += 256) {
-        const int k = i / il, j = i - k * il, s2 = sel[k];
-        ti[i] = s2 < K ? bo[(size_t)s2 * il + j] : tr[(size_t)(s2 - K) * il + j];
+    for (int i = tid; i < K * ile; i += 256) {
+        const int k = i / ile, j = i - k * ile, s2 = sel[k];
+        ti[(size_t)k * il + j] = s2 < K ? bo[(size_t)s2 * il + j] : tr[(size_t)(s2 - K) * il + j];
     }
     __syncthreads();
-    for (int i = tid; i < K * ml; i += 256) sq[i] = tq[i];
-    for (int i = tid; i < K * il; i += 256) bo[i] = ti[i];
-    for (int i = tid; i < K * ml; i += 256) { const int k = i / ml, j = i - k * ml; rs[i] = ts[(size_t)nxt[k] * ml + j]; }
-    for (int i = tid; i < K * il; i += 256) { const int k = i / il, j = i - k * il; ri[i] = tr[(size_t)nxt[k] * il + j]; }
+    for (int i = tid; i < K * mle; i += 256) { const int k = i / mle, j = i - k * mle; sq[(size_t)k * ml + j] = tq[(size_t)k * ml + j]; }
+    for (int i = tid; i < K * ile; i += 256) { const int k = i / ile, j = i - k * ile; bo[(size_t)k * il + j] = ti[(size_t)k * il + j]; }
+    for (int i = tid; i < K * mle; i += 256) { const int k = i / mle, j = i - k * mle; rs[(size_t)k * ml + j] = ts[(size_t)nxt[k] * ml + j]; }
+    for (int i = tid; i < K * ile; i += 256) { const int k = i / ile, j = i - k * ile; ri[(size_t)k * il + j] = tr[(size_t)nxt[k] * il + j]; }
     __syncthreads();
     if (tid == 0) {
         float nbs[8], nrs[8];
