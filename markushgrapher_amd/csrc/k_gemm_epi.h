@@ -255,6 +255,98 @@ MG_DEV void resid_norm_epilogue(const GemmArgs& a, const f32x16& acc0, const f32
     }
 }
 
+// The same update for a wave's TI row tiles, with the residual reads BATCHED.  Written tile by tile as above, hipcc emits every
+// 16-byte read of h (and of the gain) followed by s_waitcnt vmcnt(0): a store is pending whenever the next read's value is needed
+// and reads and writes share vmcnt on gfx9, so the compiler drains the queue each time - 16 dependent memory round trips per row
+// tile, 80 per output tile (the 43 us "epilogue" of profiles/r04_b_gemm_pp_whatif.txt is 80 x ~0.5 us of latency, not bandwidth).
+// Here: the 8 reads of a row tile are issued together (untracked, gld16_async) and added INTO the accumulators (which then hold the
+// new h: no second copy in registers), the reads of row tile i + 1 are issued before tile i's stores, and one drained wait per row
+// tile covers both (reads and writes retire out of order with respect to each other, so a counted wait cannot separate them):
+// 5 round trips per output tile.  The gains come from LDS (`gl`: the gains of this wave's 64 columns, staged by the persistent
+// kernel once per launch: `gl` = LDS address of the gains of this wave's 64 columns) or, !staged, from global memory.
+// Same arithmetic per element (h + acc is commutative) and the same order in the partial sums: bit-identical to resid_norm_epilogue.
+template <int TI, bool staged>
+MG_DEV void resid_norm_epilogue_tiles(const GemmArgs& a, f32x16 (&acc)[TI][2], const int (&mrow)[TI], int n0, int lane, mg_lds_t gl) {
+    const int half = lane >> 5, l32 = lane & 31;
+    const bool col_ok[2] = {n0 < a.N, n0 + 32 < a.N};               // (N is a multiple of 32 here: whole tiles only)
+    // addresses: a lane's 4 feature groups of a 32-column tile are 1 KiB apart in the tiled h (immediate offsets off one base per
+    // (row tile, column tile)); its two 16-byte chunks of the packed output are 1 KiB apart as well
+    auto hbase = [&](int i, int j) -> float* {
+        const int m = mrow[i] + l32;
+        return a.out_f32 + ht_off(m < a.M ? m : 0, (col_ok[j] ? n0 + 32 * j : 0) + 4 * half, a.N);
+    };
+    mg_raw16 h[8];
+    auto issue = [&](int i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float* b = hbase(i, j);
+            gld16_async_off<0>(h[j * 4 + 0], b);
+            gld16_async_off<1024>(h[j * 4 + 1], b);
+            gld16_async_off<2048>(h[j * 4 + 2], b);
+            gld16_async_off<3072>(h[j * 4 + 3], b);
+        }
+    };
+    issue(0);
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        MG_WAIT_VMCNT_TIE4(0, h[0], h[1], h[2], h[3]);
+        MG_TIE(h[4]); MG_TIE(h[5]); MG_TIE(h[6]); MG_TIE(h[7]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const uint4 r = raw16_get(h[j * 4 + g]);
+                f32x16& ac = acc[i][j];
+                ac[4 * g] += __uint_as_float(r.x); ac[4 * g + 1] += __uint_as_float(r.y);
+                ac[4 * g + 2] += __uint_as_float(r.z); ac[4 * g + 3] += __uint_as_float(r.w);
+            }
+        MG_TIE(acc[i][0]); MG_TIE(acc[i][1]);          // (the sums exist before the registers of h are handed to the next reads)
+        if (i + 1 < TI) issue(i + 1);
+        const int m = mrow[i] + l32;
+        const bool row_ok = m < a.M;
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (!col_ok[j]) continue;
+            const f32x16& ac = acc[i][j];
+            float* const hb = hbase(i, j);
+            f32x16 xg;
+            const mg_lds_t ga = gl + (32 * j + 4 * half) * 4;       // (staged: gains of columns n0 + 32 j + 4 half + 8 g .. + 3)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 hv = make_float4(ac[4 * g], ac[4 * g + 1], ac[4 * g + 2], ac[4 * g + 3]);
+                if (row_ok) { *(float4*)(hb + g * 256) = hv; ss += (hv.x * hv.x + hv.y * hv.y) + (hv.z * hv.z + hv.w * hv.w); }
+                if (a.gain) {
+                    float4 gv;
+                    if (staged) {
+                        mg_raw16 gr;
+                        if (g == 0) lds_rd16_async<0>(gr, ga); else if (g == 1) lds_rd16_async<32>(gr, ga);
+                        else if (g == 2) lds_rd16_async<64>(gr, ga); else lds_rd16_async<96>(gr, ga);
+                        MG_WAIT_LGKM_TIE(0, gr);
+                        const uint4 r = raw16_get(gr);
+                        gv = make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+                    } else {
+                        gv = *(const float4*)(a.gain + n0 + 32 * j + 8 * g + 4 * half);
+                    }
+                    xg[4 * g] = hv.x * gv.x; xg[4 * g + 1] = hv.y * gv.y; xg[4 * g + 2] = hv.z * gv.z; xg[4 * g + 3] = hv.w * gv.w;
+                }
+            }
+            if (a.gain) {
+                uint4 ch[2];
+                acc_to_chunks(xg, half, ch);
+                uint16_t* const pb = a.out_pk + pk_off(m, n0 + 32 * j + 8 * half, a.N);
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    if (row_ok) st16(pb + q * TILE_ELEMS, ch[q]);
+            }
+        }
+        if (a.part) {
+            ss += __shfl_xor(ss, 32);
+            if (half == 0 && row_ok && col_ok[0]) a.part[(size_t)m * a.ldo + (n0 >> 6)] = ss;      // ldo = partial sums per row
+        }
+    }
+}
+
 MG_DEV bool heads_region_is_T(const HeadsOut& ho, int n) {
     const int ri = n / ho.inner;
     return ho.fmt[ri] == HF_PK_T;
@@ -262,11 +354,11 @@ MG_DEV bool heads_region_is_T(const HeadsOut& ho, int n) {
 
 
 // epilogue of a wave's TI x 2 accumulator tiles (token rows mrow[i] .. mrow[i] + 31, feature columns n0w + 32 j) of the large-M kernels
-template <int EPI, int TI, int XP = 0>
-MG_DEV void xl_epilogue(const GemmArgs& a, f32x16 (&acc)[TI][2], const int (&mrow)[TI], int n0w, bool tor, int lane) {
+// (GAIN_LDS / gain_lds: EPI_RESID_NORM only, see resid_norm_epilogue_tiles)
+template <int EPI, int TI, int XP = 0, bool GAIN_LDS = false>
+MG_DEV void xl_epilogue(const GemmArgs& a, f32x16 (&acc)[TI][2], const int (&mrow)[TI], int n0w, bool tor, int lane, mg_lds_t gain_lds = mg_lds_t()) {
     if constexpr (EPI == EPI_RESID_NORM) {
-#pragma unroll
-        for (int i = 0; i < TI; ++i) resid_norm_epilogue(a, acc[i][0], acc[i][1], mrow[i], n0w, lane);
+        resid_norm_epilogue_tiles<TI, GAIN_LDS>(a, acc, mrow, n0w, lane, gain_lds);
         return;
     }
     float rsv[TI];

@@ -29,6 +29,7 @@ namespace mg {
 // Sums are accumulated in the same order as in gemm_xl_kernel (k ascending per accumulator): results are bit-identical.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int GP_RING = 8, GP_AHEAD = 6, GP_MAXT = 16;          // ring slots, copy lead (k-tiles), tiles per workgroup at most
+constexpr int GP_GAIN_MAX = 2048;                               // EPI_RESID_NORM: the next norm's gains are staged in LDS when N <= this
 
 template <int N>
 MG_DEV void wait_vmcnt_n() {
@@ -116,6 +117,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs a) {
         const int rt = a.row_tiles ? a.row_tiles[idx] : idx;
         rtab[e] = live ? rt : -1 - rt;
         if (ii == 0) rcnt[i * 2 + wrow] = cnt;
+    }
+    float* const gsm = (float*)(rcnt + GP_MAXT * 2);           // EPI_RESID_NORM: gain[0 .. N) (see resid_norm_epilogue_tiles)
+    if constexpr (EPI == EPI_RESID_NORM) {                      // (the launcher keeps N <= GP_GAIN_MAX for this epilogue)
+        if (a.gain)
+            for (int e = tid * 4; e < a.N; e += 512 * 4) *(float4*)(gsm + e) = *(const float4*)(a.gain + e);
     }
     __syncthreads();
 
@@ -264,7 +270,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs a) {
             const int v = rtab[i * XT + wr * TI + ii];
             mrow[ii] = v >= 0 ? v * 32 : a.M;                  // past the end: row index M, every store is guarded by m < M
         }
-        if (!(XP & 2) || acc[0][0][0] == 123456.789f) xl_epilogue<EPI, TI>(a, acc, mrow, n0w, tor, lane);
+        if (!(XP & 2) || acc[0][0][0] == 123456.789f) xl_epilogue<EPI, TI, 0, true>(a, acc, mrow, n0w, tor, lane, mg_lds_addr(gsm) + (n0w < a.N ? n0w : 0) * 4);
         wait_vmcnt_n<0>();            // stores and loads retire out of order with respect to each other: the counted waits of the next tile start from an empty queue
         // copy sources of the next two tiles, recomputed from the LDS table (nothing of them is live across the epilogue)
         if (has_next) {
@@ -289,8 +295,9 @@ static bool launch_pp(const GemmArgs& a_in, mgStream_t stream) {
 #endif
     int G = nblk < ncu ? nblk : ncu;
     if (G >= 8) G &= ~7;
-    if ((a.K & 127) != 0 || (nblk + nblk / 3 + G) > GP_MAXT * G) return false;   // (K/16 a multiple of the ring; balanced blocks are up to 30 % more)
-    const size_t sh = (size_t)GP_RING * (2 * TI + 8) * TILE_BYTES + (size_t)GP_MAXT * (2 * TI + 2) * sizeof(int);
+    if ((a.K & 127) != 0 || (nblk + nblk / 3 + G) > GP_MAXT * G || (EPI == EPI_RESID_NORM && a.N > GP_GAIN_MAX)) return false;   // (K/16 a multiple of the ring; balanced blocks are up to 30 % more)
+    const size_t sh = (size_t)GP_RING * (2 * TI + 8) * TILE_BYTES + (size_t)GP_MAXT * (2 * TI + 2) * sizeof(int) +
+                      (EPI == EPI_RESID_NORM ? (size_t)GP_GAIN_MAX * sizeof(float) : 0);
     static bool once = false;
     if (!once) { MG_SET_MAX_SMEM((&gemm_pp_kernel<EPI, TI>), sh); once = true; }
 #ifdef MG_TOOLS      // what-if variants with WRONG results: tools builds only

@@ -278,6 +278,7 @@ MG_DEV void glds16_async_sv(const char* src_uniform, unsigned lane_off, mg_lds_t
 #ifdef MG_EMU
 typedef uint4 mg_raw16;
 MG_DEV void gld16_async(mg_raw16& dst, const void* p) { dst = *(const uint4*)p; }
+template <int OFF> MG_DEV void gld16_async_off(mg_raw16& dst, const void* p) { dst = *(const uint4*)((const char*)p + OFF); }
 MG_DEV uint4 raw16_get(const mg_raw16& r) { return r; }
 template <int OFF> MG_DEV void lds_rd16_async(mg_raw16& dst, mg_lds_t addr) { dst = *(const uint4*)(addr + OFF); }
 #define MG_WAIT_LGKM_TIE(N, r) ((void)0)
@@ -286,6 +287,10 @@ template <int OFF> MG_DEV void lds_rd16_async(mg_raw16& dst, mg_lds_t addr) { ds
 #else
 typedef unsigned int mg_raw16 __attribute__((ext_vector_type(4)));
 MG_DEV void gld16_async(mg_raw16& dst, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory"); }
+// the same with an immediate byte offset (-4096 .. 4095): several loads off one address register pair
+template <int OFF> MG_DEV void gld16_async_off(mg_raw16& dst, const void* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(p), "n"(OFF) : "memory");
+}
 MG_DEV uint4 raw16_get(const mg_raw16& r) { return make_uint4(r.x, r.y, r.z, r.w); }
 template <int OFF> MG_DEV void lds_rd16_async(mg_raw16& dst, mg_lds_t addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));

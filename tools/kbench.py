@@ -112,6 +112,42 @@ def bench_encgemm():
     lib.mgk_gemm_set_variant(3)
 
 
+def bench_encnorm():
+    """The encoder's residual projections as the encoder runs them (EPI_RESID_NORM: tiled fp32 h += X W^T, bf16(h * gain), partial sums
+    of squares): two-stage kernel (variant 4) vs the persistent ping-pong kernel (5 / 6); bits of h, the packed output and the partial sums compared."""
+    M, d = 40960, 1024
+    lib.mgk_gemm_norm.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 2 + [C.c_int] * 3 + [C.c_void_p] * 4 + \
+                                 [C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float]
+    for name, K in [("o", 1024), ("wo", 4096)]:
+        X = (torch.randn((M * K,), device=dev) * 0.5).to(torch.bfloat16).view(torch.int16)
+        W = (torch.randn((d * K,), device=dev) * 0.05).to(torch.bfloat16).view(torch.int16)
+        h0 = torch.randn((M * d,), device=dev)
+        g = 1 + 0.2 * torch.randn((d,), device=dev)
+        h = h0.clone()
+        xo = torch.empty((M * d,), dtype=torch.int16, device=dev)
+        part = torch.zeros((M, d // 64), dtype=torch.float32, device=dev)
+        ref = None
+        for variant in (4, 5, 6):
+            lib.mgk_gemm_set_variant(variant)
+
+            def f(i):
+                lib.mgk_gemm_norm(stream(), 5, P(X), P(W), M, d, K, P(h), P(g), P(xo), P(part), d // 64, None, 0, 0.0, 0.0)
+            us = timeit(f, iters=20, warm=3)
+            same = []
+            for rep in range(3 if variant != 4 else 1):
+                h.copy_(h0); xo.zero_(); part.zero_()
+                f(0)
+                torch.cuda.synchronize()
+                got = (h.view(torch.int32).clone(), xo.clone(), part.view(torch.int32).clone())
+                if variant == 4:
+                    ref = got
+                else:
+                    same.append(all(bool(torch.equal(a_, b_)) for a_, b_ in zip(got, ref)))
+            print(f"enc norm-gemm {name:3s} M={M} N={d} K={K:4d} variant {variant}: {us:8.1f} us  {2.0 * M * d * K / us / 1e9:7.3f} PFLOP/s"
+                  + ("" if variant == 4 else f"  bits equal to variant 4: {same}"), flush=True)
+    lib.mgk_gemm_set_variant(3)
+
+
 def bench_attn():
     B, H, cap = 32, 16, 1280
     for name, group, lens in [("cross", 1, 1072), ("cross-warm", 1, 1072), ("cross-full", 1, 1280), ("self t=128", 0, 129), ("self t=400", 0, 401)]:
@@ -161,6 +197,8 @@ if __name__ == "__main__":
         bench_gemm()
     if "encgemm" in sys.argv:
         bench_encgemm()
+    if "encnorm" in sys.argv:
+        bench_encnorm()
     if "ppexp" in sys.argv:
         bench_ppexp()
     if "attn" in what:
