@@ -306,6 +306,10 @@ def main():
                     help="batches in flight per GPU: execution contexts (mg_clone) with a stream and host thread each; 1 = one batch "
                          "after the other, as the reference's loop.  (The id exchange - a few small kernels per batch on the null "
                          "stream / RCCL's stream - is a fifth queue in use for microseconds at a time; measured harmless at one GPU.)")
+    ap.add_argument("--batches-per-call", type=int, default=2,
+                    help="batches of `--batch` images handed to ONE generate call of a context (their rows side by side in the decode step: "
+                         "the decoder's weights are read once per step for all of them); every image's ids are bit-identical to a call on "
+                         "its batch alone (tests/test_engine.py::test_rows_do_not_depend_on_the_row_count)")
     args = ap.parse_args()
     if args.pmc_child:
         return pmc_child(args)
@@ -371,24 +375,39 @@ def main():
     from markushgrapher_amd.inflight import InFlight
     fl = InFlight(eng, max(1, args.inflight))
 
-    def job(ctx):
-        pix = ctx.preprocess(dev["pages_u8"])
-        out, _, _ = ctx.generate(dev["input_ids"], dev["bbox"], dev["attention_mask"], pix, num_beams=args.beams,
+    # `--batches-per-call` batches ride in one call (rows [0, B) = one batch, [B, 2B) the next ...): the same preprocess -> encoder ->
+    # decode steps per batch, the decode step's weight stream shared by the batches of the call.  A step count that is not a multiple
+    # of it ends with single-batch calls.
+    bpc = max(1, args.batches_per_call) if args.beams == 1 else 1
+    devn = {k: (torch.cat([v] * bpc, dim=0) if bpc > 1 else v) for k, v in dev.items()}
+
+    def job(ctx, nb=bpc):
+        src = devn if nb == bpc else dev
+        pix = ctx.preprocess(src["pages_u8"])
+        out, _, _ = ctx.generate(src["input_ids"], src["bbox"], src["attention_mask"], pix, num_beams=args.beams,
                                  max_length=max_length, min_length=max_length)
         return out
 
+    last_call = [None]
+
     def run_steps(k):
-        futs = [fl.submit(job) for _ in range(k)]
+        futs = [fl.submit(job) for _ in range(k // bpc)] + [fl.submit(job, 1) for _ in range(k % bpc)]
         out = None
         for f in futs:
-            out = f.result()
-            handles.append(ex.post(out))
-            if len(handles) > 1:
-                ex.wait(handles.pop(0))      # the previous batch's gather has had this batch's whole step to complete
+            res = f.result()
+            last_call[0] = res
+            for j in range(res.shape[0] // B):          # one exchange per batch, as with one batch per call
+                out = res[j * B:(j + 1) * B]
+                handles.append(ex.post(out))
+                if len(handles) > 1:
+                    ex.wait(handles.pop(0))      # the previous batch's gather has had this batch's whole step to complete
         return out
 
     torch.cuda.synchronize()
-    run_steps(max(args.warmup, 1) * len(fl) if args.warmup else 0)      # every context warms up (graph capture) `warmup` times
+    run_steps(max(args.warmup, 1) * len(fl) * bpc if args.warmup else 0)      # every context warms up (graph capture) `warmup` times
+    if args.warmup and args.steps % bpc:
+        for f in [fl.submit(job, 1) for _ in range(len(fl))]:                 # the single-batch shape of the last calls, on every context
+            f.result()
     while handles:
         ex.wait(handles.pop(0))
     # live timing of the dominant kernel on the launch stream (HIP events), sampled every N-th decode step; phase events
@@ -434,8 +453,12 @@ def main():
     # the same step with ONE batch in flight (the reference's loop shape; rounds 1-2 measured this): untimed for `value`, it gives
     # the kernel's and the phases' uncontended figures beside the in-flight ones
     solo = None
-    if len(fl) > 1 and rank == 0:
-        step()
+    ids_call = last_call[0]
+    ids_equal_solo = None
+    if (len(fl) > 1 or bpc > 1) and rank == 0:
+        ids_solo = step()
+        # every batch of the last timed call against ONE call on the batch alone (one context, one batch per call)
+        ids_equal_solo = bool(all(torch.equal(ids_call[j * B:(j + 1) * B], ids_solo) for j in range(ids_call.shape[0] // B)))
         profile_on()
         torch.cuda.synchronize(); ts = time.time()
         for _ in range(SOLO_STEPS):
@@ -445,6 +468,7 @@ def main():
         torch.cuda.synchronize(); ts = time.time() - ts
         solo = (ts,) + profile_read()
     assert ids.shape == (B, max_length), ids.shape
+    assert ids_equal_solo is not False, "ids of a batch inside a multi-batch call differ from the call on the batch alone"
 
     if rank == 0:
         H, d, dff, V = shape.num_heads, shape.d_model, shape.d_ff, shape.vocab_size
@@ -479,19 +503,26 @@ def main():
         bytes_step = 2.0 * (n_dec * 16 * d * d + d * V) + float(np.sum(2 * n_dec * 2 * d * (xlen + tbar)))
         f_step = float(np.sum(n_dec * (12 * d * d + 4 * d * dff) + n_dec * 4 * d * (xlen + tbar) + 2 * d * V))
 
-        def make_phases(n_ph, enc_ms, dec_ms):
+        # a call that holds nb batches streams the weights once per step and every batch's K/V
+        bytes_w = 2.0 * (n_dec * 16 * d * d + d * V)
+
+        def bytes_step_call(nb):
+            return bytes_w + nb * (bytes_step - bytes_w)
+
+        def make_phases(n_ph, enc_ms, dec_ms, nb=1):
             if n_ph.value <= 0 or args.beams != 1:
                 return None
             t_enc = enc_ms.value / n_ph.value * 1e-3
             t_step = dec_ms.value / n_ph.value * 1e-3 / new_tokens
-            return {"encoder_ms": round(t_enc * 1e3, 2), "decode_step_ms": round(t_step * 1e3, 4),
-                    "enc_flops": f_enc + f_xkv, "enc_mfma_frac": round((f_enc + f_xkv) / t_enc / (MFMA_PEAK_TFLOPS * 1e12), 4),
-                    "dec_bytes_step_algorithmic": int(bytes_step), "dec_hbm_frac": round(bytes_step / t_step / (HBM_PEAK_GBS * 1e9), 4),
-                    "dec_mfma_frac": round(f_step / t_step / (MFMA_PEAK_TFLOPS * 1e12), 5)}
+            return {"encoder_ms": round(t_enc * 1e3, 2), "decode_step_ms": round(t_step * 1e3, 4), "batches_per_call": nb,
+                    "enc_flops": nb * (f_enc + f_xkv), "enc_mfma_frac": round(nb * (f_enc + f_xkv) / t_enc / (MFMA_PEAK_TFLOPS * 1e12), 4),
+                    "dec_bytes_step_algorithmic": int(bytes_step_call(nb)),
+                    "dec_hbm_frac": round(bytes_step_call(nb) / t_step / (HBM_PEAK_GBS * 1e9), 4),
+                    "dec_mfma_frac": round(nb * f_step / t_step / (MFMA_PEAK_TFLOPS * 1e12), 5)}
 
-        def whole_job(n_batches, seconds):
+        def whole_job(n_batches, seconds, nb=1):
             # algorithmic bytes of all decode steps and algorithmic flops of everything, over the elapsed time of the region
-            return {"hbm_frac_decode_bytes": round(n_batches * new_tokens * bytes_step / seconds / (HBM_PEAK_GBS * 1e9), 4),
+            return {"hbm_frac_decode_bytes": round(n_batches / nb * new_tokens * bytes_step_call(nb) / seconds / (HBM_PEAK_GBS * 1e9), 4),
                     "mfma_frac_all_flops": round(n_batches * (f_enc + f_xkv + new_tokens * f_step) / seconds / (MFMA_PEAK_TFLOPS * 1e12), 4)}
 
         roof = make_roof(n_l, ms, keys, empty_ms, True)
@@ -499,16 +530,18 @@ def main():
             roof["timing"] = ("HIP events on the launch stream around the device-counter form of the launch the decode graph "
                               "replays: (record, launch, record, record); avg_launch_us = first bracket, uncorrected; "
                               "empty_bracket_us = second bracket (nothing in between); taken on the first execution context during "
-                              "the timed region, i.e. with the other %d batches' kernels sharing the GPU" % (len(fl) - 1))
-            roof["batches_in_flight"] = len(fl)
-        phases = make_phases(n_ph, enc_ms, dec_ms)
+                              "the timed region, i.e. with the other %d contexts' kernels sharing the GPU; a launch covers the %d batch(es) "
+                              "of its call" % (len(fl) - 1, bpc))
+            roof["batches_in_flight"] = len(fl) * bpc
+        phases = make_phases(n_ph, enc_ms, dec_ms, bpc)
         if phases is not None:
             phases["dec_bytes_step_fetched"] = traffic["decode_step_bytes"] if traffic else None
-            phases["batches_in_flight"] = len(fl)
-            phases["whole_job"] = whole_job(args.steps, dt)
+            phases["batches_in_flight"] = len(fl) * bpc
+            phases["whole_job"] = whole_job(args.steps, dt, bpc if args.steps % bpc == 0 else 1)
             phases["note"] = ("phase times: HIP events in mg_generate on the first execution context [preprocess excluded | encoder + "
                               "cross-K/V | decode loop] = one batch's latency while %d batches share the GPU (per-context fractions "
-                              "are of the whole GPU's peak); whole_job = algorithmic decode bytes / all algorithmic flops of the K "
+                              "are of the whole GPU's peak; a call holds `batches_per_call` batches: its encoder flops are theirs together, "
+                              "its step's algorithmic bytes = the weights once + every batch's K/V); whole_job = algorithmic decode bytes / all algorithmic flops of the K "
                               "batches over the timed region; formulas SURVEY.md §8d with S = attended positions per image (mean "
                               "%.0f), t = mean decode position; the decode step is HBM-bound (dec_mfma_frac is reported because "
                               "north_star asks for it); fetched bytes: child run of 8 steps (t < 8), they contain the product "
@@ -688,11 +721,14 @@ def main():
                                    f"decode, {new_tokens} forced new tokens (EOS suppressed), UDOP-large-shaped "
                                    "MarkushGrapher-2 VTL encoder + CXSMILES decoder, recipe weights = tests/golden/g4_bench.npz",
                        "shape": args.shape, "batch_per_gpu": B, "text_len_padded": int(L), "new_tokens": new_tokens,
-                       "num_beams": args.beams, "decode_graph": args.decode_graph, "batches_in_flight": len(fl),
+                       "num_beams": args.beams, "decode_graph": args.decode_graph, "batches_in_flight": len(fl) * bpc,
+                       "contexts": len(fl), "batches_per_call": bpc, "ids_equal_one_batch_calls": ids_equal_solo,
                        "single_rank_rccl_group": bool(force_dist),
-                       "in_flight": "execution contexts on one set of weights (mg_clone), a stream + host thread + workspace each; every "
-                                    "step is one whole batch start to end; ids identical to one-at-a-time calls; warm-up = `warmup` "
-                                    "batches per context",
+                       "in_flight": "execution contexts on one set of weights (mg_clone), a stream + host thread + workspace each; a call "
+                                    "of a context takes `batches_per_call` batches of 32 (rows side by side: one pass over the decoder's "
+                                    "weights per step for all of them); every step is one whole batch start to end; ids identical to "
+                                    "one-batch-at-a-time calls (checked in this run: ids_equal_one_batch_calls); warm-up = `warmup` "
+                                    "calls per context",
                        "parallelism": f"dp{world} (independent image shards; one RCCL all-gather of [32,512] int32 ids + lengths per batch)"},
             "roofline": roof, "phases": phases, "one_batch_in_flight": single, "extra_runs": extra,
         }

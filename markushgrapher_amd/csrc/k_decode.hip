@@ -324,10 +324,13 @@ void attention_step(const AttnStepArgs& a, mgStream_t stream) {
     const int owners = (a.rows + G - 1) / G;
     const dim3 grid(owners * a.H);
     // 8 waves per (row or image, head) - 128 keys per round, more loads in flight per CU - unless the grid alone fills
-    // the chip with the short self-attention streams (beam search: rows x heads >= 1024 workgroups), where 4 waves
-    // win.  Measured end to end: greedy B=32 (512 workgroups) 8 waves +1.2 % over 4, 16 waves -3 %; beam-5 (2560
-    // workgroups) 4 waves +4 % over 8.
-    const bool eight = a.len != nullptr || grid.x < 1024;
+    // the chip with the short self-attention streams (beam search), where 4 waves win.  Measured end to end: greedy B=32
+    // (512 workgroups) 8 waves +1.2 % over 4, 16 waves -3 %; beam-5 (2560 workgroups) 4 waves +4 % over 8.
+    // The choice must not depend on the number of rows in the call: the waves partition the keys, so 4 and 8 waves merge
+    // their online-softmax partials in different orders and a row's bits would change with its batch size (64 greedy rows
+    // used to switch to 4 waves: a row decoded in a 64-row call differed from the same row in a 32-row call).  Beam rows
+    // (ancestor table) take 4 waves, everything else 8.
+    const bool eight = a.len != nullptr || a.anc == nullptr;
     const int NW = eight ? 8 : 4;
     const dim3 block(NW * 64);
     const size_t sh = (size_t)NW * G * 8 * 10 * sizeof(float);

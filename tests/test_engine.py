@@ -350,6 +350,47 @@ def test_batch_independence_and_determinism_large():
         assert np.array_equal(_np(eng, ids1)[0], ids4[b])
 
 
+@pytest.mark.parametrize("be_name", BACKENDS)
+def test_rows_do_not_depend_on_the_row_count(be_name):
+    """A row's encoder output and greedy ids are the same bits whether its call holds one 32-row tile of decode rows or two (bench.py
+    puts two batches into one call so that a decode step streams the decoder's weights once for both): 40 images in ONE call (rows
+    32-39 in the second row tile) against five calls of 8.  Guards the rule that no kernel of the step picks its reduction shape from
+    the number of rows (the self-attention once switched from 8 to 4 key-partitioning waves at 64 rows)."""
+    shape = synth.SHAPES["mid" if be_name == "hip" else "tiny"]
+    sd = synth.recipe_state_dict(shape, gain=1.0)
+    eng = make_engine(be_name, shape, sd, max_decode_len=32)
+    n, T = 40, 14
+    inp = synth.synth_batch(shape, n, L_min=12, L_max=20, seed=11)
+    enc, _ = eng.encode(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"])
+    enc = _np(eng, enc).copy()
+    ids, _, _ = eng.generate(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"], max_length=T, min_length=T)
+    ids = _np(eng, ids).copy()
+    assert len({tuple(r) for r in ids.tolist()}) > 1          # (not one degenerate sequence)
+    for lo in range(0, n, 8):
+        part = {k: v[lo:lo + 8] for k, v in inp.items()}
+        e8, _ = eng.encode(part["input_ids"], part["bbox"], part["attention_mask"], part["pixel_values"])
+        assert np.array_equal(_np(eng, e8), enc[lo:lo + 8]), lo
+        i8, _, _ = eng.generate(part["input_ids"], part["bbox"], part["attention_mask"], part["pixel_values"], max_length=T, min_length=T)
+        assert np.array_equal(_np(eng, i8), ids[lo:lo + 8]), lo
+
+
+@pytest.mark.gpu
+def test_two_batches_in_one_call_large_shape():
+    """The benchmark's call shape: two batches of 32 (the benchmark inputs and recipe weights) as ONE 64-row call against the batch
+    alone - ids of both halves bit-identical over 48 forced tokens."""
+    shape = synth.SHAPES["large"]
+    eng = make_engine("hip", shape, synth.recipe_state_dict(shape, **synth.BENCH_RECIPE), max_decode_len=64)
+    inp = synth.synth_batch(shape, 32, seed=synth.BENCH_SEED)
+    T = 49
+    one, _, _ = eng.generate(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"], max_length=T, min_length=T)
+    one = _np(eng, one).copy()
+    two = {k: np.concatenate([v, v[::-1]], 0) for k, v in inp.items()}          # (second batch in another row order)
+    both, _, _ = eng.generate(two["input_ids"], two["bbox"], two["attention_mask"], two["pixel_values"], max_length=T, min_length=T)
+    both = _np(eng, both)
+    assert np.array_equal(both[:32], one)
+    assert np.array_equal(both[32:][::-1], one)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # edge cases: shortest / longest inputs, single image, fully padded rows, maximum decode length
 # ---------------------------------------------------------------------------------------------------------
