@@ -154,7 +154,7 @@ def ocr_stage_run(B=32, new_tokens=256):
                       "greedy, EOS impossible; vision tower / prefill: one kernel per operation with fp32 intermediates; decode step: 4 launches per layer at one row tile (rotary grouped-query attention + cache append, o_proj + norm, gate/up + SwiGLU, [down_proj + norm | next QKV]), replayed as a HIP graph"}
 
 
-def configs4_run(eng, B, new_tokens, ocr_pages=128, n_scripts=32, ocr_slots=0, main_inflight=1, ocr_inflight=1):
+def configs4_run(eng, B, new_tokens, ocr_pages=128, n_scripts=32, ocr_slots=0, main_inflight=1, ocr_inflight=1, main_batch=None):
     """BASELINE configs[4] measured as ONE loop on one GPU (markushgrapher_amd/pipeline.py): 128 IP5-M-shaped pages (1024 px u8 crops,
     resident) -> device LANCZOS -> ChemicalOCR (SmolDocling-256M geometry, 128 pages per call) -> text -> cells -> tokens -> VTL encoder +
     256-token greedy decode (continuous decoder, 32 slots).  No OCR checkpoint / tokenizer model exists offline: the OCR model's lm_head
@@ -176,10 +176,10 @@ def configs4_run(eng, B, new_tokens, ocr_pages=128, n_scripts=32, ocr_slots=0, m
     prompts = np.concatenate([scripted_prompts(s, chains, starts)] * (ocr_pages // n_scripts), axis=0)
     longest = max(len(c) for c in chains)
     pipe = Configs4Pipeline(ocr, eng, make_udop_tokenizer(), lambda row: detokenize(id_to_piece, row, s.eos_token_id, s.pad_token_id), prompts,
-                            ocr_max_new_tokens=longest + 8, max_length=new_tokens + 1, min_length=new_tokens + 1, continuous=True, main_batch=B,
+                            ocr_max_new_tokens=longest + 8, max_length=new_tokens + 1, min_length=new_tokens + 1, continuous=True, main_batch=main_batch or B,
                             ocr_slots=ocr_slots, main_inflight=main_inflight, ocr_inflight=ocr_inflight)
     if main_inflight > 1:
-        pipe.continuous = False          # forced-length decode: one mg_generate per 32 pages and context
+        pipe.continuous = False          # forced-length decode: one mg_generate per `main_batch` pages and context
     pages = torch.from_numpy(synth.synth_pages_u8(32, 1024, synth.BENCH_SEED)).cuda()
     pages = torch.cat([pages] * (ocr_pages // 32), dim=0)
 
@@ -197,6 +197,7 @@ def configs4_run(eng, B, new_tokens, ocr_pages=128, n_scripts=32, ocr_slots=0, m
     return {"pages_per_s": round(ocr_pages / dt, 2), "pages": ocr_pages, "ms_total": round(dt * 1e3, 1),
             "ocr_s": round(res.timings["ocr_s"], 3), "host_s": round(res.timings["host_s"], 3),
             "main_s": round(res.timings["main_s"], 3),
+            "vtl_pages_per_call": int(main_batch or B),
             "stages": (f"one after the other; OCR stage on {ocr_inflight} execution context(s), VTL stage on {main_inflight}"
                        + (" (host stage pipelined with it: main_s contains host_s)" if main_inflight > 1 else "")),
             "ocr_form": (f"queue form, {ocr_slots} decode rows, {res.timings.get('ocr_steps')} steps" if ocr_slots else "batch form: every call walks to its longest page"),
@@ -639,7 +640,7 @@ def main():
                     sl = slice(i * per, (i + 1) * per)
                     pix = torch.cat([ctx.preprocess(dev["pages_u8"]) for _ in range(per // B)], dim=0)
                     o, l, st = ctx.generate_stream(qf["input_ids"][sl], qf["bbox"][sl], qf["attention_mask"][sl], pix, max_length=512,
-                                                   min_length=0, chunk=B, slots=B, pool_chunks=3)
+                                                   min_length=0, chunk=B, slots=bpc * B, pool_chunks=2 + bpc)
                     return o.cpu().numpy(), l.cpu().numpy(), st
                 fl.map(job_stream, range(len(fl)))
                 torch.cuda.synchronize(); tq = time.time()
@@ -648,7 +649,7 @@ def main():
                 ids_q = np.concatenate([r[0] for r in res_q]); len_q = np.concatenate([r[1] for r in res_q])
                 same_q = all(np.array_equal(ids_q[n, :len_q[n]], ie[n % B, :len_q[n]]) for n in range(QF * B))
                 extra["eos_enabled_continuous_in_flight"] = {
-                    "images_per_s": round(QF * B / tq, 2), "queue_images": QF * B, "contexts": len(fl), "slots_per_context": B,
+                    "images_per_s": round(QF * B / tq, 2), "queue_images": QF * B, "contexts": len(fl), "slots_per_context": bpc * B,
                     "decode_steps_run_per_context": [int(r[2]) for r in res_q], "speedup_vs_batch_calls": round(QF * B / tq / (B / te), 2),
                     "ids_equal_batch_calls": bool(same_q),
                     "config": "a queue of 1024 images cut over the execution contexts of the headline run, one continuous decoder each"}
@@ -704,6 +705,11 @@ def main():
                 for c in fl.contexts:
                     c.set_stream_encoder(1)
             eng.load_state_dict({"shared.weight": sd["shared.weight"]})
+            # the contexts of the runs above keep workspaces sized by their largest call (64 rows x 512 positions: 15 GB each, the queues'
+            # K/V pools beside them); the stages below bring their own contexts
+            for c in [eng] + list(fl.contexts):
+                c.release_workspaces()
+            torch.cuda.empty_cache()
             extra["ocr_stage"] = ocr_stage_run()
             if not args.no_cpu_baseline:
                 extra["ocr_stage"]["cpu_baseline"] = ocr_cpu_baseline()
@@ -712,7 +718,9 @@ def main():
             extra["configs4_end_to_end_1gpu_one_context"] = configs4_run(eng, B, new_tokens, ocr_pages=512, ocr_slots=256)
             # the same 512 pages with several batches in flight inside each stage: the OCR stage's pages over 4 execution contexts of the
             # OCR model (128 decode rows each), the VTL stage's batches of 32 over 4 contexts, host stage pipelined with the VTL stage
-            extra["configs4_end_to_end_1gpu"] = configs4_run(eng, B, new_tokens, ocr_pages=512, ocr_slots=128, main_inflight=4, ocr_inflight=4)
+            # (the VTL calls take two batches of 32 pages each, as the headline run's calls do)
+            extra["configs4_end_to_end_1gpu"] = configs4_run(eng, B, new_tokens, ocr_pages=512, ocr_slots=128, main_inflight=4, ocr_inflight=4,
+                                                             main_batch=bpc * B)
         out = {
             "metric": METRIC, "value": round(world * B * args.steps / dt, 3), "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),

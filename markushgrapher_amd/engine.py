@@ -164,6 +164,18 @@ class Engine:
         other._ws, other._ws_bytes, other._gen_out, other.ignored_keys = None, 0, {}, list(self.ignored_keys)
         return other
 
+    def release_workspaces(self):
+        """Drop the cached workspaces and output buffers of this context (they are re-allocated by the next call that needs them).  A
+        workspace is sized by the largest call the context has seen (14 GB for 64 rows x 512 positions at the large shape): a process
+        that moves on to another stage with its own contexts gives the memory back first.  The captured decode graph replays on the
+        workspace it was captured on, so the library forgets it as well (mg_set_decode_graph re-arms the capture)."""
+        self.mem.sync()
+        self._ws, self._ws_bytes, self._gen_out = None, 0, {}
+        self._sws, self._sws_bytes = None, 0
+        if self.model:
+            prev = self.lib.mg_set_decode_graph(self.model, 0)
+            self.lib.mg_set_decode_graph(self.model, prev)
+
     def close(self):
         if self.model:
             self.lib.mg_destroy(self.model)

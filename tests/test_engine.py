@@ -357,7 +357,7 @@ def test_rows_do_not_depend_on_the_row_count(be_name):
     32-39 in the second row tile) against five calls of 8.  Guards the rule that no kernel of the step picks its reduction shape from
     the number of rows (the self-attention once switched from 8 to 4 key-partitioning waves at 64 rows)."""
     shape = synth.SHAPES["mid" if be_name == "hip" else "tiny"]
-    sd = synth.recipe_state_dict(shape, gain=1.0)
+    sd = synth.recipe_state_dict(shape, **synth.BENCH_RECIPE)          # (the recipe whose sequences do not collapse onto one token)
     eng = make_engine(be_name, shape, sd, max_decode_len=32)
     n, T = 40, 14
     inp = synth.synth_batch(shape, n, L_min=12, L_max=20, seed=11)
