@@ -307,10 +307,11 @@ def main():
                     help="batches in flight per GPU: execution contexts (mg_clone) with a stream and host thread each; 1 = one batch "
                          "after the other, as the reference's loop.  (The id exchange - a few small kernels per batch on the null "
                          "stream / RCCL's stream - is a fifth queue in use for microseconds at a time; measured harmless at one GPU.)")
-    ap.add_argument("--batches-per-call", type=int, default=2,
-                    help="batches of `--batch` images handed to ONE generate call of a context (their rows side by side in the decode step: "
-                         "the decoder's weights are read once per step for all of them); every image's ids are bit-identical to a call on "
-                         "its batch alone (tests/test_engine.py::test_rows_do_not_depend_on_the_row_count)")
+    ap.add_argument("--batches-per-call", type=int, default=4,
+                    help="at most that many batches of `--batch` images (<= 4: 128 rows) in ONE generate call of a context (their rows side "
+                         "by side in the decode step: the decoder's weights are read once per step for all of them); the `--steps` batches are "
+                         "cut into near-equal calls so that every context is busy to the end; every image's ids are bit-identical to a call "
+                         "on its batch alone (tests/test_engine.py::test_rows_do_not_depend_on_the_row_count)")
     args = ap.parse_args()
     if args.pmc_child:
         return pmc_child(args)
@@ -376,23 +377,43 @@ def main():
     from markushgrapher_amd.inflight import InFlight
     fl = InFlight(eng, max(1, args.inflight))
 
-    # `--batches-per-call` batches ride in one call (rows [0, B) = one batch, [B, 2B) the next ...): the same preprocess -> encoder ->
-    # decode steps per batch, the decode step's weight stream shared by the batches of the call.  A step count that is not a multiple
-    # of it ends with single-batch calls.
-    bpc = max(1, args.batches_per_call) if args.beams == 1 else 1
-    devn = {k: (torch.cat([v] * bpc, dim=0) if bpc > 1 else v) for k, v in dev.items()}
+    # up to `--batches-per-call` batches ride in one call (rows [0, B) = one batch, [B, 2B) the next ...): the same preprocess ->
+    # encoder -> decode steps per batch, the decode step's weight stream shared by the batches of the call.
+    bpc = max(1, min(4, args.batches_per_call)) if args.beams == 1 else 1
+    devn = {1: dev}
+    for nb_ in range(2, bpc + 1):
+        devn[nb_] = {k: torch.cat([v] * nb_, dim=0) for k, v in dev.items()}
 
-    def job(ctx, nb=bpc):
-        src = devn if nb == bpc else dev
+    def plan_calls(k):
+        """k batches over the contexts: every context gets k / n of them (the remainder spread), cut into calls of at most `bpc` batches of
+        near-equal size - all contexts stay busy until the end (20 batches on 4 contexts: a call of 3 and a call of 2 each).  Returned in
+        submission order (first calls of every context, then the second ones ...)."""
+        n = len(fl)
+        per_ctx = []
+        for i in range(n):
+            q = k // n + (1 if i < k % n else 0)
+            c = -(-q // bpc) if q else 0
+            per_ctx.append([q // c + (1 if j < q % c else 0) for j in range(c)] if c else [])
+        order = []
+        for j in range(max((len(x) for x in per_ctx), default=0)):
+            order += [x[j] for x in per_ctx if j < len(x)]
+        return order
+
+    calls_on_first = []          # batches per call of the calls that ran on the first context (the one the phase events are read from)
+
+    def job(ctx, nb):
+        src = devn[nb]
         pix = ctx.preprocess(src["pages_u8"])
         out, _, _ = ctx.generate(src["input_ids"], src["bbox"], src["attention_mask"], pix, num_beams=args.beams,
                                  max_length=max_length, min_length=max_length)
+        if ctx is eng:
+            calls_on_first.append(nb)
         return out
 
     last_call = [None]
 
-    def run_steps(k):
-        futs = [fl.submit(job) for _ in range(k // bpc)] + [fl.submit(job, 1) for _ in range(k % bpc)]
+    def run_calls(sizes):
+        futs = [fl.submit(job, nb) for nb in sizes]
         out = None
         for f in futs:
             res = f.result()
@@ -404,11 +425,18 @@ def main():
                     ex.wait(handles.pop(0))      # the previous batch's gather has had this batch's whole step to complete
         return out
 
+    # warm-up: every call size of the timed plan once on every context (graph capture per shape; len(fl) long jobs submitted together land
+    # on len(fl) different contexts), then whole plans until at least `warmup` batches have run
+    timed_plan = plan_calls(args.steps)
     torch.cuda.synchronize()
-    run_steps(max(args.warmup, 1) * len(fl) * bpc if args.warmup else 0)      # every context warms up (graph capture) `warmup` times
-    if args.warmup and args.steps % bpc:
-        for f in [fl.submit(job, 1) for _ in range(len(fl))]:                 # the single-batch shape of the last calls, on every context
-            f.result()
+    if args.warmup:
+        warmed = 0
+        for nb_ in sorted(set(timed_plan)):
+            run_calls([nb_] * len(fl))
+            warmed += nb_ * len(fl)
+        while warmed < args.warmup:
+            run_calls(timed_plan)
+            warmed += args.steps
     while handles:
         ex.wait(handles.pop(0))
     # live timing of the dominant kernel on the launch stream (HIP events), sampled every N-th decode step; phase events
@@ -439,7 +467,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.time()
-    ids = run_steps(args.steps)
+    del calls_on_first[:]
+    ids = run_calls(timed_plan)
+    nb_first = float(np.mean(calls_on_first)) if calls_on_first else float(np.mean(timed_plan))
     while handles:
         all_ids, all_len = ex.wait(handles.pop(0))      # the last batch's exchange completes inside the timed region
     torch.cuda.synchronize()
@@ -532,13 +562,13 @@ def main():
                               "replays: (record, launch, record, record); avg_launch_us = first bracket, uncorrected; "
                               "empty_bracket_us = second bracket (nothing in between); taken on the first execution context during "
                               "the timed region, i.e. with the other %d contexts' kernels sharing the GPU; a launch covers the %d batch(es) "
-                              "of its call" % (len(fl) - 1, bpc))
-            roof["batches_in_flight"] = len(fl) * bpc
-        phases = make_phases(n_ph, enc_ms, dec_ms, bpc)
+                              "of its call" % (len(fl) - 1, int(round(nb_first))))
+            roof["batches_in_flight"] = int(sum(timed_plan[:len(fl)]))
+        phases = make_phases(n_ph, enc_ms, dec_ms, nb_first)
         if phases is not None:
             phases["dec_bytes_step_fetched"] = traffic["decode_step_bytes"] if traffic else None
-            phases["batches_in_flight"] = len(fl) * bpc
-            phases["whole_job"] = whole_job(args.steps, dt, bpc if args.steps % bpc == 0 else 1)
+            phases["batches_in_flight"] = int(sum(timed_plan[:len(fl)]))
+            phases["whole_job"] = whole_job(args.steps, dt, args.steps / max(len(timed_plan), 1))
             phases["note"] = ("phase times: HIP events in mg_generate on the first execution context [preprocess excluded | encoder + "
                               "cross-K/V | decode loop] = one batch's latency while %d batches share the GPU (per-context fractions "
                               "are of the whole GPU's peak; a call holds `batches_per_call` batches: its encoder flops are theirs together, "
@@ -640,7 +670,7 @@ def main():
                     sl = slice(i * per, (i + 1) * per)
                     pix = torch.cat([ctx.preprocess(dev["pages_u8"]) for _ in range(per // B)], dim=0)
                     o, l, st = ctx.generate_stream(qf["input_ids"][sl], qf["bbox"][sl], qf["attention_mask"][sl], pix, max_length=512,
-                                                   min_length=0, chunk=B, slots=bpc * B, pool_chunks=2 + bpc)
+                                                   min_length=0, chunk=B, slots=min(bpc, 2) * B, pool_chunks=2 + min(bpc, 2))
                     return o.cpu().numpy(), l.cpu().numpy(), st
                 fl.map(job_stream, range(len(fl)))
                 torch.cuda.synchronize(); tq = time.time()
@@ -649,7 +679,7 @@ def main():
                 ids_q = np.concatenate([r[0] for r in res_q]); len_q = np.concatenate([r[1] for r in res_q])
                 same_q = all(np.array_equal(ids_q[n, :len_q[n]], ie[n % B, :len_q[n]]) for n in range(QF * B))
                 extra["eos_enabled_continuous_in_flight"] = {
-                    "images_per_s": round(QF * B / tq, 2), "queue_images": QF * B, "contexts": len(fl), "slots_per_context": bpc * B,
+                    "images_per_s": round(QF * B / tq, 2), "queue_images": QF * B, "contexts": len(fl), "slots_per_context": min(bpc, 2) * B,
                     "decode_steps_run_per_context": [int(r[2]) for r in res_q], "speedup_vs_batch_calls": round(QF * B / tq / (B / te), 2),
                     "ids_equal_batch_calls": bool(same_q),
                     "config": "a queue of 1024 images cut over the execution contexts of the headline run, one continuous decoder each"}
@@ -729,8 +759,9 @@ def main():
                                    f"decode, {new_tokens} forced new tokens (EOS suppressed), UDOP-large-shaped "
                                    "MarkushGrapher-2 VTL encoder + CXSMILES decoder, recipe weights = tests/golden/g4_bench.npz",
                        "shape": args.shape, "batch_per_gpu": B, "text_len_padded": int(L), "new_tokens": new_tokens,
-                       "num_beams": args.beams, "decode_graph": args.decode_graph, "batches_in_flight": len(fl) * bpc,
-                       "contexts": len(fl), "batches_per_call": bpc, "ids_equal_one_batch_calls": ids_equal_solo,
+                       "num_beams": args.beams, "decode_graph": args.decode_graph, "batches_in_flight": int(sum(timed_plan[:len(fl)])),
+                       "contexts": len(fl), "batches_per_call_max": bpc, "batches_per_call": timed_plan,
+                       "ids_equal_one_batch_calls": ids_equal_solo,
                        "single_rank_rccl_group": bool(force_dist),
                        "in_flight": "execution contexts on one set of weights (mg_clone), a stream + host thread + workspace each; a call "
                                     "of a context takes `batches_per_call` batches of 32 (rows side by side: one pass over the decoder's "

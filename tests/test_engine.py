@@ -354,12 +354,12 @@ def test_batch_independence_and_determinism_large():
 def test_rows_do_not_depend_on_the_row_count(be_name):
     """A row's encoder output and greedy ids are the same bits whether its call holds one 32-row tile of decode rows or two (bench.py
     puts two batches into one call so that a decode step streams the decoder's weights once for both): 40 images in ONE call (rows
-    32-39 in the second row tile) against five calls of 8.  Guards the rule that no kernel of the step picks its reduction shape from
+    32-39 in the second row tile; 104 images = four row tiles on the GPU) against calls of 8.  Guards the rule that no kernel of the step picks its reduction shape from
     the number of rows (the self-attention once switched from 8 to 4 key-partitioning waves at 64 rows)."""
     shape = synth.SHAPES["mid" if be_name == "hip" else "tiny"]
     sd = synth.recipe_state_dict(shape, **synth.BENCH_RECIPE)          # (the recipe whose sequences do not collapse onto one token)
     eng = make_engine(be_name, shape, sd, max_decode_len=32)
-    n, T = 40, 14
+    n, T = (104, 14) if be_name == "hip" else (40, 14)          # (hip: four row tiles; the emulator checks two)
     inp = synth.synth_batch(shape, n, L_min=12, L_max=20, seed=11)
     enc, _ = eng.encode(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"])
     enc = _np(eng, enc).copy()
@@ -375,20 +375,23 @@ def test_rows_do_not_depend_on_the_row_count(be_name):
 
 
 @pytest.mark.gpu
-def test_two_batches_in_one_call_large_shape():
-    """The benchmark's call shape: two batches of 32 (the benchmark inputs and recipe weights) as ONE 64-row call against the batch
-    alone - ids of both halves bit-identical over 48 forced tokens."""
+@pytest.mark.parametrize("nb", [2, 4])
+def test_several_batches_in_one_call_large_shape(nb):
+    """The benchmark's call shapes: nb batches of 32 (the benchmark inputs and recipe weights) as ONE call of 32 nb rows against the
+    batch alone - ids of every batch bit-identical over 48 forced tokens (the FFN output projection keeps its 16 K-partitioning waves
+    up to 4 row tiles for this)."""
     shape = synth.SHAPES["large"]
     eng = make_engine("hip", shape, synth.recipe_state_dict(shape, **synth.BENCH_RECIPE), max_decode_len=64)
     inp = synth.synth_batch(shape, 32, seed=synth.BENCH_SEED)
     T = 49
     one, _, _ = eng.generate(inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"], max_length=T, min_length=T)
     one = _np(eng, one).copy()
-    two = {k: np.concatenate([v, v[::-1]], 0) for k, v in inp.items()}          # (second batch in another row order)
-    both, _, _ = eng.generate(two["input_ids"], two["bbox"], two["attention_mask"], two["pixel_values"], max_length=T, min_length=T)
-    both = _np(eng, both)
-    assert np.array_equal(both[:32], one)
-    assert np.array_equal(both[32:][::-1], one)
+    many = {k: np.concatenate([v if j % 2 == 0 else v[::-1] for j in range(nb)], 0) for k, v in inp.items()}   # (odd batches in reverse row order)
+    got, _, _ = eng.generate(many["input_ids"], many["bbox"], many["attention_mask"], many["pixel_values"], max_length=T, min_length=T)
+    got = _np(eng, got)
+    for j in range(nb):
+        part = got[32 * j:32 * j + 32]
+        assert np.array_equal(part if j % 2 == 0 else part[::-1], one), j
 
 
 # ---------------------------------------------------------------------------------------------------------
