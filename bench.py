@@ -291,7 +291,7 @@ def pmc_traffic(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--shape", default="large")
     ap.add_argument("--batch", type=int, default=32)

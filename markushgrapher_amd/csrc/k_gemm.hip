@@ -1111,7 +1111,12 @@ MG_DEV void resid_block(const ResidArgs& a, int bid, char* smem) {
 //   A operand (weights): lane (r16 = l%16, kg = l/16) <- chunk (row 8*sub + r16, k-half kg&1) of k-tile 2p + kg/2
 //   B operand (tokens 16g .. 16g+15 of an m-tile): same chunk addressing on the activation tile
 //   D: lane holds features 4*kg + j (valid: kg < 2) of token 16g + r16
-template <int MT, int NW, int U, bool TRACE = false>
+// F16: the workgroup owns 16 output features (every row of the MFMA's A operand carries weights) instead of 8 - half the
+// workgroups, each pulling the whole activation block once: half the activation bytes through L2 for the projection.  The forms
+// with several row tiles use it (their time is the L2 -> CU traffic of the activations: 128 workgroups x 1 MB at 128 rows of the
+// FFN output projection); the one-tile forms keep 8 features (more workgroups streaming weights: latency).  Each output element is
+// the same chain of MFMAs and the partial sums of squares keep their 8-feature groups: bit-identical either way.
+template <int MT, int NW, int U, bool TRACE = false, bool F16 = false>
 MG_DEV void resid_block16(const ResidArgs& a, int bid, char* smem, long long* trace = nullptr) {
     static_assert(MT <= NW, "at most two finishing units per wave");
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1124,8 +1129,9 @@ MG_DEV void resid_block16(const ResidArgs& a, int bid, char* smem, long long* tr
     };
     stamp(0);
     const int r16 = lane & 15, kg = lane >> 4;
-    const int nt = bid >> 2, sub = bid & 3;
-    const bool wvalid = r16 < 8;
+    const int nt = F16 ? bid >> 1 : bid >> 2, sub = F16 ? bid & 1 : bid & 3;
+    const bool wvalid = F16 || r16 < 8;
+    const bool kgvalid = F16 || kg < 2;                       // lanes whose 4 accumulator registers are output features
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
     const int M = a.M, N = a.N;
     const int kt16 = a.K >> 4, kp = kt16 >> 1;                 // pairs of k-tiles
@@ -1133,14 +1139,14 @@ MG_DEV void resid_block16(const ResidArgs& a, int bid, char* smem, long long* tr
     const int p0 = w * per, p1 = (p0 + per) < kp ? (p0 + per) : kp;
     float* rsl = (float*)(smem + NW * 8 * 64 * sizeof(float));     // [32*MT]
     const size_t lane_off = (size_t)(kg >> 1) * TILE_BYTES + (size_t)(kg & 1) * 512;
-    const char* wp = (const char*)(a.W + pk_tile_off(nt, 0, a.K)) + lane_off + (size_t)(8 * sub + r16) * 16;
+    const char* wp = (const char*)(a.W + pk_tile_off(nt, 0, a.K)) + lane_off + (size_t)((F16 ? 16 : 8) * sub + r16) * 16;
     const int xkts = a.x_kts ? a.x_kts : kt16;
     const char* xp = (const char*)a.X + (size_t)a.x_k0 * TILE_BYTES + lane_off + (size_t)r16 * 16;
     // load order = wait order (the vector-memory queue retires in order): row-scale partials and the residual slice
     // first (small, L2), then the weight stream (HBM); the activation fragments follow in the MFMA loop
     RsRegs rsr;
     rs_issue(a.rs, M, 32 * MT, tid, NW * 64, rsr);
-    const int n0 = nt * 32 + sub * 8 + kg * 4;                  // this lane's 4 features (kg < 2)
+    const int n0 = nt * 32 + sub * (F16 ? 16 : 8) + kg * 4;     // this lane's 4 features (kgvalid)
     // the (m-tile, token group) unit this wave finishes: unit f = 2*i + g goes to wave f (2*MT <= NW), so the two token
     // groups of a tile are reduced and stored by two waves in parallel
     // (with more than NW/2 row tiles a wave takes a second unit, f + NW)
@@ -1148,7 +1154,7 @@ MG_DEV void resid_block16(const ResidArgs& a, int bid, char* smem, long long* tr
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int f = w + q * NW;
-        if (f < 2 * MT && kg < 2) {
+        if (f < 2 * MT && kgvalid) {
             const int m = 32 * (f >> 1) + 16 * (f & 1) + r16;
             if (m < M) h_pre[q] = *(const float4*)(a.h + (size_t)m * N + n0);
         }
@@ -1233,7 +1239,7 @@ MG_DEV void resid_block16(const ResidArgs& a, int bid, char* smem, long long* tr
                     v[j] = t * rsl[32 * i + 16 * g + r16];
                 }
                 float ss = 0.f;
-                if (m < M && kg < 2) {
+                if (m < M && kgvalid) {
                     float4 hv = h_pre[q];
                     hv.x += v[0]; hv.y += v[1]; hv.z += v[2]; hv.w += v[3];
                     *(float4*)(a.h + (size_t)m * N + n0) = hv;
@@ -1247,8 +1253,9 @@ MG_DEV void resid_block16(const ResidArgs& a, int bid, char* smem, long long* tr
                     if (a.x2_pk)
                         *(uint2*)(a.x2_pk + pk_off(m, a.x2_col0 + n0, x2_ld)) = make_uint2(pack_bf16(hv.x, hv.y), pack_bf16(hv.z, hv.w));
                 }
-                ss += __shfl_xor(ss, 16);                        // features 0-3 (kg 0) + 4-7 (kg 1)
-                if (m < M && kg == 0) a.part[(size_t)m * nparts + bid] = ss;
+                ss += __shfl_xor(ss, 16);                        // features 0-3 (kg 0) + 4-7 (kg 1)  [F16: and 8-11 (kg 2) + 12-15 (kg 3)]
+                if (F16) { if (m < M && (kg & 1) == 0) a.part[(size_t)m * nparts + 2 * bid + (kg >> 1)] = ss; }
+                else if (m < M && kg == 0) a.part[(size_t)m * nparts + bid] = ss;
             }
             stamp(5);
         }
@@ -1256,11 +1263,11 @@ MG_DEV void resid_block16(const ResidArgs& a, int bid, char* smem, long long* tr
     }
     stamp(6);
 }
-template <int MT, int NW>
+template <int MT, int NW, bool F16 = false>
 __global__ __launch_bounds__(NW * 64) void gemm_rows_resid_kernel(ResidArgs a) {
     MG_DYN_SMEM(smem);
     // pairs of k-tiles per wave and round: 8 covers K = 4096 over 16 waves, 4 covers K = 1024 over 8 waves, in one round
-    resid_block16<MT, NW, (NW >= 16 ? 8 : 4)>(a, blockIdx.x, smem);
+    resid_block16<MT, NW, (NW >= 16 ? 8 : 4), false, F16>(a, blockIdx.x, smem);
 }
 
 template <int NW>
@@ -1366,6 +1373,8 @@ void gemm_rows_resid_trace(const ResidArgs& r, long long* trace, mgStream_t stre
 }
 #endif
 
+static int g_resid_f16 = 1;
+void gemm_rows_set_resid_f16(int on) { g_resid_f16 = on; }
 void gemm_rows_resid(const ResidArgs& r, mgStream_t stream) {
     int mt = (r.M + 31) / 32;
     const int mts = rows_split_tiles(mt, (size_t)r.N * r.K);                  // row tiles per workgroup, grid.y = groups (shift_rows)
@@ -1390,9 +1399,18 @@ void gemm_rows_resid(const ResidArgs& r, mgStream_t stream) {
         else MG_LAUNCH((gemm_rows_resid_rowsplit_kernel<8>), grid, block, sh, stream, r);
         return;
     }
+    // several row tiles: 16 features per workgroup (see resid_block16 F16); g_resid_f16 = 0: the 8-feature form (tests, A/B runs)
+    const bool f16 = mt >= 2 && (r.N & 15) == 0 && g_resid_f16;
+    const dim3 grid16(r.N / 16);
+    // Measured and rejected (profiles/r04_r_resid_row_groups_rejected.txt): the row tiles of the long K = d_ff projection in groups over
+    // grid.y (a workgroup pulls its rows and the weight slice through ONE CU's 64 B/clk: 1.1 MB at 128 rows) - alone the launch drops
+    // from 20.5 to 12.9 (groups of 2 tiles) / 8.8 us (1 tile), with four contexts in flight the run is SLOWER (142.1 -> 141.2 / 137.6
+    // images/s): in flight the bytes moved through L2 count, not a launch's latency, and the groups re-read the weight slice.
 #define MG_RR(MTV)                                                                                 \
     case MTV:                                                                                      \
-        if (wide) MG_LAUNCH((gemm_rows_resid_kernel<MTV, 16>), grid, block, sh, stream, r);        \
+        if (f16 && wide) MG_LAUNCH((gemm_rows_resid_kernel<MTV, 16, true>), grid16, block, sh, stream, r);   \
+        else if (f16) MG_LAUNCH((gemm_rows_resid_kernel<MTV, 8, true>), grid16, block, sh, stream, r);       \
+        else if (wide) MG_LAUNCH((gemm_rows_resid_kernel<MTV, 16>), grid, block, sh, stream, r);   \
         else MG_LAUNCH((gemm_rows_resid_kernel<MTV, 8>), grid, block, sh, stream, r);              \
         break;
     switch (mt) {
@@ -1420,10 +1438,10 @@ __global__ __launch_bounds__(512) void gemm_rows_pair_split_kernel(ResidArgs r, 
     const int u = (int)blockIdx.x - nres;
     rows_split_block<EPI, 8, 8>(g, (u >> 4) * 8 + (u & 7), (u >> 3) & 1, smem);
 }
-template <int EPI, int MT, bool HALF>
+template <int EPI, int MT, bool HALF, bool F16 = false>
 __global__ __launch_bounds__(512) void gemm_rows_pair_kernel(ResidArgs r, GemmArgs g, int nres) {
     MG_DYN_SMEM(smem);
-    if ((int)blockIdx.x < nres) resid_block16<MT, 8, 4>(r, blockIdx.x, smem);
+    if ((int)blockIdx.x < nres) resid_block16<MT, 8, 4, false, F16>(r, blockIdx.x, smem);
     else if constexpr (HALF) rows_block16<EPI, MT, 8, 8>(g, (int)blockIdx.x - nres, smem);     // K = d + inner: 8 pairs per wave
     else rows_block<EPI, MT, false, 8, 16>(g, (int)blockIdx.x - nres, smem);
 }
@@ -1442,20 +1460,24 @@ void gemm_rows_pair(const ResidArgs& r, const GemmArgs& g, int epi, mgStream_t s
         MG_LAUNCH((gemm_rows_pair_split_kernel<EPI_HEADS>), dim3(nres_s + 2 * nhalf), dim3(512), shs, stream, r, g, nres_s);
         return;
     }
-    const int nres = r.N / 8, nrows = ((g.N + 31) / 32) * (full ? 1 : 2);
+    const bool f16 = mt >= 2 && (r.N & 15) == 0 && g_resid_f16;      // residual part: 16 features per workgroup (resid_block16 F16)
+    const int nres = f16 ? r.N / 16 : r.N / 8, nrows = ((g.N + 31) / 32) * (full ? 1 : 2);
     const dim3 grid(nres + nrows), block(512);
     const size_t sh = (size_t)8 * 16 * 64 * sizeof(float) + (size_t)32 * mt * sizeof(float);
+#define MG_RP2(MTV, FV)                                                                                              \
+        if (epi == EPI_PK_RELU && full) MG_LAUNCH((gemm_rows_pair_kernel<EPI_PK_RELU, MTV, false, FV>), grid, block, sh, stream, r, g, nres); \
+        else if (epi == EPI_PK_RELU) MG_LAUNCH((gemm_rows_pair_kernel<EPI_PK_RELU, MTV, true, FV>), grid, block, sh, stream, r, g, nres); \
+        else if (epi == EPI_F32_STORE) MG_LAUNCH((gemm_rows_pair_kernel<EPI_F32_STORE, MTV, true, FV>), grid, block, sh, stream, r, g, nres); \
+        else MG_LAUNCH((gemm_rows_pair_kernel<EPI_HEADS, MTV, true, FV>), grid, block, sh, stream, r, g, nres);
 #define MG_RP(MTV)                                                                                                   \
     case MTV:                                                                                                        \
-        if (epi == EPI_PK_RELU && full) MG_LAUNCH((gemm_rows_pair_kernel<EPI_PK_RELU, MTV, false>), grid, block, sh, stream, r, g, nres); \
-        else if (epi == EPI_PK_RELU) MG_LAUNCH((gemm_rows_pair_kernel<EPI_PK_RELU, MTV, true>), grid, block, sh, stream, r, g, nres); \
-        else if (epi == EPI_F32_STORE) MG_LAUNCH((gemm_rows_pair_kernel<EPI_F32_STORE, MTV, true>), grid, block, sh, stream, r, g, nres); \
-        else MG_LAUNCH((gemm_rows_pair_kernel<EPI_HEADS, MTV, true>), grid, block, sh, stream, r, g, nres);          \
+        if (f16) { MG_RP2(MTV, true) } else { MG_RP2(MTV, false) }                                                   \
         break;
     switch (mt) {
         MG_RP(1) MG_RP(2) MG_RP(3) MG_RP(4) MG_RP(5) MG_RP(6) MG_RP(7) MG_RP(8)
         default: break;
     }
+#undef MG_RP2
 #undef MG_RP
 }
 

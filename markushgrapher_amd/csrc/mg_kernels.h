@@ -87,6 +87,7 @@ void gemm_set_variant(int v);   // 0: 128x128 kernel only; 1: + 256x128 three-st
 
 // small-M (decode step) GEMM: M <= 32*MT rows of live sequences, weights streamed once.
 void gemm_rows(const GemmArgs& a, int epi, mgStream_t stream);
+void gemm_rows_set_resid_f16(int on);  // 1 (default): residual projections with several row tiles take 16 features per workgroup; 0: 8 (tests, A/B runs; same bits)
 void gemm_rows_set_split(int mode);   // row-tile split policy of the decode projections (-1 default by weight size, 0 never, 1 always one tile per workgroup)
 
 // split-K decode GEMM: P[ks][m*ldp + n] (ks < KS) = partial sums over the ks-th K range; consumers add the slabs

@@ -629,6 +629,37 @@ def test_attention_encoder_skips_padded_stages(be_name):
 
 
 @pytest.mark.parametrize("be_name", BACKENDS)
+@pytest.mark.parametrize("M,N,K", [(70, 64, 256), (128, 96 + 32, 4096), (150, 64, 256)])
+def test_residual_projection_feature_width_forms_are_bit_identical(be_name, M, N, K):
+    """Residual projections with several row tiles: 16 output features per workgroup (the default: half the activation bytes through
+    L2) against 8 (the one-tile forms' width).  Every output element is the same chain of MFMAs and the partial sums of squares keep
+    their 8-feature groups: h, the packed bf16(h * gain) and the partial sums must be the SAME BITS; K = 4096 takes the 16-wave form."""
+    if be_name == "emu" and K > 1024:
+        M = 64
+    be = get_backend(be_name)
+    be.lib.mgk_gemm_resid.argtypes = [C.c_void_p] * 5 + [C.c_float] + [C.c_void_p] * 2 + [C.c_int] * 3 + [C.c_void_p, C.c_int, C.c_float, C.c_float]
+    x, w = rnd((M, K), 310), rnd((N, K), 311, 0.1)
+    h0, g = rnd((M, N), 312), 1 + 0.2 * rnd((N,), 313)
+    Mp = (M + 31) // 32 * 32
+    Xp, Wp, G = be.buf(pk.pack_tiles(x)), be.buf(pk.pack_tiles(w)), be.buf(g)
+    res = {}
+    try:
+        for f16 in (0, 1):
+            assert be.lib.mgk_set_resid_f16(f16) == 0
+            h = be.buf(h0)
+            xp = be.zeros((Mp * N,), np.uint16)
+            part = be.zeros((Mp, N // 8), np.float32)
+            assert be.lib.mgk_gemm_resid(be.stream, be.p(Xp), be.p(Wp), be.p(h), be.p(G), 0.5, be.p(xp), be.p(part), M, N, K, None, 0, 0.0, 0.0) == 0
+            res[f16] = [np.array(a.numpy(), copy=True) for a in (h, xp, part)]
+    finally:
+        be.lib.mgk_set_resid_f16(1)
+    np.testing.assert_allclose(res[1][0], h0 + pk.bf16_round(x) @ pk.bf16_round(w).T, rtol=1e-4, atol=5e-4)
+    np.testing.assert_allclose(res[1][2][:M].sum(1), (res[1][0] ** 2).sum(1), rtol=1e-4)
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b)
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
 def test_decode_projections_row_tile_split_modes_are_bit_identical(be_name):
     """More than one 32-row tile of live sequences (beam search, the OCR stage at large batch): the decode projections either walk
     their row tiles in one workgroup (mode 0) or run one tile per workgroup (mode 1: grid.y and shifted argument views, the default
