@@ -776,6 +776,10 @@ def main():
         else:
             out["cpu_baseline"] = None
         out["setup_s"] = {"recipe_weights": round(t_weights, 1)}
+        try:
+            C.CDLL(None).fflush(None)        # RCCL's version banner sits in the C runtime's stdout buffer: out with it BEFORE the result line
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
