@@ -243,13 +243,15 @@ def pmc_child(args):
     eng = Engine(shape, max_decode_len=64)
     eng.load_state_dict(synth.recipe_state_dict(shape, **synth.BENCH_RECIPE))
     inp = synth.synth_batch(shape, args.batch, seed=synth.BENCH_SEED, return_pages=True)
+    nb = max(1, args.pmc_batches)                  # batches in the call, as in the parent's timed calls
+    inp = {k: np.concatenate([np.asarray(v)] * nb, axis=0) for k, v in inp.items()}
     pix = eng.preprocess(inp["pages_u8"])
     eng.generate(inp["input_ids"], inp["bbox"], inp["attention_mask"], pix, max_length=args.pmc_child + 1,
                  min_length=args.pmc_child + 1)
     torch.cuda.synchronize()
 
 
-def pmc_traffic(args):
+def pmc_traffic(args, nb=1):
     """HBM bytes from the L2's memory-side read counters: FETCH_SIZE per dispatch (KiB; x2 on gfx950 for wide coalesced
     streams, MI355X_MICROARCH.md 'HBM') of the cross-attention kernel and of a whole decode step, from a child run of
     this script under `rocprofv3 --pmc FETCH_SIZE --kernel-trace` (counters in their own run).  None if unavailable."""
@@ -261,7 +263,8 @@ def pmc_traffic(args):
     try:
         env = dict(os.environ, TMPDIR="/tmp")
         subprocess.run([exe, "--pmc", "FETCH_SIZE", "--kernel-trace", "-d", tmp, "-o", "pmc", "--", sys.executable,
-                        os.path.abspath(__file__), "--pmc-child", str(steps), "--shape", args.shape, "--batch", str(args.batch)],
+                        os.path.abspath(__file__), "--pmc-child", str(steps), "--shape", args.shape, "--batch", str(args.batch),
+                        "--pmc-batches", str(nb)],
                        cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=420, check=False)
         import sqlite3
         db = None
@@ -274,12 +277,13 @@ def pmc_traffic(args):
         rows = sqlite3.connect(db).execute(
             "select kernel_name, value from counters_collection where counter_name = 'FETCH_SIZE'").fetchall()
         xa = [v for n, v in rows if "attn_step_kernel<1, 8, true" in n]
+        xa = [v for v in xa if v > 0.5 * max(xa)] if xa else xa          # (the launches of the call itself)
         dec = [v for n, v in rows if any(k in n for k in ("attn_step_kernel", "gemm_rows", "greedy_select", "embed_norm_rows"))]
         if not xa or not dec:
             return None
         return {"cross_attention_bytes_per_launch": int(sum(xa) / len(xa) * 1024 * 2),
                 "decode_step_bytes": int(sum(dec) / steps * 1024 * 2),
-                "source": f"rocprofv3 --pmc FETCH_SIZE --kernel-trace on a child run of bench.py ({steps} decode steps, same batch): "
+                "source": f"rocprofv3 --pmc FETCH_SIZE --kernel-trace on a child run of bench.py ({steps} decode steps, one call of {nb} batch(es)): "
                           "FETCH_SIZE KiB x 1024 x 2 (gfx950 reports half the bytes of wide coalesced reads; other access "
                           "widths uncalibrated)"}
     except Exception:
@@ -301,6 +305,7 @@ def main():
     ap.add_argument("--no-extra-runs", action="store_true", help="skip the EOS-enabled and beam-5 side measurements")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 FETCH_SIZE child pass")
     ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-batches", type=int, default=1, help=argparse.SUPPRESS)
     ap.add_argument("--profile-every", type=int, default=16)
     ap.add_argument("--decode-graph", type=int, default=1, help="1: replay the captured decode-step HIP graph; 0: eager launches")
     ap.add_argument("--inflight", type=int, default=4,
@@ -484,6 +489,7 @@ def main():
     # the same step with ONE batch in flight (the reference's loop shape; rounds 1-2 measured this): untimed for `value`, it gives
     # the kernel's and the phases' uncontended figures beside the in-flight ones
     solo = None
+    solo_call = None
     ids_call = last_call[0]
     ids_equal_solo = None
     if (len(fl) > 1 or bpc > 1) and rank == 0:
@@ -498,6 +504,26 @@ def main():
             ex.wait(handles.pop(0))
         torch.cuda.synchronize(); ts = time.time() - ts
         solo = (ts,) + profile_read()
+        # ... and ONE call of the timed region's largest call shape alone on the first context: the dominant launch and the phases of
+        # that shape without other contexts' kernels beside them
+        nb_main = max(timed_plan) if timed_plan else 1
+        if nb_main > 1:
+            def call_alone():
+                res = job(eng, nb_main)
+                for j in range(res.shape[0] // B):
+                    handles.append(ex.post(res[j * B:(j + 1) * B]))
+                    if len(handles) > 1:
+                        ex.wait(handles.pop(0))
+            with torch.cuda.stream(fl.streams[0]):
+                call_alone()
+                profile_on()
+                torch.cuda.synchronize(); tc = time.time()
+                for _ in range(2):
+                    call_alone()
+                while handles:
+                    ex.wait(handles.pop(0))
+                torch.cuda.synchronize(); tc = time.time() - tc
+            solo_call = (tc, nb_main) + profile_read()
     assert ids.shape == (B, max_length), ids.shape
     assert ids_equal_solo is not False, "ids of a batch inside a multi-batch call differ from the call on the batch alone"
 
@@ -507,7 +533,7 @@ def main():
         # attended encoder positions per image (what the path computes on; padding excluded from the algorithmic work)
         _, msk = eng.encode(dev["input_ids"], dev["bbox"], dev["attention_mask"], eng.preprocess(dev["pages_u8"]))
         xlen = msk.sum(dim=1).cpu().numpy().astype(np.float64)
-        traffic = None if (args.no_pmc or world > 1 or args.beams != 1) else pmc_traffic(args)
+        traffic = None if (args.no_pmc or world > 1 or args.beams != 1) else pmc_traffic(args, int(round(nb_first)))
         def make_roof(n_l, ms, keys, empty_ms, with_traffic):
             if n_l.value <= 0:
                 return None
@@ -586,6 +612,14 @@ def main():
                       "whole_job": whole_job(SOLO_STEPS, ts),
                       "note": "the same step with one batch in flight (one context, one stream): the loop shape of the reference and of "
                               "rounds 1-2; kernel and phase figures without other batches' kernels beside them"}
+        call_alone_rep = None
+        if solo_call is not None:
+            tc, nbm = solo_call[0], solo_call[1]
+            call_alone_rep = {"batches_per_call": nbm, "images_per_s": round(B * nbm * 2 / tc, 2), "ms_per_call": round(tc / 2 * 1e3, 2), "calls": 2,
+                              "roofline": make_roof(*solo_call[2:6], False), "phases": make_phases(*solo_call[6:9], nbm),
+                              "note": "one call of the timed region's largest shape alone on one context (no other contexts' kernels beside it): the "
+                                      "dominant launch streams the cross-attention K/V of all its batches in one grid; agrees with the rocprofv3 kernel "
+                                      "trace of `bench.py --inflight 1` (profiles/)"}
         extra = None
         if not args.no_extra_runs and world == 1 and args.beams == 1:
             extra = {}
@@ -769,7 +803,7 @@ def main():
                                     "one-batch-at-a-time calls (checked in this run: ids_equal_one_batch_calls); warm-up = `warmup` "
                                     "calls per context",
                        "parallelism": f"dp{world} (independent image shards; one RCCL all-gather of [32,512] int32 ids + lengths per batch)"},
-            "roofline": roof, "phases": phases, "one_batch_in_flight": single, "extra_runs": extra,
+            "roofline": roof, "phases": phases, "one_call_alone": call_alone_rep, "one_batch_in_flight": single, "extra_runs": extra,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(shape, sd)
