@@ -389,20 +389,12 @@ def main():
     for nb_ in range(2, bpc + 1):
         devn[nb_] = {k: torch.cat([v] * nb_, dim=0) for k, v in dev.items()}
 
+    from markushgrapher_amd.inflight import plan_calls as _plan_calls
+
     def plan_calls(k):
-        """k batches over the contexts: every context gets k / n of them (the remainder spread), cut into calls of at most `bpc` batches of
-        near-equal size - all contexts stay busy until the end (20 batches on 4 contexts: a call of 3 and a call of 2 each).  Returned in
-        submission order (first calls of every context, then the second ones ...)."""
-        n = len(fl)
-        per_ctx = []
-        for i in range(n):
-            q = k // n + (1 if i < k % n else 0)
-            c = -(-q // bpc) if q else 0
-            per_ctx.append([q // c + (1 if j < q % c else 0) for j in range(c)] if c else [])
-        order = []
-        for j in range(max((len(x) for x in per_ctx), default=0)):
-            order += [x[j] for x in per_ctx if j < len(x)]
-        return order
+        # k batches over the contexts in near-equal calls of at most `bpc` batches (markushgrapher_amd/inflight.py): every context stays
+        # busy to the end (20 batches on 4 contexts: a call of 3 and a call of 2 each)
+        return _plan_calls(k, len(fl), bpc)
 
     calls_on_first = []          # batches per call of the calls that ran on the first context (the one the phase events are read from)
 

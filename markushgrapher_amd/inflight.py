@@ -26,6 +26,22 @@ def shared_streams(torch, device, n):
     return lst[:n]
 
 
+def plan_calls(k, n_contexts, max_per_call):
+    """Cut `k` equal-shaped batches into calls for `n_contexts` execution contexts: every context gets k / n of them (the remainder
+    spread), cut into calls of at most `max_per_call` batches of near-equal size, so that all contexts stay busy to the end (20 batches
+    on 4 contexts, at most 4 per call: a call of 3 and a call of 2 each).  Returns the batches per call in submission order (the first
+    calls of every context, then the second ones ...)."""
+    per_ctx = []
+    for i in range(n_contexts):
+        q = k // n_contexts + (1 if i < k % n_contexts else 0)
+        c = -(-q // max_per_call) if q else 0
+        per_ctx.append([q // c + (1 if j < q % c else 0) for j in range(c)] if c else [])
+    order = []
+    for j in range(max((len(x) for x in per_ctx), default=0)):
+        order += [x[j] for x in per_ctx if j < len(x)]
+    return order
+
+
 class InFlight:
     """`submit(fn, *args)` runs `fn(ctx, *args)` on the next free context and returns a future; `map(fn, items)` keeps the order.
 
@@ -82,6 +98,36 @@ class InFlight:
     def map(self, fn, items):
         futures = [self.submit(fn, it) for it in items]
         return [f.result() for f in futures]
+
+    def generate_batches(self, batches, max_batches_per_call=4, **gen_kwargs):
+        """Greedy `generate` over a list of batches (dicts with input_ids / bbox / attention_mask / pixel_values of EQUAL shapes: the same
+        number of rows and the same padded text length) with up to `max_batches_per_call` of them per call (rows side by side: one pass
+        over the decoder's weights per step for the call's batches; up to 128 rows per call every image's ids are bit-identical to a call
+        on its batch alone) and the calls spread over the contexts (plan_calls).  Returns one host array of ids per batch, in order."""
+        import numpy as np
+        torch = self._torch
+        if gen_kwargs.get("num_beams", 1) != 1:
+            max_batches_per_call = 1
+        keys = ("input_ids", "bbox", "attention_mask", "pixel_values")
+        sizes = plan_calls(len(batches), len(self), max(1, int(max_batches_per_call)))
+        rows = int(batches[0]["input_ids"].shape[0]) if batches else 0
+
+        def cat(parts):
+            if torch is not None and all(hasattr(p, "device") for p in parts):
+                return torch.cat(list(parts), dim=0)
+            return np.concatenate([np.asarray(p) for p in parts], axis=0)
+
+        def job(ctx, group):
+            args = [cat([b[k] for b in group]) for k in keys]
+            out = ctx.generate(*args, **gen_kwargs)[0]
+            out = out.cpu().numpy() if hasattr(out, "cpu") else np.array(out, copy=True)
+            return [out[j * rows:(j + 1) * rows] for j in range(len(group))]
+
+        futures, lo = [], 0
+        for nb in sizes:
+            futures.append(self.submit(job, batches[lo:lo + nb]))
+            lo += nb
+        return [ids for f in futures for ids in f.result()]
 
     def close(self):
         self._pool.shutdown(wait=True)

@@ -6,6 +6,8 @@ every context.  The reference has no counterpart: it runs one batch at a time (u
 import numpy as np
 import pytest
 
+from markushgrapher_amd import synth
+from markushgrapher_amd.inflight import InFlight
 from tests.backends import make_engine
 from tests.conftest import load_golden
 from tests.test_oracle_golden import _weights, _inputs
@@ -134,6 +136,39 @@ def test_inflight_helper_on_emulator_keeps_order_and_contexts():
     assert 1 <= len(seen) <= 2
     with pytest.raises(ValueError):
         InFlight(eng, 5)
+
+
+def test_plan_calls_keeps_every_context_busy():
+    from markushgrapher_amd.inflight import plan_calls
+    assert plan_calls(20, 4, 4) == [3, 3, 3, 3, 2, 2, 2, 2]
+    assert plan_calls(16, 4, 4) == [4, 4, 4, 4]
+    assert plan_calls(8, 4, 4) == [2, 2, 2, 2]
+    assert plan_calls(5, 4, 4) == [2, 1, 1, 1]
+    assert plan_calls(3, 4, 4) == [1, 1, 1]
+    assert plan_calls(0, 4, 4) == []
+    assert plan_calls(7, 1, 3) == [3, 2, 2]
+    for k in range(0, 40):
+        for n in (1, 2, 4):
+            for m in (1, 2, 4):
+                p = plan_calls(k, n, m)
+                assert sum(p) == k and all(1 <= x <= m for x in p)
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+def test_generate_batches_equals_one_call_per_batch(be_name):
+    """InFlight.generate_batches (several batches per call, calls spread over the contexts) returns for every batch the ids of a call
+    on the batch alone (two contexts, five batches of 9 rows: calls of 2 and 1 batches; on the GPU the calls overlap in time)."""
+    shape = synth.SHAPES["tiny" if be_name == "emu" else "mid"]
+    sd = synth.recipe_state_dict(shape, **synth.BENCH_RECIPE)
+    eng = make_engine(be_name, shape, sd, max_decode_len=32)
+    inp = synth.synth_batch(shape, 45, L_min=10, L_max=16, seed=3)
+    batches = [{k: v[9 * i:9 * i + 9] for k, v in inp.items()} for i in range(5)]
+    ref = [_gen(eng, b, max_length=8, min_length=8) for b in batches]
+    with InFlight(eng, 2) as fl:
+        got = fl.generate_batches(batches, max_batches_per_call=2, max_length=8, min_length=8)
+    assert len(got) == 5
+    for g, r in zip(got, ref):
+        assert np.array_equal(g, r)
 
 
 def test_one_call_at_a_time_per_context():
