@@ -113,7 +113,7 @@ class InFlight:
         rows = int(batches[0]["input_ids"].shape[0]) if batches else 0
 
         def cat(parts):
-            if torch is not None and all(hasattr(p, "device") for p in parts):
+            if torch is not None and all(torch.is_tensor(p) for p in parts):          # (numpy 2 arrays have a .device too)
                 return torch.cat(list(parts), dim=0)
             return np.concatenate([np.asarray(p) for p in parts], axis=0)
 
