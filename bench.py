@@ -485,6 +485,7 @@ def main():
     ids_call = last_call[0]
     ids_equal_solo = None
     if (len(fl) > 1 or bpc > 1) and rank == 0:
+        eng.set_shared_gpu(False)        # the context runs alone from here on (InFlight had set it: mg_set_shared_gpu)
         ids_solo = step()
         # every batch of the last timed call against ONE call on the batch alone (one context, one batch per call)
         ids_equal_solo = bool(all(torch.equal(ids_call[j * B:(j + 1) * B], ids_solo) for j in range(ids_call.shape[0] // B)))
@@ -516,6 +517,7 @@ def main():
                     ex.wait(handles.pop(0))
                 torch.cuda.synchronize(); tc = time.time() - tc
             solo_call = (tc, nb_main) + profile_read()
+        eng.set_shared_gpu(len(fl) > 1)
     assert ids.shape == (B, max_length), ids.shape
     assert ids_equal_solo is not False, "ids of a batch inside a multi-batch call differ from the call on the batch alone"
 

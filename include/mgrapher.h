@@ -185,6 +185,12 @@ int mg_set_decode_graph(mg_model* m, int enable);
  * patches follow its own last attended text token and its result is what the reference's batch-size-1 loop computes for it
  * (/root/reference/markushgrapher/utils/ocsr/utils_evaluation.py:140), whatever its batch mates are.  Returns the previous setting. */
 int mg_set_padding_semantics(mg_model* m, int per_image);
+/* Several execution contexts share the GPU (mg_clone; markushgrapher_amd/inflight.py sets it on the contexts it runs).  shared = 1: the one
+ * long-lived, chip-filling launch of a decode step - the cross-attention K/V stream - keeps ONE workgroup per CU resident instead of four, so
+ * that the latency-sized launches of the other contexts find wave slots (4 contexts x 128 rows: 143 -> 148 images/s; a call alone: 107 -> 103,
+ * hence off by default).  Same kernels, same results.  Takes effect from the context's next call (its captured decode step is dropped).
+ * Returns the previous setting.  No counterpart in the reference (one batch at a time, utils_evaluation.py:269-285). */
+int mg_set_shared_gpu(mg_model* m, int shared);
 /* 1 if the last mg_generate replayed a captured graph, 0 if it launched eagerly (mode 0/2, capture unavailable). */
 int mg_decode_graph_active(const mg_model* m);
 

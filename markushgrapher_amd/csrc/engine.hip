@@ -95,6 +95,7 @@ struct mg_model {
     std::vector<float> beam_div_host;
     int use_graph = 1;
     bool graph_active = false;
+    int shared_gpu = 0;       // mg_set_shared_gpu: other contexts run beside this one (the cross-attention stream keeps one workgroup per CU resident)
     // optional phase timing of mg_generate (HIP events): [start, encoder + cross-K/V done, decode loop done]
     bool phase_on = false;
     mgEvent_t phase_ev[3] = {};
@@ -620,7 +621,8 @@ static void decode_step(mg_model* m, const DecodeCtx& c, int t, const int* tdev,
         AttnStepArgs x{};
         x.q = c.dq; x.qrs = rs1; x.Kc = c.xk + li * xkv_stride; x.Vc = c.xv + li * xkv_stride; x.ctx = c.xb; x.ctx_ld = K2;
         x.ctx_col0 = d; x.rows = R; x.H = H; x.group = K; x.cap = Sx_cap; x.len = c.xlen;
-        x.live = live; x.kv_owner = (K > 1 && stream) ? c.bpool : c.slots.pool;       // (beams: one owner per image slot = group of K rows)
+        x.live = live; x.kv_owner = (K > 1 && stream) ? c.bpool : c.slots.pool;
+        x.one_wg_per_cu = m->shared_gpu;       // (beams: one owner per image slot = group of K rows)
         const bool timed = time_cross && m->prof_used + 3 <= m->prof_ev.size();
         if (timed) mg_event_record(m->prof_ev[m->prof_used], st);
         attention_step(x, st);
@@ -1665,6 +1667,14 @@ int mg_set_decode_graph(mg_model* m, int enable) {
     return prev;
 }
 int mg_decode_graph_active(const mg_model* m) { return m && m->graph_active ? 1 : 0; }
+int mg_set_shared_gpu(mg_model* m, int shared) {
+    if (!m) return fail(MG_E_ARG, "mg_set_shared_gpu: null model");
+    std::lock_guard<std::recursive_mutex> lk(m->call_mu);
+    const int prev = m->shared_gpu;
+    m->shared_gpu = shared ? 1 : 0;
+    if (prev != m->shared_gpu) { m->step_graph.reset(); m->stream_graph.reset(); }      // (the captured launches carry the LDS request)
+    return prev;
+}
 // launches timed, their summed duration, and the summed number of (image, key) rows streamed per launch
 int mg_profile_read(mg_model* m, long* launches, double* total_ms, double* total_keys) {
     if (!m) return fail(MG_E_ARG, "mg_profile_read: null model");

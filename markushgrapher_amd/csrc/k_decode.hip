@@ -333,7 +333,20 @@ void attention_step(const AttnStepArgs& a, mgStream_t stream) {
     const bool eight = a.len != nullptr || a.anc == nullptr;
     const int NW = eight ? 8 : 4;
     const dim3 block(NW * 64);
-    const size_t sh = (size_t)NW * G * 8 * 10 * sizeof(float);
+    size_t sh = (size_t)NW * G * 8 * 10 * sizeof(float);
+    // Shared GPU (several execution contexts in flight, mg_set_shared_gpu): the K/V stream of the cross-attention is the one launch of
+    // a decode step whose workgroups live long (a workgroup streams its (image, head)'s 268 KB) and whose grid fills every wave slot of
+    // the chip (4 workgroups of 8 waves per CU).  The latency-sized launches of the OTHER contexts then queue for wave slots behind it
+    // (measured at 128 rows, 4 contexts: the QKV projection 13 us alone, 82 us in flight).  One resident workgroup per CU still streams at
+    // 5.9 TB/s alone (8 waves x 8 loads in flight per lane) and leaves three quarters of the wave slots to the others: 143.2 -> 148.1
+    // images/s with four contexts, 107 -> 103 for a call alone - hence per context and off by default.  The residency is capped through
+    // the LDS request (more than half a CU's 160 KB); same kernel, same bits.
+    if (a.one_wg_per_cu && a.len && G == 1) {
+        const size_t want = (size_t)84 * 1024;
+        if (sh < want) sh = want;
+        static bool once = false;
+        if (!once) { once = true; MG_SET_MAX_SMEM((&attn_step_kernel<1, 8, true>), want); }
+    }
 #define MG_AS(GG)                                                                                         \
     case GG:                                                                                              \
         if (a.len) MG_LAUNCH((attn_step_kernel<GG, 8, true>), grid, block, sh, stream, a, (long long*)nullptr);               \

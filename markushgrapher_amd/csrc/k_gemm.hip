@@ -1569,7 +1569,23 @@ void gemm_rows_splitk(const uint16_t* X, const uint16_t* W, float* P, int M, int
     }
 }
 
-void gemm_rows(const GemmArgs& a, int epi, mgStream_t stream) {
+void gemm_rows(const GemmArgs& a_in, int epi, mgStream_t stream) {
+#ifdef MG_TOOLS      // what-if variants with WRONG results (tools build only): MG_WHATIF_KV = 1: the per-head projection does not append K / V to the
+    GemmArgs a = a_in;   // cache; 2: it appends them at position 0 whatever the step
+    {
+        static int wi = -1;
+        if (wi < 0) { const char* e = getenv("MG_WHATIF_KV"); wi = e ? atoi(e) : 0; }
+        if (wi && epi == EPI_HEADS) {
+            for (int ri = 0; ri < 3; ++ri)
+                if (a.heads.fmt[ri] == HF_STEP_KV) {
+                    if (wi == 1) a.heads.fmt[ri] = HF_NONE;
+                    else { a.heads.pos_rows = nullptr; a.heads.pos_dev = nullptr; a.heads.pos = 0; }
+                }
+        }
+    }
+#else
+    const GemmArgs& a = a_in;
+#endif
     const int mt = (a.M + 31) / 32;
     if (mt > 8) {   // many live rows: the tiled kernel is the better shape
         gemm(a, epi, stream);

@@ -279,6 +279,7 @@ struct AttnStepArgs {
     const int* pos_rows;      // continuous decoding: the row's own position t = pos_rows[row] + t_off (self: keys [0, t], bias by t - j); overrides t / t_dev
     const int* kv_owner;      // continuous decoding: entry of the K/V pool that row `owner` reads - cross form: the image's stream (len is
                               // indexed by it too); rotary form: the page's own cache, which the row also appends to
+    int one_wg_per_cu;        // cross form (len != null): request enough LDS that ONE workgroup of the K/V stream is resident per CU (see attention_step)
     const int* live;          // group == 1 only, nullable: rows with live[row] == 0 (finished: they emit pad whatever their
                               // logits are, gen:2927-2937) are skipped - their K/V streams are not read.
                               // INVARIANT this relies on: a skipped row's context columns keep stale values, so everything

@@ -120,6 +120,7 @@ class Engine:
         L.mg_finalize.argtypes = [C.c_void_p, C.c_void_p]
         L.mg_load_tensor.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]
         L.mg_set_decode_graph.argtypes = [C.c_void_p, C.c_int]
+        L.mg_set_shared_gpu.argtypes = [C.c_void_p, C.c_int]
         L.mg_decode_graph_active.argtypes = [C.c_void_p]
         L.mg_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
         L.mg_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -150,6 +151,12 @@ class Engine:
 
     def decode_graph_active(self):
         return bool(self.lib.mg_decode_graph_active(self.model))
+
+    def set_shared_gpu(self, shared: bool) -> bool:
+        """Other execution contexts run beside this one (include/mgrapher.h mg_set_shared_gpu): the cross-attention K/V stream keeps one
+        workgroup per CU resident so that the other contexts' small launches find wave slots.  InFlight sets it on its contexts.  Returns the
+        previous setting."""
+        return bool(self.lib.mg_set_shared_gpu(self.model, 1 if shared else 0))
 
     def clone(self):
         """A further execution context on this engine's weights (include/mgrapher.h mg_clone): same arena, own workspace, decode

@@ -72,6 +72,8 @@ class InFlight:
             self._free.put(i)
         self._pool = ThreadPoolExecutor(max_workers=n, thread_name_prefix="mg-inflight")
         self._lock = lock if lock is not None else threading.Lock()
+        # several contexts on one GPU: every context's cross-attention stream leaves wave slots to the others (mg_set_shared_gpu)
+        self._shared_prev = [c.set_shared_gpu(n > 1) for c in self.contexts] if hasattr(engine, "set_shared_gpu") else None
 
     def __len__(self):
         return len(self.contexts)
@@ -131,6 +133,9 @@ class InFlight:
 
     def close(self):
         self._pool.shutdown(wait=True)
+        if self._shared_prev is not None:
+            for c, prev in zip(self.contexts[:self._owned_from], self._shared_prev):
+                c.set_shared_gpu(prev)              # (the source engine goes back to what its owner had set)
         for c in self.contexts[self._owned_from:]:
             c.close()
         self.contexts = self.contexts[:self._owned_from]

@@ -138,6 +138,27 @@ def test_inflight_helper_on_emulator_keeps_order_and_contexts():
         InFlight(eng, 5)
 
 
+@pytest.mark.parametrize("be_name", BACKENDS)
+def test_shared_gpu_setting_changes_no_bits(be_name):
+    """mg_set_shared_gpu (one resident workgroup of the cross-attention stream per CU while other contexts run beside this one) is a
+    scheduling hint: ids with it on equal ids with it off; InFlight switches it on for its contexts and gives the source engine its
+    previous setting back."""
+    g = load_golden("g3_trained_tiny.npz")
+    shape, sd = _weights(g)
+    inp = _inputs(g, shape)
+    eng = make_engine(be_name, shape, sd)
+    off = _gen(eng, inp, max_length=10, min_length=10)
+    assert eng.set_shared_gpu(True) is False
+    on = _gen(eng, inp, max_length=10, min_length=10)
+    assert np.array_equal(on, off)
+    assert eng.set_shared_gpu(False) is True
+    with InFlight(eng, 2) as fl:
+        assert all(c.set_shared_gpu(True) is True for c in fl.contexts)          # InFlight had switched it on
+        got = fl.map(lambda ctx, _: _gen(ctx, inp, max_length=10, min_length=10), range(2))
+    assert all(np.array_equal(o, off) for o in got)
+    assert eng.set_shared_gpu(False) is False                                     # restored by close()
+
+
 def test_plan_calls_keeps_every_context_busy():
     from markushgrapher_amd.inflight import plan_calls
     assert plan_calls(20, 4, 4) == [3, 3, 3, 3, 2, 2, 2, 2]

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--clones", action="store_true", help="contexts = clones of one engine (shared weights) instead of separately loaded engines")
     ap.add_argument("--stagger-ms", type=float, default=0.0, help="start context i that many ms x i late")
+    ap.add_argument("--tools-lib", action="store_true", help="the tools build of the library (what-if variants: MG_WHATIF_KV ...)")
     ap.add_argument("--only", action="store_true", help="measure the full in-flight count only (plus the one-at-a-time reference)")
     args = ap.parse_args()
     import torch
@@ -37,7 +38,11 @@ def main():
         if args.clones and engs:
             engs.append(engs[0].clone())
             continue
-        e = Engine(shape, max_decode_len=512)
+        if args.tools_lib:
+            from tools import _toolslib
+            e = Engine(shape, lib=_toolslib.load(), max_decode_len=512)
+        else:
+            e = Engine(shape, max_decode_len=512)
         e.load_state_dict(sd)
         engs.append(e)
     inp = synth.synth_batch(shape, B, seed=synth.BENCH_SEED, return_pages=True)
