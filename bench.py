@@ -295,7 +295,7 @@ def pmc_traffic(args, nb=1):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--shape", default="large")
     ap.add_argument("--batch", type=int, default=32)
@@ -312,8 +312,8 @@ def main():
                     help="batches in flight per GPU: execution contexts (mg_clone) with a stream and host thread each; 1 = one batch "
                          "after the other, as the reference's loop.  (The id exchange - a few small kernels per batch on the null "
                          "stream / RCCL's stream - is a fifth queue in use for microseconds at a time; measured harmless at one GPU.)")
-    ap.add_argument("--batches-per-call", type=int, default=4,
-                    help="at most that many batches of `--batch` images (<= 4: 128 rows) in ONE generate call of a context (their rows side "
+    ap.add_argument("--batches-per-call", type=int, default=5,
+                    help="at most that many batches of `--batch` images (<= 5: 160 rows) in ONE generate call of a context (their rows side "
                          "by side in the decode step: the decoder's weights are read once per step for all of them); the `--steps` batches are "
                          "cut into near-equal calls so that every context is busy to the end; every image's ids are bit-identical to a call "
                          "on its batch alone (tests/test_engine.py::test_rows_do_not_depend_on_the_row_count)")
@@ -384,7 +384,7 @@ def main():
 
     # up to `--batches-per-call` batches ride in one call (rows [0, B) = one batch, [B, 2B) the next ...): the same preprocess ->
     # encoder -> decode steps per batch, the decode step's weight stream shared by the batches of the call.
-    bpc = max(1, min(4, args.batches_per_call)) if args.beams == 1 else 1
+    bpc = max(1, min(5, args.batches_per_call)) if args.beams == 1 else 1
     devn = {1: dev}
     for nb_ in range(2, bpc + 1):
         devn[nb_] = {k: torch.cat([v] * nb_, dim=0) for k, v in dev.items()}
@@ -698,7 +698,7 @@ def main():
                     sl = slice(i * per, (i + 1) * per)
                     pix = torch.cat([ctx.preprocess(dev["pages_u8"]) for _ in range(per // B)], dim=0)
                     o, l, st = ctx.generate_stream(qf["input_ids"][sl], qf["bbox"][sl], qf["attention_mask"][sl], pix, max_length=512,
-                                                   min_length=0, chunk=B, slots=min(bpc, 2) * B, pool_chunks=2 + min(bpc, 2))
+                                                   min_length=0, chunk=B, slots=2 * B, pool_chunks=4)
                     return o.cpu().numpy(), l.cpu().numpy(), st
                 fl.map(job_stream, range(len(fl)))
                 torch.cuda.synchronize(); tq = time.time()
@@ -707,7 +707,7 @@ def main():
                 ids_q = np.concatenate([r[0] for r in res_q]); len_q = np.concatenate([r[1] for r in res_q])
                 same_q = all(np.array_equal(ids_q[n, :len_q[n]], ie[n % B, :len_q[n]]) for n in range(QF * B))
                 extra["eos_enabled_continuous_in_flight"] = {
-                    "images_per_s": round(QF * B / tq, 2), "queue_images": QF * B, "contexts": len(fl), "slots_per_context": min(bpc, 2) * B,
+                    "images_per_s": round(QF * B / tq, 2), "queue_images": QF * B, "contexts": len(fl), "slots_per_context": 2 * B,
                     "decode_steps_run_per_context": [int(r[2]) for r in res_q], "speedup_vs_batch_calls": round(QF * B / tq / (B / te), 2),
                     "ids_equal_batch_calls": bool(same_q),
                     "config": "a queue of 1024 images cut over the execution contexts of the headline run, one continuous decoder each"}
@@ -778,7 +778,7 @@ def main():
             # OCR model (128 decode rows each), the VTL stage's batches of 32 over 4 contexts, host stage pipelined with the VTL stage
             # (the VTL calls take two batches of 32 pages each, as the headline run's calls do)
             extra["configs4_end_to_end_1gpu"] = configs4_run(eng, B, new_tokens, ocr_pages=512, ocr_slots=128, main_inflight=4, ocr_inflight=4,
-                                                             main_batch=bpc * B)
+                                                             main_batch=2 * B)
         out = {
             "metric": METRIC, "value": round(world * B * args.steps / dt, 3), "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
