@@ -1673,6 +1673,7 @@ int mg_set_shared_gpu(mg_model* m, int shared) {
     std::lock_guard<std::recursive_mutex> lk(m->call_mu);
     const int prev = m->shared_gpu;
     m->shared_gpu = shared ? 1 : 0;
+    if (m->shared_gpu) attention_step_allow_shared();
     if (prev != m->shared_gpu) { m->step_graph.reset(); m->stream_graph.reset(); }      // (the captured launches carry the LDS request)
     return prev;
 }

@@ -2,6 +2,7 @@
 // token selection.  These are the HBM-bound kernels of the path: per step the cross-attention K/V of every image
 // (2*N_dec*d*S_x bf16 bytes per image) is streamed exactly once.
 #include "mg_kernels.h"
+#include <mutex>
 
 namespace mg {
 
@@ -311,6 +312,13 @@ void attention_step_trace(const AttnStepArgs& a, long long* trace, mgStream_t st
 }
 #endif
 
+constexpr size_t AS_SHARED_LDS = (size_t)84 * 1024;      // more than half a CU's 160 KB: one resident workgroup per CU
+// the kernel attribute that permits the large LDS request, set once and outside any stream capture (mg_set_shared_gpu)
+void attention_step_allow_shared() {
+    static std::once_flag once;
+    std::call_once(once, [] { MG_SET_MAX_SMEM((&attn_step_kernel<1, 8, true>), AS_SHARED_LDS); });
+}
+
 void attention_step(const AttnStepArgs& a, mgStream_t stream) {
     const int G = a.group;
     if (a.rope.qkv) {            // rotary self-attention step: H = key/value heads, group = query heads per key/value head
@@ -341,12 +349,7 @@ void attention_step(const AttnStepArgs& a, mgStream_t stream) {
     // 5.9 TB/s alone (8 waves x 8 loads in flight per lane) and leaves three quarters of the wave slots to the others: 143.2 -> 148.1
     // images/s with four contexts, 107 -> 103 for a call alone - hence per context and off by default.  The residency is capped through
     // the LDS request (more than half a CU's 160 KB); same kernel, same bits.
-    if (a.one_wg_per_cu && a.len && G == 1) {
-        const size_t want = (size_t)84 * 1024;
-        if (sh < want) sh = want;
-        static bool once = false;
-        if (!once) { once = true; MG_SET_MAX_SMEM((&attn_step_kernel<1, 8, true>), want); }
-    }
+    if (a.one_wg_per_cu && a.len && G == 1 && sh < AS_SHARED_LDS) sh = AS_SHARED_LDS;      // (attention_step_allow_shared ran when the setting was made)
 #define MG_AS(GG)                                                                                         \
     case GG:                                                                                              \
         if (a.len) MG_LAUNCH((attn_step_kernel<GG, 8, true>), grid, block, sh, stream, a, (long long*)nullptr);               \

@@ -290,6 +290,7 @@ struct AttnStepArgs {
                               // per-row scales, per-row selection).  A kernel that reduces ACROSS rows must mask dead rows.
 };
 void attention_step(const AttnStepArgs& a, mgStream_t stream);
+void attention_step_allow_shared();      // before the first launch with AttnStepArgs::one_wg_per_cu (sets the kernel's LDS limit; not inside a stream capture)
 void attention_step_trace(const AttnStepArgs& a, long long* trace, mgStream_t stream);   // phase stamps, cross form, group 1
 
 // h[rows][d] = tok_emb[ids[row]]
