@@ -7,9 +7,13 @@ decode steps (EOS suppressed: min_length = max_length = 257, SURVEY.md §8d Cfg-
 MarkushGrapher-2 model with the recipe weights of tests/golden/g4_bench.npz (synth.BENCH_RECIPE: the configuration the
 parity tests pin on stock UDOP).  Inputs are resident in HBM when the timed region starts.  With --gpus N every rank
 runs its own 32-image shard (weak scaling) and the decoded ids are all-gathered over RCCL inside the timed region.
-Every rank keeps --inflight (default 4) such steps going at once, each on its own execution context (mg_clone: same weights,
-own workspace / decode graph / stream / host thread): all K timed steps start and end inside the timed region, ids per batch
-are bit-identical to one-at-a-time calls (tests/test_bench_config.py), `one_batch_in_flight` repeats the step the old way.
+Every rank keeps --inflight (default 4) execution contexts going at once (mg_clone: same weights, own workspace / decode graph /
+stream / host thread), and a call of a context takes up to --batches-per-call (default 5) batches of 32 side by side (the decode
+step then reads the decoder's weights once for all of them): the K timed steps are cut into near-equal calls over the contexts
+(inflight.plan_calls: 20 steps = one call of 5 batches per context), all of them start and end inside the timed region, every
+batch's ids are bit-identical to a call on the batch alone (tests/test_engine.py, tests/test_inflight.py; checked in every run:
+config.ids_equal_one_batch_calls).  `one_call_alone` repeats the largest call shape on one context, `one_batch_in_flight` the
+one-batch-at-a-time loop of the reference.
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -19,7 +23,8 @@ Prints ONE JSON line on rank 0:
                  launch duration from HIP events on the launch stream of the first context during the timed region (i.e. beside
                  the other batches' kernels); `traffic` = HBM bytes per launch from a FETCH_SIZE pass (rocprofv3 --pmc, run by this
                  script as a child on a short copy of the workload when rocprofv3 is present)
-  one_batch_in_flight   the same step with one context: images/s, the kernel's and the phases' uncontended figures
+  one_call_alone        one call of the timed region's largest shape alone on one context: the dominant launch and the phases uncontended
+  one_batch_in_flight   one batch per call on one context: images/s, the kernel's and the phases' figures (the loop of rounds 1-2)
   phases         encoder (MFMA-bound) and decode step (HBM-bound) against their own rooflines: enc_mfma_frac, dec_hbm_frac,
                  dec_mfma_frac (SURVEY.md §8d formulas), phase times from HIP events inside mg_generate
   extra_runs     EOS-enabled greedy run (max_length 512) and beam-5 (BASELINE configs[2]) on the same inputs
