@@ -96,6 +96,29 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs a) {
     } else {
         t_first = b; t_step = G; t_end = nblk;
     }
+    // Order of an XCD's tiles.  Linear (tile = bm * nbn + bn): the 32 workgroups of an XCD cover 32 / nbn row blocks x ALL nbn column tiles at a
+    // time, i.e. the whole weight matrix passes through that L2 once per round (FFN-wi: 8 MB per round and XCD against 4 MB of L2).
+    // Column groups (pp_colgroup = CG): the full row blocks of the XCD's range are walked CG column tiles at a time - 32 / CG row blocks x CG
+    // columns per round, the group's weight slab (CG x 256 x K) stays in L2 over all the range's row blocks, the activation rows are
+    // re-read nbn / CG times instead.  Same tiles, same arithmetic per tile: bit-identical.
+    int cg_lo = 0, cg_rows = 0;
+    const int CG = a.pp_colgroup;
+    if (CG > 0 && (G & 7) == 0 && nbn % CG == 0 && nbn > CG) {
+        const int T8 = (nblk + 7) >> 3, xcd = b & 7;
+        const int r0 = xcd * T8, r1 = (xcd + 1) * T8 < nblk ? (xcd + 1) * T8 : nblk;
+        cg_lo = (r0 + nbn - 1) / nbn * nbn;
+        cg_rows = (r1 / nbn * nbn - cg_lo) / nbn;
+        if (cg_rows < 0) cg_rows = 0;
+    }
+    auto tile_bm_bn = [&](int tile, int& bm, int& bn) {
+        const int q = tile - cg_lo;
+        if (cg_rows > 0 && q >= 0 && q < cg_rows * nbn) {
+            const int per = cg_rows * CG, g = q / per, rem = q - g * per;
+            bm = cg_lo / nbn + rem / CG; bn = g * CG + rem % CG;
+        } else {
+            bm = tile / nbn; bn = tile - bm * nbn;
+        }
+    };
     int n_my = t_first < t_end ? (t_end - t_first + t_step - 1) / t_step : 0;
     if (n_my > GP_MAXT) n_my = GP_MAXT;                         // (the launcher keeps tiles / workgroup <= GP_MAXT)
     if (n_my == 0) return;
@@ -107,7 +130,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs a) {
     int* rcnt = rtab + GP_MAXT * XT;
     for (int e = tid; e < n_my * XT; e += 512) {
         const int i = e / XT, r = e - i * XT;
-        const int bm = (t_first + i * t_step) / nbn;
+        int bm, bn_unused;
+        tile_bm_bn(t_first + i * t_step, bm, bn_unused);
         const int e0 = (int)((long long)bm * nrt / nbm), e1 = (int)((long long)(bm + 1) * nrt / nbm);
         const int h = e1 - e0, c0 = (h + 1) >> 1;
         const int wrow = r / TI, ii = r - wrow * TI;
@@ -135,7 +159,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs a) {
     const bool k1_is_x = w + 8 < XT;                           // fragment w + 8 is an X row tile (TI = 5: waves 0, 1)
     auto frag_off = [&](int i, int k) -> unsigned {            // byte offset of my k-th fragment's row tile in tile i (wave-uniform)
         const int f = k < 2 ? w + 8 * k : 16 + w;
-        const int tile = t_first + i * t_step, bn = tile % nbn;
+        int bm_unused, bn;
+        tile_bm_bn(t_first + i * t_step, bm_unused, bn);
         int rt;
         if (f < XT) { const int v = rtab[i * XT + f]; rt = v >= 0 ? v : -1 - v; }
         else { rt = bn * 8 + (f - XT); rt = rt < nt32 - 1 ? rt : nt32 - 1; }
@@ -189,7 +214,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs a) {
 
     for (int i = 0; i < n_my; ++i) {
         const bool has_next = i + 1 < n_my;
-        const int tile = t_first + i * t_step, bm = tile / nbn, bn = tile - bm * nbn;
+        int bm, bn;
+        tile_bm_bn(t_first + i * t_step, bm, bn);
         (void)bm;
         const int n0w = bn * GX_N + wc * 64;
         bool tor;
@@ -285,6 +311,9 @@ static bool launch_pp(const GemmArgs& a_in, mgStream_t stream) {
     static int balance = -1;
     if (balance < 0) { const char* e = getenv("MG_PP_BALANCE"); balance = e ? atoi(e) : 1; }      // (A/B runs)
     a.pp_balance = balance;
+    static int colgroup = -1;
+    if (colgroup < 0) { const char* e = getenv("MG_PP_COLGROUP"); colgroup = e ? atoi(e) : 4; }      // (A/B runs; 0: linear order.  4 column tiles: FFN-wi 316 -> 299 us, encoder 35.9 -> 35.4 ms; 2: slower)
+    a.pp_colgroup = colgroup;
     constexpr int BM = 64 * TI;
     const int nblk = ((a.M + BM - 1) / BM) * ((a.N + GX_N - 1) / GX_N);
     static int ncu = 0;

@@ -78,6 +78,7 @@ struct GemmArgs {
     // benchmark's length distribution).  Kernels without list support ignore it and compute every row - the list is an optimisation.
     const int* row_tiles;
     const int* n_row_tiles;
+    int pp_colgroup;       // set by the ping-pong kernel's launcher: > 0: an XCD's tiles ordered column group by column group (that many column tiles wide)
     int pp_balance;        // set by the ping-pong kernel's launcher: cut the row tiles into blocks of balanced height (k_gemm_pp.hip)
 };
 void gemm(const GemmArgs& a, int epi, mgStream_t stream);
