@@ -590,6 +590,15 @@ def main():
                               "of its call" % (len(fl) - 1, int(round(nb_first))))
             roof["batches_in_flight"] = int(sum(timed_plan[:len(fl)]))
         phases = make_phases(n_ph, enc_ms, dec_ms, nb_first)
+        if roof is not None and phases is not None:
+            # what the memory system delivers while all contexts decode: every context moves its call's step bytes per (contended) step time
+            agg = len(fl) * bytes_step_call(nb_first) / (phases["decode_step_ms"] * 1e-3) / 1e9
+            roof["all_contexts_decode_GBps"] = round(agg, 1)
+            roof["all_contexts_decode_frac"] = round(agg / HBM_PEAK_GBS, 4)
+            roof["note"] = ("`achieved` / `frac` are ONE context's dominant launch timed while %d other contexts' kernels share the GPU (and, with mg_set_shared_gpu, "
+                            "with one of its workgroups resident per CU): a quarter of the machine's attention, not the kernel's quality - that is "
+                            "one_call_alone.roofline (the same launch shape alone).  all_contexts_decode_*: algorithmic decode bytes of all contexts' steps over "
+                            "the contended step time = the HBM rate the decode phases sustain together" % (len(fl) - 1))
         if phases is not None:
             phases["dec_bytes_step_fetched"] = traffic["decode_step_bytes"] if traffic else None
             phases["batches_in_flight"] = int(sum(timed_plan[:len(fl)]))
