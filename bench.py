@@ -318,7 +318,7 @@ def main():
                          "after the other, as the reference's loop.  (The id exchange - a few small kernels per batch on the null "
                          "stream / RCCL's stream - is a fifth queue in use for microseconds at a time; measured harmless at one GPU.)")
     ap.add_argument("--batches-per-call", type=int, default=5,
-                    help="at most that many batches of `--batch` images (<= 5: 160 rows) in ONE generate call of a context (their rows side "
+                    help="at most that many batches of `--batch` images (<= 8: 256 rows, the C ABI's limit; 5 is the fastest) in ONE generate call of a context (their rows side "
                          "by side in the decode step: the decoder's weights are read once per step for all of them); the `--steps` batches are "
                          "cut into near-equal calls so that every context is busy to the end; every image's ids are bit-identical to a call "
                          "on its batch alone (tests/test_engine.py::test_rows_do_not_depend_on_the_row_count)")
@@ -389,7 +389,7 @@ def main():
 
     # up to `--batches-per-call` batches ride in one call (rows [0, B) = one batch, [B, 2B) the next ...): the same preprocess ->
     # encoder -> decode steps per batch, the decode step's weight stream shared by the batches of the call.
-    bpc = max(1, min(5, args.batches_per_call)) if args.beams == 1 else 1
+    bpc = max(1, min(8, args.batches_per_call)) if args.beams == 1 else 1      # (default 5: calls of 6 / 8 batches measured slower, profiles/r04_o_batches_per_call.txt)
     devn = {1: dev}
     for nb_ in range(2, bpc + 1):
         devn[nb_] = {k: torch.cat([v] * nb_, dim=0) for k, v in dev.items()}

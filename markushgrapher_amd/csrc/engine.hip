@@ -646,7 +646,7 @@ static void decode_step(mg_model* m, const DecodeCtx& c, int t, const int* tdev,
             r.X = c.dy_pk; r.W = m->at<uint16_t>(l.wo2); r.h = c.dh; r.gain = m->at<float>(last ? m->dec_ln : m->dec[li + 1].ln0);
             r.gscale = (last && m->tied) ? 1.0f / sqrtf((float)d) : 1.0f; r.x_pk = c.dx_pk; r.x2_pk = c.xa; r.x2_ld = K2; r.part = c.rs_part;
             r.M = R; r.N = d; r.K = m->dff; r.rs = rs2;
-            r.wide_tiles = 5;      // the same K partition (16 waves) for every call of up to 160 rows (5 greedy batches of 32; beam-5 at batch 32)
+            r.wide_tiles = 8;      // the same K partition (16 waves) for every call (up to 256 rows: 8 greedy batches of 32; beam-5 at batch 32 = 5 tiles)
             gemm_rows_resid(r, st);
         }
     }

@@ -1383,7 +1383,7 @@ void gemm_rows_resid(const ResidArgs& r, mgStream_t stream) {
     if (split) mt = mts;
     // 16 waves for the long K = d_ff stream up to 4 row tiles (the waves partition K: the same count for every row count a greedy
     // call can have, so that a row's sums do not depend on how many batches share its call; 8 accumulator registers per row tile in
-    // the 16x16x32 form); the decode steps ask for 5 (ResidArgs::wide_tiles: beam-5 at batch 32 = 160 rows, 29.9 -> 22.8 us alone, 111 -> 115
+    // the 16x16x32 form); the decode steps ask for 8 = every call size (ResidArgs::wide_tiles; beam-5 at batch 32 = 160 rows: 29.9 -> 22.8 us alone, 111 -> 115
     // images/s in flight; the 32x32x16 form of round 1 spilled there: 80 accumulator registers, 52 us).
     const bool wide = r.K > 2048 && mt <= (r.wide_tiles > 4 ? r.wide_tiles : 4);
     if (wide && mt == 1 && !split && r.M > 16 && ((r.N >> 3) & 7) == 0 && r.x_kts == 0) {      // one row tile: split by token group

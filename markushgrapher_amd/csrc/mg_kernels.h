@@ -128,8 +128,8 @@ struct ResidArgs {
     float* part;
     int M, N, K;
     RowScale rs;
-    int wide_tiles;        // row tiles up to which the long K = d_ff form keeps 16 K-partitioning waves (0: 4).  The decode steps pass 5, so that a
-                           // row of a call of up to 160 rows (5 greedy batches of 32; beam-5 at batch 32) sums in the order of a 32-row call
+    int wide_tiles;        // row tiles up to which the long K = d_ff form keeps 16 K-partitioning waves (0: 4).  The decode steps pass 8 (every call
+                           // the C ABI admits: 256 rows), so that a row sums in the order of a 32-row call whatever its call's size
 };
 void gemm_rows_resid(const ResidArgs& r, mgStream_t stream);
 void gemm_rows_resid_trace(const ResidArgs& r, long long* trace, mgStream_t stream);   // phase stamps, M <= 32, K = d_ff form

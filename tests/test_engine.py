@@ -375,11 +375,11 @@ def test_rows_do_not_depend_on_the_row_count(be_name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nb", [2, 4, 5])
+@pytest.mark.parametrize("nb", [2, 4, 5, 8])
 def test_several_batches_in_one_call_large_shape(nb):
     """The benchmark's call shapes: nb batches of 32 (the benchmark inputs and recipe weights) as ONE call of 32 nb rows against the
     batch alone - ids of every batch bit-identical over 48 forced tokens (the FFN output projection keeps its 16 K-partitioning waves
-    up to 5 row tiles of greedy rows for this)."""
+    at every row-tile count for this; 8 batches = the 256 rows a call may hold)."""
     shape = synth.SHAPES["large"]
     eng = make_engine("hip", shape, synth.recipe_state_dict(shape, **synth.BENCH_RECIPE), max_decode_len=64)
     inp = synth.synth_batch(shape, 32, seed=synth.BENCH_SEED)
