@@ -7,6 +7,7 @@ execution context (`Engine.clone()`: shared weights; own workspace, decode graph
 launches run in the gaps of another's.  Rows of different batches never meet, so every batch's result is exactly what a call made
 alone returns (tests/test_inflight.py); what changes is throughput (profiles/r03_inflight_ab.txt).
 """
+import os
 import queue
 import threading
 from concurrent.futures import ThreadPoolExecutor
@@ -73,7 +74,9 @@ class InFlight:
         self._pool = ThreadPoolExecutor(max_workers=n, thread_name_prefix="mg-inflight")
         self._lock = lock if lock is not None else threading.Lock()
         # several contexts on one GPU: every context's cross-attention stream leaves wave slots to the others (mg_set_shared_gpu)
-        self._shared_prev = [c.set_shared_gpu(n > 1) for c in self.contexts] if hasattr(engine, "set_shared_gpu") else None
+        # (MG_SHARED_GPU=0: leave the contexts' setting alone - A/B runs)
+        share = n > 1 and os.environ.get("MG_SHARED_GPU", "1") != "0"
+        self._shared_prev = [c.set_shared_gpu(share) for c in self.contexts] if hasattr(engine, "set_shared_gpu") else None
 
     def __len__(self):
         return len(self.contexts)
