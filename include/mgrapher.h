@@ -341,6 +341,55 @@ int mg_ocr_generate_stream(mg_ocr_model* m, void* stream, void* ws, size_t ws_by
                            const int32_t* patch_pos, const uint8_t* patch_mask, int N, int n_img, int L, int max_new_tokens, int slots, int chunk,
                            int64_t* out_ids, int32_t* out_len, long* steps_host);
 
+/* ------------------------------------------------------------------------------------------------------------------------------
+ * OCSR vision branch "e1" (SURVEY.md section 8 rows a7 / f-2).  The reference's model evaluates, inside forward() / generate() of its
+ * transformers fork,
+ *     model.encoder.molscribe_encoder    MolScribe's Swin-B (timm swin_base_patch4_window12_384; weights swin_base_char_aux_1m680k.pth)
+ *     model.encoder.molscribe_projector  an MLP projector into d_model
+ * and concatenates the result in front of the decoder with the VTL encoder's states ("late fusion", architecture_variant
+ * me-lf-stack-1): /root/reference/markushgrapher/core/common/begin.py:119-120,137-151, utils/model/utils_model_loading.py:20-36,
+ * config/predict.yaml:12,17-18, README.md:212-215.  mg_e1_* computes that branch; mg_attach_e1 makes mg_encode / mg_generate /
+ * mg_generate_stream* evaluate it themselves whenever no precomputed e1 is passed.
+ * The Swin arithmetic is stock transformers models/swin/modeling_swin.py (patch embedding + LayerNorm, (shifted-)window attention with
+ * the relative-position bias table and the -100 region mask, exact-erf GELU MLP, patch merging, final LayerNorm) and is pinned on
+ * stock SwinModel; what the fork does around it is INFERRED and therefore configuration: the branch's input = bilinear resize
+ * (torch.nn.functional.interpolate, align_corners = false) of the model's pixel_values from src_image_size to image_size followed by
+ * x * pix_scale[c] + pix_shift[c]; the projector = n_proj Linear layers (with bias) with proj_act between them.
+ * Keys of mg_e1_load_tensor: "swin." + the state-dict names of stock SwinModel(add_pooling_layer=False), and "proj.{j}.weight|bias"
+ * (markushgrapher_amd/e1_shapes.py maps timm / transformers-4.x checkpoints onto them).  v1 limits (errors, never silent): head dim
+ * 32, stage widths 64 .. 1024 (powers of two), window 4 / 8 / 12, every stage's map a multiple of the window (the reference geometry:
+ * 96 / 48 / 24 / 12 with window 12).
+ * ------------------------------------------------------------------------------------------------------------------------------ */
+typedef struct mg_e1_model mg_e1_model;
+typedef struct mg_e1_config {
+    /* SwinConfig */
+    int image_size, patch_size, num_channels, embed_dim, n_stages;
+    int depths[4], num_heads[4];
+    int window_size, mlp_ratio;
+    float layer_norm_eps;
+    /* projector: Linear(C_last -> proj_dims[0]) [act] ... Linear(-> proj_dims[n_proj - 1] = d_model); proj_act 0 none, 1 GELU (erf) */
+    int n_proj, proj_dims[4], proj_act;
+    /* input derivation */
+    int src_image_size;
+    float pix_scale[3], pix_shift[3];
+} mg_e1_config;
+
+int mg_e1_create(const mg_e1_config* cfg, mg_e1_model** out);
+void mg_e1_destroy(mg_e1_model* m);
+size_t mg_e1_weights_bytes(const mg_e1_model* m);
+int mg_e1_bind_weights(mg_e1_model* m, void* arena);
+int mg_e1_load_tensor(mg_e1_model* m, void* stream, const char* key, const void* src, int src_is_bf16, const int64_t* shape, int ndim);
+int mg_e1_finalize(mg_e1_model* m, void* stream);
+int mg_e1_out_tokens(const mg_e1_model* m);          /* M: tokens per image (144 for Swin-B at 384 px) */
+int mg_e1_workspace_bytes(const mg_e1_model* m, int B, size_t* out_bytes);
+/* pixel_values [B][num_channels][src_image_size][src_image_size] fp32 (the VTL model's input) ->
+ *   e1_out       [B][M][d_model] fp32 (nullable)        what mg_encode / mg_generate take as `e1`
+ *   features_out [B][M][C_last] fp32 (nullable)         SwinModel.last_hidden_state (the pinned part)
+ * Reads the model, writes only caller buffers: one mg_e1_model may be used by several threads / execution contexts at once (each
+ * with its own workspace and stream).  Enqueues only. */
+int mg_e1_encode(const mg_e1_model* m, void* stream, void* ws, size_t ws_bytes, const float* pixel_values, int B, float* e1_out,
+                 float* features_out);
+
 #ifdef __cplusplus
 }
 #endif

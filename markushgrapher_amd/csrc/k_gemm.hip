@@ -452,6 +452,8 @@ void gemm(const GemmArgs& a, int epi, mgStream_t stream) {
                 case EPI_PK_RELU: launch_xl<EPI_PK_RELU, 5>(a, stream); break;
                 case EPI_PK_GELU: launch_xl<EPI_PK_GELU, 5>(a, stream); break;
                 case EPI_PK: launch_xl<EPI_PK, 5>(a, stream); break;
+                case EPI_PK_BIAS: launch_xl<EPI_PK_BIAS, 5>(a, stream); break;
+                case EPI_PK_GELU_ERF: launch_xl<EPI_PK_GELU_ERF, 5>(a, stream); break;
                 case EPI_RESID_NORM: launch_xl<EPI_RESID_NORM, 5>(a, stream); break;
                 default: launch_xl<EPI_HEADS, 5>(a, stream); break;
             }
@@ -464,6 +466,8 @@ void gemm(const GemmArgs& a, int epi, mgStream_t stream) {
                 case EPI_PK_RELU: launch_xl<EPI_PK_RELU, 4>(a, stream); break;
                 case EPI_PK_GELU: launch_xl<EPI_PK_GELU, 4>(a, stream); break;
                 case EPI_PK: launch_xl<EPI_PK, 4>(a, stream); break;
+                case EPI_PK_BIAS: launch_xl<EPI_PK_BIAS, 4>(a, stream); break;
+                case EPI_PK_GELU_ERF: launch_xl<EPI_PK_GELU_ERF, 4>(a, stream); break;
                 case EPI_RESID_NORM: launch_xl<EPI_RESID_NORM, 4>(a, stream); break;
                 default: launch_xl<EPI_HEADS, 4>(a, stream); break;
             }
@@ -476,6 +480,8 @@ void gemm(const GemmArgs& a, int epi, mgStream_t stream) {
             case EPI_F32_RESID: launch_wide<EPI_F32_RESID>(a, stream); break;
             case EPI_PK_RELU: launch_wide<EPI_PK_RELU>(a, stream); break;
             case EPI_PK: launch_wide<EPI_PK>(a, stream); break;
+            case EPI_PK_BIAS: launch_wide<EPI_PK_BIAS>(a, stream); break;
+            case EPI_PK_GELU_ERF: launch_wide<EPI_PK_GELU_ERF>(a, stream); break;
             case EPI_RESID_NORM: launch_wide<EPI_RESID_NORM>(a, stream); break;
             default: launch_wide<EPI_HEADS>(a, stream); break;
         }
@@ -489,6 +495,8 @@ void gemm(const GemmArgs& a, int epi, mgStream_t stream) {
         case EPI_F32_RESID: MG_LAUNCH((gemm_big_kernel<EPI_F32_RESID>), grid, block, sh, stream, a); break;
         case EPI_PK_RELU: MG_LAUNCH((gemm_big_kernel<EPI_PK_RELU>), grid, block, sh, stream, a); break;
         case EPI_PK: MG_LAUNCH((gemm_big_kernel<EPI_PK>), grid, block, sh, stream, a); break;
+        case EPI_PK_BIAS: MG_LAUNCH((gemm_big_kernel<EPI_PK_BIAS>), grid, block, sh, stream, a); break;
+        case EPI_PK_GELU_ERF: MG_LAUNCH((gemm_big_kernel<EPI_PK_GELU_ERF>), grid, block, sh, stream, a); break;
         case EPI_RESID_NORM: MG_LAUNCH((gemm_big_kernel<EPI_RESID_NORM>), grid, block, sh, stream, a); break;
         default: MG_LAUNCH((gemm_big_kernel<EPI_HEADS>), grid, block, sh, stream, a); break;
     }

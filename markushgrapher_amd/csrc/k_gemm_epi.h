@@ -143,7 +143,7 @@ template <int EPI, bool TOR, bool APPLY_RS = false>
 MG_DEV void tile_epilogue(const GemmArgs& a, const f32x16& acc_in, int m0, int n0, int lane, int qmask = 3, float rsl = 1.0f) {
     const int half = lane >> 5, l32 = lane & 31;
     f32x16 acc = acc_in;
-    if constexpr (APPLY_RS && (EPI == EPI_PK || EPI == EPI_PK_RELU || EPI == EPI_PK_GELU || EPI == EPI_HEADS)) {
+    if constexpr (APPLY_RS && (EPI == EPI_PK || EPI == EPI_PK_RELU || EPI == EPI_PK_GELU || EPI == EPI_HEADS || EPI == EPI_PK_BIAS || EPI == EPI_PK_GELU_ERF)) {
         if (a.rs.part) {                                              // rsl: the scale of token m0 + lane%32 (both half-waves)
             if (TOR) {
 #pragma unroll
@@ -168,8 +168,23 @@ MG_DEV void tile_epilogue(const GemmArgs& a, const f32x16& acc_in, int m0, int n
                 else *p = acc[r] + bv;
             }
         }
-    } else if constexpr (EPI == EPI_PK || EPI == EPI_PK_RELU || EPI == EPI_PK_GELU) {
+    } else if constexpr (EPI == EPI_PK || EPI == EPI_PK_RELU || EPI == EPI_PK_GELU || EPI == EPI_PK_BIAS || EPI == EPI_PK_GELU_ERF) {
         f32x16 v = acc;
+        if constexpr (EPI == EPI_PK_BIAS || EPI == EPI_PK_GELU_ERF) {
+            static_assert(TOR, "bias epilogues use D = W·X^T (a lane owns a token, its registers are output features)");
+            if (a.bias) {          // register 4g + i holds feature n0 + 8g + 4 half + i: one 16-byte load per group (N is a multiple of 4)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = n0 + 8 * g + 4 * half;
+                    const float4 bv = *(const float4*)(a.bias + (n + 3 < a.N ? n : 0));
+                    v[4 * g] += bv.x; v[4 * g + 1] += bv.y; v[4 * g + 2] += bv.z; v[4 * g + 3] += bv.w;
+                }
+            }
+            if constexpr (EPI == EPI_PK_GELU_ERF) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = 0.5f * v[r] * (1.0f + erff(v[r] * 0.70710678118654752f));
+            }
+        }
         if (EPI == EPI_PK_RELU) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);

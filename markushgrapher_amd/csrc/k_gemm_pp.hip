@@ -353,6 +353,8 @@ static bool launch_pp_epi(const GemmArgs& a, int epi, mgStream_t stream) {
         case EPI_PK_RELU: return launch_pp<EPI_PK_RELU, TI>(a, stream);
         case EPI_PK_GELU: return launch_pp<EPI_PK_GELU, TI>(a, stream);
         case EPI_PK: return launch_pp<EPI_PK, TI>(a, stream);
+        case EPI_PK_BIAS: return launch_pp<EPI_PK_BIAS, TI>(a, stream);
+        case EPI_PK_GELU_ERF: return launch_pp<EPI_PK_GELU_ERF, TI>(a, stream);
         case EPI_RESID_NORM: return launch_pp<EPI_RESID_NORM, TI>(a, stream);
         default: return launch_pp<EPI_HEADS, TI>(a, stream);
     }

@@ -24,6 +24,10 @@ enum GemmEpi : int {
     EPI_PK_SWIGLU = 6,
     // large-M tile kernel only (gemm_has_gelu_epilogue): out_pk packed [M][N] = bf16(gelu_tanh(acc))   (vision-tower MLP, SiglipMLP)
     EPI_PK_GELU = 7,
+    // OCSR vision branch (Swin, swin.hip): projections with a bias vector.  out_pk packed [M][N] = bf16(acc + bias[n]) and
+    // bf16(gelu_erf(acc + bias[n])) (exact erf form: SwinMLP / hidden_act "gelu", stock modeling_swin.py:471-483); bias null = 0
+    EPI_PK_BIAS = 8,
+    EPI_PK_GELU_ERF = 9,
 };
 // Destination formats for per-head projections (head dim fixed at 64):
 enum HeadFmt : int {
