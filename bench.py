@@ -297,6 +297,32 @@ def pmc_traffic(args, nb=1):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def launcher_selftest(args, world, rank):
+    """MG_BENCH_BACKEND=gloo (tests only, no GPU, NOT a measurement): the rank set-up of the multi-GPU run - environment from
+    torch.distributed.run, process group, barrier, max-over-ranks reduction, the id exchange's all-gather on a stub payload - and one JSON
+    line from rank 0 marked as a self-test."""
+    import torch
+    import torch.distributed as dist
+    from markushgrapher_amd.dist import IdExchange
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B = args.batch
+    ex = IdExchange(B, torch.device("cpu"), pad_token_id=0)
+    ids = torch.full((B, 8), rank + 1, dtype=torch.int64)
+    dist.barrier()
+    t0 = time.time()
+    all_ids, all_len = ex.wait(ex.post(ids))
+    dist.barrier()
+    t = torch.tensor([time.time() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ok = bool(all((all_ids[r * B:(r + 1) * B, :8] == r + 1).all() for r in range(world)))
+    if rank == 0:
+        print(json.dumps({"launcher_selftest": True, "n_gpus": world, "backend": "gloo", "exchange_ok": ok, "rows_gathered": int(all_ids.shape[0]),
+                          "max_over_ranks_s": round(float(t.item()), 4)}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -325,6 +351,18 @@ def main():
     args = ap.parse_args()
     if args.pmc_child:
         return pmc_child(args)
+    # `python bench.py --gpus N` started as ONE process (no torch.distributed.run around it): start the N ranks here - the same
+    # command under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` on the loopback address - and pass its output
+    # and exit code through.  Under torch.distributed.run (WORLD_SIZE set) this is skipped: the process is a rank.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        return sys.exit(subprocess.call(cmd, env=env))
 
     import torch
     from markushgrapher_amd import synth
@@ -334,7 +372,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but torch.distributed.run started {world} processes (WORLD_SIZE={world})")
+    backend = os.environ.get("MG_BENCH_BACKEND", "nccl")      # "gloo": launcher / rendezvous test without GPUs (tests/test_dist.py); never a measurement
+    if backend == "gloo":
+        return launcher_selftest(args, world, rank)
     torch.cuda.set_device(local_rank)
     dist = None
     # MG_BENCH_FORCE_DIST=1: a process group of ONE rank over RCCL, the id exchange issued as a real all-gather - the multi-GPU code path
@@ -525,6 +566,57 @@ def main():
         eng.set_shared_gpu(len(fl) > 1)
     assert ids.shape == (B, max_length), ids.shape
     assert ids_equal_solo is not False, "ids of a batch inside a multi-batch call differ from the call on the batch alone"
+    # The reference's shipped architecture (config/predict.yaml: architecture_variant me-lf-stack-1): the OCSR vision branch (Swin-B at
+    # 384 px + MLP projector, csrc/swin.hip) attached to every context, evaluated inside the timed step from the step's own pixel_values,
+    # the decoder cross-attending over [144 e1 tokens | VTL states].  Same plan, same inputs, same clock as the headline region.
+    e1_run = None
+    if rank == 0 and world == 1 and args.beams == 1 and args.shape == "large" and not args.no_extra_runs and os.environ.get("MG_BENCH_E1", "1") != "0":
+        from markushgrapher_amd.e1 import E1Engine
+        from markushgrapher_amd.e1_shapes import PRESETS as E1_PRESETS, recipe_state_dict as e1_recipe
+        s1 = E1_PRESETS["swin_b_384"]
+        e1e = E1Engine(s1).load_state_dict(e1_recipe(s1))
+        ctx_all = [eng] + [c for c in fl.contexts if c is not eng]
+        for c in ctx_all:
+            c.attach_e1(e1e)
+        for nb_ in sorted(set(timed_plan)):
+            run_calls([nb_] * len(fl))
+        while handles:
+            ex.wait(handles.pop(0))
+        L_.mg_profile_phases(eng.model, 1)
+        torch.cuda.synchronize(); t1 = time.time()
+        run_calls(timed_plan)
+        while handles:
+            ex.wait(handles.pop(0))
+        torch.cuda.synchronize(); t1 = time.time() - t1
+        n_ph1, enc_ms1, dec_ms1 = C.c_long(0), C.c_double(0), C.c_double(0)
+        L_.mg_profile_phases_read(eng.model, C.byref(n_ph1), C.byref(enc_ms1), C.byref(dec_ms1))
+        L_.mg_profile_phases(eng.model, 0)
+        # the branch alone: one call shape of the timed plan (nb batches of 32) and one batch, on the first context's stream
+        nb_main = max(timed_plan) if timed_plan else 1
+        pix_nb = eng.preprocess(devn[nb_main]["pages_u8"])
+        alone = {}
+        for nb_, px in ((nb_main, pix_nb), (1, pix_nb[:B])):
+            e1e.encode(px)
+            torch.cuda.synchronize(); ta = time.time()
+            for _ in range(3):
+                e1e.encode(px)
+            torch.cuda.synchronize()
+            alone[nb_] = (time.time() - ta) / 3
+        from tools.e1_bench import flops_per_image as e1_flops
+        fpi = e1_flops(s1)
+        e1_run = {"images_per_s": round(B * args.steps / t1, 2), "ms_per_step": round(t1 / args.steps * 1e3, 2), "steps": args.steps,
+                  "e1_tokens_per_image": e1e.out_tokens, "e1_gflop_per_image": round(fpi / 1e9, 1),
+                  "e1_alone_ms_per_32_images": round(alone[1] * 1e3, 2), "e1_alone_ms_per_call": round(alone[nb_main] * 1e3, 2), "e1_call_images": nb_main * B,
+                  "e1_alone_mfma_frac": round(fpi * nb_main * B / alone[nb_main] / (MFMA_PEAK_TFLOPS * 1e12), 4),
+                  "encoder_phase_ms_per_call": round(enc_ms1.value / max(n_ph1.value, 1), 2), "decode_step_ms": round(dec_ms1.value / max(n_ph1.value, 1) / new_tokens, 4),
+                  "config": "the headline plan with the OCSR vision branch attached (mg_attach_e1: MolScribe Swin-B geometry 384 px, 86.9 M parameters, recipe weights, "
+                            "2-layer GELU projector INFERRED): per batch + bilinear 512 -> 384 resize + Swin-B + projector inside the step, + 144 keys per image in the "
+                            "cross-K/V projections and in every decode step's cross-attention stream; the reference's architecture_variant me-lf-stack-1"}
+        for c in ctx_all:
+            c.attach_e1(None)
+        e1e.close()
+        del pix_nb
+        torch.cuda.empty_cache()
 
     if rank == 0:
         H, d, dff, V = shape.num_heads, shape.d_model, shape.d_ff, shape.vocab_size
@@ -811,7 +903,8 @@ def main():
                                     "one-batch-at-a-time calls (checked in this run: ids_equal_one_batch_calls); warm-up = `warmup` "
                                     "calls per context",
                        "parallelism": f"dp{world} (independent image shards; one RCCL all-gather of [32,512] int32 ids + lengths per batch)"},
-            "roofline": roof, "phases": phases, "one_call_alone": call_alone_rep, "one_batch_in_flight": single, "extra_runs": extra,
+            "roofline": roof, "phases": phases, "one_call_alone": call_alone_rep, "one_batch_in_flight": single, "with_e1_branch": e1_run,
+            "extra_runs": extra,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(shape, sd)

@@ -212,9 +212,15 @@ int mgk_pack_weight(void* stream, const void* src, int src_is_bf16, int N, int K
 int mgk_rmsnorm_pack(void* stream, const float* h, const float* gain, void* x_pk, float* out_f32, int M, int d,
                      float eps, float scale);
 int mgk_im2col_pack(void* stream, const float* pix, void* x_pk, int B, int C, int I, int ps);
-/* row-tile split policy of the decode-step projections with more than 32 live rows: -1 default (by weight size), 0 never,
- * 1 always one row tile per workgroup (test / A-B hook; results are identical in every mode) */
+/* TEST / A-B SWITCHES (mgk_set_rows_split, mgk_set_resid_f16, mgk_gemm_set_variant): PROCESS-WIDE, for the parity tests and tools/.
+ * Each selects among kernels whose results are bit-identical (that is what the tests that flip them check), so a call that races
+ * with a flip still returns the right bits; they are nevertheless meant to be set while no call is running, and the product
+ * (markushgrapher_amd/) never touches them.
+ * row-tile split policy of the decode-step projections with more than 32 live rows: -1 default (by weight size), 0 never,
+ * 1 always one row tile per workgroup */
 int mgk_set_rows_split(int mode);
+/* residual projections of the decode step with several row tiles: 1 (default) 16 features per workgroup, 0: 8 */
+int mgk_set_resid_f16(int on);
 int mgk_gemm(void* stream, int mode, int epi, const void* X_pk, const void* W_pk, int M, int N, int K, float* out_f32,
              int ldo, const float* bias, void* out_pk);
 /* Deferred-RMSNorm pair of the encoder (tiled large-M kernels): epi 5 (EPI_RESID_NORM): h_tiled (fp32, tiles of
@@ -389,6 +395,12 @@ int mg_e1_workspace_bytes(const mg_e1_model* m, int B, size_t* out_bytes);
  * with its own workspace and stream).  Enqueues only. */
 int mg_e1_encode(const mg_e1_model* m, void* stream, void* ws, size_t ws_bytes, const float* pixel_values, int B, float* e1_out,
                  float* features_out);
+/* Attach the branch to a model (and to the clones made from it afterwards; NULL detaches): mg_encode / mg_generate calls that pass
+ * e1 = NULL, and every mg_generate_stream / mg_generate_stream_beam call, then evaluate mg_e1_encode on their pixel_values inside the
+ * call (in the call's own workspace: mg_workspace_bytes / mg_stream_*_workspace_bytes account for it once attached) and decode over
+ * [e1 | e2] - what the reference's model does with architecture_variant me-lf-stack-1.  A precomputed e1 passed by the caller still
+ * takes precedence.  The branch must outlive the model; d_model, src_image_size and num_channels must match the model's config. */
+int mg_attach_e1(mg_model* m, const mg_e1_model* e1);
 
 #ifdef __cplusplus
 }

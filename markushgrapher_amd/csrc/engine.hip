@@ -31,6 +31,9 @@ int fail(int code, const char* fmt, ...) {
 }  // namespace
 namespace mg {
 int fail_msg(int code, const char* msg) { g_err = msg; return code; }      // ocr.hip
+// swin.hip: the OCSR vision branch evaluated inside another entry point (no error-state reset), and what mg_attach_e1 checks
+int e1_encode_nested(const mg_e1_model* m, mgStream_t st, void* ws, size_t ws_bytes, const float* pixel_values, int B, float* e1_out, float* features_out);
+void e1_info(const mg_e1_model* m, int* tokens, int* d_model, int* src_image_size, int* channels, int* finalized);
 }
 namespace {
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -49,10 +52,11 @@ struct StepGraph {
         const void *ws, *out_ids, *top2, *stream;
         int B, L, K, max_length, min_length, early_stopping, M_e1;
         float length_penalty;
+        const void* scores;      // beam queue: beam_slot_end_kernel holds the out_scores pointer (NULL or a buffer) inside the captured launch
         bool operator==(const Key& o) const {
             return ws == o.ws && out_ids == o.out_ids && top2 == o.top2 && stream == o.stream && B == o.B && L == o.L && K == o.K && M_e1 == o.M_e1 &&
                    max_length == o.max_length && min_length == o.min_length && early_stopping == o.early_stopping &&
-                   length_penalty == o.length_penalty;
+                   length_penalty == o.length_penalty && scores == o.scores;
         }
     };
     Key key{};
@@ -127,6 +131,9 @@ struct mg_model {
     // one call at a time per execution context (mg_clone gives further contexts); recursive: mg_generate runs mg_encode
     std::recursive_mutex call_mu;
     bool tied = true;          // tie_word_embeddings: lm_head = shared.weight and logits scaled by d_model^-0.5 (stock:1554-1557)
+    // OCSR vision branch (mg_attach_e1, swin.hip): calls that pass no precomputed e1 evaluate it from pixel_values themselves
+    const mg_e1_model* e1m = nullptr;
+    int e1_M = 0;              // its tokens per image
 #ifndef MG_EMU
     hipStream_t own_stream = nullptr;
     hipEvent_t fork_ev = nullptr;
@@ -258,6 +265,9 @@ struct Ws {
     uint16_t* e1_pk;
     int* e1_map;
     uint8_t* xmask;           // teacher-forced cross-attention key mask over [e1 | encoder] positions
+    float* e1_f32;            // attached e1 branch: its output [B][M][d] and its workspace
+    char* e1_ws;
+    size_t e1_ws_bytes;
     // decode (generate)
     uint16_t *xk, *xv, *sk, *sv, *dq, *dx_pk, *dy_pk;
     uint16_t *xa, *xb;        // packed [rows][d + inner] operand windows of the pair projections: [bf16(h) | attention context]
@@ -327,6 +337,12 @@ void carve(const mg_model* m, char* base, int B, int L, int K, int max_len, int 
     w->e1_pk = c.take<uint16_t>((size_t)B * M64 * d);
     w->e1_map = c.take<int>((size_t)B * M64);
     w->xmask = c.take<uint8_t>((size_t)B * Sx_cap);
+    w->e1_f32 = nullptr; w->e1_ws = nullptr; w->e1_ws_bytes = 0;
+    if (m->e1m && Me1 > 0) {
+        w->e1_f32 = c.take<float>((size_t)B * Me1 * d);
+        (void)mg_e1_workspace_bytes(m->e1m, B, &w->e1_ws_bytes);
+        w->e1_ws = c.take<char>(w->e1_ws_bytes);
+    }
     if (max_len > 0) {
         const int R = B * K, Rp = round_up(R, 32);
         const size_t nl = m->dec.size();
@@ -401,12 +417,12 @@ struct StreamWs {
     size_t total;
 };
 void carve_stream(const mg_model* m, char* base, int chunk, int L, int slots_img, int pool_chunks, StreamWs* w, int K = 1, int max_len = 0) {
-    carve(m, base, chunk, L, 1, 0, 0, 0, &w->enc);
+    carve(m, base, chunk, L, 1, 0, 0, m->e1_M, &w->enc);
     Carver c{base};
     c.off = w->enc.total;
     const int d = m->d, inner = m->inner, H = m->H;
     const int slots = slots_img * K;                        // decode rows
-    const int Sx_cap = round_up(L + m->P, 64), Rp = round_up(slots, 32);
+    const int Sx_cap = round_up(L + m->P, 64) + round_up(m->e1_M, 64), Rp = round_up(slots, 32);      // keys of an image: [e1 tokens | encoder positions]
     const size_t nl = m->dec.size(), entries = (size_t)pool_chunks * chunk;
     w->pool_stride = entries * H * Sx_cap * 64;
     w->xk = c.take<uint16_t>(nl * w->pool_stride);
@@ -788,6 +804,7 @@ int mg_clone(const mg_model* src, mg_model** out) {
     m->fin_a = src->fin_a; m->fin_b = src->fin_b; m->fin_c = src->fin_c;
     m->use_graph = src->use_graph; m->enc_mode = src->enc_mode; m->enc_mask = src->enc_mask;
     m->row_tiles = src->row_tiles; m->trim_padding = src->trim_padding; m->fused_tail = src->fused_tail; m->tied = src->tied;
+    m->e1m = src->e1m; m->e1_M = src->e1_M;
     *out = m;
     return MG_OK;
 }
@@ -998,9 +1015,25 @@ int mg_finalize(mg_model* m, void* stream) {
     return MG_OK;
 }
 
+int mg_attach_e1(mg_model* m, const mg_e1_model* e1) {
+    if (!m) return fail(MG_E_ARG, "mg_attach_e1: null model");
+    MG_ONE_CALL(m, "mg_attach_e1");
+    if (!e1) { m->e1m = nullptr; m->e1_M = 0; m->step_graph.reset(); m->stream_graph.reset(); return MG_OK; }
+    int tokens = 0, dm = 0, src = 0, ch = 0, fin = 0;
+    e1_info(e1, &tokens, &dm, &src, &ch, &fin);
+    if (!fin) return fail(MG_E_STATE, "mg_attach_e1: mg_e1_finalize has not run on the branch");
+    if (dm != m->d || src != m->c.image_size || ch != m->c.num_channels)
+        return fail(MG_E_SHAPE, "mg_attach_e1: the branch produces %d features from %d-channel %d px inputs, the model has d_model %d and %d-channel %d px pixel_values",
+                    dm, ch, src, m->d, m->c.num_channels, m->c.image_size);
+    m->e1m = e1; m->e1_M = tokens;
+    m->step_graph.reset(); m->stream_graph.reset();       // captured steps hold the key-stream geometry of the previous setting
+    return MG_OK;
+}
+
 int mg_workspace_bytes(const mg_model* m, int B, int L, int num_beams, int max_length, int T, int M_e1, size_t* out_bytes) {
     if (!m || !out_bytes || B < 1 || L < 1 || num_beams < 1 || max_length < 0 || T < 0 || M_e1 < 0) return fail(MG_E_ARG, "mg_workspace_bytes: bad argument");
     Ws w;
+    if (M_e1 == 0) M_e1 = m->e1_M;        // attached e1 branch: sized for the calls that let the library evaluate it
     carve(m, nullptr, B, L, num_beams, max_length, T, M_e1, &w);
     *out_bytes = w.total;
     return MG_OK;
@@ -1017,8 +1050,15 @@ int mg_encode(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_
     if ((e1 == nullptr) != (M_e1 == 0) || M_e1 < 0) return fail(MG_E_ARG, "mg_encode: e1 and M_e1 must be given together");
     mgStream_t st = (mgStream_t)stream;
     Ws w;
+    const bool own_e1 = !e1 && m->e1m;            // attached OCSR branch and no precomputed tokens: evaluated here from pixel_values
+    if (own_e1) M_e1 = m->e1_M;
     carve(m, (char*)ws, B, L, 1, 0, 0, M_e1, &w);
     if (w.total > ws_bytes) return fail(MG_E_WORKSPACE, "mg_encode: workspace too small (%zu < %zu)", ws_bytes, w.total);
+    if (own_e1) {
+        const int rc1 = e1_encode_nested(m->e1m, st, w.e1_ws, w.e1_ws_bytes, pixel_values, B, w.e1_f32, nullptr);
+        if (rc1 != MG_OK) return rc1;
+        e1 = w.e1_f32;
+    }
     const int d = m->d, H = m->H, inner = m->inner, P = m->P;
     const int S = L + P, S_cap = round_up(S, 64), M = B * S_cap;
     mg_memset_async(w.counters, 0, 16 * sizeof(int), st);
@@ -1199,10 +1239,12 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
     const int K = num_beams;
     Ws w;
     if ((e1 == nullptr) != (M_e1 == 0) || M_e1 < 0) return fail(MG_E_ARG, "mg_generate: e1 and M_e1 must be given together");
+    const int M_in = M_e1;
+    if (!e1 && m->e1m) M_e1 = m->e1_M;            // attached OCSR branch: mg_encode evaluates it (same workspace layout as with precomputed tokens)
     carve(m, (char*)ws, B, L, K, max_length, 0, M_e1, &w);
     if (w.total > ws_bytes) return fail(MG_E_WORKSPACE, "mg_generate: workspace too small (%zu < %zu)", ws_bytes, w.total);
     if (m->phase_on) mg_event_record(m->phase_ev[0], st);
-    int rc = mg_encode(m, stream, ws, ws_bytes, input_ids, bbox, attention_mask, pixel_values, e1, M_e1, B, L, nullptr, nullptr);
+    int rc = mg_encode(m, stream, ws, ws_bytes, input_ids, bbox, attention_mask, pixel_values, e1, M_in, B, L, nullptr, nullptr);
     if (rc != MG_OK) return rc;
     const int d = m->d, H = m->H, inner = m->inner, S_cap = m->st_Scap, M = B * S_cap;
     const int R = B * K, T_cap = m->T_cap;
@@ -1275,7 +1317,7 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
     const bool instrumented = m->dbg_logits || m->dbg_forced;      // by-value eager launches of the same kernels
 #ifndef MG_EMU
     if (m->use_graph == 1 && !instrumented) {
-        const StepGraph::Key key{ws, out_ids, step_top2, (const void*)st, B, L, K, max_length, min_length, early_stopping, M_e1, length_penalty};
+        const StepGraph::Key key{ws, out_ids, step_top2, (const void*)st, B, L, K, max_length, min_length, early_stopping, M_e1, length_penalty, nullptr};
         StepGraph& sg = m->step_graph;
         if (!(sg.valid && sg.key == key)) {
             std::lock_guard<std::mutex> capture_lock(mg_capture_mutex());
@@ -1392,24 +1434,24 @@ int mg_stream_encoder_mode(mg_model* m, int mode, const uint32_t* cu_mask, int n
 static int generate_stream_impl(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* input_ids, const float* bbox,
                                 const uint8_t* attention_mask, const float* pixel_values, int N, int L, int chunk, int slots, int pool_chunks,
                                 int K, int max_length, int min_length, float length_penalty, int early_stopping, int64_t* out_ids,
-                                int32_t* out_len, float* out_scores, long* steps_host) {
+                                int32_t* out_len, float* out_scores, long* steps_host, const char* who) {
     entry_drain();
-    if (!m || !ws || !input_ids || !bbox || !pixel_values || !out_ids || !out_len) return fail(MG_E_ARG, "mg_generate_stream: null argument");
+    if (!m || !ws || !input_ids || !bbox || !pixel_values || !out_ids || !out_len) return fail(MG_E_ARG, "%s: null argument", who);
     MG_ONE_CALL(m, "mg_generate_stream");
-    if (!m->finalized) return fail(MG_E_STATE, "mg_generate_stream: call mg_finalize first");
-    if (N < 1 || L < 1 || chunk < 1 || pool_chunks < 2) return fail(MG_E_SHAPE, "mg_generate_stream: N, L, chunk must be >= 1, pool_chunks >= 2");
-    if (K < 1 || K > 8) return fail(MG_E_UNSUPPORTED, "mg_generate_stream: num_beams must be in [1, 8]");
-    if (slots < 1 || (long)slots * K > 256) return fail(MG_E_UNSUPPORTED, "mg_generate_stream: slots * num_beams must be in [1, 256]");
-    if (slots > pool_chunks * chunk) return fail(MG_E_SHAPE, "mg_generate_stream: slots (%d) exceed the %d pool entries", slots, pool_chunks * chunk);
-    if (max_length < 2 || max_length > m->T_cap) return fail(MG_E_SHAPE, "mg_generate_stream: max_length must be in [2, %d]", m->T_cap);
-    if (m->dbg_logits || m->dbg_forced) return fail(MG_E_STATE, "mg_generate_stream: the decode-capture instrumentation is for mg_generate");
+    if (!m->finalized) return fail(MG_E_STATE, "%s: call mg_finalize first", who);
+    if (N < 1 || L < 1 || chunk < 1 || pool_chunks < 2) return fail(MG_E_SHAPE, "%s: N, L, chunk must be >= 1, pool_chunks >= 2", who);
+    if (K < 1 || K > 8) return fail(MG_E_UNSUPPORTED, "%s: num_beams must be in [1, 8]", who);
+    if (slots < 1 || (long)slots * K > 256) return fail(MG_E_UNSUPPORTED, "%s: slots * num_beams must be in [1, 256]", who);
+    if (slots > pool_chunks * chunk) return fail(MG_E_SHAPE, "%s: slots (%d) exceed the %d pool entries", who, slots, pool_chunks * chunk);
+    if (max_length < 2 || max_length > m->T_cap) return fail(MG_E_SHAPE, "%s: max_length must be in [2, %d]", who, m->T_cap);
+    if (m->dbg_logits || m->dbg_forced) return fail(MG_E_STATE, "%s: the decode-capture instrumentation is for mg_generate", who);
     const int R = slots * K;                         // decode rows
     StreamWs w;
     carve_stream(m, (char*)ws, chunk, L, slots, pool_chunks, &w, K, max_length);
-    if (w.total > ws_bytes) return fail(MG_E_WORKSPACE, "mg_generate_stream: workspace too small (%zu < %zu)", ws_bytes, w.total);
+    if (w.total > ws_bytes) return fail(MG_E_WORKSPACE, "%s: workspace too small (%zu < %zu)", who, ws_bytes, w.total);
     mgStream_t st = (mgStream_t)stream;
     const int d = m->d, H = m->H, inner = m->inner, P = m->P;
-    const int S_cap = round_up(L + P, 64), Sx_cap = S_cap;
+    const int S_cap = round_up(L + P, 64), M64 = round_up(m->e1_M, 64), Sx_cap = S_cap + M64;
     const size_t nl = m->dec.size();
     const int n_chunks = (N + chunk - 1) / chunk;
     const int entries = pool_chunks * chunk;
@@ -1417,7 +1459,7 @@ static int generate_stream_impl(mg_model* m, void* stream, void* ws, size_t ws_b
     // streams and events
     if (m->enc_mode != 0 && !m->enc_stream_ready) {
         if (mg_stream_create(&m->enc_stream, m->enc_mode == 1, m->enc_mode == 2 ? m->enc_mask.data() : nullptr, (int)m->enc_mask.size()) != 0)
-            return fail(MG_E_HIP, "mg_generate_stream: could not create the encoder stream");
+            return fail(MG_E_HIP, "%s: could not create the encoder stream", who);
         m->enc_stream_ready = true;
     }
 #ifndef MG_EMU
@@ -1466,7 +1508,7 @@ static int generate_stream_impl(mg_model* m, void* stream, void* ws, size_t ws_b
 #ifndef MG_EMU
     if (m->use_graph == 1) {
         const StepGraph::Key key{ws, out_ids, out_len, (const void*)st, slots * 16 + K, L, chunk, max_length, min_length, N * 2 + (early_stopping ? 1 : 0),
-                                 pool_chunks, length_penalty};     // (B = slots and beams, K = chunk, early_stopping = N and the flag, M_e1 = pool_chunks)
+                                 pool_chunks, length_penalty, (const void*)out_scores};     // (B = slots and beams, K = chunk, early_stopping = N and the flag, M_e1 = pool_chunks)
         StepGraph& sg = m->stream_graph;
         if (!(sg.valid && sg.key == key)) {
             std::lock_guard<std::mutex> capture_lock(mg_capture_mutex());
@@ -1499,9 +1541,15 @@ static int generate_stream_impl(mg_model* m, void* stream, void* ws, size_t ws_b
                            pixel_values + (size_t)c0 * img_in, nullptr, 0, n, L, nullptr, nullptr);
         if (rc != MG_OK) return rc;
         Ws we;
-        carve(m, (char*)ws, n, L, 1, 0, 0, 0, &we);         // the chunk's own carving (a short last chunk uses less of the region)
+        carve(m, (char*)ws, n, L, 1, 0, 0, m->e1_M, &we);         // the chunk's own carving (a short last chunk uses less of the region)
         const size_t ent_off = (size_t)entry0 * H * Sx_cap * 64;
         for (size_t li = 0; li < nl; ++li) {
+            if (M64) {          // the e1 tokens of the attached OCSR branch: rows [0, e1_M) of every image's key stream (as mg_generate)
+                GemmArgs ke = gemm_args(we.e1_pk, m->at<uint16_t>(m->dec[li].xkv), n * M64, 2 * inner, d);
+                set_heads(ke, H, M64, Sx_cap, w.xk + li * w.pool_stride + ent_off, HF_NATURAL, w.xv + li * w.pool_stride + ent_off, HF_NATURAL, nullptr, HF_NONE);
+                ke.heads.row_map = we.e1_map;
+                gemm(ke, EPI_HEADS, es);
+            }
             GemmArgs kv = gemm_args(we.enc_pk, m->at<uint16_t>(m->dec[li].xkv), n * S_cap, 2 * inner, d);
             set_heads(kv, H, S_cap, Sx_cap, w.xk + li * w.pool_stride + ent_off, HF_NATURAL, w.xv + li * w.pool_stride + ent_off, HF_NATURAL, nullptr, HF_NONE);
             kv.heads.row_map = we.xrow;
@@ -1543,7 +1591,7 @@ static int generate_stream_impl(mg_model* m, void* stream, void* ws, size_t ws_b
             const bool timed_step = m->prof_every > 0 && (steps % m->prof_every) == 0;
 #ifndef MG_EMU
             if (graphed && !timed_step) {
-                if (hipGraphLaunch(m->stream_graph.exec, st) != hipSuccess) { quiesce(); return fail(MG_E_HIP, "mg_generate_stream: hipGraphLaunch failed"); }
+                if (hipGraphLaunch(m->stream_graph.exec, st) != hipSuccess) { quiesce(); return fail(MG_E_HIP, "%s: hipGraphLaunch failed", who); }
             } else
 #endif
                 decode_step(m, dc, 0, nullptr, timed_step, st);
@@ -1560,14 +1608,14 @@ static int generate_stream_impl(mg_model* m, void* stream, void* ws, size_t ws_b
             live_host = h[0]; done_host = h[1]; head_host = h[4]; oldest_host = h[7];
             ++rb_seen;
         }
-        if (steps > (long)N * max_length + 64L * n_chunks + 1024) { quiesce(); return fail(MG_E_HIP, "mg_generate_stream: no progress (%d of %d images after %ld steps)", done_host, N, steps); }
+        if (steps > (long)N * max_length + 64L * n_chunks + 1024) { quiesce(); return fail(MG_E_HIP, "%s: no progress (%d of %d images after %ld steps)", who, done_host, N, steps); }
     }
     int err2[2] = {0, 0};
     int& err_host = err2[0];
     if (es != st) mg_stream_sync(es);
     mg_memcpy_async(err2, w.err, 2 * sizeof(int), st);
     mg_stream_sync(st);
-    rc = check_launch("mg_generate_stream");
+    rc = check_launch(who);
     if (rc != MG_OK) return rc;
     for (int c = 0; c < (n_chunks < pool_chunks ? n_chunks : pool_chunks); ++c)
         m->stream_enc_ms += mg_event_elapsed_ms(m->chunk_ev[2 * c], m->chunk_ev[2 * c + 1]);     // the last pool_chunks chunks (statistics)
@@ -1582,7 +1630,7 @@ static int generate_stream_impl(mg_model* m, void* stream, void* ws, size_t ws_b
     }
     m->stream_steps = steps;
     if (steps_host) *steps_host = steps;
-    if (err_host != 0) return fail(MG_E_INPUT, "mg_generate_stream: %d token ids outside [0, vocab)", err_host);
+    if (err_host != 0) return fail(MG_E_INPUT, "%s: %d token ids outside [0, vocab)", who, err_host);
     return MG_OK;
 }
 
@@ -1592,7 +1640,7 @@ int mg_generate_stream(mg_model* m, void* stream, void* ws, size_t ws_bytes, con
                        const uint8_t* attention_mask, const float* pixel_values, int N, int L, int chunk, int slots, int pool_chunks,
                        int max_length, int min_length, int64_t* out_ids, int32_t* out_len, long* steps_host) {
     return generate_stream_impl(m, stream, ws, ws_bytes, input_ids, bbox, attention_mask, pixel_values, N, L, chunk, slots, pool_chunks, 1,
-                                max_length, min_length, 1.0f, 0, out_ids, out_len, nullptr, steps_host);
+                                max_length, min_length, 1.0f, 0, out_ids, out_len, nullptr, steps_host, "mg_generate_stream");
 }
 int mg_stream_beam_workspace_bytes(const mg_model* m, int chunk, int L, int slots, int pool_chunks, int num_beams, int max_length, size_t* out_bytes) {
     if (!m || !out_bytes || chunk < 1 || L < 1 || slots < 1 || pool_chunks < 2 || num_beams < 1 || num_beams > 8 || max_length < 2)
@@ -1607,7 +1655,7 @@ int mg_generate_stream_beam(mg_model* m, void* stream, void* ws, size_t ws_bytes
                             int num_beams, int max_length, int min_length, float length_penalty, int early_stopping, int64_t* out_ids,
                             int32_t* out_len, float* out_scores, long* steps_host) {
     return generate_stream_impl(m, stream, ws, ws_bytes, input_ids, bbox, attention_mask, pixel_values, N, L, chunk, slots, pool_chunks,
-                                num_beams, max_length, min_length, length_penalty, early_stopping, out_ids, out_len, out_scores, steps_host);
+                                num_beams, max_length, min_length, length_penalty, early_stopping, out_ids, out_len, out_scores, steps_host, "mg_generate_stream_beam");
 }
 
 // Live timing of the dominant decode kernel (single-query cross-attention over the image K/V stream): when enabled,
@@ -1664,7 +1712,7 @@ int mg_set_decode_graph(mg_model* m, int enable) {
     if (!m) return fail(MG_E_ARG, "mg_set_decode_graph: null model");
     const int prev = m->use_graph;
     m->use_graph = enable < 0 ? 0 : (enable > 2 ? 1 : enable);
-    if (m->use_graph != 1) m->step_graph.reset();
+    if (m->use_graph != 1) { m->step_graph.reset(); m->stream_graph.reset(); }      // (both captured steps: batch form and the greedy / beam queues)
     return prev;
 }
 int mg_decode_graph_active(const mg_model* m) { return m && m->graph_active ? 1 : 0; }

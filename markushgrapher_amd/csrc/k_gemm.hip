@@ -6,6 +6,7 @@
 //   * swapping the two MFMA operands transposes the accumulator for free, which lets each epilogue store
 //     16-byte chunks in the layout its consumer wants (packed rows, packed transposed, or row-major fp32).
 #include "k_gemm_epi.h"
+#include <atomic>
 
 namespace mg {
 
@@ -427,7 +428,9 @@ static void launch_wide(const GemmArgs& a, mgStream_t stream) {
 // 0: 128x128 two-stage kernel only; 1: + 256x128 three-stage kernel for M >= 256; 2: + 256x256 kernel wherever it fits;
 // 4: + 320x256; 5 / 6: persistent ping-pong kernel with 256- / 320-row tiles (k_gemm_pp.hip);
 // 3 (default): by shape = 6 where the ping-pong kernel applies, else 4
-static int g_gemm_variant = 3;
+// (the three test / A-B switches of this file are process-wide: atomics, so that a host thread of another execution context never reads a torn
+// value; they select among kernels with IDENTICAL results and are meant to be set while no call is running - see include/mgrapher.h)
+static std::atomic<int> g_gemm_variant{3};
 void gemm_set_variant(int v) { g_gemm_variant = v; }
 
 bool gemm_has_gelu_epilogue(int M, int N) { return g_gemm_variant >= 2 && M >= 320 && N >= GX_N; }
@@ -435,16 +438,17 @@ bool gemm_has_gelu_epilogue(int M, int N) { return g_gemm_variant >= 2 && M >= 3
 void gemm(const GemmArgs& a, int epi, mgStream_t stream) {
     static bool env_read = false;
     if (!env_read) { env_read = true; if (const char* e = getenv("MG_GEMM_VARIANT")) g_gemm_variant = atoi(e); }   // A/B runs
+    const int gv = g_gemm_variant;          // one read per call (the switch is process-wide)
     // default (3): the persistent ping-pong kernel with 320-row tiles where its shape rules hold (K % 128 == 0), measured against the
     // two-stage kernel at M = 40960 (us): QKV 292 -> 245, O 166 -> 156, wi 356 -> 301, wo 434 -> 396, cross-KV 154 -> 146 (profiles/r04_b_*)
-    if ((g_gemm_variant == 3 || g_gemm_variant == 5 || g_gemm_variant == 6) && a.M >= 320 && a.N >= GX_N) {        // ping-pong persistent kernel, TI = 4 (variant 5) / 5
-        if (gemm_pp(a, epi, g_gemm_variant == 5 ? 4 : 5, stream)) return;
+    if ((gv == 3 || gv == 5 || gv == 6) && a.M >= 320 && a.N >= GX_N) {        // ping-pong persistent kernel, TI = 4 (variant 5) / 5
+        if (gemm_pp(a, epi, gv == 5 ? 4 : 5, stream)) return;
     }
-    if (g_gemm_variant >= 2 && a.M >= 320 && a.N >= GX_N) {
+    if (gv >= 2 && a.M >= 320 && a.N >= GX_N) {
         // measured at M = 40960 (PFLOP/s, 256x128 / 256x256 / 320x256): QKV 0.72 / 0.92 / 1.01, O 0.47 / 0.45 / 0.53,
         // wi 0.78 / 0.99 / 1.04, wo 0.73 / 0.69 / 0.80, cross-KV 0.97 / 1.10 / 1.09 -> the 320-row tile by default
-        const bool five = g_gemm_variant >= 3;
-        const bool four = g_gemm_variant == 2;
+        const bool five = gv >= 3;
+        const bool four = gv == 2;
         if (five) {
             switch (epi) {
                 case EPI_F32_STORE: launch_xl<EPI_F32_STORE, 5>(a, stream); break;
@@ -474,7 +478,7 @@ void gemm(const GemmArgs& a, int epi, mgStream_t stream) {
             return;
         }
     }
-    if (g_gemm_variant >= 1 && a.M >= GW_M) {
+    if (gv >= 1 && a.M >= GW_M) {
         switch (epi) {
             case EPI_F32_STORE: launch_wide<EPI_F32_STORE>(a, stream); break;
             case EPI_F32_RESID: launch_wide<EPI_F32_RESID>(a, stream); break;
@@ -516,7 +520,7 @@ void gemm(const GemmArgs& a, int epi, mgStream_t stream) {
 // Larger weights (the main decoder at beam search, 160 rows = 5 tiles, 6-18 MB per projection) do NOT split: one tile per workgroup
 // measured 61.7 -> 51.2 images/s and two groups of tiles 67.4 -> 60.5 (profiles/r02_rows_split_ab.txt) - the other groups' workgroups
 // pull the weight slice from HBM again instead of finding it in L2.
-static int g_rows_split_mode = -1;      // -1: by weight size (default); 0: never; 1: always one tile per workgroup  (tests, A/B runs)
+static std::atomic<int> g_rows_split_mode{-1};      // -1: by weight size (default); 0: never; 1: always one tile per workgroup  (tests, A/B runs)
 void gemm_rows_set_split(int mode) { g_rows_split_mode = mode; }
 static int rows_split_tiles(int mt, size_t weight_elems) {          // row tiles per workgroup; mt = no split
     static bool env_read = false;
@@ -1381,7 +1385,7 @@ void gemm_rows_resid_trace(const ResidArgs& r, long long* trace, mgStream_t stre
 }
 #endif
 
-static int g_resid_f16 = 1;
+static std::atomic<int> g_resid_f16{1};
 void gemm_rows_set_resid_f16(int on) { g_resid_f16 = on; }
 void gemm_rows_resid(const ResidArgs& r, mgStream_t stream) {
     int mt = (r.M + 31) / 32;

@@ -325,6 +325,8 @@ static bool launch_pp(const GemmArgs& a_in, mgStream_t stream) {
     int G = nblk < ncu ? nblk : ncu;
     if (G >= 8) G &= ~7;
     if ((a.K & 127) != 0 || (nblk + nblk / 3 + G) > GP_MAXT * G || (EPI == EPI_RESID_NORM && a.N > GP_GAIN_MAX)) return false;   // (K/16 a multiple of the ring; balanced blocks are up to 30 % more)
+    // the kernel addresses its operands by 32-bit byte offsets: an operand of 2 GiB or more goes to the two-stage kernel instead
+    if ((size_t)((a.M + 31) / 32) * 32 * (size_t)a.K * 2 > 0x7fffffffull || (size_t)((a.N + 31) / 32) * 32 * (size_t)a.K * 2 > 0x7fffffffull) return false;
     const size_t sh = (size_t)GP_RING * (2 * TI + 8) * TILE_BYTES + (size_t)GP_MAXT * (2 * TI + 2) * sizeof(int) +
                       (EPI == EPI_RESID_NORM ? (size_t)GP_GAIN_MAX * sizeof(float) : 0);
     static bool once = false;

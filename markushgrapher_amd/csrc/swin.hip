@@ -22,6 +22,7 @@
 using namespace mg;
 
 namespace mg {
+int e1_encode_nested(const mg_e1_model* m, mgStream_t st, void* ws, size_t ws_bytes, const float* pixel_values, int B, float* e1_out, float* features_out);
 void ocr_pack_aug(const float* W, const float* bias, float scale, uint16_t* dst, int row0, int N, int K, int Kaug, int Nfill, int rstride, mgStream_t st);
 }
 
@@ -296,15 +297,24 @@ int mg_e1_workspace_bytes(const mg_e1_model* m, int B, size_t* out_bytes) {
 }
 
 int mg_e1_encode(const mg_e1_model* m, void* stream, void* ws, size_t ws_bytes, const float* pixel_values, int B, float* e1_out, float* features_out) {
-    (void)mg_peek_error();
+    (void)mg_peek_error();               // whatever is pending in the runtime's per-thread last-error slot was not caused by this call
     mg_err_site() = MgErrSite{0, nullptr};
+    return mg::e1_encode_nested(m, (mgStream_t)stream, ws, ws_bytes, pixel_values, B, e1_out, features_out);
+}
+
+}  // extern "C"
+
+namespace mg {
+void e1_info(const mg_e1_model* m, int* tokens, int* d_model, int* src_image_size, int* channels, int* finalized) {
+    *tokens = m->M_out; *d_model = m->d_model; *src_image_size = m->c.src_image_size; *channels = m->c.num_channels; *finalized = m->finalized ? 1 : 0;
+}
+int e1_encode_nested(const mg_e1_model* m, mgStream_t st, void* ws, size_t ws_bytes, const float* pixel_values, int B, float* e1_out, float* features_out) {
     if (!m || !ws || !pixel_values || (!e1_out && !features_out)) return failf(MG_E_ARG, "mg_e1_encode: null argument");
     if (!m->finalized) return failf(MG_E_STATE, "mg_e1_encode: mg_e1_finalize has not run");
     if (B < 1 || B > 4096) return failf(MG_E_SHAPE, "mg_e1_encode: B = %d out of range", B);
     Ws w;
     carve(m, (char*)ws, B, &w);
     if (ws_bytes < w.total) return failf(MG_E_WORKSPACE, "mg_e1_encode: workspace %zu < %zu bytes", ws_bytes, w.total);
-    mgStream_t st = (mgStream_t)stream;
     const mg_e1_config& c = m->c;
     // the branch's own input: bilinear resize of the VTL model's pixel_values + per-channel affine (INFERRED: e1_shapes.py)
     const float* pix = pixel_values;
@@ -400,5 +410,4 @@ int mg_e1_encode(const mg_e1_model* m, void* stream, void* ws, size_t ws_bytes, 
     }
     return check("mg_e1_encode");
 }
-
-}  // extern "C"
+}  // namespace mg

@@ -108,6 +108,7 @@ class Engine:
         self._ws_bytes = 0
         self._gen_out = {}
         self.ignored_keys = []
+        self._e1_engine = None
 
     def _declare(self):
         L = self.lib
@@ -120,6 +121,7 @@ class Engine:
         L.mg_finalize.argtypes = [C.c_void_p, C.c_void_p]
         L.mg_load_tensor.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]
         L.mg_set_decode_graph.argtypes = [C.c_void_p, C.c_int]
+        L.mg_attach_e1.argtypes = [C.c_void_p, C.c_void_p]
         L.mg_set_shared_gpu.argtypes = [C.c_void_p, C.c_int]
         L.mg_decode_graph_active.argtypes = [C.c_void_p]
         L.mg_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
@@ -169,7 +171,19 @@ class Engine:
         other.model = C.c_void_p()
         self._chk(self.lib.mg_clone(self.model, C.byref(other.model)))
         other._ws, other._ws_bytes, other._gen_out, other.ignored_keys = None, 0, {}, list(self.ignored_keys)
+        other._e1_engine = self._e1_engine      # mg_clone carries the attachment; the branch's weights are shared and kept alive
         return other
+
+    def attach_e1(self, e1_engine):
+        """Attach the OCSR vision branch (e1.E1Engine; None detaches): generate() / encode() / the queue forms called without `e1=` then
+        evaluate it from pixel_values inside the call and decode over [e1 | e2] (include/mgrapher.h mg_attach_e1) - the reference's
+        `architecture_variant: me-lf-stack-1`.  Clones made afterwards inherit it."""
+        self.mem.sync()
+        self._chk(self.lib.mg_attach_e1(self.model, e1_engine.model if e1_engine is not None else None))
+        self._e1_engine = e1_engine
+        self._ws, self._ws_bytes, self._gen_out = None, 0, {}
+        self._sws, self._sws_bytes = None, 0
+        return self
 
     def release_workspaces(self):
         """Drop the cached workspaces and output buffers of this context (they are re-allocated by the next call that needs them).  A

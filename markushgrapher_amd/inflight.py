@@ -76,7 +76,8 @@ class InFlight:
         # several contexts on one GPU: every context's cross-attention stream leaves wave slots to the others (mg_set_shared_gpu)
         # (MG_SHARED_GPU=0: leave the contexts' setting alone - A/B runs)
         share = n > 1 and os.environ.get("MG_SHARED_GPU", "1") != "0"
-        self._shared_prev = [c.set_shared_gpu(share) for c in self.contexts] if hasattr(engine, "set_shared_gpu") else None
+        # only ever switched ON here: with one context or MG_SHARED_GPU=0 whatever the owner had set stays (and so do its captured graphs)
+        self._shared_prev = [c.set_shared_gpu(True) for c in self.contexts] if (share and hasattr(engine, "set_shared_gpu")) else None
 
     def __len__(self):
         return len(self.contexts)
@@ -116,6 +117,11 @@ class InFlight:
         keys = ("input_ids", "bbox", "attention_mask", "pixel_values")
         sizes = plan_calls(len(batches), len(self), max(1, int(max_batches_per_call)))
         rows = int(batches[0]["input_ids"].shape[0]) if batches else 0
+        for i, b in enumerate(batches):            # a short last batch (the usual dataloader tail) would be cut at the wrong offsets below
+            for k in keys:
+                if tuple(b[k].shape) != tuple(batches[0][k].shape):
+                    raise ValueError(f"generate_batches: batch {i} has {k} of shape {tuple(b[k].shape)}, batch 0 has {tuple(batches[0][k].shape)}: "
+                                     "batches must have equal shapes (pad the tail batch or pass it in a call of its own)")
 
         def cat(parts):
             if torch is not None and all(torch.is_tensor(p) for p in parts):          # (numpy 2 arrays have a .device too)

@@ -44,6 +44,9 @@ class MarkushgrapherConfig:
         # branch (e1) this package does not compute (ref default: core/common/arguments.py:258; set at begin.py:120)
         self.architecture_variant = kw.pop("architecture_variant", "none")
         self.allow_missing_e1 = bool(kw.pop("allow_missing_e1", False))
+        # geometry of the OCSR vision branch: overrides of e1_shapes.PRESETS["swin_b_384"] (MolScribe's Swin-B), e.g. {"pix_scale": [...]};
+        # d_model / src_image_size follow this config, the projector's layer sizes follow the checkpoint's tensors
+        self.e1 = dict(kw.pop("e1", None) or {})
         self.output_attentions = kw.pop("output_attentions", False)
         self.max_length = kw.pop("max_length", 512)
         self.tie_word_embeddings = bool(kw.pop("tie_word_embeddings", True))      # UDOP / T5 default
@@ -66,6 +69,8 @@ class MarkushgrapherConfig:
         d = self.to_shape().to_dict()
         d.update(architecture_variant=self.architecture_variant, model_type=self.model_type,
                  tie_word_embeddings=self.tie_word_embeddings, max_length=self.max_length)
+        if self.e1:
+            d["e1"] = {k: (list(v) if isinstance(v, tuple) else v) for k, v in self.e1.items()}
         return d
 
 
@@ -95,12 +100,12 @@ class _ParamTree(nn.Module):
 
 
 class _E1Branch(_ParamTree):
-    """`encoder.molscribe_encoder` / `encoder.molscribe_projector` (OCSR e1 branch): the fork's Swin-B
-    encoder + MLP projector are NOT computed by this package (their source is not in the reference tree).  The modules exist
-    as tensor containers: whatever `encoder.molscribe_*` tensors a checkpoint holds are kept with their names and dtypes, so
-    `.state_dict()` / `.parameters()` / save_weights_separately (ref: utils/model/utils_model_loading.py:6-46) and
-    `model.safe_load(model.encoder.molscribe_projector, states)` (ref: begin.py:151) round-trip them unchanged; the tokens
-    they would produce have to be supplied as `e1=` to forward() / generate()."""
+    """`encoder.molscribe_encoder` / `encoder.molscribe_projector` (OCSR e1 branch).  The modules are tensor
+    containers with the checkpoint's own names and dtypes, so `.state_dict()` / `.parameters()` / save_weights_separately
+    (ref: utils/model/utils_model_loading.py:6-46) and `model.safe_load(model.encoder.molscribe_projector, states)`
+    (ref: begin.py:151) round-trip them unchanged; the computation - Swin encoder + projector on the HIP engine (e1.E1Engine,
+    csrc/swin.hip) - is set up from these tensors when the model is first used (e1_shapes.canonical_*_keys maps timm /
+    transformers namings onto the library's).  With an incomplete branch the tokens have to be supplied as `e1=`."""
 
     def load_state_dict(self, state_dict, strict=False):
         self._modules.clear()
@@ -189,11 +194,55 @@ class MarkushgrapherForConditionalGeneration(nn.Module):
         module.load_state_dict(state_dict, strict=False)
         self._engine = None
 
-    def init_molscribe_weights(self):
-        """ref: begin.py:137-138 loads the pretrained MolScribe Swin-B into the fork's e1 branch.  That branch is not part of
-        this package (source and weights unavailable): nothing to initialise; callers are told once."""
-        warnings.warn("markushgrapher_amd: init_molscribe_weights() is a no-op - the OCSR vision branch (e1) is not computed by "
-                      "this package; pass its projected embeddings as e1= to forward()/generate()", stacklevel=2)
+    MOLSCRIBE_CKPT = os.path.join("external", "MolScribe", "ckpts", "swin_base_char_aux_1m680k.pth")     # ref: setup.sh:79-82
+
+    def init_molscribe_weights(self, path: Optional[str] = None):
+        """ref: begin.py:137-138 - loads the pretrained MolScribe Swin-B (`swin_base_char_aux_1m680k.pth`, ref: setup.sh:79-82) into
+        `encoder.molscribe_encoder`.  The checkpoint is looked up at `path`, $MG_MOLSCRIBE_CKPT, or the reference's install location
+        relative to the working directory; its `encoder` entry (MolScribe saves {'encoder': ..., 'decoder': ...}, keys possibly behind
+        `module.`) is kept under timm's own names.  Without the file the branch keeps what the model checkpoint held (the published
+        MarkushGrapher-2 weights carry their frozen copy) and the caller is told."""
+        cand = [p for p in (path, os.environ.get("MG_MOLSCRIBE_CKPT"), self.MOLSCRIBE_CKPT) if p]
+        hit = next((p for p in cand if os.path.exists(p)), None)
+        if hit is None:
+            have = len(self.encoder.molscribe_encoder.state_dict())
+            warnings.warn(f"markushgrapher_amd: init_molscribe_weights(): no MolScribe checkpoint at {cand}; encoder.molscribe_encoder keeps the "
+                          f"{have} tensors of the model checkpoint", stacklevel=2)
+            return
+        ck = torch.load(hit, map_location="cpu", weights_only=True)
+        enc = ck.get("encoder", ck) if isinstance(ck, dict) else ck
+        enc = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in enc.items()}
+        self.encoder.molscribe_encoder.load_state_dict(enc)
+        self._engine = None
+
+    def _e1_setup(self):
+        """(E1Shape, canonical state dict) of the OCSR branch when both modules hold a complete set of tensors, else None."""
+        from . import e1_shapes
+        enc_sd = self.encoder.molscribe_encoder.state_dict()
+        prj_sd = self.encoder.molscribe_projector.state_dict()
+        if not enc_sd or not prj_sd:
+            return None
+        import dataclasses
+        canon = dict(e1_shapes.canonical_encoder_keys(enc_sd))
+        canon.update(e1_shapes.canonical_projector_keys(prj_sd))
+        over = {k: (tuple(v) if isinstance(v, list) else v) for k, v in self.config.e1.items()}
+        base = dataclasses.replace(e1_shapes.PRESETS["swin_b_384"], d_model=self.config.d_model, src_image_size=self.config.image_size, **over)
+        shape = e1_shapes.shape_from_state(base, canon)
+        if shape.d_model != self.config.d_model:
+            raise ValueError(f"encoder.molscribe_projector ends in {shape.d_model} features, d_model is {self.config.d_model}")
+        want = {k: tuple(shp) for k, shp, _ in e1_shapes.state_dict_spec(shape)}
+        missing = [k for k in want if k not in canon]
+        if missing:
+            raise ValueError(f"encoder.molscribe_*: {len(missing)} tensors of the OCSR branch are missing, e.g. {missing[:3]}")
+        bad = [k for k in want if tuple(canon[k].shape) != want[k]]
+        if bad:
+            raise ValueError(f"encoder.molscribe_*: shape mismatch for {bad[:3]} (expected {[want[k] for k in bad[:3]]})")
+        return shape, {k: canon[k] for k in want}
+
+    def computes_e1(self) -> bool:
+        """True when `encoder.molscribe_encoder` and `encoder.molscribe_projector` hold a complete branch: forward() / generate() then
+        evaluate it themselves."""
+        return len(self.encoder.molscribe_encoder.state_dict()) > 0 and len(self.encoder.molscribe_projector.state_dict()) > 0
 
     def requires_e1(self) -> bool:
         """True when the configured architecture fuses the OCSR branch: variant 'me-lf-stack-*' (ref: config/predict.yaml:12,
@@ -204,9 +253,17 @@ class MarkushgrapherForConditionalGeneration(nn.Module):
     def _check_e1(self, e1):
         if e1 is not None or not self.requires_e1():
             return
-        msg = (f"architecture_variant={self.config.architecture_variant!r} / encoder.molscribe_* tensors: this model fuses the "
-               "OCSR vision branch (e1), which markushgrapher_amd does not compute (SURVEY.md §8 a7/f-2). Pass the projected "
-               "embeddings as e1=[B, M, d_model]; running without them differs from the reference.")
+        if self.computes_e1():
+            try:
+                self._e1_setup()
+            except (KeyError, ValueError) as err:
+                raise RuntimeError(f"the encoder.molscribe_* tensors do not form a usable OCSR branch (e1): {err}. Load the complete "
+                                   "branch or pass the projected embeddings as e1=[B, M, d_model].") from err
+            return
+        msg = (f"architecture_variant={self.config.architecture_variant!r}: this model fuses the OCSR vision branch (e1), but "
+               "encoder.molscribe_encoder / encoder.molscribe_projector hold no weights to compute it from (load a checkpoint that "
+               "carries them, or init_molscribe_weights() + safe_load(model.encoder.molscribe_projector, ...)). Alternatively pass "
+               "the projected embeddings as e1=[B, M, d_model]; running without them differs from the reference.")
         if self.config.allow_missing_e1 or os.environ.get("MG_ALLOW_MISSING_E1") == "1":
             if not self._warned_e1:
                 warnings.warn(msg + " (allow_missing_e1: continuing with the VTL branch only)", stacklevel=3)
@@ -262,6 +319,11 @@ class MarkushgrapherForConditionalGeneration(nn.Module):
             if not tied:                        # untied config: the checkpoint's head is used, without the d_model^-0.5 scale
                 sd["lm_head.weight"] = self.lm_head.weight.data
             eng.load_state_dict(sd)
+            if self.computes_e1():              # the OCSR branch on the HIP engine, attached: calls without e1= evaluate it themselves
+                from .e1 import E1Engine
+                shape1, sd1 = self._e1_setup()
+                e1e = E1Engine(shape1, mem=TorchMem(dev)).load_state_dict({k: v.data for k, v in sd1.items()})
+                eng.attach_e1(e1e)
             self._engine, self._engine_device = eng, dev
         return self._engine
 

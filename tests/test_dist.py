@@ -192,3 +192,27 @@ def test_id_exchange_over_rccl_single_rank_group():
         torch.cuda.synchronize()
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` as the driver invokes it (ONE process, WORLD_SIZE unset) must start its ranks itself.  Here without
+    GPUs: MG_BENCH_BACKEND=gloo sends the ranks through the launcher self-test (rendezvous on 127.0.0.1, process group, barrier,
+    max-over-ranks reduction, the id exchange's all-gather) instead of the measurement; rank 0 prints one JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MG_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, cwd=root,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["launcher_selftest"] and out["n_gpus"] == 2 and out["exchange_ok"] and out["rows_gathered"] == 64
+    # a rank count that disagrees with --gpus is refused (torch.distributed.run with another --nproc-per-node)
+    env2 = dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env2, cwd=root, stdout=subprocess.PIPE,
+                        stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r2.returncode != 0 and "started 3 processes" in (r2.stderr + r2.stdout)

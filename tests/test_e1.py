@@ -239,3 +239,110 @@ def test_e1_swin_b_geometry_against_stock():
     e32 = _np(eng.encode(big))
     assert e32.shape == (32, 144, 1024) and np.isfinite(e32).all()
     assert np.array_equal(e32[:2], e1)
+
+
+# ---- the branch attached to the VTL model (mg_attach_e1): generate() / forward() / the queue forms without `e1=` ---------------------
+def _attached(be_name, with_branch=True):
+    from tests.backends import make_engine
+    from tests.test_oracle_golden import _weights, _inputs
+    g = load_golden("g3_trained_tiny.npz")
+    shape, sd = _weights(g)
+    inp = _inputs(g, shape)
+    s1 = PRESETS["tiny"]
+    assert s1.d_model == shape.d_model and s1.src_image_size == shape.image_size
+    sd1 = recipe_state_dict(s1)
+    eng = make_engine(be_name, shape, sd)
+    e1e = make_e1(be_name, s1, sd1)
+    if with_branch:
+        eng.attach_e1(e1e)
+    return g, shape, sd, inp, s1, sd1, eng, e1e
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+def test_attached_branch_equals_precomputed_tokens_and_oracle(be_name):
+    """With the branch attached, a call WITHOUT e1 computes it from pixel_values itself: same bits as passing E1Engine.encode's
+    output, greedy ids and teacher-forced logits against the oracle chain SwinOracle.e1 -> Oracle(e1=...) (fusion INFERRED: unpinned)."""
+    import torch
+    from oracle.swin_oracle import SwinOracle
+    from oracle.udop_oracle import Oracle
+    g, shape, sd, inp, s1, sd1, eng, e1e = _attached(be_name)
+    args = (inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"])
+    T = int(g["max_length"])
+    e1 = _np(e1e.encode(inp["pixel_values"]))
+    ids_own, _, _ = eng.generate(*args, max_length=T)
+    ids_pre, _, _ = eng.generate(*args, max_length=T, e1=e1)
+    ids_own, ids_pre = eng.mem.numpy(ids_own), eng.mem.numpy(ids_pre)
+    assert np.array_equal(ids_own, ids_pre)
+    with torch.no_grad():
+        e1_ref = SwinOracle(s1, sd1).e1(inp["pixel_values"]).numpy()
+    assert np.abs(e1 - e1_ref).max() < 0.02 * np.abs(e1_ref).max() + 0.02
+    o = Oracle(shape, sd)
+    labels = g["labels"]
+    dec_ids = Oracle.shift_right(labels, shape.decoder_start_token_id, shape.pad_token_id).numpy()
+    dam = (labels != -100).astype(np.uint8)
+    logits, _, _ = eng.forward_logits(*args, dec_ids, dam)
+    ref = o.forward(inp["input_ids"], inp["bbox"], inp["pixel_values"], inp["attention_mask"], labels=labels,
+                    decoder_attention_mask=dam.astype(np.int64), e1=e1_ref).numpy()
+    tol = 0.015 * np.abs(ref).max() + 0.02
+    assert np.abs(eng.mem.numpy(logits) - ref).max() < tol
+    plain = o.forward(inp["input_ids"], inp["bbox"], inp["pixel_values"], inp["attention_mask"], labels=labels,
+                      decoder_attention_mask=dam.astype(np.int64)).numpy()
+    assert np.abs(ref - plain).max() > 5 * tol                                   # the tokens matter (the trained ids are robust to them)
+    rec = []
+    ref_ids = o.greedy(inp["input_ids"], inp["bbox"], inp["pixel_values"], inp["attention_mask"], max_length=T, record=rec, e1=e1_ref)
+    compared = 0
+    for b in range(ids_own.shape[0]):
+        for t in range(1, min(ids_own.shape[1], ref_ids.shape[1])):
+            srt = np.sort(rec[t - 1][b].numpy())
+            if srt[-1] - srt[-2] < 4 * tol:
+                break
+            assert ids_own[b, t] == ref_ids[b, t], (b, t)
+            compared += 1
+    assert compared >= 2 * ids_own.shape[0]
+    # beam search and a clone made after the attachment take the same path
+    b_own, s_own, _ = eng.generate(*args, num_beams=3, max_length=T)
+    b_pre, s_pre, _ = eng.clone().generate(*args, num_beams=3, max_length=T, e1=e1)
+    assert np.array_equal(eng.mem.numpy(b_own), eng.mem.numpy(b_pre))
+    # detaching gives the plain VTL model back
+    eng.attach_e1(None)
+    ids0, _, _ = eng.generate(*args, max_length=T)
+    assert np.array_equal(eng.mem.numpy(ids0), g["greedy_ids"])
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+def test_attached_branch_in_the_queue_forms(be_name):
+    """mg_generate_stream / mg_generate_stream_beam with the branch attached: every image's ids equal generate()'s for that image."""
+    g, shape, sd, inp, s1, sd1, eng, e1e = _attached(be_name)
+    T = int(g["max_length"])
+    order = np.array([0, 3, 5, 1, 2, 4, 4, 0])
+    q = {k: np.ascontiguousarray(v[order]) for k, v in inp.items()}
+    rows, brows = [], []
+    for b in range(inp["input_ids"].shape[0]):
+        one = {k: v[b:b + 1] for k, v in inp.items()}
+        ids, _, _ = eng.generate(one["input_ids"], one["bbox"], one["attention_mask"], one["pixel_values"], max_length=T)
+        rows.append(eng.mem.numpy(ids)[0].copy())
+        ids, _, _ = eng.generate(one["input_ids"], one["bbox"], one["attention_mask"], one["pixel_values"], num_beams=3, max_length=T)
+        brows.append(eng.mem.numpy(ids)[0].copy())
+    ids, lens, _ = eng.generate_stream(q["input_ids"], q["bbox"], q["attention_mask"], q["pixel_values"], max_length=T, chunk=3, slots=3, pool_chunks=2)
+    ids, lens = eng.mem.numpy(ids), eng.mem.numpy(lens)
+    for n, b in enumerate(order):
+        row = rows[b]
+        e = np.nonzero(row == shape.eos_token_id)[0]
+        want = int(e[0]) + 1 if len(e) else len(row)
+        assert lens[n] == want and np.array_equal(ids[n, :want], row[:want]), (n, b)
+    bids, blens, _, _ = eng.generate_stream_beam(q["input_ids"], q["bbox"], q["attention_mask"], q["pixel_values"], num_beams=3, max_length=T,
+                                                 chunk=3, slots=2, pool_chunks=2)
+    bids, blens = eng.mem.numpy(bids), eng.mem.numpy(blens)
+    for n, b in enumerate(order):
+        row = brows[b]
+        e = np.nonzero(row == shape.eos_token_id)[0]
+        want = int(e[0]) + 1 if len(e) else len(row)
+        assert blens[n] == want and np.array_equal(bids[n, :want], row[:want]), (n, b)
+
+
+def test_attach_rejects_a_branch_of_the_wrong_geometry():
+    from markushgrapher_amd.engine import MgError
+    g, shape, sd, inp, s1, sd1, eng, e1e = _attached("emu", with_branch=False)
+    bad = dataclasses.replace(s1, d_model=128)
+    with pytest.raises(MgError, match="mg_attach_e1"):
+        eng.attach_e1(make_e1("emu", bad, recipe_state_dict(bad)))

@@ -141,8 +141,106 @@ def test_e1_branch_tensors_round_trip_and_missing_e1_is_loud(tmp_path):
     plain.config.architecture_variant = "me-lf-stack-1"                 # ref: begin.py:120 with config/predict.yaml:12
     with pytest.raises(RuntimeError, match="me-lf-stack-1"):
         plain.generate(**kw, max_length=8)
-    with pytest.warns(UserWarning, match="no-op"):
+    with pytest.warns(UserWarning, match="no MolScribe checkpoint"):
         plain.init_molscribe_weights()
+
+
+def _e1_checkpoint_tensors():
+    """A complete tiny OCSR branch under the names a MarkushGrapher-2 checkpoint is INFERRED to use: timm naming behind
+    `encoder.molscribe_encoder.`, an nn.Sequential(Linear, GELU, Linear) behind `encoder.molscribe_projector.`."""
+    from markushgrapher_amd import e1_shapes
+    from tests.test_e1 import _to_timm
+    s1 = e1_shapes.PRESETS["tiny"]
+    sd1 = e1_shapes.recipe_state_dict(s1)
+    out = {"encoder.molscribe_encoder." + k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in _to_timm(sd1, prefix="transformer.").items()}
+    for j, idx in enumerate((0, 2)):
+        out[f"encoder.molscribe_projector.{idx}.weight"] = torch.from_numpy(sd1[f"proj.{j}.weight"])
+        out[f"encoder.molscribe_projector.{idx}.bias"] = torch.from_numpy(sd1[f"proj.{j}.bias"])
+    over = dict(image_size=s1.image_size, embed_dim=s1.embed_dim, depths=list(s1.depths), num_heads=list(s1.num_heads), window_size=s1.window_size)
+    return s1, sd1, out, over
+
+
+def test_complete_e1_branch_is_recognised_and_round_trips(tmp_path):
+    """A checkpoint that carries the whole OCSR branch: the model knows it computes e1 itself, derives the branch geometry (projector
+    sizes from the tensors, the rest from config.e1) and keeps everything through save_pretrained / from_pretrained."""
+    m, shape = tiny_model()
+    s1, sd1, extra, over = _e1_checkpoint_tensors()
+    m.config.architecture_variant = "me-lf-stack-1"
+    m.config.e1 = over
+    sd = dict(m.state_dict())
+    sd.update(extra)
+    missing, unexpected = m.load_state_dict(sd)
+    assert not missing and not unexpected
+    assert m.requires_e1() and m.computes_e1()
+    m._check_e1(None)                                   # nothing to complain about: the branch is complete
+    shp, canon = m._e1_setup()
+    assert shp.proj_dims == s1.proj_dims and shp.d_model == s1.d_model and shp.src_image_size == shape.image_size and shp.depths == s1.depths
+    assert set(canon) == set(sd1) and all(np.array_equal(canon[k].float().numpy(), sd1[k]) for k in sd1)
+    m.save_pretrained(str(tmp_path))
+    m2 = MarkushgrapherForConditionalGeneration.from_pretrained(str(tmp_path))
+    assert m2.config.architecture_variant == "me-lf-stack-1" and m2.config.e1["window_size"] == s1.window_size and m2.computes_e1()
+    shp2, canon2 = m2._e1_setup()
+    assert shp2 == shp and all(torch.equal(canon2[k], canon[k]) for k in canon)
+    # MolScribe's own checkpoint file ({'encoder': {...}} behind `module.`) through init_molscribe_weights(path)
+    ck = {"encoder": {"module." + k[len("encoder.molscribe_encoder."):]: v for k, v in extra.items() if k.startswith("encoder.molscribe_encoder.")}, "decoder": {}}
+    torch.save(ck, str(tmp_path / "swin.pth"))
+    m3, _ = tiny_model()
+    m3.config.e1 = over
+    m3.init_molscribe_weights(str(tmp_path / "swin.pth"))
+    m3.safe_load(m3.encoder.molscribe_projector, {k[len("encoder.molscribe_projector."):]: v for k, v in extra.items() if "projector" in k})
+    assert m3.computes_e1()
+    shp3, canon3 = m3._e1_setup()
+    assert shp3 == shp and all(torch.equal(canon3[k].float(), canon[k].float()) for k in canon)
+    # a branch of the wrong width is refused with a message that names it
+    bad = dict(extra)
+    bad["encoder.molscribe_projector.2.weight"] = torch.zeros(32, 128)
+    bad["encoder.molscribe_projector.2.bias"] = torch.zeros(32)
+    m4, _ = tiny_model()
+    m4.config.e1 = over
+    sd4 = dict(m4.state_dict()); sd4.update(bad)
+    m4.load_state_dict(sd4)
+    with pytest.raises(RuntimeError, match="usable OCSR branch"):
+        m4._check_e1(None)
+
+
+@pytest.mark.gpu
+def test_generate_on_a_me_lf_stack_1_model_without_e1_argument():
+    """The reference's shipped configuration (config/predict.yaml:12 `architecture_variant: me-lf-stack-1`) through the HF surface:
+    generate() / forward() / generate_queue() without `e1=` evaluate the OCSR branch themselves; ids equal those of the same call with
+    the branch's tokens passed in, and the oracle chain SwinOracle.e1 -> Oracle(e1=...)."""
+    from oracle.swin_oracle import SwinOracle
+    from oracle.udop_oracle import Oracle
+    m, shape = tiny_model()
+    s1, sd1, extra, over = _e1_checkpoint_tensors()
+    m.config.architecture_variant = "me-lf-stack-1"
+    m.config.e1 = over
+    sd = dict(m.state_dict()); sd.update(extra)
+    m.load_state_dict(sd)
+    dev = torch.device("cuda:0")
+    m = m.to(dev)
+    g = load_golden("g3_trained_tiny.npz")
+    kw = dict(input_ids=torch.from_numpy(g["input_ids"]).to(dev), bbox=torch.from_numpy(g["bbox"]).to(dev),
+              pixel_values=torch.from_numpy(g["pixel_values"]).to(dev), attention_mask=torch.from_numpy(g["attention_mask"]).to(dev))
+    T = int(g["max_length"])
+    ids = m.generate(**kw, max_length=T).cpu().numpy()
+    e1 = m._eng()._e1_engine.encode(kw["pixel_values"])
+    ids_pre = m.generate(**kw, max_length=T, e1=e1).cpu().numpy()
+    assert np.array_equal(ids, ids_pre)
+    with torch.no_grad():
+        e1_ref = SwinOracle(s1, sd1).e1(g["pixel_values"]).numpy()
+    assert np.abs(e1.cpu().numpy() - e1_ref).max() < 0.02 * np.abs(e1_ref).max() + 0.02
+    w = {k: v.float().numpy() for k, v in m.state_dict().items() if not k.startswith("encoder.molscribe_")}
+    ref = Oracle(shape, w).greedy(g["input_ids"], g["bbox"], g["pixel_values"], g["attention_mask"], max_length=T, e1=e1_ref)
+    assert np.array_equal(ids[:, :ref.shape[1]], ref)
+    out = m(**kw, labels=torch.from_numpy(g["labels"]).to(dev))
+    assert torch.isfinite(out.logits).all() and out.loss is not None
+    b5 = m.generate(**kw, num_beams=5, max_length=T).cpu().numpy()
+    assert np.array_equal(b5, m.generate(**kw, num_beams=5, max_length=T, e1=e1).cpu().numpy())
+    enc = [dict(input_ids=kw["input_ids"][i:i + 1], bbox=kw["bbox"][i:i + 1], pixel_values=kw["pixel_values"][i:i + 1]) for i in range(ids.shape[0])]
+    rows = m.generate_queue(enc, max_length=T, slots=3, chunk=3)
+    for i, r in enumerate(rows):
+        one = m.generate(**enc[i], max_length=T).cpu().numpy()[0]
+        assert np.array_equal(r.cpu().numpy(), one[:len(r)])
 
 
 @pytest.mark.gpu
