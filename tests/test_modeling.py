@@ -229,7 +229,7 @@ def test_generate_on_a_me_lf_stack_1_model_without_e1_argument():
     with torch.no_grad():
         e1_ref = SwinOracle(s1, sd1).e1(g["pixel_values"]).numpy()
     assert np.abs(e1.cpu().numpy() - e1_ref).max() < 0.02 * np.abs(e1_ref).max() + 0.02
-    w = {k: v.float().numpy() for k, v in m.state_dict().items() if not k.startswith("encoder.molscribe_")}
+    w = {k: v.float().cpu().numpy() for k, v in m.state_dict().items() if not k.startswith("encoder.molscribe_")}
     ref = Oracle(shape, w).greedy(g["input_ids"], g["bbox"], g["pixel_values"], g["attention_mask"], max_length=T, e1=e1_ref)
     assert np.array_equal(ids[:, :ref.shape[1]], ref)
     out = m(**kw, labels=torch.from_numpy(g["labels"]).to(dev))
