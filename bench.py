@@ -397,10 +397,21 @@ def main():
     eng.load_state_dict(sd)
     eng.set_decode_graph(args.decode_graph)
     # each rank gets its own shard of the global batch (independent images, no data-path exchange)
-    inp = synth.synth_batch(shape, B, seed=synth.BENCH_SEED + rank, return_pages=True)
-    dev = {k: eng.mem.asarray(v, {"input_ids": np.int64, "bbox": np.float32, "attention_mask": np.uint8,
-                                  "pixel_values": np.float32, "pages_u8": np.uint8}[k]) for k, v in inp.items()}
-    L = inp["input_ids"].shape[1]
+    # DIFFERENT images in every batch of the timed region: batch j of this rank is drawn with its own seed (j = 0: the batch the parity
+    # fixture tests/golden/g4_bench.npz pins), all batches padded to the pool's longest text (ids 0 / box 0 / mask 0, as the reference's
+    # collator pads: ref core/trainers/data_collator.py:55-108), so that a call really holds 160 different images at a common L_max
+    n_pool = max(1, min(args.steps, int(os.environ.get("MG_BENCH_DISTINCT", "20"))))
+    pool_np = [synth.synth_batch(shape, B, seed=synth.BENCH_SEED + rank + 1000 * j, return_pages=True) for j in range(n_pool)]
+    L = max(p_["input_ids"].shape[1] for p_ in pool_np)
+    for p_ in pool_np:
+        padn = L - p_["input_ids"].shape[1]
+        if padn:
+            p_["input_ids"] = np.pad(p_["input_ids"], ((0, 0), (0, padn)))
+            p_["attention_mask"] = np.pad(p_["attention_mask"], ((0, 0), (0, padn)))
+            p_["bbox"] = np.pad(p_["bbox"], ((0, 0), (0, padn), (0, 0)))
+    dtypes = {"input_ids": np.int64, "bbox": np.float32, "attention_mask": np.uint8, "pixel_values": np.float32, "pages_u8": np.uint8}
+    pool = [{k: eng.mem.asarray(v, dtypes[k]) for k, v in p_.items() if k != "pixel_values"} for p_ in pool_np]
+    inp, dev = pool_np[0], pool[0]
     # the exchange: static [B, 512] int32 ids + [B] int32 lengths per rank, posted asynchronously and
     # double-buffered (markushgrapher_amd/dist.py), so the gather of batch i overlaps the encoder of batch i+1
     # (at world == 1 the exchange degenerates to its single-rank copy path, which runs all the same: the packing of the static
@@ -431,9 +442,15 @@ def main():
     # up to `--batches-per-call` batches ride in one call (rows [0, B) = one batch, [B, 2B) the next ...): the same preprocess ->
     # encoder -> decode steps per batch, the decode step's weight stream shared by the batches of the call.
     bpc = max(1, min(8, args.batches_per_call)) if args.beams == 1 else 1      # (default 5: calls of 6 / 8 batches measured slower, profiles/r04_o_batches_per_call.txt)
-    devn = {1: dev}
-    for nb_ in range(2, bpc + 1):
-        devn[nb_] = {k: torch.cat([v] * nb_, dim=0) for k, v in dev.items()}
+    call_cache = {}
+
+    def call_inputs(first, nb):
+        # batches first .. first + nb - 1 of the pool (cyclic) side by side; built once per (first, nb), outside the timed region
+        key = (first % n_pool, nb)
+        if key not in call_cache:
+            parts = [pool[(first + i) % n_pool] for i in range(nb)]
+            call_cache[key] = parts[0] if nb == 1 else {k: torch.cat([q[k] for q in parts], dim=0) for k in parts[0]}
+        return call_cache[key]
 
     from markushgrapher_amd.inflight import plan_calls as _plan_calls
 
@@ -444,8 +461,8 @@ def main():
 
     calls_on_first = []          # batches per call of the calls that ran on the first context (the one the phase events are read from)
 
-    def job(ctx, nb):
-        src = devn[nb]
+    def job(ctx, nb, first=0):
+        src = call_inputs(first, nb)
         pix = ctx.preprocess(src["pages_u8"])
         out, _, _ = ctx.generate(src["input_ids"], src["bbox"], src["attention_mask"], pix, num_beams=args.beams,
                                  max_length=max_length, min_length=max_length)
@@ -456,11 +473,14 @@ def main():
     last_call = [None]
 
     def run_calls(sizes):
-        futs = [fl.submit(job, nb) for nb in sizes]
+        firsts = [int(sum(sizes[:i])) for i in range(len(sizes))]
+        for nb, first in zip(sizes, firsts):
+            call_inputs(first, nb)
+        futs = [fl.submit(job, nb, first) for nb, first in zip(sizes, firsts)]
         out = None
-        for f in futs:
+        for f, nb, first in zip(futs, sizes, firsts):
             res = f.result()
-            last_call[0] = res
+            last_call[0] = (res, first)
             for j in range(res.shape[0] // B):          # one exchange per batch, as with one batch per call
                 out = res[j * B:(j + 1) * B]
                 handles.append(ex.post(out))
@@ -528,13 +548,17 @@ def main():
     # the kernel's and the phases' uncontended figures beside the in-flight ones
     solo = None
     solo_call = None
-    ids_call = last_call[0]
+    ids_call, first_call = last_call[0]
     ids_equal_solo = None
     if (len(fl) > 1 or bpc > 1) and rank == 0:
         eng.set_shared_gpu(False)        # the context runs alone from here on (InFlight had set it: mg_set_shared_gpu)
-        ids_solo = step()
-        # every batch of the last timed call against ONE call on the batch alone (one context, one batch per call)
-        ids_equal_solo = bool(all(torch.equal(ids_call[j * B:(j + 1) * B], ids_solo) for j in range(ids_call.shape[0] // B)))
+        # every batch of the last timed call against ONE call on that batch alone (one context, one batch per call, same padded length)
+        eq = []
+        for j in range(ids_call.shape[0] // B):
+            one = job(eng, 1, first_call + j)
+            eq.append(bool(torch.equal(ids_call[j * B:(j + 1) * B], one)))
+        ids_equal_solo = bool(all(eq))
+        step()
         profile_on()
         torch.cuda.synchronize(); ts = time.time()
         for _ in range(SOLO_STEPS):
@@ -593,7 +617,7 @@ def main():
         L_.mg_profile_phases(eng.model, 0)
         # the branch alone: one call shape of the timed plan (nb batches of 32) and one batch, on the first context's stream
         nb_main = max(timed_plan) if timed_plan else 1
-        pix_nb = eng.preprocess(devn[nb_main]["pages_u8"])
+        pix_nb = eng.preprocess(call_inputs(0, nb_main)["pages_u8"])
         alone = {}
         for nb_, px in ((nb_main, pix_nb), (1, pix_nb[:B])):
             e1e.encode(px)
@@ -622,8 +646,11 @@ def main():
         H, d, dff, V = shape.num_heads, shape.d_model, shape.d_ff, shape.vocab_size
         n_enc, n_dec, P = shape.num_layers, shape.num_decoder_layers, shape.num_patches
         # attended encoder positions per image (what the path computes on; padding excluded from the algorithmic work)
-        _, msk = eng.encode(dev["input_ids"], dev["bbox"], dev["attention_mask"], eng.preprocess(dev["pages_u8"]))
-        xlen = msk.sum(dim=1).cpu().numpy().astype(np.float64)
+        xl = []
+        for q in pool:          # (work per batch below = the mean over the pool's batches: xlen holds 32 x n_pool images, sums are divided by n_pool)
+            _, msk = eng.encode(q["input_ids"], q["bbox"], q["attention_mask"], eng.preprocess(q["pages_u8"]))
+            xl.append(msk.sum(dim=1).cpu().numpy().astype(np.float64))
+        xlen = np.concatenate(xl)
         traffic = None if (args.no_pmc or world > 1 or args.beams != 1) else pmc_traffic(args, int(round(nb_first)))
         def make_roof(n_l, ms, keys, empty_ms, with_traffic):
             if n_l.value <= 0:
@@ -644,12 +671,12 @@ def main():
             return r
 
         # F_enc = N_enc*S*(8d^2 + 4*d*dff + 4*S*d) + 2*P*768*d;  F_xkv = N_dec*S_x*4d^2  (per image, S = attended positions)
-        f_enc = float(np.sum(n_enc * xlen * (8 * d * d + 4 * d * dff + 4 * xlen * d) + 2 * P * (shape.num_channels * shape.patch_size ** 2) * d))
-        f_xkv = float(np.sum(n_dec * xlen * 4 * d * d))
+        f_enc = float(np.sum(n_enc * xlen * (8 * d * d + 4 * d * dff + 4 * xlen * d) + 2 * P * (shape.num_channels * shape.patch_size ** 2) * d)) / n_pool
+        f_xkv = float(np.sum(n_dec * xlen * 4 * d * d)) / n_pool
         tbar = (new_tokens - 1) / 2.0
         # Bytes_step = 2*(N_dec*16d^2 + d*V) + sum_b 2*N_dec*2*d*(S_x + t);  F_step = N_dec*(12d^2 + 4*d*dff) + N_dec*4*d*(S_x+t) + 2*d*V
-        bytes_step = 2.0 * (n_dec * 16 * d * d + d * V) + float(np.sum(2 * n_dec * 2 * d * (xlen + tbar)))
-        f_step = float(np.sum(n_dec * (12 * d * d + 4 * d * dff) + n_dec * 4 * d * (xlen + tbar) + 2 * d * V))
+        bytes_step = 2.0 * (n_dec * 16 * d * d + d * V) + float(np.sum(2 * n_dec * 2 * d * (xlen + tbar))) / n_pool
+        f_step = float(np.sum(n_dec * (12 * d * d + 4 * d * dff) + n_dec * 4 * d * (xlen + tbar) + 2 * d * V)) / n_pool
 
         # a call that holds nb batches streams the weights once per step and every batch's K/V
         bytes_w = 2.0 * (n_dec * 16 * d * d + d * V)
@@ -895,7 +922,9 @@ def main():
                        "shape": args.shape, "batch_per_gpu": B, "text_len_padded": int(L), "new_tokens": new_tokens,
                        "num_beams": args.beams, "decode_graph": args.decode_graph, "batches_in_flight": int(sum(timed_plan[:len(fl)])),
                        "contexts": len(fl), "batches_per_call_max": bpc, "batches_per_call": timed_plan,
-                       "ids_equal_one_batch_calls": ids_equal_solo,
+                       "ids_equal_one_batch_calls": ids_equal_solo, "distinct_batches": n_pool,
+                       "inputs": f"{n_pool} different batches of 32 images per rank (seed + 1000 j; j = 0 is the batch of tests/golden/g4_bench.npz), padded to the "
+                                 f"pool's longest text ({int(L)} tokens): the calls of the timed region hold different images in every row",
                        "single_rank_rccl_group": bool(force_dist),
                        "in_flight": "execution contexts on one set of weights (mg_clone), a stream + host thread + workspace each; a call "
                                     "of a context takes `batches_per_call` batches of 32 (rows side by side: one pass over the decoder's "
@@ -903,6 +932,13 @@ def main():
                                     "one-batch-at-a-time calls (checked in this run: ids_equal_one_batch_calls); warm-up = `warmup` "
                                     "calls per context",
                        "parallelism": f"dp{world} (independent image shards; one RCCL all-gather of [32,512] int32 ids + lengths per batch)"},
+            # the three readings of "bs = 32 per GPU" side by side at the top level: `value` = 32-image batches packed into calls of
+            # `rows_per_decode_step` rows on `contexts` contexts; one batch per call on one context; the dominant kernel alone
+            "images_per_s_one_batch_in_flight": single["images_per_s"] if single else None,
+            "rows_per_decode_step": int(B * max(timed_plan)) if timed_plan else B,
+            "kernel_alone_frac": (call_alone_rep or {}).get("roofline", {}).get("frac") if call_alone_rep and call_alone_rep.get("roofline") else
+                                 ((single or {}).get("roofline") or {}).get("frac"),
+            "images_per_s_with_e1_branch": e1_run["images_per_s"] if e1_run else None,
             "roofline": roof, "phases": phases, "one_call_alone": call_alone_rep, "one_batch_in_flight": single, "with_e1_branch": e1_run,
             "extra_runs": extra,
         }

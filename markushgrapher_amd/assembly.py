@@ -275,8 +275,9 @@ _CXSMI = re.compile(re.escape("<cxsmi>") + r"(.*?)" + re.escape("</cxsmi>"))
 
 
 def text_to_cxsmiles_opt(text, task="mdu"):
-    """utils_evaluation.py:303-345: strip the task tags, `</s>` and spaces; for "mdu" only the first
-    <cxsmi>...</cxsmi> span is kept (None when absent)."""
+    """utils_evaluation.py:306-352: strip the task tags, `</s>` and spaces; for "mdu" only the first
+    <cxsmi>...</cxsmi> span is kept (None when absent).  Pinned on the outputs of those reference lines themselves
+    (tools/make_golden_cxsmiles_opt.py -> tests/golden/host_cxsmiles_opt.json)."""
     if task == "ocsr":
         return text.replace("<smi>", "").replace("</smi>", "").replace("</s>", "").replace(" ", "")
     if task == "mdu":

@@ -183,3 +183,16 @@ def test_id_decoder_matches_the_reference_method():
     assert len(g["cases"]) >= 20
     for c in g["cases"]:
         assert dec[c["encode_index"]].decode(c["ids"]) == c["text"], (c["encode_index"], [g["tokens"][i] for i in c["ids"]], c["text"])
+
+
+def test_text_to_cxsmiles_opt_pinned_on_the_reference_lines():
+    """text_to_cxsmiles_opt against the outputs of the reference's OWN inline lines (utils/ocsr/utils_evaluation.py:306-352, exec'd
+    unmodified by tools/make_golden_cxsmiles_opt.py with the names they use supplied by a harness): 15 texts x the three task names."""
+    import json
+    import os
+    from markushgrapher_amd import assembly as A
+    d = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "host_cxsmiles_opt.json")))
+    assert len(d["cases"]) == 45 and {c["task"] for c in d["cases"]} == {"ocsr", "ocxsr", "mdu"}
+    for c in d["cases"]:
+        assert A.text_to_cxsmiles_opt(c["text"], c["task"]) == c["opt"], c
+    assert sum(c["opt"] is None for c in d["cases"]) >= 4          # mdu texts without a <cxsmi> span: the reference's except branch

@@ -366,6 +366,39 @@ def g4long():
          step_top_idx=top.indices.numpy().astype(np.int32), oracle_top8_maxdiff=np.float32(d))
 
 
+def g4beam():
+    """G4-beam: beam-5 (the reference's shipped decode mode, config/predict.yaml:13; BASELINE configs[2]) on ALL 32 bench images from stock
+    UDOP, in chunks of 4 images at the batch's padded text length (an image's result does not depend on its batch mates): best
+    hypothesis, its sequence score and the gap to the second-best hypothesis (num_return_sequences = 2), so that the test can compare ids
+    wherever stock's own choice is not a near-tie."""
+    print("G4-beam: beam-5, 16 forced new tokens, all 32 bench images, stock UDOP-large")
+    shape = synth.SHAPES["large"]
+    sd = synth.recipe_state_dict(shape, **synth.BENCH_RECIPE)
+    m = stock_model(shape, sd)
+    inp = bench_inputs(shape)
+    B = inp["input_ids"].shape[0]
+    NEW = 16
+    t = {k: torch.from_numpy(v) for k, v in inp.items()}
+    ids, sc, gap, second = [], [], [], []
+    t0 = time.time()
+    with torch.no_grad():
+        for c0 in range(0, B, 4):
+            sl = slice(c0, c0 + 4)
+            kw = dict(input_ids=t["input_ids"][sl], bbox=t["bbox"][sl].clone(), pixel_values=t["pixel_values"][sl], attention_mask=t["attention_mask"][sl])
+            gb = m.generate(**kw, num_beams=5, num_return_sequences=2, max_length=NEW + 1, min_length=NEW + 1, do_sample=False,
+                            return_dict_in_generate=True, output_scores=True)
+            seq = gb.sequences.numpy().reshape(4, 2, -1)
+            ss = gb.sequences_scores.numpy().reshape(4, 2)
+            ids.append(seq[:, 0]); second.append(seq[:, 1]); sc.append(ss[:, 0]); gap.append(ss[:, 0] - ss[:, 1])
+            print(f"   chunk {c0 // 4}: {time.time() - t0:.0f}s", flush=True)
+    ids, second, sc, gap = np.concatenate(ids), np.concatenate(second), np.concatenate(sc), np.concatenate(gap)
+    old = dict(np.load(os.path.join(OUT, "g4_bench.npz")))
+    nb = int(old["beam_rows"])
+    assert np.array_equal(ids[:nb], old["beam_ids"]) and np.abs(sc[:nb] - old["beam_scores"]).max() < 1e-5, "the 4-image beam block of g4_bench.npz is not reproduced"
+    print(f"   gaps best - second hypothesis: min {gap.min():.4f} median {np.median(gap):.4f} max {gap.max():.4f}")
+    save("g4_beam32.npz", new_tokens=np.int64(NEW), beam_ids=ids, beam_second_ids=second, beam_scores=sc.astype(np.float32), beam_gap=gap.astype(np.float32))
+
+
 def tables():
     print("bucket tables (stock:422-468 evaluated by torch on every integer distance)")
     save("bucket_tables.npz",
