@@ -221,6 +221,14 @@ int mgk_im2col_pack(void* stream, const float* pix, void* x_pk, int B, int C, in
 int mgk_set_rows_split(int mode);
 /* residual projections of the decode step with several row tiles: 1 (default) 16 features per workgroup, 0: 8 */
 int mgk_set_resid_f16(int on);
+/* projections of the decode step with several row tiles: 1 the K-slab form (K chunks as workgroups, partial sums merged by the last
+ * arrival in the one-workgroup forms' order) where the caller provides its scratch, 0 (default: measured faster) the one-workgroup forms */
+int mgk_set_rows_mt(int on);
+/* mgk_gemm_resid with the scratch of the K-slab form: kpart [16][M padded to 32][N] fp32, ticket [N / 32] i32 zero-initialised;
+ * wide_tiles as ResidArgs (8 in the decode steps) */
+int mgk_gemm_resid_mt(void* stream, const void* X_pk, const void* W_pk, float* h, const float* gain, float gscale, void* x_pk,
+                      float* part, int M, int N, int K, const float* rs_part, int rs_nparts, float rs_inv_d, float rs_eps, int wide_tiles,
+                      float* kpart, int* ticket);
 int mgk_gemm(void* stream, int mode, int epi, const void* X_pk, const void* W_pk, int M, int N, int K, float* out_f32,
              int ldo, const float* bias, void* out_pk);
 /* Deferred-RMSNorm pair of the encoder (tiled large-M kernels): epi 5 (EPI_RESID_NORM): h_tiled (fp32, tiles of

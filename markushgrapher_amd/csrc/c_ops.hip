@@ -190,6 +190,19 @@ int mgk_gemm_resid(void* stream, const void* X_pk, const void* W_pk, float* h, c
     return MG_OK;
 }
 
+int mgk_gemm_resid_mt(void* stream, const void* X_pk, const void* W_pk, float* h, const float* gain, float gscale, void* x_pk,
+                      float* part, int M, int N, int K, const float* rs_part, int rs_nparts, float rs_inv_d, float rs_eps, int wide_tiles,
+                      float* kpart, int* ticket) {
+    if ((K & 63) || (N & 31) || M > 256) return MG_E_SHAPE;
+    ResidArgs r{};
+    r.X = (const uint16_t*)X_pk; r.W = (const uint16_t*)W_pk; r.h = h; r.gain = gain; r.gscale = gscale; r.x_pk = (uint16_t*)x_pk;
+    r.part = part; r.M = M; r.N = N; r.K = K; r.rs = RowScale{rs_part, rs_nparts, rs_inv_d, rs_eps};
+    r.wide_tiles = wide_tiles; r.kpart = kpart; r.ticket = ticket;
+    gemm_rows_resid(r, (mgStream_t)stream);
+    return MG_OK;
+}
+int mgk_set_rows_mt(int on) { gemm_rows_set_mt(on); return MG_OK; }
+
 #ifdef MG_TOOLS
 int mgk_gemm_resid_trace(void* stream, const void* X_pk, const void* W_pk, float* h, const float* gain, void* x_pk, float* part, int N,
                          int K, const float* rs_part, long long* trace) {

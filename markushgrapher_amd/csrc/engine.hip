@@ -275,6 +275,7 @@ struct Ws {
     float4* ptop;             // fused greedy tail: per-workgroup top-2 partials of the lm_head launch [rows][V/32]
     float* stopv;             // [rows][4] logits of the stop tokens
     size_t slab_stride;
+    int* tickets;             // arrival counters of the K-slab projections (zero between launches)
     int64_t* next_ids;
     int *unfinished, *anc, *beam_idx;
     float* beam_div;          // [T_cap + 1] length-penalty divisor per cur_len
@@ -363,6 +364,7 @@ void carve(const mg_model* m, char* base, int B, int L, int K, int max_len, int 
             if (d > ldmax) ldmax = d;
             w->slab_stride = (size_t)Rp * ldmax;
             w->slabs = c.take<float>(16 * w->slab_stride);
+            w->tickets = c.take<int>(512);
             w->rs_part = c.take<float>((size_t)Rp * (d / 8));
             w->rs_part1 = c.take<float>((size_t)Rp * (d / 8));
             w->rs_part2 = c.take<float>((size_t)Rp * (d / 8));
@@ -406,7 +408,8 @@ struct StreamWs {
     size_t pool_stride;       // elements between layers
     int* xlen_pool;           // [pool entries]
     uint16_t *sk, *sv, *dq, *dx_pk, *dy_pk, *xa, *xb;
-    float *dh, *logits, *rs_part, *rs_part1, *rs_part2;
+    float *dh, *logits, *rs_part, *rs_part1, *rs_part2, *kpart;
+    int* tickets;
     int64_t* next_ids;
     int *unfinished, *pos, *img, *pool, *ctr, *err;
     // beam queue form (K > 1): `slots` image slots of K rows each; per-slot K/V owner, slot -> image assignment of the step, ancestor
@@ -440,6 +443,13 @@ void carve_stream(const mg_model* m, char* base, int chunk, int L, int slots_img
     w->rs_part2 = c.take<float>((size_t)Rp * (d / 8));
     w->xa = c.take<uint16_t>((size_t)Rp * (d + inner));
     w->xb = c.take<uint16_t>((size_t)Rp * (d + inner));
+    {
+        int ldmax = 3 * inner;
+        if (m->dff > ldmax) ldmax = m->dff;
+        if (d > ldmax) ldmax = d;
+        w->kpart = c.take<float>((size_t)16 * Rp * ldmax);
+        w->tickets = c.take<int>(512);
+    }
     w->next_ids = c.take<int64_t>(Rp);
     w->unfinished = c.take<int>(Rp);
     w->pos = c.take<int>(Rp);
@@ -551,6 +561,8 @@ struct DecodeCtx {
     size_t skv_stride;
     uint16_t *dq, *dx_pk, *dy_pk, *xa, *xb;
     float *dh, *logits, *rs_part, *rs_part1, *rs_part2;
+    float* kpart;             // K-slab projections with several row tiles: partial sums [16][rows padded][<= ldmax], and their arrival counters
+    int* tickets;
     float4* ptop;             // fused greedy tail (null: separate embed / selection launches)
     float* stopv;
     int64_t* next_ids;
@@ -663,6 +675,7 @@ static void decode_step(mg_model* m, const DecodeCtx& c, int t, const int* tdev,
             r.gscale = (last && m->tied) ? 1.0f / sqrtf((float)d) : 1.0f; r.x_pk = c.dx_pk; r.x2_pk = c.xa; r.x2_ld = K2; r.part = c.rs_part;
             r.M = R; r.N = d; r.K = m->dff; r.rs = rs2;
             r.wide_tiles = 8;      // the same K partition (16 waves) for every call (up to 256 rows: 8 greedy batches of 32; beam-5 at batch 32 = 5 tiles)
+            r.kpart = c.kpart; r.ticket = c.tickets;
             gemm_rows_resid(r, st);
         }
     }
@@ -1300,6 +1313,8 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
     dc.sk = w.sk; dc.sv = w.sv; dc.skv_stride = skv_stride;
     dc.dq = w.dq; dc.dx_pk = w.dx_pk; dc.dy_pk = w.dy_pk; dc.xa = w.xa; dc.xb = w.xb;
     dc.dh = w.dh; dc.logits = w.logits; dc.rs_part = w.rs_part; dc.rs_part1 = w.rs_part1; dc.rs_part2 = w.rs_part2;
+    dc.kpart = w.slabs; dc.tickets = w.tickets;
+    mg_memset_async(w.tickets, 0, 512 * sizeof(int), st);
     dc.next_ids = w.next_ids; dc.unfinished = w.unfinished; dc.anc = w.anc; dc.beam_idx = w.beam_idx; dc.beam_div = w.beam_div;
     dc.beam_state = w.beam_state; dc.counters = counters;
     dc.B = B; dc.K = K; dc.R = R; dc.max_length = max_length; dc.min_length = min_length; dc.early_stopping = early_stopping;
@@ -1496,6 +1511,8 @@ static int generate_stream_impl(mg_model* m, void* stream, void* ws, size_t ws_b
     dc.sk = w.sk; dc.sv = w.sv; dc.skv_stride = (size_t)R * H * m->T_cap * 64;
     dc.dq = w.dq; dc.dx_pk = w.dx_pk; dc.dy_pk = w.dy_pk; dc.xa = w.xa; dc.xb = w.xb;
     dc.dh = w.dh; dc.logits = w.logits; dc.rs_part = w.rs_part; dc.rs_part1 = w.rs_part1; dc.rs_part2 = w.rs_part2;
+    dc.kpart = w.kpart; dc.tickets = w.tickets;
+    mg_memset_async(w.tickets, 0, 512 * sizeof(int), st);
     dc.next_ids = w.next_ids; dc.unfinished = w.unfinished; dc.counters = w.ctr;
     dc.B = slots; dc.K = K; dc.R = R; dc.max_length = max_length; dc.min_length = min_length; dc.length_penalty = length_penalty;
     dc.early_stopping = early_stopping;

@@ -1282,6 +1282,133 @@ __global__ __launch_bounds__(NW * 64) void gemm_rows_resid_kernel(ResidArgs a) {
     resid_block16<MT, NW, (NW >= 16 ? 8 : 4), false, F16>(a, blockIdx.x, smem);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Residual projection over SEVERAL row tiles (64 .. 256 live rows), K-slab form.  The one-workgroup forms above give a workgroup
+// a slice of output features and ALL of K, so every one of the N/16 workgroups pulls the whole activation block [rows][K] through
+// its CU (1.3 MB at 160 rows of the FFN output projection; 84 MB of L2 -> CU traffic for 8.4 MB of weights) - and only N/16 CUs
+// work.  Here the K CHUNKS that the waves of those forms take (chunk s = pairs of k-tiles [s per, (s+1) per)) become workgroups:
+// workgroup (feature tile nt of 32, chunk s) reads the activation slab [rows][chunk] once for 32 features (two 16-feature MFMA
+// tiles share every activation fragment), keeps its whole weight slab and its whole activation slab in flight at once (ONE memory
+// round trip, no LDS, no barrier in the main phase), and leaves its partial sums p_s in kpart.  The LAST workgroup of a feature tile
+// to arrive (ticket) adds p_0 .. p_{S-1} IN THAT ORDER - the order in which the one-workgroup forms add their waves' partials -
+// applies the row scale and runs their epilogue: every output element is the same chain of MFMAs and the same chain of additions,
+// i.e. the SAME BITS as gemm_rows_resid_kernel / gemm_rows_resid_split_kernel (tests/test_kernels.py), whatever the row count.
+// A wave owns one 32-row tile; workgroups of a feature tile sit on one XCD (ids 8 apart) so the partials meet in one L2.
+// ---------------------------------------------------------------------------------------------------------
+template <int MT, int PER>
+__global__ __launch_bounds__(64 * MT) void gemm_rows_resid_mt_kernel(ResidArgs a, int S, int fmode) {
+    MG_DYN_SMEM(smem);
+    float* rsl = (float*)smem;                                   // [32 * MT] (finishing workgroup)
+    int* flag = (int*)(rsl + 32 * MT);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int M = a.M, N = a.N;
+    const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3;
+    const int nt = (j / S) * 8 + xcd, s = j - (j / S) * S;       // feature tile (32 features), K chunk
+    const int kt16 = a.K >> 4, xkts = a.x_kts ? a.x_kts : kt16;
+    const int p0 = s * PER;
+    const size_t lane_off = (size_t)(kg >> 1) * TILE_BYTES + (size_t)(kg & 1) * 512;
+    const char* wp = (const char*)(a.W + pk_tile_off(nt, 0, a.K)) + lane_off + (size_t)r16 * 16 + (size_t)(2 * p0) * TILE_BYTES;
+    const char* xp = (const char*)a.X + ((size_t)a.x_k0 + (size_t)w * xkts + 2 * p0) * TILE_BYTES + lane_off + (size_t)r16 * 16;
+    uint4 wf[2][PER], xf[PER][2];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        wf[0][u] = ld16_stream(wp + (size_t)u * (2 * TILE_BYTES));
+        wf[1][u] = ld16_stream(wp + (size_t)u * (2 * TILE_BYTES) + 256);          // features 16 .. 31 of the tile: rows 16 .. 31 of each k-half
+        xf[u][0] = ld16(xp + (size_t)u * (2 * TILE_BYTES));
+        xf[u][1] = ld16(xp + (size_t)u * (2 * TILE_BYTES) + 256);
+    }
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) acc[ft][g] = acc4_zero();
+#pragma unroll
+    for (int u = 0; u < PER; ++u)
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) acc[ft][g] = mfma16(wf[ft][u], xf[u][g], acc[ft][g]);
+    // partial sums: lane (token r16 of group g, kg) holds features 16 ft + 4 kg + j of row 32 w + 16 g + r16
+    const int Mp = 32 * MT;
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            float* dst = a.kpart + ((size_t)s * Mp + (size_t)(32 * w + 16 * g + r16)) * N + nt * 32 + 16 * ft + 4 * kg;
+            *(float4*)dst = make_float4(acc[ft][g][0], acc[ft][g][1], acc[ft][g][2], acc[ft][g][3]);
+        }
+    // hand-off to the last arrival (cdna_hip_programming.md, in-launch split-K reduction): every wave drains its stores, ONE lane
+    // releases at agent scope (the XCD's L2 writes its dirty lines back: the L2s of the 8 XCDs are not coherent with each other) and
+    // takes the ticket; the workgroup that draws S - 1 acquires once (its L1 may hold the partials of the previous launch) and reads
+    if (fmode == 6) return;                                      // (timing experiments, MG_MT_FENCE: 6 = main phase only, 5 = no finishing)
+#ifndef MG_EMU
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    __syncthreads();
+    if (tid == 0) {
+#ifndef MG_EMU
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        *flag = __hip_atomic_fetch_add(a.ticket + nt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+        *flag = atomicAdd(a.ticket + nt, 1);
+#endif
+    }
+    __syncthreads();
+    if (*flag != S - 1) return;
+    if (fmode == 5) { if (tid == 0) a.ticket[nt] = 0; return; }
+    if (tid == 0) {
+#ifndef MG_EMU
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+        a.ticket[nt] = 0;                                        // (nobody else touches it before the next launch)
+    }
+    __syncthreads();
+    // ---- last arrival: sum the chunks in order, then the epilogue of resid_block16 (F16 form: 16-feature blocks 2 nt, 2 nt + 1) ----
+    block_row_scales(a.rs, M, Mp, rsl, tid, 64 * MT);
+    __syncthreads();
+    const int nparts = N >> 3;
+    const int x_ld = a.x_ld ? a.x_ld : N, x2_ld = a.x2_ld ? a.x2_ld : N;
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int m = 32 * w + 16 * g + r16;
+            const int n0 = nt * 32 + 16 * ft + 4 * kg;
+            const float* src = a.kpart + (size_t)m * N + n0;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int s0 = 0; s0 < S; s0 += 8) {                  // the loads of 8 chunks in flight together, added in chunk order
+                float4 pv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) pv[q] = *(const float4*)(src + (size_t)(s0 + q < S ? s0 + q : S - 1) * Mp * N);
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (s0 + q < S) { v[0] += pv[q].x; v[1] += pv[q].y; v[2] += pv[q].z; v[3] += pv[q].w; }
+            }
+            const float rs = rsl[m];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] *= rs;
+            float ss2 = 0.f;
+            if (m < M) {
+                float4 hv = *(const float4*)(a.h + (size_t)m * N + n0);
+                hv.x += v[0]; hv.y += v[1]; hv.z += v[2]; hv.w += v[3];
+                *(float4*)(a.h + (size_t)m * N + n0) = hv;
+                ss2 = (hv.x * hv.x + hv.y * hv.y) + (hv.z * hv.z + hv.w * hv.w);
+                if (a.x_pk) {
+                    const float4 gn = *(const float4*)(a.gain + n0);
+                    const float gs = a.gscale;
+                    *(uint2*)(a.x_pk + pk_off(m, a.x_col0 + n0, x_ld)) =
+                        make_uint2(pack_bf16(hv.x * gn.x * gs, hv.y * gn.y * gs), pack_bf16(hv.z * gn.z * gs, hv.w * gn.w * gs));
+                }
+                if (a.x2_pk)
+                    *(uint2*)(a.x2_pk + pk_off(m, a.x2_col0 + n0, x2_ld)) = make_uint2(pack_bf16(hv.x, hv.y), pack_bf16(hv.z, hv.w));
+            }
+            ss2 += __shfl_xor(ss2, 16);                          // features 0-3 (kg 0) + 4-7 (kg 1), 8-11 (kg 2) + 12-15 (kg 3)
+            if (m < M && (kg & 1) == 0) a.part[(size_t)m * nparts + 2 * (2 * nt + ft) + (kg >> 1)] = ss2;
+        }
+}
+
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void gemm_rows_resid_rowsplit_kernel(ResidArgs a) {     // grid.y = row tile (shift_rows)
     MG_DYN_SMEM(smem);
@@ -1386,6 +1513,15 @@ void gemm_rows_resid_trace(const ResidArgs& r, long long* trace, mgStream_t stre
 #endif
 
 static std::atomic<int> g_resid_f16{1};
+// K-slab form of the projections with several row tiles: OFF by default.  Measured (profiles/r05_e_rows_mt_kslab.txt, FFN output projection at 160
+// rows, launches back to back): one-workgroup form 15.8 us; K-slab form 6.8 us for the main phase (activation traffic through L2 halved, all
+// CUs at work) + 12 us for 512 workgroups' agent-scope releases (each XCD L2 writes back the partial sums just stored) + 23 us for the last
+// arrival of a feature tile reading 16 chunks x 160 rows x 32 features of partials (327 KB through one CU) = 42 us; in flight 147.5 -> 126
+// images/s.  The chunk count is fixed by the summation order every row count shares (16 wave partials added in order), so the finisher's
+// read volume cannot shrink without changing every form's bits.  Kept (tests keep it bit-identical; MG_ROWS_MT=1 / mgk_set_rows_mt) as the
+// starting point of a form with write-through partial stores and a second, chip-wide reduce launch.
+static std::atomic<int> g_rows_mt{0};
+void gemm_rows_set_mt(int on) { g_rows_mt = on; }
 void gemm_rows_set_resid_f16(int on) { g_resid_f16 = on; }
 void gemm_rows_resid(const ResidArgs& r, mgStream_t stream) {
     int mt = (r.M + 31) / 32;
@@ -1410,6 +1546,26 @@ void gemm_rows_resid(const ResidArgs& r, mgStream_t stream) {
         if (wide) MG_LAUNCH((gemm_rows_resid_rowsplit_kernel<16>), grid, block, sh, stream, r);
         else MG_LAUNCH((gemm_rows_resid_rowsplit_kernel<8>), grid, block, sh, stream, r);
         return;
+    }
+    // several row tiles, K-slab form: the chunks of the one-workgroup form's waves as workgroups (same bits; see gemm_rows_resid_mt_kernel)
+    { static bool env_read = false; if (!env_read) { env_read = true; if (const char* e = getenv("MG_ROWS_MT")) g_rows_mt = atoi(e); } }   // A/B runs
+    if (r.kpart && r.ticket && mt >= 2 && !split && (r.N & 255) == 0 && g_rows_mt) {
+        const int NWf = wide ? 16 : 8, kp = r.K >> 5, per = (kp + NWf - 1) / NWf;
+        if (per * NWf == kp && (per == 8 || per == 4 || per == 2)) {
+            const int S = NWf;
+            static int fmode = -1;
+            if (fmode < 0) { const char* e = getenv("MG_MT_FENCE"); fmode = e ? atoi(e) : 0; }
+            const dim3 gridk((r.N / 32) * S), blockk(64 * mt);
+            const size_t shk = (size_t)32 * mt * sizeof(float) + 16;
+#define MG_RMT(MTV)                                                                                   \
+    case MTV:                                                                                         \
+        if (per == 8) MG_LAUNCH((gemm_rows_resid_mt_kernel<MTV, 8>), gridk, blockk, shk, stream, r, S, fmode);       \
+        else if (per == 4) MG_LAUNCH((gemm_rows_resid_mt_kernel<MTV, 4>), gridk, blockk, shk, stream, r, S, fmode);  \
+        else MG_LAUNCH((gemm_rows_resid_mt_kernel<MTV, 2>), gridk, blockk, shk, stream, r, S, fmode);                \
+        return;
+            switch (mt) { MG_RMT(2) MG_RMT(3) MG_RMT(4) MG_RMT(5) MG_RMT(6) MG_RMT(7) MG_RMT(8) default: break; }
+#undef MG_RMT
+        }
     }
     // several row tiles: 16 features per workgroup (see resid_block16 F16); g_resid_f16 = 0: the 8-feature form (tests, A/B runs)
     const bool f16 = mt >= 2 && (r.N & 15) == 0 && g_resid_f16;

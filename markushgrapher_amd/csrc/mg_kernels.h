@@ -93,6 +93,7 @@ void gemm_set_variant(int v);   // 0: 128x128 kernel only; 1: + 256x128 three-st
 // small-M (decode step) GEMM: M <= 32*MT rows of live sequences, weights streamed once.
 void gemm_rows(const GemmArgs& a, int epi, mgStream_t stream);
 void gemm_rows_set_resid_f16(int on);  // 1 (default): residual projections with several row tiles take 16 features per workgroup; 0: 8 (tests, A/B runs; same bits)
+void gemm_rows_set_mt(int on);   // 1: K-slab form (default 0: measured slower, k_gemm.hip) of the projections with several row tiles where the caller provides kpart / ticket; 0: one-workgroup forms (same bits)
 void gemm_rows_set_split(int mode);   // row-tile split policy of the decode projections (-1 default by weight size, 0 never, 1 always one tile per workgroup)
 
 // split-K decode GEMM: P[ks][m*ldp + n] (ks < KS) = partial sums over the ks-th K range; consumers add the slabs
@@ -134,6 +135,11 @@ struct ResidArgs {
     RowScale rs;
     int wide_tiles;        // row tiles up to which the long K = d_ff form keeps 16 K-partitioning waves (0: 4).  The decode steps pass 8 (every call
                            // the C ABI admits: 256 rows), so that a row sums in the order of a 32-row call whatever its call's size
+    // Several row tiles, K-slab form (gemm_rows_resid_mt_kernel): the K chunks that the waves of the one-workgroup forms take become
+    // workgroups - kpart [chunks][rows padded to 32][N] fp32 partial sums, ticket [N / 32] zero-initialised arrival counters (left at
+    // zero by every launch).  Both null: the one-workgroup forms.
+    float* kpart;
+    int* ticket;
 };
 void gemm_rows_resid(const ResidArgs& r, mgStream_t stream);
 void gemm_rows_resid_trace(const ResidArgs& r, long long* trace, mgStream_t stream);   // phase stamps, M <= 32, K = d_ff form

@@ -802,3 +802,46 @@ def test_gemm_row_tile_list(be_name, M, N, K, variant):
         assert np.array_equal(a_[rowlive], b_[rowlive])
     assert np.array_equal(res["list"][0][~rowlive], h0[~rowlive])                   # dead rows of the residual stream untouched
     assert np.all(res["list"][2][~rowlive] == 0)
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+@pytest.mark.parametrize("M,N,K", [(150, 256, 4096), (64, 256, 1024), (96, 512, 512)])
+def test_residual_projection_k_slab_form_is_bit_identical(be_name, M, N, K):
+    """Residual projection over several row tiles, K-slab form (gemm_rows_resid_mt_kernel: the K chunks of the one-workgroup form's
+    waves become workgroups, the last arrival of a feature tile adds the partial sums in the waves' order): h, bf16(h * gain) and the
+    partial sums of squares must be the SAME BITS as the one-workgroup form's, with a deferred row scale on the input, a partial last
+    row tile, and twice in a row on the same scratch (the tickets return to zero)."""
+    if be_name == "emu" and K > 1024:
+        M = 40
+    be = get_backend(be_name)
+    at = [C.c_void_p] * 5 + [C.c_float] + [C.c_void_p] * 2 + [C.c_int] * 3 + [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+    be.lib.mgk_gemm_resid_mt.argtypes = at
+    x, w = rnd((M, K), 410), rnd((N, K), 411, 0.1)
+    h0, g = rnd((M, N), 412), 1 + 0.2 * rnd((N,), 413)
+    Mp = (M + 31) // 32 * 32
+    rsp = np.abs(rnd((Mp, 16), 414)) + 0.5
+    Xp, Wp, G, RS = be.buf(pk.pack_tiles(x)), be.buf(pk.pack_tiles(w)), be.buf(g), be.buf(rsp)
+    res = {}
+    try:
+        for mode in (0, 1, 2):
+            assert be.lib.mgk_set_rows_mt(1 if mode else 0) == 0
+            if mode < 2:
+                kpart = be.zeros((16 * Mp * N,), np.float32)
+                ticket = be.zeros((N // 32,), np.int32)
+            h = be.buf(h0)
+            xp = be.zeros((Mp * N,), np.uint16)
+            part = be.zeros((Mp, N // 8), np.float32)
+            assert be.lib.mgk_gemm_resid_mt(be.stream, be.p(Xp), be.p(Wp), be.p(h), be.p(G), 0.5, be.p(xp), be.p(part), M, N, K, be.p(RS), 16,
+                                            1.0 / 16, 1e-6, 8, be.p(kpart), be.p(ticket)) == 0
+            res[mode] = [np.array(a.numpy(), copy=True) for a in (h, xp, part)]
+            assert not ticket.numpy().any()
+    finally:
+        be.lib.mgk_set_rows_mt(0)            # (the default: the K-slab form is measured slower than the one-workgroup forms, k_gemm.hip)
+    r = 1.0 / np.sqrt(rsp.sum(1)[:M] / 16 + 1e-6)
+    np.testing.assert_allclose(res[1][0], h0 + (pk.bf16_round(x) @ pk.bf16_round(w).T) * r[:, None], rtol=1e-4, atol=5e-4)
+    for mode in (1, 2):
+        for a, b in zip(res[0], res[mode]):
+            va, vb = (a.view(np.uint32), b.view(np.uint32)) if a.dtype == np.float32 else (a, b)
+            if a.ndim == 2 and a.shape[0] == Mp:
+                va, vb = va[:M], vb[:M]
+            assert np.array_equal(va, vb), mode
