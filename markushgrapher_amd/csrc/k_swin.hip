@@ -17,8 +17,9 @@
 namespace mg {
 
 namespace {
-
 int grid_for(size_t n) { const size_t g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 65535 ? 65535 : g)); }
+}  // namespace
+// (the kernels below have external names so that kernel traces show them)
 
 // ---------------------------------------------------------------------------------------------------------
 // input derivation (INFERRED piece of the fork: see e1_shapes.py) and im2col
@@ -71,77 +72,71 @@ __global__ __launch_bounds__(256) void swin_im2col_pack_kernel(const float* pix,
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// LayerNorm (+ patch-merging gather) -> packed bf16 / fp32
-// TPR lanes share a row, each holds CPL chunks of 8 features in registers (TPR * CPL * 8 = C): one pass over h, mean and
-// centred variance from registers, reductions by xor-shuffles inside the TPR-lane group.
+// LayerNorm (+ patch-merging gather) over the TILED fp32 residual stream (ht_off: [rows/32][C/4][32 rows][4 features], the layout
+// the encoder GEMMs' residual epilogue reads and writes in 16-byte groups) -> packed bf16 / fp32.
+// A workgroup takes one 32-row tile: thread (row r = tid % 32, q = tid / 32) owns the 4-feature groups q, q + 8, ...: the 32 threads
+// of a q read 512 contiguous bytes per group.  Row statistics: in-thread sums, the two q of a wave by one xor-32 exchange, the four
+// waves through LDS in a fixed order.  KEEP: the row's values stay in registers (C <= 1024); else three passes over L2 (the merges).
 // ---------------------------------------------------------------------------------------------------------
-template <int TPR, int CPL>
+template <int GPT, bool KEEP>
 __global__ __launch_bounds__(256) void swin_ln_kernel(SwinLnArgs a) {
-    constexpr int RPB = 256 / TPR;                      // rows per workgroup
-    const int tid = threadIdx.x, lr = tid % TPR;
-    const int m = blockIdx.x * RPB + tid / TPR;
+    MG_DYN_SMEM(smem);
+    float (*red)[4][32] = (float (*)[4][32])smem;          // [2][4][32]
+    const int tid = threadIdx.x, r = tid & 31, q = tid >> 5, wv = tid >> 6;
+    const int T = blockIdx.x, m = 32 * T + r, C = a.C;
     const bool ok = m < a.M;
-    const int C = a.C;
-    float v[CPL][8];
-    const float* src[CPL];
-    float* hrow[CPL];
-    int col[CPL];
-#pragma unroll
-    for (int i = 0; i < CPL; ++i) {
-        const int c = lr + TPR * i;                      // chunk of 8 features
-        col[i] = 8 * c;
-        const int mm = ok ? m : 0;
-        if (a.merge_R > 0) {
-            const int Cin = C >> 2, R = a.merge_R, R2 = R >> 1;
-            const int part = col[i] / Cin, cin = col[i] - part * Cin;
-            const int b = mm / (R2 * R2), r = mm - b * R2 * R2, oi = r / R2, oj = r - oi * R2;
-            const int sy = 2 * oi + (part & 1), sx = 2 * oj + (part >> 1);       // stock:318-320: [row::2, col::2] for col in (0, 1) for row in (0, 1)
-            hrow[i] = a.h + ((size_t)b * R * R + (size_t)sy * R + sx) * Cin + cin;
-        } else {
-            hrow[i] = a.h + (size_t)mm * C + col[i];
+    const int mm = ok ? m : a.M - 1;
+    // source of feature group g (4 features) of this thread's row
+    const int Cin = a.merge_R > 0 ? (C >> 2) : C;
+    int mb = 0, oi = 0, oj = 0;
+    if (a.merge_R > 0) { const int R2 = a.merge_R >> 1; mb = mm / (R2 * R2); const int rr = mm - mb * R2 * R2; oi = rr / R2; oj = rr - oi * R2; }
+    auto src = [&](int g) -> const float* {
+        const int n = 4 * g;
+        if (a.merge_R > 0) {        // stock:318-320: [row::2, col::2] for col in (0, 1) for row in (0, 1), concatenated on the feature axis
+            const int part = n / Cin, cin = n - part * Cin, R = a.merge_R;
+            const int ms = (mb * R + 2 * oi + (part & 1)) * R + 2 * oj + (part >> 1);
+            return a.h_in + ht_off(ms, cin, Cin);
         }
-        src[i] = hrow[i];
-        const float4 x0 = *(const float4*)src[i], x1 = *(const float4*)(src[i] + 4);
-        v[i][0] = x0.x; v[i][1] = x0.y; v[i][2] = x0.z; v[i][3] = x0.w; v[i][4] = x1.x; v[i][5] = x1.y; v[i][6] = x1.z; v[i][7] = x1.w;
-    }
+        return a.in_tiled ? a.h_in + ht_off(mm, n, C) : a.h_in + (size_t)mm * C + n;
+    };
+    float4 v[KEEP ? GPT : 1];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < CPL; ++i)
+    for (int i = 0; i < GPT; ++i) {
+        const float4 x = *(const float4*)src(q + 8 * i);
+        if (KEEP) v[i] = x;
+        s += (x.x + x.y) + (x.z + x.w);
+    }
+    s += __shfl_xor(s, 32);
+    if ((tid & 32) == 0) red[0][wv][r] = s;
+    __syncthreads();
+    const float mean = (((red[0][0][r] + red[0][1][r]) + red[0][2][r]) + red[0][3][r]) / (float)C;
+    float qv = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s += v[i][j];
-#pragma unroll
-    for (int msk = TPR >> 1; msk >= 1; msk >>= 1) s += __shfl_xor(s, msk);
-    const float mean = s / (float)C;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < CPL; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; q += d * d; }
-#pragma unroll
-    for (int msk = TPR >> 1; msk >= 1; msk >>= 1) q += __shfl_xor(q, msk);
-    const float rstd = rsqrtf(q / (float)C + a.eps);
+    for (int i = 0; i < GPT; ++i) {
+        const float4 x = KEEP ? v[KEEP ? i : 0] : *(const float4*)src(q + 8 * i);
+        const float d0 = x.x - mean, d1 = x.y - mean, d2 = x.z - mean, d3 = x.w - mean;
+        qv += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+    qv += __shfl_xor(qv, 32);
+    if ((tid & 32) == 0) red[1][wv][r] = qv;
+    __syncthreads();
+    const float rstd = rsqrtf((((red[1][0][r] + red[1][1][r]) + red[1][2][r]) + red[1][3][r]) / (float)C + a.eps);
     if (!ok) return;
 #pragma unroll
-    for (int i = 0; i < CPL; ++i) {
-        const float4 w0 = *(const float4*)(a.w + col[i]), w1 = *(const float4*)(a.w + col[i] + 4);
-        const float4 b0 = *(const float4*)(a.b + col[i]), b1 = *(const float4*)(a.b + col[i] + 4);
-        const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-        const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-        float y[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) y[j] = (v[i][j] - mean) * rstd * wv[j] + bv[j];
-        if (a.add_bias) {                                  // (merge_R == 0 only: the launcher checks)
-            const float4 a0 = *(const float4*)(a.add_bias + col[i]), a1 = *(const float4*)(a.add_bias + col[i] + 4);
-            *(float4*)hrow[i] = make_float4(v[i][0] + a0.x, v[i][1] + a0.y, v[i][2] + a0.z, v[i][3] + a0.w);
-            *(float4*)(hrow[i] + 4) = make_float4(v[i][4] + a1.x, v[i][5] + a1.y, v[i][6] + a1.z, v[i][7] + a1.w);
+    for (int i = 0; i < GPT; ++i) {
+        const int g = q + 8 * i, n = 4 * g;
+        const float4 x = KEEP ? v[KEEP ? i : 0] : *(const float4*)src(g);
+        const float4 wg = *(const float4*)(a.w + n), bg = *(const float4*)(a.b + n);
+        const float y0 = (x.x - mean) * rstd * wg.x + bg.x, y1 = (x.y - mean) * rstd * wg.y + bg.y;
+        const float y2 = (x.z - mean) * rstd * wg.z + bg.z, y3 = (x.w - mean) * rstd * wg.w + bg.w;
+        if (a.h_out) {                                     // tiled copy of the row (+ the bias of the projection accumulated into it later)
+            float4 o = a.h_out_norm ? make_float4(y0, y1, y2, y3) : x;
+            if (a.add_bias) { const float4 ab = *(const float4*)(a.add_bias + n); o.x += ab.x; o.y += ab.y; o.z += ab.z; o.w += ab.w; }
+            *(float4*)(a.h_out + ht_off(m, n, C)) = o;
         }
-        if (a.out_f32) {
-            float* o = a.out_f32 + (size_t)m * C + col[i];
-            *(float4*)o = make_float4(y[0], y[1], y[2], y[3]);
-            *(float4*)(o + 4) = make_float4(y[4], y[5], y[6], y[7]);
-        }
-        if (a.x_pk)
-            st16(a.x_pk + pk_off(m, col[i], C), make_uint4(pack_bf16(y[0], y[1]), pack_bf16(y[2], y[3]), pack_bf16(y[4], y[5]), pack_bf16(y[6], y[7])));
+        if (a.out_f32) *(float4*)(a.out_f32 + (size_t)m * C + n) = make_float4(y0, y1, y2, y3);
+        if (a.x_pk) *(uint2*)(a.x_pk + pk_off(m, n, C)) = make_uint2(pack_bf16(y0, y1), pack_bf16(y2, y3));
     }
 }
 
@@ -286,8 +281,6 @@ __global__ __launch_bounds__(256) void swin_transpose_kernel(const float* src, f
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n * H; i += gridDim.x * 256) { const int h = i / n, j = i - h * n; dst[i] = src[(size_t)j * H + h]; }
 }
 
-}  // namespace
-
 void swin_resize(const float* src, float* dst, int B, int C, int S, int I, const SwinPixAffine& af, mgStream_t st) {
     MG_LAUNCH(swin_resize_kernel, dim3(grid_for((size_t)B * C * I * I)), dim3(256), 0, st, src, dst, B, C, S, I, af);
 }
@@ -299,15 +292,15 @@ void swin_im2col_pack(const float* pix, uint16_t* x_pk, int B, int C, int I, int
 
 bool swin_ln_supported(int C) { return C == 64 || C == 128 || C == 256 || C == 512 || C == 1024 || C == 2048 || C == 4096; }
 void swin_layernorm(const SwinLnArgs& a, mgStream_t st) {
-#define MG_SWIN_LN(TPR, CPL) MG_LAUNCH((swin_ln_kernel<TPR, CPL>), dim3((a.M + 256 / TPR - 1) / (256 / TPR)), dim3(256), 0, st, a)
+#define MG_SWIN_LN(GPT, KEEP) MG_LAUNCH((swin_ln_kernel<GPT, KEEP>), dim3((a.M + 31) / 32), dim3(256), 2 * 4 * 32 * sizeof(float), st, a)
     switch (a.C) {
-        case 64: MG_SWIN_LN(8, 1); break;
-        case 128: MG_SWIN_LN(16, 1); break;
-        case 256: MG_SWIN_LN(32, 1); break;
-        case 512: MG_SWIN_LN(64, 1); break;
-        case 1024: MG_SWIN_LN(64, 2); break;
-        case 2048: MG_SWIN_LN(64, 4); break;
-        default: MG_SWIN_LN(64, 8); break;
+        case 64: MG_SWIN_LN(2, true); break;
+        case 128: MG_SWIN_LN(4, true); break;
+        case 256: MG_SWIN_LN(8, true); break;
+        case 512: MG_SWIN_LN(16, true); break;
+        case 1024: MG_SWIN_LN(32, true); break;
+        case 2048: MG_SWIN_LN(64, false); break;
+        default: MG_SWIN_LN(128, false); break;
     }
 #undef MG_SWIN_LN
 }

@@ -13,15 +13,21 @@ void swin_resize(const float* src, float* dst, int B, int C, int S, int I, const
 // (Conv2d with kernel = stride = patch as a matrix product, stock:254-286)
 void swin_im2col_pack(const float* pix, uint16_t* x_pk, int B, int C, int I, int ps, int Kp, mgStream_t st);
 
-// LayerNorm over the C features of M rows of the fp32 row-major residual stream (stock nn.LayerNorm: biased variance, eps inside the root):
+// LayerNorm over the C features of M rows of the fp32 residual stream (stock nn.LayerNorm: biased variance, eps inside the root):
+//   h_in      the rows: TILED (ht_off, in_tiled = 1: what the GEMMs' residual epilogue EPI_RESID_NORM reads and writes) or row-major
+//             (in_tiled = 0: the output of a plain fp32-store GEMM - patch embedding, patch-merging reduction)
 //   x_pk (nullable)    packed bf16 [M][C] = LN(row) * w + b
-//   out_f32 (nullable) row-major fp32 [M][C] of the same (may alias h: embeddings.norm runs in place)
-//   add_bias (nullable) h[m] += add_bias after the row has been read: the bias of the residual projection (o_proj / fc2) whose
-//                      product is accumulated into h later in the same sub-layer (EPI_F32_RESID has no bias slot)
-// merge_R > 0: patch merging (stock:309-326) - output row (b, i, j) of the (merge_R/2)^2 map normalises the concatenation
-//   [h(2i, 2j) | h(2i+1, 2j) | h(2i, 2j+1) | h(2i+1, 2j+1)] of the merge_R^2 map, C = 4 * (width of h)
+//   out_f32 (nullable) row-major fp32 [M][C] of the same
+//   h_out (nullable)   TILED [M][C]: the row itself + add_bias (nullable): the residual stream the following projections accumulate into,
+//                      with the bias of the projection (o_proj / fc2) whose product is added later in the same sub-layer (the residual
+//                      epilogue has no bias slot); may be h_in itself when that is tiled
+// merge_R > 0: patch merging (stock:309-326) - h_in is the TILED merge_R^2 map of width C / 4, output row (b, i, j) of the
+//   (merge_R/2)^2 map normalises the concatenation [h(2i, 2j) | h(2i+1, 2j) | h(2i, 2j+1) | h(2i+1, 2j+1)]
 struct SwinLnArgs {
-    float* h;
+    const float* h_in;
+    int in_tiled;
+    float* h_out;
+    int h_out_norm;        // 1: h_out receives the NORMALISED row (embeddings.norm: its output is the residual stream)
     const float* w;
     const float* b;
     const float* add_bias;

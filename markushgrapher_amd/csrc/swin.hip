@@ -86,7 +86,7 @@ struct mg_e1_model {
 namespace {
 
 struct Ws {
-    float *pix, *ha, *hb, *feats;
+    float *pix, *ha, *rm, *feats;
     uint16_t *xim, *x, *qkv, *ctx, *y, *xf, *pa, *pb;
     size_t total;
 };
@@ -98,8 +98,8 @@ void carve(const mg_e1_model* m, char* base, int B, Ws* w) {
     const int M0p = round_up((int)M0, 32);
     w->pix = cv.take<float>((size_t)B * c.num_channels * I * I);
     w->xim = cv.take<uint16_t>(pk_elems(M0p, m->Kp));
-    w->ha = cv.take<float>(M0 * C0);
-    w->hb = cv.take<float>(M0 * C0 / 2 + 64);
+    w->ha = cv.take<float>((size_t)M0p * C0);          // the tiled residual stream (rows padded to whole 32-row tiles)
+    w->rm = cv.take<float>(M0 * C0);                  // row-major outputs of the plain fp32-store GEMMs (patch embedding, merge reductions)
     // packed activations: the widest of every stage (rows shrink 4x, widths grow 2x per stage: stage 0 is the largest; rows padded to 32)
     size_t x_e = 0, q_e = 0, y_e = 0;
     for (int i = 0; i < m->ns; ++i) {
@@ -326,29 +326,35 @@ int e1_encode_nested(const mg_e1_model* m, mgStream_t st, void* ws, size_t ws_by
         swin_resize(pixel_values, w.pix, B, c.num_channels, c.src_image_size, c.image_size, af, st);
         pix = w.pix;
     }
-    // patch embedding (stock:277-286) + LayerNorm (stock:229)
+    // patch embedding (stock:277-286) + LayerNorm (stock:229).  The residual stream h lives in the TILED fp32 layout (ht_off) of the
+    // main encoder: the residual projections (o_proj, fc2) update it through the batched 16-byte epilogue EPI_RESID_NORM (no gain, no
+    // partial sums: LayerNorm needs the mean as well and stays a kernel of its own), the LayerNorm kernel reads 512-byte runs of it.
+    // Plain fp32-store GEMMs (patch embedding, merge reductions) leave row-major rows in `rm`; the LayerNorm that follows converts.
     const int M0 = B * m->g * m->g, C0 = c.embed_dim;
     swin_im2col_pack(pix, w.xim, B, c.num_channels, c.image_size, c.patch_size, m->Kp, st);
+    float* h = w.ha;
     {
         GemmArgs pe = ga(w.xim, m->at<uint16_t>(m->patch_w), M0, C0, m->Kp);
-        pe.out_f32 = w.ha; pe.ldo = C0; pe.bias = m->rawp("swin.embeddings.patch_embeddings.projection.bias");
+        pe.out_f32 = w.rm; pe.ldo = C0; pe.bias = m->rawp("swin.embeddings.patch_embeddings.projection.bias");
         gemm(pe, EPI_F32_STORE, st);
         SwinLnArgs n{};
-        n.h = w.ha; n.w = m->rawp("swin.embeddings.norm.weight"); n.b = m->rawp("swin.embeddings.norm.bias"); n.out_f32 = w.ha; n.M = M0; n.C = C0;
+        n.h_in = w.rm; n.in_tiled = 0; n.h_out = h; n.h_out_norm = 1;
+        n.w = m->rawp("swin.embeddings.norm.weight"); n.b = m->rawp("swin.embeddings.norm.bias"); n.M = M0; n.C = C0;
         n.eps = 1e-5f;                                                  // nn.LayerNorm default (stock:183), not config.layer_norm_eps
         swin_layernorm(n, st);
     }
-    float* h = w.ha;
-    float* hn = w.hb;
+    bool from_rm = false;                          // the stage's rows still sit row-major in w.rm (after a merge)
     for (int i = 0; i < m->ns; ++i) {
         const int C = m->dim[i], H = c.num_heads[i], R = m->res[i], M = B * R * R, F = c.mlp_ratio * C;
         for (size_t j = 0; j < m->blk[i].size(); ++j) {
             const Block& b = m->blk[i][j];
             const int shift = ((j & 1) && R > c.window_size) ? c.window_size / 2 : 0;      // stock:650, 576-582
             SwinLnArgs n1{};                       // x = LN1(h);  h += o_proj.bias (the projection below adds its product)
-            n1.h = h; n1.w = m->rawp(b.p + "layernorm_before.weight"); n1.b = m->rawp(b.p + "layernorm_before.bias");
+            n1.h_in = from_rm ? w.rm : h; n1.in_tiled = from_rm ? 0 : 1; n1.h_out = h;
+            n1.w = m->rawp(b.p + "layernorm_before.weight"); n1.b = m->rawp(b.p + "layernorm_before.bias");
             n1.add_bias = m->rawp(b.p + "attention.o_proj.bias"); n1.x_pk = w.x; n1.M = M; n1.C = C; n1.eps = c.layer_norm_eps;
             swin_layernorm(n1, st);
+            from_rm = false;
             GemmArgs q = ga(w.x, m->at<uint16_t>(b.wqkv), M, 3 * C, C);
             q.out_pk = w.qkv; q.bias = m->at<float>(b.bqkv);
             gemm(q, EPI_PK_BIAS, st);
@@ -356,35 +362,36 @@ int e1_encode_nested(const mg_e1_model* m, mgStream_t st, void* ws, size_t ws_by
             t.qkv = w.qkv; t.ctx = w.ctx; t.table = m->at<float>(b.tab); t.B = B; t.R = R; t.C = C; t.H = H; t.w = c.window_size; t.shift = shift;
             swin_attention(t, st);
             GemmArgs o = ga(w.ctx, m->at<uint16_t>(b.wo), M, C, C);
-            o.out_f32 = h; o.ldo = C;
-            gemm(o, EPI_F32_RESID, st);
+            o.out_f32 = h;
+            gemm(o, EPI_RESID_NORM, st);
             SwinLnArgs n2{};                       // x = LN2(h);  h += fc2.bias
-            n2.h = h; n2.w = m->rawp(b.p + "layernorm_after.weight"); n2.b = m->rawp(b.p + "layernorm_after.bias");
+            n2.h_in = h; n2.in_tiled = 1; n2.h_out = h; n2.w = m->rawp(b.p + "layernorm_after.weight"); n2.b = m->rawp(b.p + "layernorm_after.bias");
             n2.add_bias = m->rawp(b.p + "mlp.fc2.bias"); n2.x_pk = w.x; n2.M = M; n2.C = C; n2.eps = c.layer_norm_eps;
             swin_layernorm(n2, st);
             GemmArgs f1 = ga(w.x, m->at<uint16_t>(b.w1), M, F, C);
             f1.out_pk = w.y; f1.bias = m->rawp(b.p + "mlp.fc1.bias");
             gemm(f1, EPI_PK_GELU_ERF, st);
             GemmArgs f2 = ga(w.y, m->at<uint16_t>(b.w2), M, C, F);
-            f2.out_f32 = h; f2.ldo = C;
-            gemm(f2, EPI_F32_RESID, st);
+            f2.out_f32 = h;
+            gemm(f2, EPI_RESID_NORM, st);
         }
         if (i + 1 < m->ns) {                       // patch merging (stock:309-326): gather 2 x 2, LayerNorm(4C) (nn.LayerNorm default eps), Linear(4C -> 2C) without bias
             const std::string p = "swin.encoder.layers." + std::to_string(i) + ".downsample.";
             SwinLnArgs n{};
-            n.h = h; n.w = m->rawp(p + "norm.weight"); n.b = m->rawp(p + "norm.bias"); n.x_pk = w.x; n.M = M / 4; n.C = 4 * C; n.merge_R = R; n.eps = 1e-5f;
+            n.h_in = h; n.in_tiled = 1; n.w = m->rawp(p + "norm.weight"); n.b = m->rawp(p + "norm.bias"); n.x_pk = w.x; n.M = M / 4; n.C = 4 * C; n.merge_R = R; n.eps = 1e-5f;
             swin_layernorm(n, st);
             GemmArgs r = ga(w.x, m->at<uint16_t>(m->wred[i]), M / 4, 2 * C, 4 * C);
-            r.out_f32 = hn; r.ldo = 2 * C;
+            r.out_f32 = w.rm; r.ldo = 2 * C;
             gemm(r, EPI_F32_STORE, st);
-            float* tmp = h; h = hn; hn = tmp;
+            from_rm = true;
         }
     }
     // final LayerNorm (stock:885-887) = SwinModel.last_hidden_state
     const int Mo = B * m->M_out;
     {
         SwinLnArgs n{};
-        n.h = h; n.w = m->rawp("swin.layernorm.weight"); n.b = m->rawp("swin.layernorm.bias"); n.x_pk = w.xf; n.out_f32 = features_out ? features_out : w.feats;
+        n.h_in = from_rm ? w.rm : h; n.in_tiled = from_rm ? 0 : 1;
+        n.w = m->rawp("swin.layernorm.weight"); n.b = m->rawp("swin.layernorm.bias"); n.x_pk = w.xf; n.out_f32 = features_out ? features_out : w.feats;
         n.M = Mo; n.C = m->C_out; n.eps = c.layer_norm_eps;
         swin_layernorm(n, st);
     }
