@@ -224,6 +224,8 @@ int mgk_set_resid_f16(int on);
 /* projections of the decode step with several row tiles: 1 the K-slab form (K chunks as workgroups, partial sums merged by the last
  * arrival in the one-workgroup forms' order) where the caller provides its scratch, 0 (default: measured faster) the one-workgroup forms */
 int mgk_set_rows_mt(int on);
+/* encoder attention: 1 (default) one 32-query tile per wave / 8 waves per workgroup, 2 two tiles per wave / 4 waves (same bits, slower) */
+int mgk_set_attention_qt(int qt);
 /* mgk_gemm_resid with the scratch of the K-slab form: kpart [16][M padded to 32][N] fp32, ticket [N / 32] i32 zero-initialised;
  * wide_tiles as ResidArgs (8 in the decode steps) */
 int mgk_gemm_resid_mt(void* stream, const void* X_pk, const void* W_pk, float* h, const float* gain, float gscale, void* x_pk,

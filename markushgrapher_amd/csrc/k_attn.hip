@@ -13,6 +13,7 @@
 // (double-buffered, fragment order, conflict-free b128 reads); per-key metadata (mask, box centres) and the
 // three bias tables of head h live in LDS for the whole workgroup.
 #include "mg_kernels.h"
+#include <atomic>
 
 namespace mg {
 
@@ -287,8 +288,16 @@ MG_DEV float fast_exp2(float x) {
 // (the stage list therefore lives in LDS, and the loads of the prologue are retired by hand before the loop).
 // XP != 0: timing experiments of the tools build only (MG_ATT_EXP, WRONG results): 1 = no index-word copies (stale LDS is read),
 // 2 = no table lookup (bias 0), 4 = no exp2 (weights = shifted scores), 8 = K / V^T copies of the first two stages only
-template <int XP = 0>
-__global__ __launch_bounds__(512) void attention_enc_kernel(AttnArgs a) {
+// QT = 32-query tiles per wave.  QT = 1 (default): 8 waves (two per SIMD), the form of rounds 2-4.  QT = 2 (round 5, measured slower, see the launcher): 4 waves (one per SIMD, up to
+// 512 registers per lane), each with TWO query tiles: every K / V^T fragment read from LDS feeds two MFMAs (half the fragment reads
+// per query: the LDS port and the dependent read -> MFMA latencies were what a stage waited on, not the matrix pipe) and the two tiles'
+// softmax chains are independent instruction streams the scheduler interleaves.  A query's arithmetic is the same sequence of
+// operations in both forms: results are bit-identical (tests/test_kernels.py).
+template <int XP = 0, int QT = 1>
+__global__ __launch_bounds__(512 / QT) void attention_enc_kernel(AttnArgs a) {
+    constexpr int NWV = AE_WAVES / QT;                   // waves per workgroup
+    constexpr int NTH = 64 * NWV;
+    constexpr int FPW = 16 / NWV;                        // K / V^T fragments a wave copies per stage
     MG_DYN_SMEM(smem);
     const int tid = threadIdx.x, lane = tid & 63;
 #ifdef MG_EMU
@@ -313,7 +322,7 @@ __global__ __launch_bounds__(512) void attention_enc_kernel(AttnArgs a) {
         const uint8_t* qv = a.qbv + (size_t)b * n128;
         const bool any = qv[2 * qb] | ((2 * qb + 1 < n128) ? qv[2 * qb + 1] : 0);
         if (!any) {
-            for (int i = tid; i < AE_QB * 8; i += 512) {
+            for (int i = tid; i < AE_QB * 8; i += NTH) {
                 const int q = qb * AE_QB + (i >> 3), c = (i & 7) * 8;
                 if (q < a.Sq_cap) st16(a.ctx + pk_off(b * a.Sq_cap + q, h * 64 + c, HD), make_uint4(0, 0, 0, 0));
             }
@@ -321,71 +330,81 @@ __global__ __launch_bounds__(512) void attention_enc_kernel(AttnArgs a) {
         }
     }
     char* st_base = smem;
-    char* ix_base = smem + AE_RING * AT_STAGE_BYTES + w * (4 * TILE_BYTES);      // + slot * AE_IDX_BYTES
+    char* ix_base = smem + AE_RING * AT_STAGE_BYTES + w * (4 * QT * TILE_BYTES);      // + slot * AE_IDX_BYTES; tile t of the wave: + t * 4 KiB
     float* hv = (float*)(smem + AE_RING * AT_STAGE_BYTES + AE_DEPTH * AE_IDX_BYTES);
     float* t1d = hv + AE_HV + 4;
     int* ksl = (int*)(t1d + 2 * AE_D1 + 4);
     const int nst = kst ? kst[0] : (a.Sk + AT_KEYS - 1) / AT_KEYS;
-    for (int i = tid; i < nst && i < AE_MAXST; i += 512) ksl[i] = kst ? kst[1 + i] : i;
-    for (int i = tid; i < AE_HV; i += 512)
+    for (int i = tid; i < nst && i < AE_MAXST; i += NTH) ksl[i] = kst ? kst[1 + i] : i;
+    for (int i = tid; i < AE_HV; i += NTH)
         hv[i] = (a.tabh[(size_t)(i & 31) * a.H + h] + a.tabv[(size_t)(i >> 5) * a.H + h]) * AE_LOG2E;
     if (tid < 4) hv[AE_HV + tid] = AT_NEG;
-    for (int i = tid; i < 2 * AE_D1 + 1; i += 512) {
+    for (int i = tid; i < 2 * AE_D1 + 1; i += NTH) {
         int d = i - AE_D1;
         d = d < -128 ? -128 : (d > 128 ? 128 : d);
         t1d[i] = a.tab1[(size_t)a.bk1[d + 128] * a.H + h] * AE_LOG2E;
     }
 
-    const int q0 = qb * AE_QB + w * 32;
-    int qrt = q0 >> 5;
+    const int q0w = qb * AE_QB + w * 32 * QT;            // first query of the wave; tile t starts at q0w + 32 t
     const int qrt_max = (a.Sq_cap >> 5) - 1;
-    if (qrt > qrt_max) qrt = qrt_max;
-    const uint16_t* Qb = a.Q + (((size_t)b * a.H + h) * (size_t)(a.Sq_cap >> 5) + (size_t)qrt) * (4 * TILE_ELEMS);
-    mg_raw16 qr[4];
+    mg_raw16 qr[QT][4];
+    int qi[QT];
+    const uint16_t* bix[QT];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) gld16_async(qr[kt], (const char*)(Qb + kt * TILE_ELEMS) + lane * 16);
-    const int qi = q0 + l32;
-    const int qcl = qi < a.Sk_cap ? qi : a.Sk_cap - 1;
+    for (int t = 0; t < QT; ++t) {
+        int qrt = (q0w + 32 * t) >> 5;
+        if (qrt > qrt_max) qrt = qrt_max;
+        const uint16_t* Qb = a.Q + (((size_t)b * a.H + h) * (size_t)(a.Sq_cap >> 5) + (size_t)qrt) * (4 * TILE_ELEMS);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) gld16_async(qr[t][kt], (const char*)(Qb + kt * TILE_ELEMS) + lane * 16);
+        qi[t] = q0w + 32 * t + l32;
+        const int qcl = qi[t] < a.Sk_cap ? qi[t] : a.Sk_cap - 1;
+        bix[t] = a.bidx + ((size_t)b * (size_t)(a.Sk_cap >> 5) * (size_t)a.Sk_cap + (size_t)qcl) * 32 + half * 16;
+    }
     // a wave in a 128-query block without an attended position (the granularity of attn_lists, and what the first form of
     // the kernel skipped: padded rows next to attended ones are still computed, as the reference does) keeps loading its
     // share of the stages and meeting the barriers, but computes nothing; its context rows are cleared (later GEMMs must
-    // see finite values)
-    int act = q0 < a.Sq_cap ? 1 : 0;
-    if (a.qbv && act) act = a.qbv[(size_t)b * ((a.Sq_cap + 127) / 128) + (q0 >> 7)] ? 1 : 0;
+    // see finite values).  (QT = 2: the wave's 64 queries lie inside one 128-query block.)
+    int act = q0w < a.Sq_cap ? 1 : 0;
+    if (a.qbv && act) act = a.qbv[(size_t)b * ((a.Sq_cap + 127) / 128) + (q0w >> 7)] ? 1 : 0;
     __syncthreads();               // tables and stage list complete
     // retire every load of the prologue by hand (the Q fragments were raw loads: nothing may touch them before this wait):
     // from here on the vector-memory queue holds only the hand-counted copies below
-    MG_WAIT_VMCNT_TIE4(0, qr[0], qr[1], qr[2], qr[3]);
-    uint4 qf[4];
+    MG_WAIT_VMCNT_TIE4(0, qr[0][0], qr[0][1], qr[0][2], qr[0][3]);
+    if constexpr (QT == 2) { MG_TIE(qr[QT - 1][0]); MG_TIE(qr[QT - 1][1]); MG_TIE(qr[QT - 1][2]); MG_TIE(qr[QT - 1][3]); }
+    uint4 qf[QT][4];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) qf[kt] = raw16_get(qr[kt]);
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) qf[t][kt] = raw16_get(qr[t][kt]);
     // 1-D term of a tile whose pairs are all >= 128 positions apart (saturated bucket, stock:455-466): keys left / right
     const float c_left = t1d[0], c_right = t1d[2 * AE_D1];
 
-    const uint16_t* bix = a.bidx + ((size_t)b * (size_t)(a.Sk_cap >> 5) * (size_t)a.Sk_cap + (size_t)qcl) * 32 + half * 16;
     const size_t bix_tile = (size_t)a.Sk_cap * 32;
     const uint16_t* Kb = a.K + ((size_t)b * a.H + h) * (size_t)(a.Sk_cap >> 5) * (4 * TILE_ELEMS);
     const uint16_t* Vb = a.Vt + ((size_t)b * a.H + h) * 2 * (size_t)(a.Sk_cap >> 4) * TILE_ELEMS;
     const int krt_max = (a.Sk_cap >> 5) - 1, vkt_max = (a.Sk_cap >> 4) - 1;
     auto sid = [&](int i) { return ksl[i]; };
     // issue everything this wave copies for the i-th visited stage: its index words (active waves; 16 keys = 32 B per lane
-    // and 32-key tile, as 4 x 16 B per lane -> 4 copies of 1 KiB) into index slot i % AE_DEPTH, then its two K / V^T
+    // and 32-key tile, as 4 x 16 B per lane -> 4 copies of 1 KiB per query tile) into index slot i % AE_DEPTH, then its K / V^T
     // fragments into ring slot i % AE_RING (fragments 0..7 = K: key-tile f/4, dk-tile f%4; 8..15 = V^T: d-tile, key-k-tile)
     auto issue = [&](int i) {
         const int st = sid(i);
         if (act && !(XP & 1)) {
             char* ix = ix_base + (i % AE_DEPTH) * AE_IDX_BYTES;
 #pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2) {
-                const uint16_t* p = bix + (size_t)(st * 2 + t2) * bix_tile;
-                glds16_async(p, ix + (t2 * 2) * TILE_BYTES);
-                glds16_async(p + 8, ix + (t2 * 2 + 1) * TILE_BYTES);
-            }
+            for (int t = 0; t < QT; ++t)
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2) {
+                    const uint16_t* p = bix[t] + (size_t)(st * 2 + t2) * bix_tile;
+                    glds16_async(p, ix + (t * 4 + t2 * 2) * TILE_BYTES);
+                    glds16_async(p + 8, ix + (t * 4 + t2 * 2 + 1) * TILE_BYTES);
+                }
         }
         char* dst = st_base + (i % AE_RING) * AT_STAGE_BYTES;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int f = w * 2 + k;
+        for (int k = 0; k < FPW; ++k) {
+            const int f = w * FPW + k;
             const char* src;
             if (f < 8) {
                 int krt = st * 2 + (f >> 2);
@@ -400,18 +419,22 @@ __global__ __launch_bounds__(512) void attention_enc_kernel(AttnArgs a) {
             if (!(XP & 8) || i < 2) glds16_async(src + lane * 16, dst + f * TILE_BYTES);
         }
     };
-    constexpr int XW_ACT = ((XP & 1) ? 0 : 4) + ((XP & 8) ? 0 : 2), XW_IDLE = (XP & 8) ? 0 : 2;      // copies per wave and stage
+    constexpr int XW_ACT = ((XP & 1) ? 0 : 4) + ((XP & 8) ? 0 : 2), XW_IDLE = (XP & 8) ? 0 : 2;      // copies per wave and stage (QT = 1 experiments)
 
-    f32x16 o[2] = {acc_zero(), acc_zero()};
-    float lsum = 0.f, m_run = AT_NEG;
+    f32x16 o[QT][2];
+    float lsum[QT], m_run[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) { o[t][0] = acc_zero(); o[t][1] = acc_zero(); lsum[t] = 0.f; m_run[t] = AT_NEG; }
     static_assert(AE_DEPTH == 2, "wait counts below");
     issue(0);
     if (1 < nst) issue(1);
     for (int sti = 0; sti < nst; ++sti) {
         // own copies of stage sti have landed when at most those of the one later stage in flight are outstanding
         if constexpr (XP == 0) {
-            if (sti + 1 < nst && !(a.dbg & 1)) { if (act) MG_WAIT_VMCNT(6); else MG_WAIT_VMCNT(2); }
-            else MG_WAIT_VMCNT(0);
+            if (sti + 1 < nst && !(a.dbg & 1)) {
+                if constexpr (QT == 1) { if (act) MG_WAIT_VMCNT(6); else MG_WAIT_VMCNT(2); }
+                else { if (act) MG_WAIT_VMCNT(12); else MG_WAIT_VMCNT(4); }
+            } else MG_WAIT_VMCNT(0);
         } else {                       // (experiments: same structure with the variant's copy counts)
             if (sti + 1 < nst && sti >= 2) {
                 if (act) { if constexpr (XW_ACT == 6) MG_WAIT_VMCNT(6); else if constexpr (XW_ACT == 4) MG_WAIT_VMCNT(4); else if constexpr (XW_ACT == 2) MG_WAIT_VMCNT(2); else MG_WAIT_VMCNT(0); }
@@ -424,121 +447,140 @@ __global__ __launch_bounds__(512) void attention_enc_kernel(AttnArgs a) {
             if (sti + AE_DEPTH < nst) issue(sti + AE_DEPTH);
             continue;
         }
-        uint4 bcur[4];
+        uint4 bcur[QT][4];
         {
             const char* ix = ix_base + (sti % AE_DEPTH) * AE_IDX_BYTES + lane * 16;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) bcur[i] = ld16(ix + i * TILE_BYTES);
+            for (int t = 0; t < QT; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bcur[t][i] = ld16(ix + (t * 4 + i) * TILE_BYTES);
         }
         MG_WAIT_LGKM0();             // index words are in registers: their slot is refilled for stage sti + AE_DEPTH
         if (sti + AE_DEPTH < nst) issue(sti + AE_DEPTH);
         const char* kb = st_base + (sti % AE_RING) * AT_STAGE_BYTES + lane * 16;
         const char* vb = kb + 8 * TILE_BYTES;
-        f32x16 s[2] = {acc_zero(), acc_zero()};
+        f32x16 s[QT][2];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {           // the two key tiles alternate: two independent accumulator chains
-            s[0] = mfma32(ld16(kb + (0 * 4 + kt) * TILE_BYTES), qf[kt], s[0]);
-            s[1] = mfma32(ld16(kb + (1 * 4 + kt) * TILE_BYTES), qf[kt], s[1]);
-        }
-        // scores in the log2 domain: v = s*log2e + hv[pair] (+ 1-D term near the diagonal); tile maxima
-        float cst[2], tmx[2];
+        for (int t = 0; t < QT; ++t) { s[t][0] = acc_zero(); s[t][1] = acc_zero(); }
 #pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2) {
-            const int k0 = st * AT_KEYS + t2 * 32;
-            const int dk = k0 - q0;                                   // wave-uniform
-            const uint32_t* bw = (const uint32_t*)&bcur[t2 * 2];
-            float tm = AT_NEG;
-            if (dk > -(128 + 31) && dk < 128 + 31) {                 // some pair of the tile is closer than 128: per-score term
-                const char* tl = (const char*)t1d + (k0 - qi + 4 * half + AE_D1) * 4;
+        for (int kt = 0; kt < 4; ++kt) {           // the two key tiles alternate: independent accumulator chains; a fragment feeds QT MFMAs
+            const uint4 k0f = ld16(kb + (0 * 4 + kt) * TILE_BYTES), k1f = ld16(kb + (1 * 4 + kt) * TILE_BYTES);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const uint32_t e = (r & 1) ? (bw[r >> 1] >> 16) : (bw[r >> 1] & 0xFFFFu);
-                    const float bias = ((XP & 2) ? __uint_as_float(e) : *(const float*)((const char*)hv + e)) + *(const float*)(tl + ((r & 3) + 8 * (r >> 2)) * 4);
-                    const float v = fmaf(s[t2][r], AE_LOG2E, bias);
-                    s[t2][r] = v;
-                    tm = fmaxf(tm, v);
-                }
-                cst[t2] = 0.f;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const uint32_t e = (r & 1) ? (bw[r >> 1] >> 16) : (bw[r >> 1] & 0xFFFFu);
-                    const float v = fmaf(s[t2][r], AE_LOG2E, (XP & 2) ? __uint_as_float(e) : *(const float*)((const char*)hv + e));
-                    s[t2][r] = v;
-                    tm = fmaxf(tm, v);
-                }
-                cst[t2] = dk < 0 ? c_left : c_right;
+            for (int t = 0; t < QT; ++t) {
+                s[t][0] = mfma32(k0f, qf[t][kt], s[t][0]);
+                s[t][1] = mfma32(k1f, qf[t][kt], s[t][1]);
             }
-            tmx[t2] = tm + cst[t2];
         }
-        float mloc = fmaxf(tmx[0], tmx[1]);
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-        const float m_new = fmaxf(m_run, mloc);
-        const float alpha = fast_exp2(m_run - m_new);
-        m_run = m_new;
-        uint4 pch[4];
-        float psum = 0.f;
+        uint4 pch[QT][4];
 #pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2) {
-            const float mt = m_new - cst[t2];
-            f32x16 p;
+        for (int t = 0; t < QT; ++t) {
+            const int q0 = q0w + 32 * t;
+            // scores in the log2 domain: v = s*log2e + hv[pair] (+ 1-D term near the diagonal); tile maxima
+            float cst[2], tmx[2];
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                const int k0 = st * AT_KEYS + t2 * 32;
+                const int dk = k0 - q0;                                   // wave-uniform
+                const uint32_t* bw = (const uint32_t*)&bcur[t][t2 * 2];
+                float tm = AT_NEG;
+                if (dk > -(128 + 31) && dk < 128 + 31) {                 // some pair of the tile is closer than 128: per-score term
+                    const char* tl = (const char*)t1d + (k0 - qi[t] + 4 * half + AE_D1) * 4;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const uint32_t e = (r & 1) ? (bw[r >> 1] >> 16) : (bw[r >> 1] & 0xFFFFu);
+                        const float bias = ((XP & 2) ? __uint_as_float(e) : *(const float*)((const char*)hv + e)) + *(const float*)(tl + ((r & 3) + 8 * (r >> 2)) * 4);
+                        const float v = fmaf(s[t][t2][r], AE_LOG2E, bias);
+                        s[t][t2][r] = v;
+                        tm = fmaxf(tm, v);
+                    }
+                    cst[t2] = 0.f;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const uint32_t e = (r & 1) ? (bw[r >> 1] >> 16) : (bw[r >> 1] & 0xFFFFu);
+                        const float v = fmaf(s[t][t2][r], AE_LOG2E, (XP & 2) ? __uint_as_float(e) : *(const float*)((const char*)hv + e));
+                        s[t][t2][r] = v;
+                        tm = fmaxf(tm, v);
+                    }
+                    cst[t2] = dk < 0 ? c_left : c_right;
+                }
+                tmx[t2] = tm + cst[t2];
+            }
+            float mloc = fmaxf(tmx[0], tmx[1]);
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+            const float m_new = fmaxf(m_run[t], mloc);
+            const float alpha = fast_exp2(m_run[t] - m_new);
+            m_run[t] = m_new;
+            float psum = 0.f;
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                const float mt = m_new - cst[t2];
+                f32x16 p;
 #ifdef MG_EMU
 #pragma unroll
-            for (int r = 0; r < 16; ++r) p[r] = fast_exp2(s[t2][r] - mt);
+                for (int r = 0; r < 16; ++r) p[r] = fast_exp2(s[t][t2][r] - mt);
 #else
-            typedef float mg_f32x2 __attribute__((ext_vector_type(2)));
-            const mg_f32x2 mt2 = {mt, mt};
+                typedef float mg_f32x2 __attribute__((ext_vector_type(2)));
+                const mg_f32x2 mt2 = {mt, mt};
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {                      // packed subtract: half an instruction per score
-                const mg_f32x2 sv = {s[t2][r], s[t2][r + 1]};
-                const mg_f32x2 d = sv - mt2;
-                if constexpr (XP & 4) { p[r] = d.x; p[r + 1] = d.y; } else { p[r] = fast_exp2(d.x); p[r + 1] = fast_exp2(d.y); }
+                for (int r = 0; r < 16; r += 2) {                      // packed subtract: half an instruction per score
+                    const mg_f32x2 sv = {s[t][t2][r], s[t][t2][r + 1]};
+                    const mg_f32x2 d = sv - mt2;
+                    if constexpr (XP & 4) { p[r] = d.x; p[r + 1] = d.y; } else { p[r] = fast_exp2(d.x); p[r + 1] = fast_exp2(d.y); }
+                }
+#endif
+                const PackedAcc pa = acc_pack(p);
+                packed_to_chunks_swap(pa, half, &pch[t][2 * t2]);
             }
-#endif
-            const PackedAcc pa = acc_pack(p);
-            packed_to_chunks_swap(pa, half, &pch[2 * t2]);
-        }
-        // the row sum is taken over the ROUNDED values (two per v_dot2 with a ones pair), so that O / l stays a convex
-        // combination of the value rows whatever the rounding of the dominant weights; summed after the half-wave exchange
-        // (which only permutes a query's weights between its two lanes), so the packed words die right there
+            // the row sum is taken over the ROUNDED values (two per v_dot2 with a ones pair), so that O / l stays a convex
+            // combination of the value rows whatever the rounding of the dominant weights; summed after the half-wave exchange
+            // (which only permutes a query's weights between its two lanes), so the packed words die right there
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            psum = dot2_bf16(pch[c].x, 0x3F803F80u, psum); psum = dot2_bf16(pch[c].y, 0x3F803F80u, psum);
-            psum = dot2_bf16(pch[c].z, 0x3F803F80u, psum); psum = dot2_bf16(pch[c].w, 0x3F803F80u, psum);
-        }
+            for (int c = 0; c < 4; ++c) {
+                psum = dot2_bf16(pch[t][c].x, 0x3F803F80u, psum); psum = dot2_bf16(pch[t][c].y, 0x3F803F80u, psum);
+                psum = dot2_bf16(pch[t][c].z, 0x3F803F80u, psum); psum = dot2_bf16(pch[t][c].w, 0x3F803F80u, psum);
+            }
 #ifdef MG_EMU
-        const bool rescale = true;
+            const bool rescale = true;
 #else
-        const bool rescale = __any(alpha != 1.0f);
+            const bool rescale = __any(alpha != 1.0f);
 #endif
-        if (rescale) {
-            lsum *= alpha;
+            if (rescale) {
+                lsum[t] *= alpha;
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
+                for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) o[t][dt][r] *= alpha;
+            }
+            lsum[t] += psum;
         }
-        lsum += psum;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const uint4 v0 = ld16(vb + (0 * 4 + kk) * TILE_BYTES), v1 = ld16(vb + (1 * 4 + kk) * TILE_BYTES);
-            o[0] = mfma32(v0, pch[kk], o[0]);
-            o[1] = mfma32(v1, pch[kk], o[1]);
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                o[t][0] = mfma32(v0, pch[t][kk], o[t][0]);
+                o[t][1] = mfma32(v1, pch[t][kk], o[t][1]);
+            }
         }
     }
-    lsum += __shfl_xor(lsum, 32);          // the two halves hold different keys of the same query
-    const float inv = act ? 1.0f / lsum : 0.f;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
-        f32x16 v;
+    for (int t = 0; t < QT; ++t) {
+        float ls = lsum[t];
+        ls += __shfl_xor(ls, 32);          // the two halves hold different keys of the same query
+        const float inv = act ? 1.0f / ls : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = o[dt][r] * inv;
-        uint4 ch[2];
-        acc_to_chunks(v, half, ch);
-        if (qi < a.Sq_cap) {
+        for (int dt = 0; dt < 2; ++dt) {
+            f32x16 v;
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
-                st16(a.ctx + pk_off(b * a.Sq_cap + qi, h * 64 + dt * 32 + q * 16 + half * 8, HD), ch[q]);
+            for (int r = 0; r < 16; ++r) v[r] = o[t][dt][r] * inv;
+            uint4 ch[2];
+            acc_to_chunks(v, half, ch);
+            if (qi[t] < a.Sq_cap) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    st16(a.ctx + pk_off(b * a.Sq_cap + qi[t], h * 64 + dt * 32 + q * 16 + half * 8, HD), ch[q]);
+            }
         }
     }
 }
@@ -657,6 +699,9 @@ void row_tile_list(const uint8_t* kmask, int rows, int* list, int* count, mgStre
     MG_LAUNCH(row_tile_list_kernel, dim3(1), dim3(256), (size_t)(256 * sizeof(int)), stream, kmask, n_tiles, list, count);
 }
 
+static std::atomic<int> g_att_qt{-1};          // query tiles per wave of the encoder attention: -1 = MG_ATT_QT or the default (2); process-wide test / A-B switch
+void attention_set_qt(int qt) { g_att_qt = qt; }
+
 void attention(const AttnArgs& a_in, mgStream_t stream) {
     AttnArgs a = a_in;
     static int dbg = -1;
@@ -668,7 +713,7 @@ void attention(const AttnArgs& a_in, mgStream_t stream) {
     if (a.mode == ATT_ENC) {
         const int nqe = (a.Sq_cap + AE_QB - 1) / AE_QB;
         static bool once = false;
-        if (!once) { MG_SET_MAX_SMEM(&attention_enc_kernel<0>, AE_SMEM); once = true; }
+        if (!once) { MG_SET_MAX_SMEM((&attention_enc_kernel<0, 1>), AE_SMEM); once = true; }
 #ifdef MG_TOOLS      // what-if variants with WRONG results: tools builds only
         static int xp = -1;
         if (xp < 0) { const char* e = getenv("MG_ATT_EXP"); xp = e ? atoi(e) : 0; }
@@ -680,7 +725,20 @@ void attention(const AttnArgs& a_in, mgStream_t stream) {
             return;
         }
 #endif
-        MG_LAUNCH(attention_enc_kernel<0>, dim3(a.B * a.H * nqe), dim3(512), (size_t)AE_SMEM, stream, a);
+        // Measured and rejected in round 5 (profiles/r05_g_attention_two_tiles_per_wave.txt): QT = 2 - two query tiles per wave, 4 waves per
+        // workgroup (one per SIMD, 168 + accumulator registers), every K / V^T fragment read feeding two MFMAs: bit-identical, 561 us per
+        // launch against 430 us for the 8-wave form at the benchmark shape (encoder 36.4 against 33.2 ms per batch on the same box): two
+        // WAVES per SIMD hide the stage's dependent LDS -> MFMA -> exp2 latencies, two instruction streams inside one wave do not (the
+        // near-diagonal branches are per tile and keep the scheduler from interleaving them).  Kept behind MG_ATT_QT=2 / mgk_set_attention_qt.
+        int qt = g_att_qt;
+        if (qt < 0) { const char* e = getenv("MG_ATT_QT"); qt = e ? atoi(e) : 1; g_att_qt = qt; }
+        if (qt == 2) {
+            static bool once2 = false;
+            if (!once2) { MG_SET_MAX_SMEM((&attention_enc_kernel<0, 2>), AE_SMEM); once2 = true; }
+            MG_LAUNCH((attention_enc_kernel<0, 2>), dim3(a.B * a.H * nqe), dim3(256), (size_t)AE_SMEM, stream, a);
+        } else {
+            MG_LAUNCH((attention_enc_kernel<0, 1>), dim3(a.B * a.H * nqe), dim3(512), (size_t)AE_SMEM, stream, a);
+        }
     } else if (a.mode == ATT_DEC_SELF) MG_LAUNCH((attention_kernel<ATT_DEC_SELF>), grid, block, sh, stream, a);
     else MG_LAUNCH((attention_kernel<ATT_CROSS>), grid, block, sh, stream, a);
 }

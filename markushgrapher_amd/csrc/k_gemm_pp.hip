@@ -28,7 +28,7 @@ namespace mg {
 //        = after barrier 2h+4 (A) / 2h+5 (B).
 // Sums are accumulated in the same order as in gemm_xl_kernel (k ascending per accumulator): results are bit-identical.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int GP_RING = 8, GP_AHEAD = 6, GP_MAXT = 48;          // ring slots, copy lead (k-tiles), tiles per workgroup at most
+constexpr int GP_RING = 8, GP_AHEAD = 6, GP_MAXT = 56;          // ring slots, copy lead (k-tiles), tiles per workgroup at most
 constexpr int GP_GAIN_MAX = 2048;                               // EPI_RESID_NORM: the next norm's gains are staged in LDS when N <= this
 
 template <int N>

@@ -256,6 +256,7 @@ void attn_lists(const uint8_t* kmask, int B, int Sk, int S_cap, int* kst, uint8_
 // live 32-row tiles of a [rows] key mask (rows a multiple of 32, mask 16-byte aligned) -> ascending tile ids + count (GemmArgs::row_tiles)
 void row_tile_list(const uint8_t* kmask, int rows, int* list, int* count, mgStream_t stream);
 void attention(const AttnArgs& a, mgStream_t stream);
+void attention_set_qt(int qt);   // encoder attention: 1 (default) one 32-query tile per wave, 8 waves; 2: two tiles per wave, 4 waves (same bits, measured slower; tests, A/B runs)
 
 // ---------------------------------------------------------------------------------------------
 // decode step (single query per live sequence)

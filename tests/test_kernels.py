@@ -309,6 +309,19 @@ def test_attention_encoder_bias(be_name, S, S_cap, B, H):
     got = pk.unpack_tiles(ctx.numpy(), B * S_cap, H * 64).reshape(B, S_cap, H, 64).transpose(0, 2, 1, 3)[:, :, :S]
     np.testing.assert_allclose(got, ref, rtol=0, atol=2e-2)
     assert np.abs(got - ref).mean() < 2e-3
+    # the default 8-wave form (one query tile per wave) against the form with two tiles per wave / 4 waves: the same bits
+    first = np.array(ctx.numpy(), copy=True)
+    try:
+        be.lib.mgk_set_attention_qt(2)
+        ctx1 = be.zeros((B * S_cap * H * 64,), np.uint16)
+        assert be.lib.mgk_attention(be.stream, 0, be.p(Q), be.p(K), be.p(V), be.p(ctx1), B, H, S, S, S_cap, S_cap,
+                                    be.p(be.buf(mask)), be.p(be.buf(w1)), 32, be.p(be.buf(wh)), be.p(be.buf(wv)),
+                                    be.p(be.buf(cx)), be.p(be.buf(cy)), be.p(be.buf(bk1)), be.p(be.buf(bkhv)), be.p(bidx)) == 0
+        one = pk.unpack_tiles(ctx1.numpy(), B * S_cap, H * 64).reshape(B, S_cap, H, 64).transpose(0, 2, 1, 3)[:, :, :S]
+    finally:
+        be.lib.mgk_set_attention_qt(1)
+    two = pk.unpack_tiles(first, B * S_cap, H * 64).reshape(B, S_cap, H, 64).transpose(0, 2, 1, 3)[:, :, :S]
+    assert np.array_equal(one.view(np.uint32), two.view(np.uint32))
 
 
 @pytest.mark.parametrize("be_name", BACKENDS)
