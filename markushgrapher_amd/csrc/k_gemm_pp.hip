@@ -28,7 +28,9 @@ namespace mg {
 //        = after barrier 2h+4 (A) / 2h+5 (B).
 // Sums are accumulated in the same order as in gemm_xl_kernel (k ascending per accumulator): results are bit-identical.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int GP_RING = 8, GP_AHEAD = 6, GP_MAXT = 56;          // ring slots, copy lead (k-tiles), tiles per workgroup at most
+constexpr int GP_RING = 8, GP_AHEAD = 6, GP_MAXT = 48;          // ring slots, copy lead (k-tiles), tiles per workgroup at most
+// (GP_MAXT = 56 - which would keep the FFN-wi of a 160-image call on this kernel - was measured in round 5: the per-head form <EPI_HEADS> then
+//  compiles to code that runs 606 instead of 279 us per launch at the benchmark shape, encoder 43.2 against 35.3 ms per batch; 48 stays)
 constexpr int GP_GAIN_MAX = 2048;                               // EPI_RESID_NORM: the next norm's gains are staged in LDS when N <= this
 
 template <int N>
