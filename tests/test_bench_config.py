@@ -263,3 +263,63 @@ def test_g4_four_batches_in_flight_equal_the_call_made_alone():
             got = fl.map(run, [0, 1, 0, 0, 1, 0, 1, 1])
             for k, (o, t2) in zip([0, 1, 0, 0, 1, 0, 1, 1], got):
                 assert np.array_equal(o, want[k][0]) and np.array_equal(t2, want[k][1])
+
+
+def test_g4_with_the_ocsr_branch_attached_at_production_dimensions():
+    """The reference's shipped architecture (me-lf-stack-1) at the benchmark's dimensions: UDOP-large + the Swin-B geometry attached
+    (mg_attach_e1), B = 32 on the bench inputs.  (i) a call that lets the library evaluate the branch gives the same ids as the call that
+    is handed the branch's tokens (same bits: the attached path is the precomputed-token path fed from the call's own workspace), for the
+    32-row call and a 64-row call; (ii) 2 images against the CPU oracle chain SwinOracle.e1 -> Oracle(e1=...): the e1 block itself and
+    teacher-forced logits at the reference's top-8 within LOGIT_TOL (fusion INFERRED: parity unpinned, oracle = the build's own);
+    (iii) the tokens matter (logits differ from the VTL-only model's by far more than the tolerance)."""
+    import torch
+    from markushgrapher_amd.e1 import E1Engine
+    from markushgrapher_amd import e1_shapes
+    from oracle.swin_oracle import SwinOracle
+    from oracle.udop_oracle import Oracle
+    g, shape, eng, args = _setup()
+    s1 = e1_shapes.PRESETS["swin_b_384"]
+    sd1 = e1_shapes.recipe_state_dict(s1)
+    e1e = E1Engine(s1).load_state_dict(sd1)
+    new = int(g["new_tokens"])
+    ids_plain, _, _ = eng.generate(*args, max_length=new + 1, min_length=new + 1)
+    ids_plain = eng.mem.numpy(ids_plain).copy()
+    eng.attach_e1(e1e)
+    try:
+        e1 = e1e.encode(args[3])
+        own, _, _ = eng.generate(*args, max_length=new + 1, min_length=new + 1)
+        pre, _, _ = eng.generate(*args, max_length=new + 1, min_length=new + 1, e1=e1)
+        own, pre = eng.mem.numpy(own).copy(), eng.mem.numpy(pre).copy()
+        assert np.array_equal(own, pre)
+        assert (own != ids_plain).any()                      # 144 more keys per image change what is decoded
+        two = tuple(torch.cat([a, a]) if torch.is_tensor(a) else np.concatenate([a, a]) for a in args)
+        own64, _, _ = eng.generate(*two, max_length=new + 1, min_length=new + 1)
+        own64 = eng.mem.numpy(own64)
+        assert np.array_equal(own64[:32], own) and np.array_equal(own64[32:], own)       # rows do not depend on the call's row count
+        # (ii) two images against the oracle chain
+        nb, T = 2, 8
+        sub = tuple(a[:nb] for a in args)
+        labels = g["labels"][:nb, :T]
+        dec_ids = Oracle.shift_right(labels, shape.decoder_start_token_id, shape.pad_token_id).numpy()
+        dam = (labels != -100).astype(np.uint8)
+        logits, _, _ = eng.forward_logits(*sub, dec_ids, dam)
+        logits = eng.mem.numpy(logits)
+        pix = eng.mem.numpy(args[3][:nb])
+        with torch.no_grad():
+            e1_ref = SwinOracle(s1, sd1).e1(pix).numpy()
+        assert np.abs(eng.mem.numpy(e1[:nb]) - e1_ref).max() < 0.02 * np.abs(e1_ref).max() + 0.02
+        sd = synth.recipe_state_dict(shape, **synth.BENCH_RECIPE)
+        o = Oracle(shape, sd)
+        inp = [np.asarray(a[:nb]) if isinstance(a, np.ndarray) else None for a in args[:3]]
+        ref = o.forward(inp[0], inp[1], pix, inp[2], labels=labels, decoder_attention_mask=dam.astype(np.int64), e1=e1_ref).numpy()
+        plain = o.forward(inp[0], inp[1], pix, inp[2], labels=labels, decoder_attention_mask=dam.astype(np.int64)).numpy()
+        live = labels != -100
+        top = np.argsort(-ref, axis=-1)[..., :8]
+        err = np.abs(np.take_along_axis(logits, top, -1) - np.take_along_axis(ref, top, -1))[live]
+        assert err.max() < LOGIT_TOL, err.max()
+        assert np.abs(ref - plain)[live].max() > 5 * LOGIT_TOL
+    finally:
+        eng.attach_e1(None)
+        e1e.close()
+    back, _, _ = eng.generate(*args, max_length=new + 1, min_length=new + 1)
+    assert np.array_equal(eng.mem.numpy(back), ids_plain)       # detached: the plain VTL model again, bit for bit
