@@ -260,9 +260,27 @@ __global__ __launch_bounds__(256) void key_mask_kernel(uint8_t* mask, int B, int
     for (int i = blockIdx.x * 256 + threadIdx.x; i < B * T_cap; i += gridDim.x * 256) mask[i] = (i % T_cap) < T;
 }
 
+// row-major [M][d] fp32 <-> the tiled residual layout ht_off (M a multiple of 32): thread = (row of a tile, 4-feature group), so the tiled side moves
+// in 512-byte runs
+__global__ __launch_bounds__(256) void tile_f32_kernel(const float* src, float* dst, int M, int d, int to_tiled) {
+    const size_t n = (size_t)M * (d >> 2);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int r = (int)(i & 31);
+        const size_t t = i >> 5;
+        const int g = (int)(t % (size_t)(d >> 2)), m = (int)(t / (size_t)(d >> 2)) * 32 + r;
+        const size_t rm = (size_t)m * d + 4 * g, tl = ht_off(m, 4 * g, d);
+        if (to_tiled) *(float4*)(dst + tl) = *(const float4*)(src + rm);
+        else *(float4*)(dst + rm) = *(const float4*)(src + tl);
+    }
+}
+
 int grid_for(size_t n) { const size_t g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 65535 ? 65535 : g)); }
 
 }  // namespace
+
+void ocr_tile_f32(const float* src, float* dst, int M, int d, int to_tiled, mgStream_t st) {
+    MG_LAUNCH(tile_f32_kernel, dim3(grid_for((size_t)M * (d >> 2))), dim3(256), 0, st, src, dst, M, d, to_tiled);
+}
 
 void ocr_layernorm_pack(float* h, const float* w, const float* b, const float* add_bias, uint16_t* x_pk, float* out_f32, int M, int d,
                         int Kaug, float eps, mgStream_t st) {

@@ -136,8 +136,12 @@ __global__ __launch_bounds__(256) void swin_ln_kernel(SwinLnArgs a) {
             *(float4*)(a.h_out + ht_off(m, n, C)) = o;
         }
         if (a.out_f32) *(float4*)(a.out_f32 + (size_t)m * C + n) = make_float4(y0, y1, y2, y3);
-        if (a.x_pk) *(uint2*)(a.x_pk + pk_off(m, n, C)) = make_uint2(pack_bf16(y0, y1), pack_bf16(y2, y3));
+        if (a.x_pk) *(uint2*)(a.x_pk + pk_off(m, n, a.kaug ? a.kaug : C)) = make_uint2(pack_bf16(y0, y1), pack_bf16(y2, y3));
     }
+    // kaug > C (the ChemicalOCR tower's projections carry their bias in a constant-one column, ocr.hip): columns C .. kaug - 1 = [1, 0, 0, ...]
+    if (a.x_pk && a.kaug > C)
+        for (int c8 = q; 8 * c8 < a.kaug - C; c8 += 8)
+            st16(a.x_pk + pk_off(m, C + 8 * c8, a.kaug), make_uint4(c8 == 0 ? 0x00003F80u : 0u, 0u, 0u, 0u));
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -298,6 +302,7 @@ void swin_layernorm(const SwinLnArgs& a, mgStream_t st) {
         case 128: MG_SWIN_LN(4, true); break;
         case 256: MG_SWIN_LN(8, true); break;
         case 512: MG_SWIN_LN(16, true); break;
+        case 768: MG_SWIN_LN(24, true); break;           // (SigLIP-base width: the ChemicalOCR vision tower, ocr.hip)
         case 1024: MG_SWIN_LN(32, true); break;
         case 2048: MG_SWIN_LN(64, false); break;
         default: MG_SWIN_LN(128, false); break;

@@ -22,6 +22,8 @@ void ocr_slots_init(int* unfinished, int* pos, int* img, int* pool, int64_t* nex
 void ocr_fill_ints(int* p, int v, int n, mgStream_t st);
 void ocr_add_int(int* dst, const int* src, mgStream_t st);
 void ocr_set_int(int* dst, int v, mgStream_t st);
+// row-major [M][d] fp32 <-> tiled (ht_off) copies, M a multiple of 32
+void ocr_tile_f32(const float* src, float* dst, int M, int d, int to_tiled, mgStream_t st);
 void ocr_row_maps(int* last_rows, int* all_rows, uint8_t* key_mask, int B, int T, int T_cap, mgStream_t st);
 // engine.hip: sets the thread-local message mg_last_error() returns
 int fail_msg(int code, const char* msg);

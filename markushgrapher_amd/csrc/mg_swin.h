@@ -36,8 +36,9 @@ struct SwinLnArgs {
     int M, C;
     int merge_R;
     float eps;
+    int kaug;              // 0 = C; > C: x_pk has kaug columns per row, columns C .. kaug - 1 = [1, 0, ...] (bias-in-K projections of the OCR tower)
 };
-bool swin_ln_supported(int C);
+bool swin_ln_supported(int C);      // widths of the Swin branch (powers of two 64 .. 4096); the kernel also takes 768
 void swin_layernorm(const SwinLnArgs& a, mgStream_t st);
 
 // (Shifted-)window attention of one Swin block (stock:418-468, 529-563, 584-626), head dim 32:

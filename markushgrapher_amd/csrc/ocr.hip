@@ -7,6 +7,7 @@
 // Round-2 form: every operation its own launch, fp32 intermediates between GEMM and activation, eager decode steps.
 #include "mg_kernels.h"
 #include "mg_ocr.h"
+#include "mg_swin.h"
 #include "../../include/mgrapher.h"
 
 #include <math.h>
@@ -109,9 +110,9 @@ namespace {
 struct Ws {
     // vision
     uint16_t *xim, *vx, *vq, *vk, *vvt, *vctx, *vy, *xs;
-    float *patch, *vh, *vtmp, *vout, *feats;
+    float *patch, *vh, *vht, *vtmp, *vout, *feats;
     // text
-    float *h, *qkv, *gu, *logits, *rs_a, *rs_b;
+    float *h, *ht, *qkv, *gu, *logits, *rs_a, *rs_b;
     uint16_t* xw;            // decode step: packed [rows][t_hidden + t_inter] = [bf16(h) | SwiGLU output]
     uint16_t *x, *q, *k, *vt, *ctx, *y, *xc, *Kc, *Vc;
     uint8_t *kmask, *vmask;
@@ -130,6 +131,7 @@ void carve(const mg_ocr_model* m, char* base, int B, int n_img, int L, int max_n
     w->xim = cv.take<uint16_t>(pk_elems((int)(N * m->P), 3 * c.patch_size * c.patch_size));
     w->patch = cv.take<float>(N * m->P * vh);
     w->vh = cv.take<float>(MV * vh);
+    w->vht = cv.take<float>(MV * vh);          // the tower's residual stream in the tiled layout (second form)
     w->vx = cv.take<uint16_t>(pk_elems((int)MV, m->vka));
     w->vq = cv.take<uint16_t>(MV * vh); w->vk = cv.take<uint16_t>(MV * vh); w->vvt = cv.take<uint16_t>(MV * vh);
     w->vctx = cv.take<uint16_t>(pk_elems((int)MV, (int)vh));
@@ -139,6 +141,7 @@ void carve(const mg_ocr_model* m, char* base, int B, int n_img, int L, int max_n
     w->xs = cv.take<uint16_t>(pk_elems((int)(N * m->T_img), (int)(vh * c.scale_factor * c.scale_factor)));
     w->feats = cv.take<float>(N * m->T_img * td);
     w->h = cv.take<float>(MT * td);
+    w->ht = cv.take<float>(MT * td);           // the prefill's residual stream in the tiled layout (second form)
     w->x = cv.take<uint16_t>(pk_elems((int)MT, (int)td));
     w->qkv = cv.take<float>(MT * m->qkvn);
     w->q = cv.take<uint16_t>(MT * H * 64); w->k = cv.take<uint16_t>(MT * H * 64); w->vt = cv.take<uint16_t>(MT * H * 64);
@@ -181,11 +184,24 @@ void image_features(const mg_ocr_model* m, const Ws& w, const float* pix, const 
     gemm(pe, EPI_F32_STORE, st);
     const bool masked = patch_mask != nullptr || P != Pc;
     ocr_add_pos(w.patch, m->at<uint16_t>(m->pos_emb), patch_pos, patch_mask, masked ? w.vmask : nullptr, w.vh, N, P, Pc, vh, st);
+    // Second form (round 5): the residual stream in the main encoder's TILED fp32 layout - the two residual projections of a layer run on
+    // the batched 16-byte residual epilogue (EPI_RESID_NORM without gain; the row-major read-modify-write epilogue was 273 us per launch
+    // at 32 pages), LayerNorm on the tile-wise kernel of the OCSR branch (512-byte runs; constant-one column and the bias hand-off as
+    // before).  Widths that kernel is not instantiated for keep the first form.  MG_OCR_TILED=0: first form (A/B runs; same operations).
+    static int tiled_env = -1;
+    if (tiled_env < 0) { const char* e = getenv("MG_OCR_TILED"); tiled_env = e ? atoi(e) : 1; }
+    const bool tiled = tiled_env && (MV % 32) == 0 && (vh == 64 || vh == 128 || vh == 256 || vh == 512 || vh == 768 || vh == 1024);
+    auto layer_norm = [&](bool first, const float* wt, const float* bs, const float* add_bias, uint16_t* x_pk, float* out_f32, int Kaug) {
+        if (!tiled) { ocr_layernorm_pack(w.vh, wt, bs, add_bias, x_pk, out_f32, MV, vh, Kaug, c.v_eps, st); return; }
+        SwinLnArgs n{};
+        n.h_in = first ? w.vh : w.vht; n.in_tiled = first ? 0 : 1; n.h_out = (first || add_bias) ? w.vht : nullptr;
+        n.w = wt; n.b = bs; n.add_bias = add_bias; n.x_pk = x_pk; n.out_f32 = out_f32; n.M = MV; n.C = vh; n.eps = c.v_eps; n.kaug = Kaug;
+        swin_layernorm(n, st);
+    };
     for (int i = 0; i < c.v_layers; ++i) {
         const std::string p = v + "encoder.layers." + std::to_string(i) + ".";
         const VLayer& l = m->vl[i];
-        ocr_layernorm_pack(w.vh, m->rawp(p + "layer_norm1.weight"), m->rawp(p + "layer_norm1.bias"), m->rawp(p + "self_attn.out_proj.bias"),
-                           w.vx, nullptr, MV, vh, m->vka, c.v_eps, st);
+        layer_norm(i == 0, m->rawp(p + "layer_norm1.weight"), m->rawp(p + "layer_norm1.bias"), m->rawp(p + "self_attn.out_proj.bias"), w.vx, nullptr, m->vka);
         GemmArgs a = ga(w.vx, m->at<uint16_t>(l.wqkv), MV, 3 * vh, m->vka);
         a.heads.ptr[0] = w.vq; a.heads.ptr[1] = w.vk; a.heads.ptr[2] = w.vvt;
         a.heads.fmt[0] = HF_PK_ROWS; a.heads.fmt[1] = HF_PK_ROWS; a.heads.fmt[2] = HF_PK_T;
@@ -196,10 +212,9 @@ void image_features(const mg_ocr_model* m, const Ws& w, const float* pix, const 
         t.mode = ATT_CROSS; t.kmask = patch_mask ? w.vmask : nullptr;      // padded frames: masked patches are not attended as keys
         attention(t, st);
         GemmArgs o = ga(w.vctx, m->at<uint16_t>(l.wo), MV, vh, vh);
-        o.out_f32 = w.vh; o.ldo = vh;
-        gemm(o, EPI_F32_RESID, st);
-        ocr_layernorm_pack(w.vh, m->rawp(p + "layer_norm2.weight"), m->rawp(p + "layer_norm2.bias"), m->rawp(p + "mlp.fc2.bias"), w.vx,
-                           nullptr, MV, vh, m->vka, c.v_eps, st);
+        if (tiled) { o.out_f32 = w.vht; gemm(o, EPI_RESID_NORM, st); }
+        else { o.out_f32 = w.vh; o.ldo = vh; gemm(o, EPI_F32_RESID, st); }
+        layer_norm(false, m->rawp(p + "layer_norm2.weight"), m->rawp(p + "layer_norm2.bias"), m->rawp(p + "mlp.fc2.bias"), w.vx, nullptr, m->vka);
         GemmArgs f1 = ga(w.vx, m->at<uint16_t>(l.fc1), MV, vi, m->vka);
         if (gemm_has_gelu_epilogue(MV, vi)) {          // GELU in the GEMM epilogue: no fp32 round trip of [rows][v_inter]
             f1.out_pk = w.vy;
@@ -210,11 +225,10 @@ void image_features(const mg_ocr_model* m, const Ws& w, const float* pix, const 
             ocr_gelu_pack(w.vtmp, w.vy, MV, vi, vi, st);
         }
         GemmArgs f2 = ga(w.vy, m->at<uint16_t>(l.fc2), MV, vh, vi);
-        f2.out_f32 = w.vh; f2.ldo = vh;
-        gemm(f2, EPI_F32_RESID, st);
+        if (tiled) { f2.out_f32 = w.vht; gemm(f2, EPI_RESID_NORM, st); }
+        else { f2.out_f32 = w.vh; f2.ldo = vh; gemm(f2, EPI_F32_RESID, st); }
     }
-    ocr_layernorm_pack(w.vh, m->rawp(v + "post_layernorm.weight"), m->rawp(v + "post_layernorm.bias"), nullptr, nullptr, w.vout, MV, vh, vh,
-                       c.v_eps, st);
+    layer_norm(c.v_layers == 0, m->rawp(v + "post_layernorm.weight"), m->rawp(v + "post_layernorm.bias"), nullptr, nullptr, w.vout, vh);
     const int sf = c.scale_factor, F = vh * sf * sf;
     ocr_pixel_shuffle_pack(w.vout, w.xs, N, m->g, Pc, vh, sf, st);
     GemmArgs cn = ga(w.xs, m->at<uint16_t>(m->conn), N * m->T_img, c.t_hidden, F);
@@ -229,10 +243,25 @@ void prefill(const mg_ocr_model* m, const Ws& w, const int64_t* ids, const float
     const int td = c.t_hidden, ti = c.t_inter, H = c.t_heads, KV = c.t_kv_heads, T_cap = round_up(L, 64), MT = B * T_cap;
     ocr_row_maps(w.last_rows, w.all_rows, w.kmask, B, L, T_cap, st);
     ocr_merge_embed(ids, m->at<uint16_t>(m->tok_emb), feats, w.h, B, L, T_cap, td, c.vocab, c.image_token_id, n_img * m->T_img, w.counters + 3, st);
+    // Second form (round 5): the residual stream of the prefill in the TILED fp32 layout (w.ht) - o_proj / down_proj on the batched residual
+    // epilogue instead of the row-major read-modify-write one, RMSNorm from 512-byte runs; the row-major copy w.h (what the callers read the
+    // last positions from) is restored at the end.  MG_OCR_TILED=0: first form.
+    static int tiled_env = -1;
+    if (tiled_env < 0) { const char* e = getenv("MG_OCR_TILED"); tiled_env = e ? atoi(e) : 1; }
+    const bool tiled = tiled_env && (td % 32) == 0;
+    if (tiled) ocr_tile_f32(w.h, w.ht, MT, td, 1, st);
+    auto norm = [&](const float* gain) {
+        if (tiled) rmsnorm_pack_tiled(w.ht, gain, w.x, nullptr, MT, td, c.rms_eps, st);
+        else rmsnorm_pack(w.h, gain, w.x, nullptr, MT, td, c.rms_eps, 1.0f, st);
+    };
+    auto resid = [&](GemmArgs& g) {
+        if (tiled) { g.out_f32 = w.ht; gemm(g, EPI_RESID_NORM, st); }
+        else { g.out_f32 = w.h; g.ldo = td; gemm(g, EPI_F32_RESID, st); }
+    };
     for (int i = 0; i < c.t_layers; ++i) {
         const std::string p = "model.text_model.layers." + std::to_string(i) + ".";
         const TLayer& l = m->tl[i];
-        rmsnorm_pack(w.h, m->rawp(p + "input_layernorm.weight"), w.x, nullptr, MT, td, c.rms_eps, 1.0f, st);
+        norm(m->rawp(p + "input_layernorm.weight"));
         GemmArgs a = ga(w.x, m->at<uint16_t>(l.wqkv), MT, m->qkvn, td);
         a.out_f32 = w.qkv; a.ldo = m->qkvn;
         gemm(a, EPI_F32_STORE, st);
@@ -242,17 +271,16 @@ void prefill(const mg_ocr_model* m, const Ws& w, const int64_t* ids, const float
         t.mode = ATT_DEC_SELF; t.kmask = w.kmask; t.tab1 = m->at<float>(m->zero_tab); t.tab1_len = 1;
         attention(t, st);
         GemmArgs o = ga(w.ctx, m->at<uint16_t>(l.wo), MT, td, H * 64);
-        o.out_f32 = w.h; o.ldo = td;
-        gemm(o, EPI_F32_RESID, st);
-        rmsnorm_pack(w.h, m->rawp(p + "post_attention_layernorm.weight"), w.x, nullptr, MT, td, c.rms_eps, 1.0f, st);
+        resid(o);
+        norm(m->rawp(p + "post_attention_layernorm.weight"));
         GemmArgs gu = ga(w.x, m->at<uint16_t>(l.wgu), MT, 2 * ti, td);
         gu.out_f32 = w.gu; gu.ldo = 2 * ti;
         gemm(gu, EPI_F32_STORE, st);
         ocr_silu_mul_pack(w.gu, w.y, MT, ti, st);
         GemmArgs dn = ga(w.y, m->at<uint16_t>(l.wd), MT, td, ti);
-        dn.out_f32 = w.h; dn.ldo = td;
-        gemm(dn, EPI_F32_RESID, st);
+        resid(dn);
     }
+    if (tiled) ocr_tile_f32(w.ht, w.h, MT, td, 0, st);
 }
 
 // One decode step for B rows: token ids in w.next_ids, position `pos`; logits -> w.logits.
