@@ -159,7 +159,7 @@ def ocr_stage_run(B=32, new_tokens=256):
                       "greedy, EOS impossible; vision tower / prefill: one kernel per operation with fp32 intermediates; decode step: 4 launches per layer at one row tile (rotary grouped-query attention + cache append, o_proj + norm, gate/up + SwiGLU, [down_proj + norm | next QKV]), replayed as a HIP graph"}
 
 
-def configs4_run(eng, B, new_tokens, ocr_pages=128, n_scripts=32, ocr_slots=0, main_inflight=1, ocr_inflight=1, main_batch=None):
+def configs4_run(eng, B, new_tokens, ocr_pages=128, n_scripts=32, ocr_slots=0, main_inflight=1, ocr_inflight=1, main_batch=None, overlap_slab=0):
     """BASELINE configs[4] measured as ONE loop on one GPU (markushgrapher_amd/pipeline.py): 128 IP5-M-shaped pages (1024 px u8 crops,
     resident) -> device LANCZOS -> ChemicalOCR (SmolDocling-256M geometry, 128 pages per call) -> text -> cells -> tokens -> VTL encoder +
     256-token greedy decode (continuous decoder, 32 slots).  No OCR checkpoint / tokenizer model exists offline: the OCR model's lm_head
@@ -182,7 +182,7 @@ def configs4_run(eng, B, new_tokens, ocr_pages=128, n_scripts=32, ocr_slots=0, m
     longest = max(len(c) for c in chains)
     pipe = Configs4Pipeline(ocr, eng, make_udop_tokenizer(), lambda row: detokenize(id_to_piece, row, s.eos_token_id, s.pad_token_id), prompts,
                             ocr_max_new_tokens=longest + 8, max_length=new_tokens + 1, min_length=new_tokens + 1, continuous=True, main_batch=main_batch or B,
-                            ocr_slots=ocr_slots, main_inflight=main_inflight, ocr_inflight=ocr_inflight)
+                            ocr_slots=ocr_slots, main_inflight=main_inflight, ocr_inflight=ocr_inflight, overlap_slab=overlap_slab)
     if main_inflight > 1:
         pipe.continuous = False          # forced-length decode: one mg_generate per `main_batch` pages and context
     pages = torch.from_numpy(synth.synth_pages_u8(32, 1024, synth.BENCH_SEED)).cuda()
@@ -203,7 +203,7 @@ def configs4_run(eng, B, new_tokens, ocr_pages=128, n_scripts=32, ocr_slots=0, m
             "ocr_s": round(res.timings["ocr_s"], 3), "host_s": round(res.timings["host_s"], 3),
             "main_s": round(res.timings["main_s"], 3),
             "vtl_pages_per_call": int(main_batch or B),
-            "stages": (f"one after the other; OCR stage on {ocr_inflight} execution context(s), VTL stage on {main_inflight}"
+            "stages": ((f"OVERLAPPED: OCR of the next slab of {overlap_slab} pages on {ocr_inflight} context(s) with their own streams while the VTL stage's {main_inflight} contexts decode the previous slab (ocr_s = busy time of the OCR worker, main_s = the whole loop)" if res.timings.get("overlapped") else f"one after the other; OCR stage on {ocr_inflight} execution context(s), VTL stage on {main_inflight}")
                        + (" (host stage pipelined with it: main_s contains host_s)" if main_inflight > 1 else "")),
             "ocr_form": (f"queue form, {ocr_slots} decode rows, {res.timings.get('ocr_steps')} steps" if ocr_slots else "batch form: every call walks to its longest page"),
             "ocr_steps_longest_page": longest, "ocr_tokens_mean": round(float(np.mean([len(c) for c in chains])), 1),

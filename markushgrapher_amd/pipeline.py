@@ -98,7 +98,7 @@ class Configs4Pipeline:
 
     def __init__(self, ocr, main, tokenizer, ocr_detok: Callable, ocr_prompt_ids, ocr_max_new_tokens: int = 4096, question: str = QUESTION,
                  max_length: int = 512, min_length: int = 0, num_beams: int = 1, continuous: bool = False, main_batch: int = 32,
-                 ocr_slots: int = 0, per_image_padding: bool = True, main_inflight: int = 1, ocr_inflight: int = 1):
+                 ocr_slots: int = 0, per_image_padding: bool = True, main_inflight: int = 1, ocr_inflight: int = 1, overlap_slab: int = 0):
         self.ocr, self.main, self.tokenizer, self.ocr_detok = ocr, main, _MemoTokenizer(tokenizer), ocr_detok
         self.ocr_prompt_ids = np.asarray(ocr_prompt_ids, np.int64)
         self.ocr_max_new_tokens, self.question = int(ocr_max_new_tokens), question
@@ -111,6 +111,11 @@ class Configs4Pipeline:
         # > 1: the OCR stage splits its pages over that many execution contexts of the OCR model (mg_ocr_clone), a thread + stream each
         self.ocr_inflight = int(ocr_inflight)
         self._ocr_ctx = []
+        # > 0 (with main_inflight > 1): the two GPU stages OVERLAP - the pages go through the OCR stage in slabs of that many pages on the OCR
+        # contexts' OWN streams while the VTL contexts decode the previous slab.  The OCR decode step is a chain of ~120 latency-sized
+        # launches (0.06 of the HBM peak), the VTL stage is bandwidth- / matrix-bound: each fills what the other leaves idle.
+        self.overlap_slab = int(overlap_slab)
+        self._ocr_streams = None
         # pages of one batch have different token counts; with per-image padding semantics every page is computed as the reference
         # computes it (alone, unpadded: its batch size is 1), whatever the batch was padded to (mg_set_padding_semantics)
         # (the engine's previous setting is put back by close(): other users of `main` keep stock batched semantics)
@@ -140,7 +145,12 @@ class Configs4Pipeline:
             return pix, new, steps
         import threading
         from .inflight import shared_streams
-        streams = shared_streams(torch, self.main.mem.device, n)             # the VTL contexts' streams (the stages alternate)
+        if self.overlap_slab > 0:                                             # stages overlap: the OCR contexts keep streams of their own
+            if self._ocr_streams is None or len(self._ocr_streams) < n:
+                self._ocr_streams = [torch.cuda.Stream(self.main.mem.device) for _ in range(n)]
+            streams = self._ocr_streams
+        else:
+            streams = shared_streams(torch, self.main.mem.device, n)         # the VTL contexts' streams (the stages alternate)
         while len(self._ocr_ctx) < n:
             self._ocr_ctx.append((self.ocr if not self._ocr_ctx else self.ocr.clone(), streams[len(self._ocr_ctx)]))
         torch.cuda.current_stream().synchronize()                             # pix is complete before the other streams read it
@@ -228,6 +238,8 @@ class Configs4Pipeline:
         t = {}
         now = timer or (lambda: 0.0)
         t0 = now()
+        if self.overlap_slab > 0 and self.main_inflight > 1 and int(pages_u8.shape[0]) > self.overlap_slab:
+            return self._call_overlapped(pages_u8, now)
         pix, new, steps = self.stage_ocr(pages_u8)
         if steps is not None:
             t["ocr_steps"] = steps
@@ -260,6 +272,57 @@ class Configs4Pipeline:
         out = self.stage_main(pix, ids_in, bbox, mask)
         t["main_s"] = now() - t2
         return PipelineResult(ids=out, ocr_new_ids=new, ocr_texts=texts, cells=cells, input_ids=ids_in, bbox=bbox, attention_mask=mask, timings=t)
+
+    def _call_overlapped(self, pages_u8, now):
+        """OCR of slab k + 1 (a worker thread driving the OCR contexts on their own streams) while the host stage and the VTL contexts work on
+        slab k.  Same per-page results as the stage-after-stage loop: a page's OCR ids depend on the page only, its VTL ids on its own inputs."""
+        import queue
+        import threading
+        import time as _time
+        B, mb, slab = int(pages_u8.shape[0]), self.main_batch, self.overlap_slab
+        fl = self._contexts(self.main_inflight)
+        per = mb * (4 if (self.continuous and self.num_beams == 1) else 1)
+        q = queue.Queue(maxsize=2)
+        stat = {"ocr_busy": 0.0, "steps": 0}
+        errs = []
+
+        def ocr_worker():
+            try:
+                for p0 in range(0, B, slab):
+                    h0 = _time.perf_counter()
+                    pix, new, steps = self.stage_ocr(pages_u8[p0:p0 + slab], page0=p0)
+                    stat["ocr_busy"] += _time.perf_counter() - h0
+                    stat["steps"] = max(stat["steps"], steps or 0)
+                    q.put((p0, pix, new))
+            except BaseException as e:
+                errs.append(e)
+            finally:
+                q.put(None)
+        t0 = now()
+        th = threading.Thread(target=ocr_worker)
+        th.start()
+        host_busy, parts, futures = 0.0, [], []
+        while True:
+            item = q.get()
+            if item is None:
+                break
+            p0, pix, new = item
+            h0 = _time.perf_counter()
+            part = self.stage_host(new)
+            host_busy += _time.perf_counter() - h0
+            parts.append((new,) + part)
+            ids_in, bbox, mask = part[2:]
+            for c0 in range(0, int(ids_in.shape[0]), per):
+                futures.append(fl.submit(lambda ctx, a: self.stage_main(*a, engine=ctx),
+                                         (pix[c0:c0 + per], ids_in[c0:c0 + per], bbox[c0:c0 + per], mask[c0:c0 + per])))
+        th.join()
+        if errs:
+            raise errs[0]
+        out = self._stack_rows([f.result() for f in futures])
+        t = {"ocr_s": stat["ocr_busy"], "host_s": host_busy, "main_s": now() - t0, "overlapped": True}
+        if stat["steps"]:
+            t["ocr_steps"] = stat["steps"]
+        return self._assemble(parts, out, t)
 
     def _assemble(self, parts, out, timings):
         """parts: per group (ocr new ids, texts, cells, input_ids, bbox, attention_mask), each padded to its own widths."""
