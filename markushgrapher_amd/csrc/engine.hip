@@ -616,6 +616,13 @@ static void decode_step(mg_model* m, const DecodeCtx& c, int t, const int* tdev,
     // Fused tail (greedy batch calls): the selection kernel of step t has already left the embedding + first norm of step t + 1
     // (the caller embeds the start token once in front of the first step); otherwise a step starts with its own embedding launch.
     const bool fused_tail = c.ptop != nullptr;
+    // tools build only (tools/whatif_decode.py: WRONG results, valid timing): launches of the step left out by bit - 1 QKV, 2 self-attention,
+    // 4 [Wo | cross-Q], 8 cross-attention, 16 [Wxo | FFN-wi], 32 FFN-wo, 64 lm_head
+#ifdef MG_TOOLS
+    static const int whatif = [] { const char* e = getenv("MG_WHATIF_STEP"); return e ? atoi(e) : 0; }();
+#else
+    constexpr int whatif = 0;
+#endif
     if (!fused_tail)
         embed_norm_rows(c.next_ids, m->at<uint16_t>(m->tok_emb), c.dh, m->at<float>(m->dec[0].ln0), c.dx_pk, c.xa, K2, 0, R, d, m->V,
                         counters + 3, eps, st);
@@ -629,13 +636,13 @@ static void decode_step(mg_model* m, const DecodeCtx& c, int t, const int* tdev,
                 set_heads(a, H, R, T_cap, c.dq, HF_STEP_Q, sk, HF_STEP_KV, sv, HF_STEP_KV);
                 a.heads.pos = t; a.heads.pos_dev = tdev; a.heads.pos_rows = c.slots.pos;
                 a.rs = li == 0 ? none : rs0;      // layer 0 reads the explicitly normalised embedding
-                gemm_rows(a, EPI_HEADS, st);      // q -> dq, k/v appended to the cache at position t
+                if (!(whatif & 1)) gemm_rows(a, EPI_HEADS, st);      // q -> dq, k/v appended to the cache at position t
             }
             AttnStepArgs s{};
             s.q = c.dq; s.Kc = sk; s.Vc = sv; s.ctx = c.xa; s.ctx_ld = K2; s.ctx_col0 = d; s.rows = R; s.H = H; s.group = 1;
             s.cap = T_cap; s.n_keys = t + 1; s.bias = m->at<float>(m->dec_tab); s.anc = K > 1 ? c.anc : nullptr; s.t = t; s.t_dev = tdev;
             s.live = live; s.pos_rows = c.slots.pos;
-            attention_step(s, st);
+            if (!(whatif & 2)) attention_step(s, st);
         }
         {   // h += Wo·ctx (partials of sum h^2 -> rs1, bf16(h) -> xb)   |   cross-attention q (un-normalised) -> dq
             ResidArgs r{};
@@ -643,7 +650,7 @@ static void decode_step(mg_model* m, const DecodeCtx& c, int t, const int* tdev,
             r.part = c.rs_part1; r.M = R; r.N = d; r.K = inner;
             GemmArgs g = gemm_args(c.xa, m->at<uint16_t>(l.xq2), R, inner, K2);
             set_heads(g, H, R, T_cap, c.dq, HF_STEP_Q, nullptr, HF_NONE, nullptr, HF_NONE);
-            gemm_rows_pair(r, g, EPI_HEADS, st);
+            if (!(whatif & 4)) gemm_rows_pair(r, g, EPI_HEADS, st);
         }
         // cross-attention over the image's compacted K/V stream (all beams of an image share one pass)
         AttnStepArgs x{};
@@ -653,7 +660,7 @@ static void decode_step(mg_model* m, const DecodeCtx& c, int t, const int* tdev,
         x.one_wg_per_cu = m->shared_gpu;       // (beams: one owner per image slot = group of K rows)
         const bool timed = time_cross && m->prof_used + 3 <= m->prof_ev.size();
         if (timed) mg_event_record(m->prof_ev[m->prof_used], st);
-        attention_step(x, st);
+        if (!(whatif & 8)) attention_step(x, st);
         if (timed) {   // third event right behind the second: the empty bracket calibrates what two records alone cost
             mg_event_record(m->prof_ev[m->prof_used + 1], st);
             mg_event_record(m->prof_ev[m->prof_used + 2], st);
@@ -665,7 +672,7 @@ static void decode_step(mg_model* m, const DecodeCtx& c, int t, const int* tdev,
             r.M = R; r.N = d; r.K = inner;
             GemmArgs g = gemm_args(c.xb, m->at<uint16_t>(l.wi2), R, m->dff, K2);
             g.out_pk = c.dy_pk;
-            gemm_rows_pair(r, g, EPI_PK_RELU, st);
+            if (!(whatif & 16)) gemm_rows_pair(r, g, EPI_PK_RELU, st);
         }
         {   // FFN output (input scaled by rs2); leaves bf16(h·gain) for the next QKV / lm_head (gain = next layer's ln0,
             // or the final norm with the d_model^-0.5 of the tied head), bf16(h) for the next pair, partials -> rs0
@@ -676,12 +683,12 @@ static void decode_step(mg_model* m, const DecodeCtx& c, int t, const int* tdev,
             r.M = R; r.N = d; r.K = m->dff; r.rs = rs2;
             r.wide_tiles = 8;      // the same K partition (16 waves) for every call (up to 256 rows: 8 greedy batches of 32; beam-5 at batch 32 = 5 tiles)
             r.kpart = c.kpart; r.ticket = c.tickets;
-            gemm_rows_resid(r, st);
+            if (!(whatif & 32)) gemm_rows_resid(r, st);
         }
     }
     if (fused_tail) {          // lm_head with per-workgroup top-2 partials (no fp32 logits), stop token kept apart for MinLength
         TopOut top{c.ptop, c.stopv, {m->c.eos_token_id, -1, -1, -1}, 0};
-        gemm_rows_splitk(c.dx_pk, m->at<uint16_t>(m->lm_head), c.logits, R, m->V, d, ldl, 0, 1, rs0, st, &top);
+        if (!(whatif & 64)) gemm_rows_splitk(c.dx_pk, m->at<uint16_t>(m->lm_head), c.logits, R, m->V, d, ldl, 0, 1, rs0, st, &top);
     } else {
         gemm_rows_splitk(c.dx_pk, m->at<uint16_t>(m->lm_head), c.logits, R, m->V, d, ldl, 0, 1, rs0, st);
     }
