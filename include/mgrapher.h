@@ -212,7 +212,7 @@ int mgk_pack_weight(void* stream, const void* src, int src_is_bf16, int N, int K
 int mgk_rmsnorm_pack(void* stream, const float* h, const float* gain, void* x_pk, float* out_f32, int M, int d,
                      float eps, float scale);
 int mgk_im2col_pack(void* stream, const float* pix, void* x_pk, int B, int C, int I, int ps);
-/* TEST / A-B SWITCHES (mgk_set_rows_split, mgk_set_resid_f16, mgk_gemm_set_variant): PROCESS-WIDE, for the parity tests and tools/.
+/* TEST / A-B SWITCHES (mgk_set_rows_split, mgk_set_resid_f16, mgk_gemm_set_variant, mgk_set_rows_mt, mgk_set_attention_qt, mgk_set_pp_parts): PROCESS-WIDE, for the parity tests and tools/.
  * Each selects among kernels whose results are bit-identical (that is what the tests that flip them check), so a call that races
  * with a flip still returns the right bits; they are nevertheless meant to be set while no call is running, and the product
  * (markushgrapher_amd/) never touches them.
@@ -222,10 +222,14 @@ int mgk_set_rows_split(int mode);
 /* residual projections of the decode step with several row tiles: 1 (default) 16 features per workgroup, 0: 8 */
 int mgk_set_resid_f16(int on);
 /* projections of the decode step with several row tiles: 1 the K-slab form (K chunks as workgroups, partial sums merged by the last
- * arrival in the one-workgroup forms' order) where the caller provides its scratch, 0 (default: measured faster) the one-workgroup forms */
+ * arrival in the one-workgroup forms' order) where the caller provides its scratch, 2 the same in two launches (partial sums, then a
+ * chip-wide merge launch), 0 (default: measured faster) the one-workgroup forms */
 int mgk_set_rows_mt(int on);
 /* encoder attention: 1 (default) one 32-query tile per wave / 8 waves per workgroup, 2 two tiles per wave / 4 waves (same bits, slower) */
 int mgk_set_attention_qt(int qt);
+/* persistent ping-pong GEMM: the row tiles of one problem over several launches - 0 (default) never (problems with more tiles per workgroup
+ * than the kernel's table holds go to the two-stage kernel: measured equally fast), 1 when needed, 2 .. 8 always that many (same bits) */
+int mgk_set_pp_parts(int mode);
 /* mgk_gemm_resid with the scratch of the K-slab form: kpart [16][M padded to 32][N] fp32, ticket [N / 32] i32 zero-initialised;
  * wide_tiles as ResidArgs (8 in the decode steps) */
 int mgk_gemm_resid_mt(void* stream, const void* X_pk, const void* W_pk, float* h, const float* gain, float gscale, void* x_pk,

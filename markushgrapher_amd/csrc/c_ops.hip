@@ -203,6 +203,7 @@ int mgk_gemm_resid_mt(void* stream, const void* X_pk, const void* W_pk, float* h
 }
 int mgk_set_rows_mt(int on) { gemm_rows_set_mt(on); return MG_OK; }
 int mgk_set_attention_qt(int qt) { attention_set_qt(qt); return MG_OK; }
+int mgk_set_pp_parts(int mode) { gemm_pp_set_parts(mode); return MG_OK; }
 
 #ifdef MG_TOOLS
 int mgk_gemm_resid_trace(void* stream, const void* X_pk, const void* W_pk, float* h, const float* gain, void* x_pk, float* part, int N,

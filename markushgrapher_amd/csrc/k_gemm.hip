@@ -1419,6 +1419,59 @@ __global__ __launch_bounds__(64 * MT) void gemm_rows_resid_mt_kernel(ResidArgs a
         }
 }
 
+// Second launch of the K-slab form's TWO-LAUNCH variant (mode 2): the partial sums gemm_rows_resid_mt_kernel left in kpart (it returns after its
+// stores: no ticket, no fences - the launch boundary publishes them) are added in chunk order and the epilogue of resid_block16 runs, spread
+// over the chip: workgroup = (feature tile of 32, 32-row tile), wave = (16-feature half, token group).  Same additions in the same order as the
+// last-arrival code above and as the one-workgroup forms: same bits.
+__global__ __launch_bounds__(256) void gemm_rows_resid_merge_kernel(ResidArgs a, int S, int Mp) {
+    MG_DYN_SMEM(smem);
+    float* rsl = (float*)smem;                                   // [32]: row scales of this row tile
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int ft = wv >> 1, g = wv & 1;
+    const int nt = blockIdx.x, w = blockIdx.y;
+    const int M = a.M, N = a.N;
+    const int m = 32 * w + 16 * g + r16;
+    const int n0 = nt * 32 + 16 * ft + 4 * kg;
+    const float* src = a.kpart + (size_t)m * N + n0;
+    float4 pv[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) pv[q] = *(const float4*)(src + (size_t)(q < S ? q : S - 1) * Mp * N);
+    float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m < M) hv = *(const float4*)(a.h + (size_t)m * N + n0);
+    {   // row scales of the tile's 32 rows (the rows of the other tiles are not needed here)
+        RowScale rs = a.rs;
+        if (rs.part) rs.part += (size_t)32 * w * rs.nparts;
+        block_row_scales(rs, M - 32 * w, 32, rsl, tid, 256);
+    }
+    __syncthreads();
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+        if (q < S) { v[0] += pv[q].x; v[1] += pv[q].y; v[2] += pv[q].z; v[3] += pv[q].w; }
+    const float rs = rsl[16 * g + r16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] *= rs;
+    const int nparts = N >> 3;
+    const int x_ld = a.x_ld ? a.x_ld : N, x2_ld = a.x2_ld ? a.x2_ld : N;
+    float ss2 = 0.f;
+    if (m < M) {
+        hv.x += v[0]; hv.y += v[1]; hv.z += v[2]; hv.w += v[3];
+        *(float4*)(a.h + (size_t)m * N + n0) = hv;
+        ss2 = (hv.x * hv.x + hv.y * hv.y) + (hv.z * hv.z + hv.w * hv.w);
+        if (a.x_pk) {
+            const float4 gn = *(const float4*)(a.gain + n0);
+            const float gs = a.gscale;
+            *(uint2*)(a.x_pk + pk_off(m, a.x_col0 + n0, x_ld)) =
+                make_uint2(pack_bf16(hv.x * gn.x * gs, hv.y * gn.y * gs), pack_bf16(hv.z * gn.z * gs, hv.w * gn.w * gs));
+        }
+        if (a.x2_pk)
+            *(uint2*)(a.x2_pk + pk_off(m, a.x2_col0 + n0, x2_ld)) = make_uint2(pack_bf16(hv.x, hv.y), pack_bf16(hv.z, hv.w));
+    }
+    ss2 += __shfl_xor(ss2, 16);
+    if (m < M && (kg & 1) == 0) a.part[(size_t)m * nparts + 2 * (2 * nt + ft) + (kg >> 1)] = ss2;
+}
+
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void gemm_rows_resid_rowsplit_kernel(ResidArgs a) {     // grid.y = row tile (shift_rows)
     MG_DYN_SMEM(smem);
@@ -1567,14 +1620,18 @@ void gemm_rows_resid(const ResidArgs& r, mgStream_t stream) {
             if (fmode < 0) { const char* e = getenv("MG_MT_FENCE"); fmode = e ? atoi(e) : 0; }
             const dim3 gridk((r.N / 32) * S), blockk(64 * mt);
             const size_t shk = (size_t)32 * mt * sizeof(float) + 16;
+            const bool two = g_rows_mt.load() == 2 && S <= 16;     // two-launch variant: partial sums, then a chip-wide merge launch
+            const int fm = two ? 6 : fmode;
 #define MG_RMT(MTV)                                                                                   \
     case MTV:                                                                                         \
-        if (per == 8) MG_LAUNCH((gemm_rows_resid_mt_kernel<MTV, 8>), gridk, blockk, shk, stream, r, S, fmode);       \
-        else if (per == 4) MG_LAUNCH((gemm_rows_resid_mt_kernel<MTV, 4>), gridk, blockk, shk, stream, r, S, fmode);  \
-        else MG_LAUNCH((gemm_rows_resid_mt_kernel<MTV, 2>), gridk, blockk, shk, stream, r, S, fmode);                \
-        return;
+        if (per == 8) MG_LAUNCH((gemm_rows_resid_mt_kernel<MTV, 8>), gridk, blockk, shk, stream, r, S, fm);       \
+        else if (per == 4) MG_LAUNCH((gemm_rows_resid_mt_kernel<MTV, 4>), gridk, blockk, shk, stream, r, S, fm);  \
+        else MG_LAUNCH((gemm_rows_resid_mt_kernel<MTV, 2>), gridk, blockk, shk, stream, r, S, fm);                \
+        break;
             switch (mt) { MG_RMT(2) MG_RMT(3) MG_RMT(4) MG_RMT(5) MG_RMT(6) MG_RMT(7) MG_RMT(8) default: break; }
 #undef MG_RMT
+            if (two) MG_LAUNCH(gemm_rows_resid_merge_kernel, dim3(r.N / 32, mt), dim3(256), 32 * sizeof(float), stream, r, S, 32 * mt);
+            return;
         }
     }
     // several row tiles: 16 features per workgroup (see resid_block16 F16); g_resid_f16 = 0: the 8-feature form (tests, A/B runs)

@@ -2,6 +2,8 @@
 // Operands, epilogues and results are those of gemm_xl_kernel (k_gemm.hip); gemm() dispatches here by variant.
 #include "k_gemm_epi.h"
 
+#include <atomic>
+
 namespace mg {
 
 // ---------------------------------------------------------------------------------------------------------
@@ -70,7 +72,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs a) {
     const int nbn = (a.N + GX_N - 1) / GX_N;
     const int n_list = a.row_tiles ? *a.n_row_tiles : 0;
     const int mt32 = (a.M + 31) >> 5, nt32 = (a.N + 31) >> 5;
-    const int nrt = a.row_tiles ? n_list : mt32;                // 32-row tiles to compute
+    const int rt_all = a.row_tiles ? n_list : mt32;             // 32-row tiles to compute: all of them, or this launch's part (pp_parts > 1)
+    const int rt0 = a.pp_parts > 1 ? (int)((long long)a.pp_part * rt_all / a.pp_parts) : 0;
+    const int nrt = (a.pp_parts > 1 ? (int)((long long)(a.pp_part + 1) * rt_all / a.pp_parts) : rt_all) - rt0;
     const int KT = a.K >> 4;                                    // 16-wide k-tiles per output tile (a multiple of GP_RING)
     const int G = gridDim.x, b = blockIdx.x;
     // Row blocks of BALANCED height: a persistent workgroup runs whole tiles, so the launch takes ceil(tiles / G) tile times whatever
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs a) {
         const int cnt = wrow == 0 ? c0 : h - c0;
         const bool live = ii < cnt;
         const int idx = e0 + (live ? (wrow == 0 ? ii : c0 + ii) : 0);
-        const int rt = a.row_tiles ? a.row_tiles[idx] : idx;
+        const int rt = a.row_tiles ? a.row_tiles[rt0 + idx] : rt0 + idx;
         rtab[e] = live ? rt : -1 - rt;
         if (ii == 0) rcnt[i * 2 + wrow] = cnt;
     }
@@ -307,6 +311,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs a) {
         }
     }
 }
+// row tiles of one problem over several launches: -1 = MG_PP_PARTS or 0; 0 never (fall back to the two-stage kernel: the default), 1 when the tile table is too small, 2 .. 8: always that many (tests)
+static std::atomic<int> g_pp_parts{-1};
+void gemm_pp_set_parts(int mode) { g_pp_parts = mode; }
+
 template <int EPI, int TI>
 static bool launch_pp(const GemmArgs& a_in, mgStream_t stream) {
     GemmArgs a = a_in;
@@ -326,7 +334,18 @@ static bool launch_pp(const GemmArgs& a_in, mgStream_t stream) {
 #endif
     int G = nblk < ncu ? nblk : ncu;
     if (G >= 8) G &= ~7;
-    if ((a.K & 127) != 0 || (nblk + nblk / 3 + G) > GP_MAXT * G || (EPI == EPI_RESID_NORM && a.N > GP_GAIN_MAX)) return false;   // (K/16 a multiple of the ring; balanced blocks are up to 30 % more)
+    if ((a.K & 127) != 0 || (EPI == EPI_RESID_NORM && a.N > GP_GAIN_MAX)) return false;   // (K/16 a multiple of the ring)
+    // more tiles per workgroup than the kernel's tile table holds (balanced blocks are up to 30 % more; the FFN input projection of a 160-image
+    // call: 10240 tiles): the row tiles in `parts` launches (every output tile is the same arithmetic whichever launch computes it)
+    int parts = 1;
+    int mode = g_pp_parts.load();
+    if (mode < 0) { const char* e = getenv("MG_PP_PARTS"); mode = e ? atoi(e) : 0; g_pp_parts = mode; }      // (A/B runs)
+    // Measured (profiles/r05_o_pp_parts_ab.txt, headline regime, same box, two runs each): FFN-wi of the 160-image calls as two launches of this
+    // kernel against one launch of the two-stage kernel: encoder phase 190.3 against 189.1 ms per call, 147.1 against 146.8 images/s - no
+    // difference, so the default stays 0 (such problems go to the two-stage kernel).
+    while (parts < 8 && ((nblk + parts - 1) / parts + (nblk + parts - 1) / parts / 3 + G) > GP_MAXT * G) ++parts;
+    if (parts > 1 && (!mode || parts >= 8)) return false;
+    if (mode > parts && mode <= 8) parts = mode;                  // (tests: that many launches whatever the size)
     // the kernel addresses its operands by 32-bit byte offsets: an operand of 2 GiB or more goes to the two-stage kernel instead
     if ((size_t)((a.M + 31) / 32) * 32 * (size_t)a.K * 2 > 0x7fffffffull || (size_t)((a.N + 31) / 32) * 32 * (size_t)a.K * 2 > 0x7fffffffull) return false;
     const size_t sh = (size_t)GP_RING * (2 * TI + 8) * TILE_BYTES + (size_t)GP_MAXT * (2 * TI + 2) * sizeof(int) +
@@ -346,7 +365,11 @@ static bool launch_pp(const GemmArgs& a_in, mgStream_t stream) {
         }
     }
 #endif
-    MG_LAUNCH((gemm_pp_kernel<EPI, TI>), dim3(G), dim3(512), sh, stream, a);
+    a.pp_parts = parts;
+    for (int p = 0; p < parts; ++p) {
+        a.pp_part = p;
+        MG_LAUNCH((gemm_pp_kernel<EPI, TI>), dim3(G), dim3(512), sh, stream, a);
+    }
     return true;
 }
 template <int TI>

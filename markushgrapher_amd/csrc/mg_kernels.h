@@ -84,10 +84,13 @@ struct GemmArgs {
     const int* n_row_tiles;
     int pp_colgroup;       // set by the ping-pong kernel's launcher: > 0: an XCD's tiles ordered column group by column group (that many column tiles wide)
     int pp_balance;        // set by the ping-pong kernel's launcher: cut the row tiles into blocks of balanced height (k_gemm_pp.hip)
+    int pp_part, pp_parts; // set by the ping-pong kernel's launcher: this launch computes part pp_part of pp_parts of the row tiles (list entries or tiles
+                           // [part * n / parts, (part + 1) * n / parts)): a problem with more tiles per workgroup than the kernel's table holds runs as several launches
 };
 void gemm(const GemmArgs& a, int epi, mgStream_t stream);
 bool gemm_has_gelu_epilogue(int M, int N);     // EPI_PK_GELU exists in the 320x256 / 256x256 tile kernels only
 bool gemm_pp(const GemmArgs& a, int epi, int ti, mgStream_t stream);   // k_gemm_pp.hip: persistent ping-pong tile kernel (ti = 4, 5); false = shape not supported
+void gemm_pp_set_parts(int mode); // ping-pong kernel: row tiles of one problem over several launches - 0 (default) never, 1 when its tile table is too small, 2 .. 8 always that many (tests; same bits)
 void gemm_set_variant(int v);   // 0: 128x128 kernel only; 1: + 256x128 three-stage; 2: + 256x256; 4: + 320x256 wherever it fits; 3 (default): by shape
 
 // small-M (decode step) GEMM: M <= 32*MT rows of live sequences, weights streamed once.

@@ -818,6 +818,52 @@ def test_gemm_row_tile_list(be_name, M, N, K, variant):
 
 
 @pytest.mark.parametrize("be_name", BACKENDS)
+@pytest.mark.parametrize("parts", [2, 3])
+def test_gemm_pp_row_tiles_over_several_launches(be_name, parts):
+    """Ping-pong kernel, a problem's row tiles in several launches (what keeps the FFN input projection of a 160-image call on it: more
+    tiles per workgroup than its table holds): every output tile is the same arithmetic whichever launch computes it - same bits as
+    one launch, with and without a row-tile list, fp32 store and tiled residual + packed + partial-sum epilogue."""
+    be = get_backend(be_name)
+    be.lib.mgk_gemm_set_variant(5)                # (put back by the autouse fixture _default_gemm_variant)
+    be.lib.mgk_gemm_row_tiles.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 2 + [C.c_int] * 3 + [C.c_void_p] * 4 + \
+                                         [C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    M, N, K = 1280 + 96, 512, 128
+    x, w = rnd((M, K), 410), rnd((N, K), 411, 0.2)
+    nt = (M + 31) // 32
+    live = np.ones(nt, bool)
+    live[[0, 3, 4, 17, nt - 2]] = False
+    mask = np.zeros(nt * 32, np.uint8)
+    for t in np.nonzero(live)[0]:
+        mask[32 * t + (5 * t) % 32] = 1
+    mask = mask[:M].copy()
+    X, W = be.buf(pk.pack_tiles(x)), be.buf(pk.pack_tiles(w))
+    h0, g = rnd((nt * 32, N), 412), 1 + 0.2 * rnd((N,), 413)
+    np4 = (N // 64 + 3) // 4 * 4
+    res = {}
+    try:
+        for mode in (1, parts):                   # (1: only when the kernel's tile table is too small - one launch at this size)
+            assert be.lib.mgk_set_pp_parts(mode) == 0
+            full = be.zeros((M, N), np.float32)
+            assert be.lib.mgk_gemm(be.stream, 0, 0, be.p(X), be.p(W), M, N, K, be.p(full), N, None, None) == 0
+            mk, scratch = be.buf(mask), be.zeros((nt + 1,), np.int32)
+            out = be.buf(np.full((M, N), -7.0, np.float32))
+            assert be.lib.mgk_gemm_row_tiles(be.stream, 0, be.p(X), be.p(W), M, N, K, be.p(out), None, None, None, 0, None, 0, 0.0, 0.0, be.p(mk), be.p(scratch)) == 0
+            h = be.buf(_tile_f32(h0))
+            xo = be.buf(np.full((nt * 32 * N,), 0x7fc0, np.uint16))
+            part = be.zeros((nt * 32, np4), np.float32)
+            assert be.lib.mgk_gemm_row_tiles(be.stream, 5, be.p(X), be.p(W), M, N, K, be.p(h), be.p(be.buf(g)), be.p(xo), be.p(part), np4, None, 0,
+                                             0.0, 0.0, be.p(mk), be.p(scratch)) == 0
+            res[mode] = (full.numpy().copy(), out.numpy().copy(), h.numpy().copy(), xo.numpy().copy(), part.numpy().copy())
+    finally:
+        be.lib.mgk_set_pp_parts(0)               # (the default)
+    np.testing.assert_allclose(res[1][0], pk.bf16_round(x) @ pk.bf16_round(w).T, rtol=1e-4, atol=1e-4)
+    rowlive = np.repeat(live, 32)[:M]
+    assert np.all(res[1][1][~rowlive] == -7.0) and np.array_equal(res[1][1][rowlive], res[1][0][rowlive])
+    for a_, b_ in zip(res[1], res[parts]):
+        assert np.array_equal(a_.view(np.uint8), b_.view(np.uint8))
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
 @pytest.mark.parametrize("M,N,K", [(150, 256, 4096), (64, 256, 1024), (96, 512, 512)])
 def test_residual_projection_k_slab_form_is_bit_identical(be_name, M, N, K):
     """Residual projection over several row tiles, K-slab form (gemm_rows_resid_mt_kernel: the K chunks of the one-workgroup form's
@@ -836,8 +882,10 @@ def test_residual_projection_k_slab_form_is_bit_identical(be_name, M, N, K):
     Xp, Wp, G, RS = be.buf(pk.pack_tiles(x)), be.buf(pk.pack_tiles(w)), be.buf(g), be.buf(rsp)
     res = {}
     try:
-        for mode in (0, 1, 2):
-            assert be.lib.mgk_set_rows_mt(1 if mode else 0) == 0
+        # 0: one-workgroup form; 1: K-slab form, merged by the last arrival; 2: again on the same scratch (the tickets are back at zero);
+        # 3: K-slab form in two launches (partial sums, then the chip-wide merge launch)
+        for mode in (0, 1, 2, 3):
+            assert be.lib.mgk_set_rows_mt({0: 0, 1: 1, 2: 1, 3: 2}[mode]) == 0
             if mode < 2:
                 kpart = be.zeros((16 * Mp * N,), np.float32)
                 ticket = be.zeros((N // 32,), np.int32)
@@ -852,7 +900,7 @@ def test_residual_projection_k_slab_form_is_bit_identical(be_name, M, N, K):
         be.lib.mgk_set_rows_mt(0)            # (the default: the K-slab form is measured slower than the one-workgroup forms, k_gemm.hip)
     r = 1.0 / np.sqrt(rsp.sum(1)[:M] / 16 + 1e-6)
     np.testing.assert_allclose(res[1][0], h0 + (pk.bf16_round(x) @ pk.bf16_round(w).T) * r[:, None], rtol=1e-4, atol=5e-4)
-    for mode in (1, 2):
+    for mode in (1, 2, 3):
         for a, b in zip(res[0], res[mode]):
             va, vb = (a.view(np.uint32), b.view(np.uint32)) if a.dtype == np.float32 else (a, b)
             if a.ndim == 2 and a.shape[0] == Mp:

@@ -12,6 +12,7 @@ def main():
     ap.add_argument("--slots", type=int, nargs="+", default=[32, 48])
     ap.add_argument("--queue", type=int, default=8, help="batches of 32 images in the queue")
     ap.add_argument("--eos-scale", type=float, default=12.0)
+    ap.add_argument("--tools-lib", action="store_true", help="the tools build of the library (MG_WHATIF_STEP what-if runs: wrong results, valid timing)")
     args = ap.parse_args()
     import torch
     from markushgrapher_amd import synth
@@ -21,7 +22,11 @@ def main():
     emb = sd["shared.weight"].copy()
     emb[shape.eos_token_id] = synth.round_bf16(sd["shared.weight"][shape.eos_token_id] * np.float32(args.eos_scale))
     sd["shared.weight"] = emb
-    eng = Engine(shape, max_decode_len=512)
+    if args.tools_lib:
+        from tools import _toolslib
+        eng = Engine(shape, lib=_toolslib.load(), max_decode_len=512)
+    else:
+        eng = Engine(shape, max_decode_len=512)
     eng.load_state_dict(sd)
     B = 32
     inp = synth.synth_batch(shape, B, seed=synth.BENCH_SEED, return_pages=True)

@@ -23,7 +23,7 @@ if __name__ == "__main__":
         xp = torch.zeros(Mp * N, dtype=torch.int16, device="cuda"); part = torch.zeros(Mp * (N // 8), device="cuda")
         kpart = torch.zeros(16 * Mp * N, device="cuda"); ticket = torch.zeros(N // 32, dtype=torch.int32, device="cuda")
         out = []
-        for mode in (0, 1):
+        for mode in (0, 1, 2):
             lib.mgk_set_rows_mt(mode)
             def run():
                 lib.mgk_gemm_resid_mt(st, X.data_ptr(), W.data_ptr(), h.data_ptr(), g.data_ptr(), C.c_float(1.0), xp.data_ptr(), part.data_ptr(), M, N, K,
@@ -37,4 +37,4 @@ if __name__ == "__main__":
             e1.record(); torch.cuda.synchronize()
             out.append(e0.elapsed_time(e1) / 400 * 1e3)
         lib.mgk_set_rows_mt(0)
-        print(f"M={M} N={N} K={K}: one-workgroup form {out[0]:.2f} us, K-slab form {out[1]:.2f} us per launch (back-to-back launches, weights {N * K * 2 / 1e6:.1f} MB)")
+        print(f"M={M} N={N} K={K}: one-workgroup form {out[0]:.2f} us, K-slab form {out[1]:.2f} us, K-slab in two launches {out[2]:.2f} us per projection (back-to-back, weights {N * K * 2 / 1e6:.1f} MB)")
