@@ -1582,7 +1582,10 @@ static std::atomic<int> g_resid_f16{1};
 // arrival of a feature tile reading 16 chunks x 160 rows x 32 features of partials (327 KB through one CU) = 42 us; in flight 147.5 -> 126
 // images/s.  The chunk count is fixed by the summation order every row count shares (16 wave partials added in order), so the finisher's
 // read volume cannot shrink without changing every form's bits.  Kept (tests keep it bit-identical; MG_ROWS_MT=1 / mgk_set_rows_mt) as the
-// starting point of a form with write-through partial stores and a second, chip-wide reduce launch.
+// starting point; the form with a second, chip-wide merge launch instead of tickets and fences (g_rows_mt = 2, gemm_rows_resid_merge_kernel) runs the
+// same projection in 12.1 us and a call alone 4 % faster (decode step 4.87 -> 4.68 ms, beam queue on one context 25.3 -> 26.5 images/s), but with four
+// contexts in flight the headline loses 1.3 % (147.5 -> 145.5): it writes and re-reads 10.5 MB of partial sums per launch, and in flight the bytes a
+// launch moves are what it costs.  Off by default as well.
 static std::atomic<int> g_rows_mt{0};
 void gemm_rows_set_mt(int on) { g_rows_mt = on; }
 void gemm_rows_set_resid_f16(int on) { g_resid_f16 = on; }
