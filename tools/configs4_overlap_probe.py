@@ -22,8 +22,9 @@ def main():
              dict(ocr_slots=128, main_inflight=2, ocr_inflight=2, main_batch=64, overlap_slab=128),
              dict(ocr_slots=128, main_inflight=3, ocr_inflight=1, main_batch=64, overlap_slab=128),
              dict(ocr_slots=128, main_inflight=4, ocr_inflight=4, main_batch=64, overlap_slab=256))
-    if len(sys.argv) > 1:
-        cases = [cases[int(a)] for a in sys.argv[1:]]
+    if len(sys.argv) > 1:          # indices into the list above, or JSON dicts of configs4_run keywords
+        import json
+        cases = [cases[int(a)] if a.isdigit() else json.loads(a) for a in sys.argv[1:]]
     for kw in cases:
         r = bench.configs4_run(eng, 32, 256, ocr_pages=512, **kw)
         print(kw, {k: r[k] for k in keep}, r["ocr_strings_as_scripted"], flush=True)
