@@ -12,6 +12,7 @@ def main():
     ap.add_argument("--slots", type=int, nargs="+", default=[32, 48])
     ap.add_argument("--queue", type=int, default=8, help="batches of 32 images in the queue")
     ap.add_argument("--eos-scale", type=float, default=12.0)
+    ap.add_argument("--contexts", type=int, default=1, help="> 1: the queue on that many execution contexts at once (markushgrapher_amd/inflight.py), a queue of --queue batches each")
     ap.add_argument("--tools-lib", action="store_true", help="the tools build of the library (MG_WHATIF_STEP what-if runs: wrong results, valid timing)")
     args = ap.parse_args()
     import torch
@@ -45,6 +46,26 @@ def main():
     Q = args.queue
     q = {k: torch.cat([dev[k]] * Q, dim=0) for k in ("input_ids", "bbox", "attention_mask")}
     eng.set_stream_encoder(0)
+    if args.contexts > 1:
+        from markushgrapher_amd.inflight import InFlight
+        fl = InFlight(eng, args.contexts)
+        for c in fl.contexts:
+            c.set_stream_encoder(0)
+        for slots in args.slots:
+            def job(ctx, i):
+                pix = torch.cat([ctx.preprocess(dev["pages_u8"]) for _ in range(Q)], dim=0)
+                o, l, sc, st = ctx.generate_stream_beam(q["input_ids"], q["bbox"], q["attention_mask"], pix, num_beams=5, max_length=512, min_length=0,
+                                                        chunk=B, slots=slots, pool_chunks=3)
+                return o.cpu().numpy(), l.cpu().numpy(), st
+            fl.map(job, range(len(fl)))
+            torch.cuda.synchronize(); t0 = time.time()
+            res = fl.map(job, range(len(fl)))
+            torch.cuda.synchronize(); tq = time.time() - t0
+            same = all(np.array_equal(o[n, :min(int(l[n]), ref.shape[1])], ref[n % B, :min(int(l[n]), ref.shape[1])]) for o, l, _ in res for n in range(Q * B))
+            print("queue on %d contexts, %d image slots each: %.2f images/s, steps %s, hypotheses equal %s"
+                  % (len(fl), slots, len(fl) * Q * B / tq, [int(r[2]) for r in res], same), flush=True)
+        fl.close()
+        return
     for slots in args.slots:
         def queue():
             pix = torch.cat([eng.preprocess(dev["pages_u8"]) for _ in range(Q)], dim=0)
