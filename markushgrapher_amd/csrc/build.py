@@ -39,6 +39,25 @@ def _headers():
     return hs
 
 
+class _BuildLock:
+    """One builder at a time per output directory (pytest-xdist workers all ask for the emulator library at once)."""
+
+    def __init__(self, path):
+        self.path = path
+
+    def __enter__(self):
+        import fcntl
+        os.makedirs(os.path.dirname(self.path), exist_ok=True)
+        self.f = open(self.path, "w")
+        fcntl.flock(self.f, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *exc):
+        import fcntl
+        fcntl.flock(self.f, fcntl.LOCK_UN)
+        self.f.close()
+
+
 def _run(cmd):
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
@@ -77,6 +96,11 @@ def build_hip(force=False, verbose=False, objdir=None, out=None, defines=()):
 def build_emu(force=False, opt="-O1"):
     objdir = os.path.join(EMU_DIR, "_build")
     os.makedirs(objdir, exist_ok=True)
+    with _BuildLock(os.path.join(objdir, ".lock")):
+        return _build_emu(force, opt, objdir)
+
+
+def _build_emu(force, opt, objdir):
     jobs = []
     objs = []
     srcs = [os.path.join(HERE, s) for s in _sources()] + [os.path.join(EMU_DIR, "simt_emu.cpp")]
