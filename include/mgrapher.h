@@ -355,11 +355,20 @@ int mg_ocr_generate(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, co
  * page emits a stop token / reaches max_new_tokens takes the next page (a pointer change: the cache is already there), so the
  * call runs sum(lengths) / slots steps instead of walking every row to the longest page.  Per-page ids equal mg_ocr_generate's.
  * out_ids [N][max_new_tokens] i64 (pad after the stop token), out_len [N] i32 (device), *steps_host decode steps (nullable).
- * Same input contract as mg_ocr_generate (equal prompt length L and n_img frames for every page).  SYNCHRONISES. */
+ * Same input contract as mg_ocr_generate (equal prompt length L and n_img frames for every page; prompts of different lengths:
+ * mg_ocr_generate_stream_ragged below).  SYNCHRONISES. */
 int mg_ocr_stream_workspace_bytes(const mg_ocr_model* m, int N, int n_img, int L, int max_new_tokens, int slots, int chunk, size_t* out_bytes);
 int mg_ocr_generate_stream(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* input_ids, const float* pixel_values,
                            const int32_t* patch_pos, const uint8_t* patch_mask, int N, int n_img, int L, int max_new_tokens, int slots, int chunk,
                            int64_t* out_ids, int32_t* out_len, long* steps_host);
+/* The same with prompts of DIFFERENT lengths: input_ids [N][L] holds every page's prompt_len[n] <= L tokens LEFT-ALIGNED (anything behind them is
+ * never attended), prompt_len [N] i32 on the device (null: mg_ocr_generate_stream).  What stock transformers computes for the left-padded batch the
+ * Idefics3 processor makes of such prompts (position = cumsum(attention_mask) - 1, pad keys masked: every row as if alone; modeling_llama.py
+ * position_ids, generation/utils.py prepare_inputs_for_generation) - the reference itself never makes one: its transformers backend calls
+ * generate() one page at a time with one prompt (markushgrapher/ocr/chemical_ocr.py:366-392).  Every page still carries n_img frames. */
+int mg_ocr_generate_stream_ragged(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* input_ids, const int32_t* prompt_len,
+                                  const float* pixel_values, const int32_t* patch_pos, const uint8_t* patch_mask, int N, int n_img, int L,
+                                  int max_new_tokens, int slots, int chunk, int64_t* out_ids, int32_t* out_len, long* steps_host);
 
 /* ------------------------------------------------------------------------------------------------------------------------------
  * OCSR vision branch "e1" (SURVEY.md section 8 rows a7 / f-2).  The reference's model evaluates, inside forward() / generate() of its

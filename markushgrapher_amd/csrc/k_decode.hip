@@ -36,10 +36,11 @@ __global__ __launch_bounds__(NW * 64) void attn_step_kernel(AttnStepArgs a, long
     const int owner = blockIdx.x / a.H, h = blockIdx.x - owner * a.H;
     if constexpr (G == 1 || ROPE) { if (a.live && a.live[owner] == 0) return; }       // finished / idle row (whole workgroup: uniform)
     else { if (a.live && a.kv_owner && a.live[owner * G] == 0) return; }              // beam queue form: idle image slot (its G rows share the flag)
-    const int tcur = a.pos_rows ? a.pos_rows[owner] + a.t_off : (a.t_dev ? *a.t_dev + a.t_off : a.t);
+    int tcur = a.pos_rows ? a.pos_rows[owner] + a.t_off : (a.t_dev ? *a.t_dev + a.t_off : a.t);
     // the K/V stream this row reads (and, for self-attention, appends to): a pool entry of the continuous decoders (cross form: the
     // image's encoder K/V; rotary form: the page's own cache), else the row itself
     const int kvo = a.kv_owner ? a.kv_owner[owner] : owner;
+    if constexpr (ROPE) { if (a.t_off_rows) tcur += a.t_off_rows[kvo]; }      // prompts of different lengths: the page's own length - t_off
     const int nkeys_all = XA ? a.len[kvo] : ((a.t_dev || a.pos_rows) ? tcur + 1 : a.n_keys);
     // with an in-kernel append the newest key (position t) comes from registers, the cache holds [0, t)
     const bool app0 = ROPE || ((G == 1) && a.qkv.P && a.self_append);

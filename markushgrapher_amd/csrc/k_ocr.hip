@@ -244,10 +244,11 @@ __global__ __launch_bounds__(256) void ocr_init_kernel(int64_t* out_ids, int* un
         if (r == 0) { counters[0] = rows; counters[1] = -1; counters[2] = 0; counters[5] = 0; counters[6] = 0; }
     }
 }
-__global__ __launch_bounds__(256) void last_rows_kernel(int* dst_row, int B, int T, int T_cap) {     // row b*T_cap + T-1 -> b, others dropped
+// (lens != null: prompts of different lengths, left-aligned in their rows - row b holds lens[b] <= T tokens)
+__global__ __launch_bounds__(256) void last_rows_kernel(int* dst_row, int B, int T, int T_cap, const int* lens) {     // row b*T_cap + T-1 -> b, others dropped
     for (int i = blockIdx.x * 256 + threadIdx.x; i < B * T_cap; i += gridDim.x * 256) {
         const int b = i / T_cap, t = i - b * T_cap;
-        dst_row[i] = t == T - 1 ? b : -1;
+        dst_row[i] = t == (lens ? lens[b] : T) - 1 ? b : -1;
     }
 }
 __global__ __launch_bounds__(256) void all_rows_kernel(int* dst_row, int B, int T, int T_cap) {      // row b*T_cap + t -> b*T + t
@@ -256,8 +257,15 @@ __global__ __launch_bounds__(256) void all_rows_kernel(int* dst_row, int B, int 
         dst_row[i] = t < T ? b * T + t : -1;
     }
 }
-__global__ __launch_bounds__(256) void key_mask_kernel(uint8_t* mask, int B, int T, int T_cap) {
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < B * T_cap; i += gridDim.x * 256) mask[i] = (i % T_cap) < T;
+__global__ __launch_bounds__(256) void key_mask_kernel(uint8_t* mask, int B, int T, int T_cap, const int* lens) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < B * T_cap; i += gridDim.x * 256) mask[i] = (i % T_cap) < (lens ? lens[i / T_cap] : T);
+}
+__global__ __launch_bounds__(256) void len_delta_kernel(const int* lens, int* delta, int N, int L, int* err) {      // delta[n] = lens[n] - L; a length outside [1, L] is reported
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
+        const int l = lens[i];
+        if (l < 1 || l > L) atomicAdd(err, 1);
+        delta[i] = (l < 1 ? 1 : (l > L ? L : l)) - L;
+    }
 }
 
 // row-major [M][d] fp32 <-> the tiled residual layout ht_off (M a multiple of 32): thread = (row of a tile, 4-feature group), so the tiled side moves
@@ -334,11 +342,14 @@ void ocr_slots_init(int* unfinished, int* pos, int* img, int* pool, int64_t* nex
 void ocr_fill_ints(int* p, int v, int n, mgStream_t st) { MG_LAUNCH(ocr_fill_ints_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, st, p, v, n); }
 void ocr_add_int(int* dst, const int* src, mgStream_t st) { MG_LAUNCH(ocr_add_int_kernel, dim3(1), dim3(64), 0, st, dst, src); }
 void ocr_set_int(int* dst, int v, mgStream_t st) { MG_LAUNCH(ocr_set_int_kernel, dim3(1), dim3(64), 0, st, dst, v); }
-void ocr_row_maps(int* last_rows, int* all_rows, uint8_t* key_mask, int B, int T, int T_cap, mgStream_t st) {
+void ocr_row_maps(int* last_rows, int* all_rows, uint8_t* key_mask, int B, int T, int T_cap, mgStream_t st, const int* lens) {
     const int g = grid_for((size_t)B * T_cap);
-    MG_LAUNCH(last_rows_kernel, dim3(g), dim3(256), 0, st, last_rows, B, T, T_cap);
+    MG_LAUNCH(last_rows_kernel, dim3(g), dim3(256), 0, st, last_rows, B, T, T_cap, lens);
     MG_LAUNCH(all_rows_kernel, dim3(g), dim3(256), 0, st, all_rows, B, T, T_cap);
-    MG_LAUNCH(key_mask_kernel, dim3(g), dim3(256), 0, st, key_mask, B, T, T_cap);
+    MG_LAUNCH(key_mask_kernel, dim3(g), dim3(256), 0, st, key_mask, B, T, T_cap, lens);
+}
+void ocr_len_delta(const int* lens, int* delta, int N, int L, int* err, mgStream_t st) {
+    MG_LAUNCH(len_delta_kernel, dim3(grid_for((size_t)N)), dim3(256), 0, st, lens, delta, N, L, err);
 }
 
 }  // namespace mg

@@ -294,6 +294,8 @@ struct AttnStepArgs {
     // [rows][H][cap][64] and attends over [0, t] for the group's query heads in one pass over the cache.  qkv == null: not used.
     struct Rope { const float* qkv; int ld; const float* cs; RowScale rs; float qscale; } rope;
     const int* pos_rows;      // continuous decoding: the row's own position t = pos_rows[row] + t_off (self: keys [0, t], bias by t - j); overrides t / t_dev
+    const int* t_off_rows;    // rotary form, nullable: per K/V pool entry (page) an offset added to the row's position (prompts of different lengths:
+                              // the page's prompt length minus t_off)
     const int* kv_owner;      // continuous decoding: entry of the K/V pool that row `owner` reads - cross form: the image's stream (len is
                               // indexed by it too); rotary form: the page's own cache, which the row also appends to
     int one_wg_per_cu;        // cross form (len != null): request enough LDS that ONE workgroup of the K/V stream is resident per CU (see attention_step)

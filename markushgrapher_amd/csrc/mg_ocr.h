@@ -24,7 +24,9 @@ void ocr_add_int(int* dst, const int* src, mgStream_t st);
 void ocr_set_int(int* dst, int v, mgStream_t st);
 // row-major [M][d] fp32 <-> tiled (ht_off) copies, M a multiple of 32
 void ocr_tile_f32(const float* src, float* dst, int M, int d, int to_tiled, mgStream_t st);
-void ocr_row_maps(int* last_rows, int* all_rows, uint8_t* key_mask, int B, int T, int T_cap, mgStream_t st);
+// lens (nullable): prompts of different lengths, left-aligned in their rows: row b's last position is lens[b] - 1 and its keys are [0, lens[b])
+void ocr_row_maps(int* last_rows, int* all_rows, uint8_t* key_mask, int B, int T, int T_cap, mgStream_t st, const int* lens = nullptr);
+void ocr_len_delta(const int* lens, int* delta, int N, int L, int* err, mgStream_t st);     // delta[n] = lens[n] - L (lengths outside [1, L] counted in *err)
 // engine.hip: sets the thread-local message mg_last_error() returns
 int fail_msg(int code, const char* msg);
 }  // namespace mg

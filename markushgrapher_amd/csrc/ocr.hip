@@ -87,7 +87,7 @@ struct mg_ocr_model {
     bool graph_active = false;
     struct Key { const void *ws, *out, *stream; int B, n_img, L, max_new; bool operator==(const Key& o) const { return ws == o.ws && out == o.out && stream == o.stream && B == o.B && n_img == o.n_img && L == o.L && max_new == o.max_new; } } gkey{};   // n_img: the text-side buffers are carved behind the vision buffers
     bool gvalid = false;
-    struct SKey { const void *ws, *out, *out_len, *stream; int N, slots, L, max_new, chunk, n_img; bool operator==(const SKey& o) const { return ws == o.ws && out == o.out && out_len == o.out_len && stream == o.stream && N == o.N && slots == o.slots && L == o.L && max_new == o.max_new && chunk == o.chunk && n_img == o.n_img; } } skey{};   // chunk, n_img: the decode rows, K/V pages and slot table are carved behind the prefill region they size
+    struct SKey { const void *ws, *out, *out_len, *stream; int N, slots, L, max_new, chunk, n_img, ragged; bool operator==(const SKey& o) const { return ws == o.ws && out == o.out && out_len == o.out_len && stream == o.stream && N == o.N && slots == o.slots && L == o.L && max_new == o.max_new && chunk == o.chunk && n_img == o.n_img && ragged == o.ragged; } } skey{};   // chunk, n_img: the decode rows, K/V pages and slot table are carved behind the prefill region they size
     bool svalid = false;
 #ifndef MG_EMU
     hipGraphExec_t sexec = nullptr;
@@ -238,10 +238,12 @@ void image_features(const mg_ocr_model* m, const Ws& w, const float* pix, const 
 
 // text model over the whole prompt (teacher-forced / prefill): leaves the final hidden states in w.h (before the last norm)
 // and the rotated keys / values of every layer in the decode caches
-void prefill(const mg_ocr_model* m, const Ws& w, const int64_t* ids, const float* feats, int B, int n_img, int L, int cap, mgStream_t st) {
+// lens (nullable, device [B]): prompts of different lengths, left-aligned in their rows (row b: lens[b] tokens, then padding): the padding is
+// behind every real token (causal attention never reads it) and its keys are masked; the row's last position is lens[b] - 1
+void prefill(const mg_ocr_model* m, const Ws& w, const int64_t* ids, const float* feats, int B, int n_img, int L, int cap, mgStream_t st, const int* lens = nullptr) {
     const mg_ocr_config& c = m->c;
     const int td = c.t_hidden, ti = c.t_inter, H = c.t_heads, KV = c.t_kv_heads, T_cap = round_up(L, 64), MT = B * T_cap;
-    ocr_row_maps(w.last_rows, w.all_rows, w.kmask, B, L, T_cap, st);
+    ocr_row_maps(w.last_rows, w.all_rows, w.kmask, B, L, T_cap, st, lens);
     ocr_merge_embed(ids, m->at<uint16_t>(m->tok_emb), feats, w.h, B, L, T_cap, td, c.vocab, c.image_token_id, n_img * m->T_img, w.counters + 3, st);
     // Second form (round 5): the residual stream of the prefill in the TILED fp32 layout (w.ht) - o_proj / down_proj on the batched residual
     // epilogue instead of the row-major read-modify-write one, RMSNorm from 512-byte runs; the row-major copy w.h (what the callers read the
@@ -290,7 +292,7 @@ void prefill(const mg_ocr_model* m, const Ws& w, const int64_t* ids, const float
 // projections that read it (rotary / cache kernel, SiLU kernel, lm_head) apply r(row) = rsqrt(mean h^2 + eps) themselves.
 // q != null (queue form, mg_ocr_generate_stream): the B rows are SLOTS - row r decodes page q->pool[r] at its own position
 // pos + q->pos[r] and reads / appends to that page's cache; idle slots are skipped by the attention launches.
-struct SlotView { const int* pos; const int* pool; const int* live; };
+struct SlotView { const int* pos; const int* pool; const int* live; const int* toff; };      // toff (nullable): per page, its prompt length - L
 void decode_step(const mg_ocr_model* m, const Ws& w, int B, int pos, const int* pos_dev, int cap, mgStream_t st, const SlotView* q = nullptr) {
     const mg_ocr_config& c = m->c;
     const int td = c.t_hidden, ti = c.t_inter, H = c.t_heads, KV = c.t_kv_heads, K2 = td + ti;
@@ -315,7 +317,7 @@ void decode_step(const mg_ocr_model* m, const Ws& w, int B, int pos, const int* 
         AttnStepArgs s{};         // rotary embedding, cache append and grouped-query attention over [0, pos] in one launch
         s.Kc = Kc; s.Vc = Vc; s.Kc_w = Kc; s.Vc_w = Vc; s.ctx = w.ctx; s.rows = B; s.H = KV; s.group = H / KV; s.cap = cap; s.n_keys = pos + 1; s.t = pos;
         s.t_dev = pos_dev; s.t_off = pos;
-        if (q) { s.pos_rows = q->pos; s.kv_owner = q->pool; s.live = q->live; }
+        if (q) { s.pos_rows = q->pos; s.kv_owner = q->pool; s.live = q->live; s.t_off_rows = q->toff; }
         s.rope.qkv = w.qkv; s.rope.ld = m->qkvn; s.rope.cs = m->at<float>(m->rope_cs); s.rope.rs = i == 0 ? none : rs_a;
         s.rope.qscale = 0.125f;
         attention_step(s, st);
@@ -709,13 +711,20 @@ int mg_ocr_stream_workspace_bytes(const mg_ocr_model* m, int N, int n_img, int L
     carve(m, nullptr, slots, 0, 1, 0, false, &b);
     const int cap = round_up(L + max_new_tokens, 64);
     const size_t kv = (size_t)N * m->c.t_kv_heads * cap * 64 * m->c.t_layers * sizeof(uint16_t);
-    *out_bytes = align_up(a.total, 256) + align_up(b.total, 256) + 2 * align_up(kv, 256) + align_up((size_t)N * 8, 256) + 8 * 4096;
+    *out_bytes = align_up(a.total, 256) + align_up(b.total, 256) + 2 * align_up(kv, 256) + align_up((size_t)N * 8, 256) + 8 * 4096 + align_up((size_t)N * 4, 256);
     return MG_OK;
 }
 
 int mg_ocr_generate_stream(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* input_ids, const float* pixel_values,
                            const int32_t* patch_pos, const uint8_t* patch_mask, int N, int n_img, int L, int max_new_tokens, int slots, int chunk,
                            int64_t* out_ids, int32_t* out_len, long* steps_host) {
+    return mg_ocr_generate_stream_ragged(m, stream, ws, ws_bytes, input_ids, nullptr, pixel_values, patch_pos, patch_mask, N, n_img, L, max_new_tokens, slots, chunk,
+                                         out_ids, out_len, steps_host);
+}
+
+int mg_ocr_generate_stream_ragged(mg_ocr_model* m, void* stream, void* ws, size_t ws_bytes, const int64_t* input_ids, const int32_t* prompt_len,
+                                  const float* pixel_values, const int32_t* patch_pos, const uint8_t* patch_mask, int N, int n_img, int L, int max_new_tokens,
+                                  int slots, int chunk, int64_t* out_ids, int32_t* out_len, long* steps_host) {
     int rc = check_args(m, chunk < N ? chunk : N, n_img, L, "mg_ocr_generate_stream");
     if (rc != MG_OK) return rc;
     std::unique_lock<std::recursive_mutex> call_lock;
@@ -759,8 +768,10 @@ int mg_ocr_generate_stream(mg_ocr_model* m, void* stream, void* ws, size_t ws_by
     int* sctr = (int*)base; base += 4096;
     int* scratch_unf = (int*)base; base += 4096;          // prefill-side selection: flags / counter it needs but nobody reads
     int* err = (int*)base; base += 4096;
+    int* toff = (int*)base; base += align_up((size_t)N * 4, 256);          // per page: prompt length - L (prompts of different lengths)
     mg_memset_async(sctr, 0, 4096, st);
     mg_memset_async(err, 0, 4096, st);
+    if (prompt_len) ocr_len_delta(prompt_len, toff, N, L, err, st);
     mg_memset_async(out_len, 0, (size_t)N * sizeof(int32_t), st);
     ocr_init(out_ids, scratch_unf, sctr + 512, N < 1024 ? N : 1024, max_new_tokens, c.pad_token_id, st);      // (pads the first rows; the rest below)
     if (N > 1024) for (int r0 = 1024; r0 < N; r0 += 1024)
@@ -779,7 +790,7 @@ int mg_ocr_generate_stream(mg_ocr_model* m, void* stream, void* ws, size_t ws_by
                            patch_mask ? patch_mask + (size_t)c0 * n_img * P : nullptr, n * n_img, st);
         Ws wc = w;
         wc.Kc = Kbig + (size_t)c0 * page_kv; wc.Vc = Vbig + (size_t)c0 * page_kv; wc.kv_layer = kv_layer;
-        prefill(m, wc, input_ids + (size_t)c0 * L, (pixel_values && n_img > 0) ? w.feats : nullptr, n, n_img, L, cap, st);
+        prefill(m, wc, input_ids + (size_t)c0 * L, (pixel_values && n_img > 0) ? w.feats : nullptr, n, n_img, L, cap, st, prompt_len ? prompt_len + c0 : nullptr);
         rmsnorm_pack_rows(w.h, m->rawp("model.text_model.norm.weight"), w.xc, w.last_rows, n * T_cap, c.t_hidden, c.rms_eps, 1.0f, st);
         GemmArgs lg = ga(w.xc, m->at<uint16_t>(m->lm_head), n, c.vocab, c.t_hidden);
         lg.out_f32 = w.logits; lg.ldo = c.vocab;
@@ -803,7 +814,7 @@ int mg_ocr_generate_stream(mg_ocr_model* m, void* stream, void* ws, size_t ws_by
     tab.max_len = max_new_tokens;
     Ws w = wd;
     w.Kc = Kbig; w.Vc = Vbig; w.kv_layer = kv_layer;
-    const SlotView view{spos, spool, wd.unfinished};
+    const SlotView view{spos, spool, wd.unfinished, prompt_len ? toff : nullptr};
     auto step = [&]() {
         decode_step(m, w, slots, L, nullptr, cap, st, &view);
         ArgmaxArgs g{};
@@ -820,7 +831,7 @@ int mg_ocr_generate_stream(mg_ocr_model* m, void* stream, void* ws, size_t ws_by
     bool graphed = false;
 #ifndef MG_EMU
     if (m->use_graph == 1) {
-        const mg_ocr_model::SKey key{ws, out_ids, out_len, (const void*)st, N, slots, L, max_new_tokens, chunk, n_img};
+        const mg_ocr_model::SKey key{ws, out_ids, out_len, (const void*)st, N, slots, L, max_new_tokens, chunk, n_img, prompt_len ? 1 : 0};
         if (!(m->svalid && m->skey == key)) {
             std::lock_guard<std::mutex> capture_lock(mg_capture_mutex());
             m->sreset();
@@ -860,7 +871,7 @@ int mg_ocr_generate_stream(mg_ocr_model* m, void* stream, void* ws, size_t ws_by
     rc = check("mg_ocr_generate_stream");
     if (rc != MG_OK) return rc;
     if (steps_host) *steps_host = steps;
-    if (bad) return failf(MG_E_INPUT, "mg_ocr_generate_stream: %d bad inputs (token id outside the vocabulary, or a sequence whose <image> count differs from n_img * %d)", bad, m->T_img);
+    if (bad) return failf(MG_E_INPUT, "mg_ocr_generate_stream: %d bad inputs (token id outside the vocabulary, a sequence whose <image> count differs from n_img * %d, or a prompt length outside [1, L])", bad, m->T_img);
     return MG_OK;
 }
 

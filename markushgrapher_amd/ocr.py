@@ -50,6 +50,8 @@ class OcrEngine:
         L.mg_ocr_stream_workspace_bytes.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.POINTER(C.c_size_t)]
         L.mg_ocr_generate_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + \
                                             [C.c_int] * 6 + [C.c_void_p, C.c_void_p, C.POINTER(C.c_long)]
+        L.mg_ocr_generate_stream_ragged.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + \
+                                                   [C.c_int] * 6 + [C.c_void_p, C.c_void_p, C.POINTER(C.c_long)]
         s = shape
         cfg = MgOcrConfig(s.v_hidden, s.v_inter, s.v_layers, s.v_heads, s.image_size, s.patch_size, s.t_hidden, s.t_inter, s.t_layers,
                           s.t_heads, s.t_kv_heads, s.vocab, s.scale_factor, s.image_token_id, s.eos_token_id, s.pad_token_id,
@@ -186,9 +188,35 @@ class OcrEngine:
                                           self.mem.ptr(msk) if msk is not None else None, B, n_img, L, self.mem.ptr(out)))
         return out
 
-    def generate_stream(self, input_ids, pixel_values=None, max_new_tokens=4096, slots=128, chunk=128, pixel_attention_mask=None):
+    @staticmethod
+    def left_align(input_ids, attention_mask):
+        """A LEFT-PADDED batch (what the Idefics3 processor returns for prompts of different lengths: zeros of `attention_mask` in front) ->
+        (ids with every row's real tokens moved to the front, prompt lengths int32 [N]).  Stock gives a real token the position
+        cumsum(mask) - 1 and masks the pad keys: a row's result is that of the row alone without its padding, which is what the
+        library computes from the left-aligned row and its length (mg_ocr_generate_stream_ragged)."""
+        ids = np.asarray(input_ids.cpu() if hasattr(input_ids, "cpu") else input_ids, dtype=np.int64)
+        am = np.asarray(attention_mask.cpu() if hasattr(attention_mask, "cpu") else attention_mask) != 0
+        if ids.shape != am.shape or ids.ndim != 2:
+            raise ValueError("left_align: input_ids and attention_mask are [N, L] arrays of one shape")
+        lens = am.sum(axis=1).astype(np.int32)
+        out = np.empty_like(ids)
+        for n in range(ids.shape[0]):
+            p = ids.shape[1] - int(lens[n])
+            if lens[n] < 1 or am[n, :p].any() or not am[n, p:].all():
+                raise ValueError(f"left_align: row {n} is not a left-padded prompt (zeros in front of the ones, at least one token)")
+            out[n, :lens[n]] = ids[n, p:]
+            out[n, lens[n]:] = ids[n, :p]               # (the pad tokens, behind the prompt now: never attended)
+        return out, lens
+
+    def generate_stream(self, input_ids, pixel_values=None, max_new_tokens=4096, slots=128, chunk=128, pixel_attention_mask=None, attention_mask=None):
         """Queue form (include/mgrapher.h mg_ocr_generate_stream): N pages through `slots` decode rows -> (new ids [N, max_new_tokens]
-        padded after each page's stop token, lengths [N], decode steps).  Page n's ids equal generate()'s for that page."""
+        padded after each page's stop token, lengths [N], decode steps).  Page n's ids equal generate()'s for that page.
+        attention_mask [N, L] (optional): a left-padded batch of prompts of different lengths (left_align)."""
+        lens = None
+        if attention_mask is not None:
+            input_ids, lens_np = self.left_align(input_ids, attention_mask)
+            if int(lens_np.min()) < input_ids.shape[1]:
+                lens = self.mem.asarray(lens_np, np.int32)
         ids, pv, N, n_img, L = self._inputs(input_ids, pixel_values)
         pos, msk = self.patch_inputs(pixel_attention_mask) if pv is not None else (None, None)
         slots, chunk = min(slots, 256), min(chunk, 256, N)
@@ -203,10 +231,11 @@ class OcrEngine:
             self._sout = (self.mem.empty((N, max_new_tokens), np.int64), self.mem.empty((N,), np.int32))
             self._sout_key = key
         steps = C.c_long(0)
-        self._chk(self.lib.mg_ocr_generate_stream(self.model, self.mem.stream(), self.mem.ptr(self._sws), self._sws_bytes, self.mem.ptr(ids),
-                                                  self.mem.ptr(pv) if pv is not None else None, self.mem.ptr(pos) if pos is not None else None,
-                                                  self.mem.ptr(msk) if msk is not None else None, N, n_img, L, max_new_tokens, slots, chunk,
-                                                  self.mem.ptr(self._sout[0]), self.mem.ptr(self._sout[1]), C.byref(steps)))
+        self._chk(self.lib.mg_ocr_generate_stream_ragged(self.model, self.mem.stream(), self.mem.ptr(self._sws), self._sws_bytes, self.mem.ptr(ids),
+                                                         self.mem.ptr(lens) if lens is not None else None,
+                                                         self.mem.ptr(pv) if pv is not None else None, self.mem.ptr(pos) if pos is not None else None,
+                                                         self.mem.ptr(msk) if msk is not None else None, N, n_img, L, max_new_tokens, slots, chunk,
+                                                         self.mem.ptr(self._sout[0]), self.mem.ptr(self._sout[1]), C.byref(steps)))
         return self.mem.copy(self._sout[0]), self.mem.copy(self._sout[1]), int(steps.value)
 
     def generate(self, input_ids, pixel_values=None, max_new_tokens=4096, capture_steps=0, pixel_attention_mask=None):

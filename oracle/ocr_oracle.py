@@ -182,6 +182,31 @@ class OcrOracle:
         hs, _ = self.text(self.embed(input_ids, pixel_values, pixel_attention_mask))
         return self._r(hs) @ self.w["lm_head.weight"].T
 
+    def generate_padded(self, input_ids, attention_mask, pixel_values, max_new_tokens, return_logits=False, pixel_attention_mask=None):
+        """A LEFT-PADDED batch as the Idefics3 processor makes one from prompts of different lengths (padding_side = "left"): attention_mask
+        [B][L] = 0 over the leading pad tokens.  Stock gives every real token the position cumsum(mask) - 1 (generation/utils.py
+        `prepare_inputs_for_generation`, modeling_llama.py position_ids) and masks the pad keys (masking_utils / _update_causal_mask), so a
+        row's result is the result of that row ALONE without its padding; restated exactly so: each row through generate() on its own.
+        Returns new ids [B][n] (rows padded with pad_token_id to the longest) and, optionally, the step logits [B][n][V]."""
+        ids = torch.as_tensor(input_ids, dtype=torch.long)
+        am = torch.as_tensor(attention_mask).bool()
+        B = ids.shape[0]
+        news, logs = [], []
+        for b in range(B):
+            p = int((~am[b]).sum())
+            assert bool(am[b, p:].all()) and not bool(am[b, :p].any()), "left padding: zeros in front, ones behind"
+            pv = None if pixel_values is None else torch.as_tensor(pixel_values)[b:b + 1]
+            pam = None if pixel_attention_mask is None else torch.as_tensor(pixel_attention_mask)[b:b + 1]
+            r = self.generate(ids[b:b + 1, p:], pv, max_new_tokens, return_logits=True, pixel_attention_mask=pam)
+            news.append(r[0][0]); logs.append(r[1][0])
+        n = max(int(x.shape[0]) for x in news)
+        new = torch.full((B, n), self.s.pad_token_id, dtype=torch.long)
+        lg = torch.zeros((B, n, logs[0].shape[-1]))
+        for b in range(B):
+            new[b, :news[b].shape[0]] = news[b]
+            lg[b, :logs[b].shape[0]] = logs[b]
+        return (new, lg) if return_logits else new
+
     def generate(self, input_ids, pixel_values, max_new_tokens, return_logits=False, pixel_attention_mask=None):
         """Greedy search (generation/utils.py:2783-2975): returns new ids [B][n <= max_new_tokens] (pad after EOS)."""
         s = self.s

@@ -19,8 +19,8 @@ def pytest_cmdline_main(config):
     overrides.  The emulator library is built once behind a file lock (csrc/build.py), so the workers may all ask for it at once."""
     if os.environ.get("PYTEST_XDIST_WORKER") or hasattr(config, "workerinput") or not config.pluginmanager.hasplugin("xdist"):
         return None
-    if "not gpu" not in (getattr(config.option, "markexpr", "") or "") or getattr(config.option, "numprocesses", None):
-        return None
+    if "not gpu" not in (getattr(config.option, "markexpr", "") or "") or getattr(config.option, "numprocesses", None) is not None:
+        return None                                   # (-n given, even -n 0: the caller chose)
     want = os.environ.get("MG_TESTS_WORKERS")
     n = int(want) if want is not None else min(4, os.cpu_count() or 1)
     if n > 1:

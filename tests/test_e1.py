@@ -206,6 +206,26 @@ def test_e1_resize_and_renormalisation(be_name):
     assert np.abs(_np(f) - fo).max() < EMU_MAX
 
 
+@pytest.mark.parametrize("be_name", BACKENDS)
+def test_e1_odd_batch_rows_do_not_meet(be_name):
+    """B = 3 (row counts that are not whole 32-row tiles in the last two stages: 48 and 192 rows) against the oracle; the images of a batch
+    never meet: the first two rows carry the bits of the B = 2 call."""
+    import torch
+    from oracle.swin_oracle import SwinOracle
+    s = PRESETS["tiny"]
+    sd = recipe_state_dict(s)
+    src = synth_pixels(s, 3)
+    eng = make_e1(be_name, s, sd)
+    e3, f3 = (_np(a) for a in eng.encode(src, want_features=True))
+    e2, f2 = (_np(a) for a in eng.encode(src[:2], want_features=True))
+    assert f3.shape == (3, s.out_tokens, s.out_dim) and np.isfinite(e3).all()
+    assert np.array_equal(f3[:2], f2) and np.array_equal(e3[:2], e2)
+    orc = SwinOracle(s, sd, emulate_bf16=True)
+    with torch.no_grad():
+        fo = orc.features(orc.derive_input(src)).numpy()
+    assert np.abs(f3 - fo).max() < EMU_MAX
+
+
 @pytest.mark.gpu
 def test_e1_window12_against_stock():
     g = load_golden("swin_w12.npz")

@@ -491,6 +491,48 @@ def test_ocr_queue_form_equals_batch_form(be_name, slots, chunk):
             assert lens2[k] == 1 and new2[k, 0] == base[0, 0] and np.all(new2[k, 1:] == s.pad_token_id)
 
 
+def test_oracle_left_padded_batch_reproduces_stock():
+    """ocr_tiny_ragged.npz: stock Idefics3 generate() on a LEFT-PADDED batch of three prompts of different lengths; the oracle restates it
+    as every row alone without its padding (generate_padded)."""
+    import torch
+    from oracle.ocr_oracle import OcrOracle
+    g = load_golden("ocr_tiny_ragged.npz")
+    s = PRESETS["tiny"]
+    sd = recipe_state_dict(s, gain=float(g["gain"]))
+    _, pix = synth_inputs(s, int(g["B"]))
+    with torch.no_grad():
+        new, lg = OcrOracle(s, sd).generate_padded(g["input_ids"], g["attention_mask"], pix, int(g["new_tokens"]), return_logits=True)
+    assert np.array_equal(new.numpy(), g["new_ids"])
+    top = np.take_along_axis(lg.numpy(), g["step_top8_idx"], axis=-1)
+    assert np.abs(top - g["step_top8_val"]).max() < 2e-4 * max(1.0, float(np.abs(g["step_top8_val"]).max()))
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+@pytest.mark.parametrize("slots,chunk", [(2, 3), (4, 2)])
+def test_ocr_prompts_of_different_lengths(be_name, slots, chunk):
+    """mg_ocr_generate_stream_ragged: the left-padded batch of the stock fixture (prompt lengths L, L - 3, L - 5), repeated in another order, through the
+    queue form: every page's new ids equal stock's (all margins of the fixture > 0.07), and equal what the equal-length path returns for that page's
+    prompt alone."""
+    g = load_golden("ocr_tiny_ragged.npz")
+    s = PRESETS["tiny"]
+    sd = recipe_state_dict(s, gain=float(g["gain"]))
+    B, n = int(g["B"]), int(g["new_tokens"])
+    _, pix = synth_inputs(s, B)
+    eng = make_ocr(be_name, s, sd)
+    order = np.array([1, 2, 0, 2, 1])
+    new, lens, _ = eng.generate_stream(g["input_ids"][order], pix[order], n, slots=slots, chunk=chunk, attention_mask=g["attention_mask"][order])
+    new, lens = np.asarray(eng.mem.numpy(new)).copy(), np.asarray(eng.mem.numpy(lens)).copy()
+    assert np.all(lens == n) and np.array_equal(new, g["new_ids"][order])
+    for b in range(B):                                   # the same prompt alone, unpadded, through the equal-length batch form
+        p = int((g["attention_mask"][b] == 0).sum())
+        alone, _ = eng.generate(g["input_ids"][b:b + 1, p:], pix[b:b + 1], n)
+        assert np.array_equal(np.asarray(eng.mem.numpy(alone)), g["new_ids"][b:b + 1])
+    # not a left-padded row: refused on the host; a length outside [1, L]: refused by the library
+    bad = g["attention_mask"].copy(); bad[1, -1] = 0
+    with pytest.raises(ValueError, match="left-padded"):
+        eng.generate_stream(g["input_ids"], pix, n, slots=2, chunk=2, attention_mask=bad)
+
+
 @pytest.mark.parametrize("be_name", BACKENDS)
 def test_ocr_clone_is_a_second_context_on_the_same_weights(be_name):
     """mg_ocr_clone: batch and queue form through a clone equal the source's (own workspace and captured graphs); on the GPU the two

@@ -1,7 +1,7 @@
 """Mints tests/golden/ocr_tiny.npz and ocr_smoldocling.npz: outputs of STOCK transformers `Idefics3ForConditionalGeneration`
 (the class the reference's ChemicalOCR loads, markushgrapher/ocr/chemical_ocr.py:76-84) on recipe weights and inputs
 (markushgrapher_amd/ocr_shapes.py), after asserting that oracle/ocr_oracle.py reproduces them.  Only data is written.
-    python tools/make_golden_ocr.py [tiny] [smoldocling]
+    python tools/make_golden_ocr.py [tiny] [tiny2] [tiny3] [ragged] [smoldocling]
 """
 import os
 import sys
@@ -96,6 +96,47 @@ def mint(name, B, new_tokens, gain, eos_from_step=None, n_img=1, tag=None, maske
     print(f"[{name}] wrote {path} {os.path.getsize(path)} bytes; margins min {float(out['step_margin'].min()):.4f} median {float(np.median(out['step_margin'])):.4f}")
 
 
+def mint_ragged(B=3, new_tokens=8, gain=0.7, drops=(0, 3, 5)):
+    """ocr_tiny_ragged.npz: prompts of DIFFERENT lengths as one left-padded batch (what the Idefics3 processor returns for them:
+    padding_side = left) through stock generate(); the oracle restates it as every row alone (generate_padded)."""
+    s = PRESETS["tiny"]
+    sd = recipe_state_dict(s, gain=gain)
+    ids, pix = synth_inputs(s, B)
+    L = ids.shape[1]
+    padded, mask = np.full_like(ids, s.pad_token_id), np.zeros_like(ids)
+    for b in range(B):
+        d = drops[b]
+        row = ids[b, :L - d]                      # the row's last d text tokens left out (every row keeps its <image> block)
+        padded[b, d:] = row
+        mask[b, d:] = 1
+    m = stock_model(s, sd)
+    m.generation_config.pad_token_id = s.pad_token_id
+    tid, tam, tpix = torch.from_numpy(padded), torch.from_numpy(mask), torch.from_numpy(pix)
+    pam = torch.ones(B, 1, s.image_size, s.image_size, dtype=torch.bool)
+    with torch.no_grad():
+        gen = m.generate(input_ids=tid, attention_mask=tam, pixel_values=tpix, pixel_attention_mask=pam, max_new_tokens=new_tokens, do_sample=False,
+                         output_scores=True, return_dict_in_generate=True)
+    new = gen.sequences[:, L:]
+    scores = torch.stack(gen.scores, dim=1)
+    orc = OcrOracle(s, sd)
+    with torch.no_grad():
+        on, osc = orc.generate_padded(padded, mask, pix, new_tokens, return_logits=True)
+    n = min(on.shape[1], new.shape[1])
+    same = bool((on[:, :n] == new[:, :n]).all()) and on.shape[1] == new.shape[1]
+    e_s = float((osc[:, :n] - scores[:, :n]).abs().max())
+    print(f"[ragged] stock left-padded batch vs the oracle's row-alone restatement: step logits {e_s:.2e} (max |logit| {float(scores.abs().max()):.2f}), ids equal {same}; "
+          f"new ids {new.tolist()}")
+    assert same and e_s < 2e-4 * max(1.0, float(scores.abs().max())), "oracle does not reproduce stock on the left-padded batch"
+    top = torch.topk(scores, 8, dim=-1)
+    srt = torch.sort(scores, dim=-1, descending=True).values
+    path = os.path.join(ROOT, "tests", "golden", "ocr_tiny_ragged.npz")
+    np.savez_compressed(path, shape=np.array("tiny"), B=B, new_tokens=new_tokens, gain=np.float32(gain), drops=np.array(drops), input_ids=padded,
+                        attention_mask=mask, new_ids=new.numpy(), step_top8_val=top.values.numpy(), step_top8_idx=top.indices.numpy(),
+                        step_margin=(srt[..., 0] - srt[..., 1]).numpy(),
+                        versions=np.array(f"transformers {__import__('transformers').__version__} torch {torch.__version__}"))
+    print(f"[ragged] wrote {path} {os.path.getsize(path)} bytes; margins min {float((srt[..., 0] - srt[..., 1]).min()):.4f}")
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["tiny", "smoldocling"]
     if "tiny" in what:
@@ -104,5 +145,7 @@ if __name__ == "__main__":
         mint("tiny", B=2, new_tokens=6, gain=0.7, n_img=2, tag="tiny2")      # two frames per page (a page split by the processor)
     if "tiny3" in what or not sys.argv[1:]:
         mint("tiny", B=3, new_tokens=6, gain=0.7, tag="tiny3", masked=True)   # partially masked frames (non-square pages)
+    if "ragged" in what or not sys.argv[1:]:
+        mint_ragged()
     if "smoldocling" in what:
         mint("smoldocling", B=2, new_tokens=8, gain=1.0)
