@@ -682,7 +682,7 @@ static void decode_step(mg_model* m, const DecodeCtx& c, int t, const int* tdev,
             r.gscale = (last && m->tied) ? 1.0f / sqrtf((float)d) : 1.0f; r.x_pk = c.dx_pk; r.x2_pk = c.xa; r.x2_ld = K2; r.part = c.rs_part;
             r.M = R; r.N = d; r.K = m->dff; r.rs = rs2;
             r.wide_tiles = 8;      // the same K partition (16 waves) for every call (up to 256 rows: 8 greedy batches of 32; beam-5 at batch 32 = 5 tiles)
-            r.kpart = c.kpart; r.ticket = c.tickets;
+            r.kpart = c.kpart; r.ticket = c.tickets; r.alone = m->shared_gpu ? 0 : 1;
             if (!(whatif & 32)) gemm_rows_resid(r, st);
         }
     }

@@ -1615,7 +1615,12 @@ void gemm_rows_resid(const ResidArgs& r, mgStream_t stream) {
     }
     // several row tiles, K-slab form: the chunks of the one-workgroup form's waves as workgroups (same bits; see gemm_rows_resid_mt_kernel)
     { static bool env_read = false; if (!env_read) { env_read = true; if (const char* e = getenv("MG_ROWS_MT")) g_rows_mt = atoi(e); } }   // A/B runs
-    if (r.kpart && r.ticket && mt >= 2 && !split && (r.N & 255) == 0 && g_rows_mt) {
+    // A call that has the GPU to itself (ResidArgs::alone: no other execution context in flight) takes the two-launch K-slab form from 4 row tiles
+    // on: 23 % (160 rows) to 35 % (256 rows) faster alone, slower below ~ 100 rows, and a loss with other contexts beside it (profiles/r05_e_*).
+    static int alone_env = -1;
+    if (alone_env < 0) { const char* e = getenv("MG_ROWS_MT_ALONE"); alone_env = e ? atoi(e) : 1; }
+    const int rows_mt = g_rows_mt ? g_rows_mt.load() : ((r.alone && alone_env && mt >= 4) ? 2 : 0);
+    if (r.kpart && r.ticket && mt >= 2 && !split && (r.N & 255) == 0 && rows_mt) {
         const int NWf = wide ? 16 : 8, kp = r.K >> 5, per = (kp + NWf - 1) / NWf;
         if (per * NWf == kp && (per == 8 || per == 4 || per == 2)) {
             const int S = NWf;
@@ -1623,7 +1628,7 @@ void gemm_rows_resid(const ResidArgs& r, mgStream_t stream) {
             if (fmode < 0) { const char* e = getenv("MG_MT_FENCE"); fmode = e ? atoi(e) : 0; }
             const dim3 gridk((r.N / 32) * S), blockk(64 * mt);
             const size_t shk = (size_t)32 * mt * sizeof(float) + 16;
-            const bool two = g_rows_mt.load() == 2 && S <= 16;     // two-launch variant: partial sums, then a chip-wide merge launch
+            const bool two = rows_mt == 2 && S <= 16;              // two-launch variant: partial sums, then a chip-wide merge launch
             const int fm = two ? 6 : fmode;
 #define MG_RMT(MTV)                                                                                   \
     case MTV:                                                                                         \

@@ -136,6 +136,8 @@ struct ResidArgs {
     float* part;
     int M, N, K;
     RowScale rs;
+    int alone;             // 1: the call has the GPU to itself (no other execution context beside it): forms that are faster alone but move more bytes
+                           // may be taken - the K-slab form in two launches from 4 row tiles on (k_gemm.hip); same bits either way
     int wide_tiles;        // row tiles up to which the long K = d_ff form keeps 16 K-partitioning waves (0: 4).  The decode steps pass 8 (every call
                            // the C ABI admits: 256 rows), so that a row sums in the order of a 32-row call whatever its call's size
     // Several row tiles, K-slab form (gemm_rows_resid_mt_kernel): the K chunks that the waves of the one-workgroup forms take become
