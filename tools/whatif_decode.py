@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--new-tokens", type=int, default=256)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--product-lib", action="store_true", help="the product library (no what-if: the reference line)")
+    ap.add_argument("--rows-split", type=int, default=-1, help="row-tile split policy of the decode projections (mgk_set_rows_split): -1 default, 0 never, 1 one row tile per workgroup")
     ap.add_argument("--resid-f16", type=int, default=1, help="0: residual projections with 8 instead of 16 features per workgroup (twice their activation bytes through L2)")
     args = ap.parse_args()
     import torch
@@ -40,6 +41,8 @@ def main():
     eng.load_state_dict(synth.recipe_state_dict(shape, **synth.BENCH_RECIPE))
     if not args.resid_f16:
         eng.lib.mgk_set_resid_f16(0)
+    if args.rows_split >= 0:
+        eng.lib.mgk_set_rows_split(args.rows_split)
     B, nb, max_length = args.batch, args.batches_per_call, args.new_tokens + 1
     pool = [synth.synth_batch(shape, B, seed=synth.BENCH_SEED + 1000 * j, return_pages=True) for j in range(nb)]
     L = max(p["input_ids"].shape[1] for p in pool)
