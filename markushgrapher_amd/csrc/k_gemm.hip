@@ -1615,10 +1615,12 @@ void gemm_rows_resid(const ResidArgs& r, mgStream_t stream) {
     }
     // several row tiles, K-slab form: the chunks of the one-workgroup form's waves as workgroups (same bits; see gemm_rows_resid_mt_kernel)
     { static bool env_read = false; if (!env_read) { env_read = true; if (const char* e = getenv("MG_ROWS_MT")) g_rows_mt = atoi(e); } }   // A/B runs
-    // A call that has the GPU to itself (ResidArgs::alone: no other execution context in flight) takes the two-launch K-slab form from 4 row tiles
-    // on: 23 % (160 rows) to 35 % (256 rows) faster alone, slower below ~ 100 rows, and a loss with other contexts beside it (profiles/r05_e_*).
+    // MG_ROWS_MT_ALONE=1: a call that has the GPU to itself (ResidArgs::alone: no other execution context in flight) takes the two-launch K-slab form
+    // from 4 row tiles on.  The launch is 23 % (160 rows) to 35 % (256 rows) faster back to back, but inside a decode step the gain is 0.5 - 3.5 % of
+    // the step depending on the box and the cross-attention launch of the same call was timed 7 % slower beside it (103 -> 111 us, profiles/r05_e_*):
+    // off by default.
     static int alone_env = -1;
-    if (alone_env < 0) { const char* e = getenv("MG_ROWS_MT_ALONE"); alone_env = e ? atoi(e) : 1; }
+    if (alone_env < 0) { const char* e = getenv("MG_ROWS_MT_ALONE"); alone_env = e ? atoi(e) : 0; }
     const int rows_mt = g_rows_mt ? g_rows_mt.load() : ((r.alone && alone_env && mt >= 4) ? 2 : 0);
     if (r.kpart && r.ticket && mt >= 2 && !split && (r.N & 255) == 0 && rows_mt) {
         const int NWf = wide ? 16 : 8, kp = r.K >> 5, per = (kp + NWf - 1) / NWf;
