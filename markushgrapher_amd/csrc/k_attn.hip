@@ -293,7 +293,10 @@ MG_DEV float fast_exp2(float x) {
 // per query: the LDS port and the dependent read -> MFMA latencies were what a stage waited on, not the matrix pipe) and the two tiles'
 // softmax chains are independent instruction streams the scheduler interleaves.  A query's arithmetic is the same sequence of
 // operations in both forms: results are bit-identical (tests/test_kernels.py).
-template <int XP = 0, int QT = 1>
+// PLAIN (round 5, the ChemicalOCR vision tower: ATT_CROSS over full frames): no relative bias and no key mask - no index words are copied or read, no
+// table exists, a score is s * log2(e); the caller guarantees kmask == null and Sk == Sk_cap.  Everything else (stages, softmax bookkeeping, the two
+// products) is the encoder's second form.
+template <int XP = 0, int QT = 1, bool PLAIN = false>
 __global__ __launch_bounds__(512 / QT) void attention_enc_kernel(AttnArgs a) {
     constexpr int NWV = AE_WAVES / QT;                   // waves per workgroup
     constexpr int NTH = 64 * NWV;
@@ -336,13 +339,15 @@ __global__ __launch_bounds__(512 / QT) void attention_enc_kernel(AttnArgs a) {
     int* ksl = (int*)(t1d + 2 * AE_D1 + 4);
     const int nst = kst ? kst[0] : (a.Sk + AT_KEYS - 1) / AT_KEYS;
     for (int i = tid; i < nst && i < AE_MAXST; i += NTH) ksl[i] = kst ? kst[1 + i] : i;
-    for (int i = tid; i < AE_HV; i += NTH)
-        hv[i] = (a.tabh[(size_t)(i & 31) * a.H + h] + a.tabv[(size_t)(i >> 5) * a.H + h]) * AE_LOG2E;
-    if (tid < 4) hv[AE_HV + tid] = AT_NEG;
-    for (int i = tid; i < 2 * AE_D1 + 1; i += NTH) {
-        int d = i - AE_D1;
-        d = d < -128 ? -128 : (d > 128 ? 128 : d);
-        t1d[i] = a.tab1[(size_t)a.bk1[d + 128] * a.H + h] * AE_LOG2E;
+    if constexpr (!PLAIN) {
+        for (int i = tid; i < AE_HV; i += NTH)
+            hv[i] = (a.tabh[(size_t)(i & 31) * a.H + h] + a.tabv[(size_t)(i >> 5) * a.H + h]) * AE_LOG2E;
+        if (tid < 4) hv[AE_HV + tid] = AT_NEG;
+        for (int i = tid; i < 2 * AE_D1 + 1; i += NTH) {
+            int d = i - AE_D1;
+            d = d < -128 ? -128 : (d > 128 ? 128 : d);
+            t1d[i] = a.tab1[(size_t)a.bk1[d + 128] * a.H + h] * AE_LOG2E;
+        }
     }
 
     const int q0w = qb * AE_QB + w * 32 * QT;            // first query of the wave; tile t starts at q0w + 32 t
@@ -359,7 +364,7 @@ __global__ __launch_bounds__(512 / QT) void attention_enc_kernel(AttnArgs a) {
         for (int kt = 0; kt < 4; ++kt) gld16_async(qr[t][kt], (const char*)(Qb + kt * TILE_ELEMS) + lane * 16);
         qi[t] = q0w + 32 * t + l32;
         const int qcl = qi[t] < a.Sk_cap ? qi[t] : a.Sk_cap - 1;
-        bix[t] = a.bidx + ((size_t)b * (size_t)(a.Sk_cap >> 5) * (size_t)a.Sk_cap + (size_t)qcl) * 32 + half * 16;
+        bix[t] = PLAIN ? nullptr : a.bidx + ((size_t)b * (size_t)(a.Sk_cap >> 5) * (size_t)a.Sk_cap + (size_t)qcl) * 32 + half * 16;
     }
     // a wave in a 128-query block without an attended position (the granularity of attn_lists, and what the first form of
     // the kernel skipped: padded rows next to attended ones are still computed, as the reference does) keeps loading its
@@ -378,7 +383,7 @@ __global__ __launch_bounds__(512 / QT) void attention_enc_kernel(AttnArgs a) {
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) qf[t][kt] = raw16_get(qr[t][kt]);
     // 1-D term of a tile whose pairs are all >= 128 positions apart (saturated bucket, stock:455-466): keys left / right
-    const float c_left = t1d[0], c_right = t1d[2 * AE_D1];
+    const float c_left = PLAIN ? 0.f : t1d[0], c_right = PLAIN ? 0.f : t1d[2 * AE_D1];
 
     const size_t bix_tile = (size_t)a.Sk_cap * 32;
     const uint16_t* Kb = a.K + ((size_t)b * a.H + h) * (size_t)(a.Sk_cap >> 5) * (4 * TILE_ELEMS);
@@ -390,7 +395,7 @@ __global__ __launch_bounds__(512 / QT) void attention_enc_kernel(AttnArgs a) {
     // fragments into ring slot i % AE_RING (fragments 0..7 = K: key-tile f/4, dk-tile f%4; 8..15 = V^T: d-tile, key-k-tile)
     auto issue = [&](int i) {
         const int st = sid(i);
-        if (act && !(XP & 1)) {
+        if (act && !(XP & 1) && !PLAIN) {
             char* ix = ix_base + (i % AE_DEPTH) * AE_IDX_BYTES;
 #pragma unroll
             for (int t = 0; t < QT; ++t)
@@ -430,7 +435,10 @@ __global__ __launch_bounds__(512 / QT) void attention_enc_kernel(AttnArgs a) {
     if (1 < nst) issue(1);
     for (int sti = 0; sti < nst; ++sti) {
         // own copies of stage sti have landed when at most those of the one later stage in flight are outstanding
-        if constexpr (XP == 0) {
+        if constexpr (XP == 0 && PLAIN) {        // (two fragment copies per wave and stage, active or not)
+            static_assert(QT == 1 || !PLAIN, "the plain form exists for one query tile per wave");
+            if (sti + 1 < nst && !(a.dbg & 1)) MG_WAIT_VMCNT(2); else MG_WAIT_VMCNT(0);
+        } else if constexpr (XP == 0) {
             if (sti + 1 < nst && !(a.dbg & 1)) {
                 if constexpr (QT == 1) { if (act) MG_WAIT_VMCNT(6); else MG_WAIT_VMCNT(2); }
                 else { if (act) MG_WAIT_VMCNT(12); else MG_WAIT_VMCNT(4); }
@@ -448,14 +456,14 @@ __global__ __launch_bounds__(512 / QT) void attention_enc_kernel(AttnArgs a) {
             continue;
         }
         uint4 bcur[QT][4];
-        {
+        if constexpr (!PLAIN) {
             const char* ix = ix_base + (sti % AE_DEPTH) * AE_IDX_BYTES + lane * 16;
 #pragma unroll
             for (int t = 0; t < QT; ++t)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) bcur[t][i] = ld16(ix + (t * 4 + i) * TILE_BYTES);
+            MG_WAIT_LGKM0();         // index words are in registers: their slot is refilled for stage sti + AE_DEPTH
         }
-        MG_WAIT_LGKM0();             // index words are in registers: their slot is refilled for stage sti + AE_DEPTH
         if (sti + AE_DEPTH < nst) issue(sti + AE_DEPTH);
         const char* kb = st_base + (sti % AE_RING) * AT_STAGE_BYTES + lane * 16;
         const char* vb = kb + 8 * TILE_BYTES;
@@ -483,7 +491,16 @@ __global__ __launch_bounds__(512 / QT) void attention_enc_kernel(AttnArgs a) {
                 const int dk = k0 - q0;                                   // wave-uniform
                 const uint32_t* bw = (const uint32_t*)&bcur[t][t2 * 2];
                 float tm = AT_NEG;
-                if (dk > -(128 + 31) && dk < 128 + 31) {                 // some pair of the tile is closer than 128: per-score term
+                if constexpr (PLAIN) {
+                    (void)bw; (void)dk;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = s[t][t2][r] * AE_LOG2E;
+                        s[t][t2][r] = v;
+                        tm = fmaxf(tm, v);
+                    }
+                    cst[t2] = 0.f;
+                } else if (dk > -(128 + 31) && dk < 128 + 31) {                 // some pair of the tile is closer than 128: per-score term
                     const char* tl = (const char*)t1d + (k0 - qi[t] + 4 * half + AE_D1) * 4;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -740,7 +757,20 @@ void attention(const AttnArgs& a_in, mgStream_t stream) {
             MG_LAUNCH((attention_enc_kernel<0, 1>), dim3(a.B * a.H * nqe), dim3(512), (size_t)AE_SMEM, stream, a);
         }
     } else if (a.mode == ATT_DEC_SELF) MG_LAUNCH((attention_kernel<ATT_DEC_SELF>), grid, block, sh, stream, a);
-    else MG_LAUNCH((attention_kernel<ATT_CROSS>), grid, block, sh, stream, a);
+    else {
+        // bias-free attention over full rows of keys (the ChemicalOCR vision tower: 1024 patches per frame, no mask unless a frame is padded): the
+        // encoder's second-form kernel without its bias path - 253 -> us per launch at 32 frames (profiles/r05_s_*); MG_ATT_PLAIN=0: the first form
+        static int plain = -1;
+        if (plain < 0) { const char* e = getenv("MG_ATT_PLAIN"); plain = e ? atoi(e) : 1; }
+        if (plain && !a.kmask && a.Sk == a.Sk_cap && a.Sq == a.Sq_cap && (a.Sk_cap & 63) == 0 && (a.Sq_cap % AE_QB) == 0 && (a.Sk_cap >> 6) <= AE_MAXST && !a.kst && !a.qbv) {
+            const int nqe = a.Sq_cap / AE_QB;
+            static bool oncep = false;
+            if (!oncep) { MG_SET_MAX_SMEM((&attention_enc_kernel<0, 1, true>), AE_SMEM); oncep = true; }
+            MG_LAUNCH((attention_enc_kernel<0, 1, true>), dim3(a.B * a.H * nqe), dim3(512), (size_t)AE_SMEM, stream, a);
+            return;
+        }
+        MG_LAUNCH((attention_kernel<ATT_CROSS>), grid, block, sh, stream, a);
+    }
 }
 
 }  // namespace mg

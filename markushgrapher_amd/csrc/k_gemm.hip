@@ -441,15 +441,15 @@ void gemm(const GemmArgs& a, int epi, mgStream_t stream) {
     const int gv = g_gemm_variant;          // one read per call (the switch is process-wide)
     // default (3): the persistent ping-pong kernel with 320-row tiles where its shape rules hold (K % 128 == 0), measured against the
     // two-stage kernel at M = 40960 (us): QKV 292 -> 245, O 166 -> 156, wi 356 -> 301, wo 434 -> 396, cross-KV 154 -> 146 (profiles/r04_b_*)
-    // Small problems (round 5: the ChemicalOCR prefill at M = 4096, N = 576; the last Swin stages): fewer 320 x 256 tiles than a third of the
-    // CUs leave most of the chip idle (o_proj of the prefill: 32 workgroups, 80 us for 2.7 GFLOP) - they take the 256 x 128 / 128 x 128
+    // Small problems (round 5: the ChemicalOCR prefill at M = 4096, N = 576; the last Swin stages): fewer 320 x 256 tiles than
+    // CUs leave part of the chip idle (o_proj of the prefill: 32 workgroups, 80 us for 2.7 GFLOP) - they take the 256 x 128 / 128 x 128
     // kernels, whose grids are 2.5 - 5 x larger.  Every output element is the same k-ascending chain of MFMAs in all tile kernels.
     static int small_env = -1;
-    if (small_env < 0) { const char* e = getenv("MG_GEMM_SMALL"); small_env = e ? atoi(e) : 1; }
+    if (small_env < 0) { const char* e = getenv("MG_GEMM_SMALL"); small_env = e ? atoi(e) : 256; if (small_env == 1) small_env = 256; }      // (the tile-count threshold: fewer 320 x 256 tiles than CUs; 0: off.  96 -> 256: OCSR branch at 32 images 10.55 -> 9.68 ms, OCR tower + prefill 17.99 -> 17.84 ms)
     const long tiles_xl = (long)((a.M + 319) / 320) * ((a.N + GX_N - 1) / GX_N);
     // (not for the main encoder's deferred-RMSNorm chain - gain / partial sums / row scales: its GEMMs of one geometry stay on ONE kernel family,
     //  with or without the live-row-tile list, so that the list changes no bits)
-    const bool small = gv == 3 && small_env && tiles_xl < 96 && epi != EPI_PK_GELU && !a.row_tiles && !a.part && !a.gain && !a.rs.part;
+    const bool small = gv == 3 && small_env && tiles_xl < small_env && epi != EPI_PK_GELU && !a.row_tiles && !a.part && !a.gain && !a.rs.part;
     if (!small && (gv == 3 || gv == 5 || gv == 6) && a.M >= 320 && a.N >= GX_N) {        // ping-pong persistent kernel, TI = 4 (variant 5) / 5
         if (gemm_pp(a, epi, gv == 5 ? 4 : 5, stream)) return;
     }
@@ -488,7 +488,7 @@ void gemm(const GemmArgs& a, int epi, mgStream_t stream) {
         }
     }
     const long tiles_w = (long)((a.M + GW_M - 1) / GW_M) * ((a.N + GW_N - 1) / GW_N);
-    if (gv >= 1 && a.M >= GW_M && !(small && tiles_w < 96)) {
+    if (gv >= 1 && a.M >= GW_M && !(small && tiles_w < 96)) {      // (fewer than 96 of the 256 x 128 tiles as well: the 128 x 128 kernel)
         switch (epi) {
             case EPI_F32_STORE: launch_wide<EPI_F32_STORE>(a, stream); break;
             case EPI_F32_RESID: launch_wide<EPI_F32_RESID>(a, stream); break;

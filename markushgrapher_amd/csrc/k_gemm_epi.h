@@ -181,7 +181,7 @@ MG_DEV void tile_epilogue(const GemmArgs& a, const f32x16& acc_in, int m0, int n
         }
     } else if constexpr (EPI == EPI_PK || EPI == EPI_PK_RELU || EPI == EPI_PK_GELU || EPI == EPI_PK_BIAS || EPI == EPI_PK_GELU_ERF) {
         f32x16 v = acc;
-        if constexpr (EPI == EPI_PK_BIAS || EPI == EPI_PK_GELU_ERF) {
+        if constexpr (EPI == EPI_PK_BIAS || EPI == EPI_PK_GELU_ERF || EPI == EPI_PK_GELU) {      // (EPI_PK_GELU: bias optional - the ChemicalOCR tower's fc1)
             static_assert(TOR, "bias epilogues use D = W·X^T (a lane owns a token, its registers are output features)");
             if (a.bias) {          // register 4g + i holds feature n0 + 8g + 4 half + i: one 16-byte load per group (N is a multiple of 4)
 #pragma unroll

@@ -22,7 +22,7 @@ enum GemmEpi : int {
     // decode-step kernels only (gemm_rows): W rows interleaved gate_0, up_0, gate_1, up_1, ...; out_pk packed [M][N/2] =
     // bf16(silu(r g_j) * (r u_j)) with r the deferred RMSNorm scale of the row (Llama MLP, modeling_llama.py LlamaMLP)
     EPI_PK_SWIGLU = 6,
-    // large-M tile kernel only (gemm_has_gelu_epilogue): out_pk packed [M][N] = bf16(gelu_tanh(acc))   (vision-tower MLP, SiglipMLP)
+    // large-M tile kernel only (gemm_has_gelu_epilogue): out_pk packed [M][N] = bf16(gelu_tanh(acc + bias[n])), bias null = 0   (vision-tower MLP, SiglipMLP)
     EPI_PK_GELU = 7,
     // OCSR vision branch (Swin, swin.hip): projections with a bias vector.  out_pk packed [M][N] = bf16(acc + bias[n]) and
     // bf16(gelu_erf(acc + bias[n])) (exact erf form: SwinMLP / hidden_act "gelu", stock modeling_swin.py:471-483); bias null = 0

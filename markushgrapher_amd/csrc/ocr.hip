@@ -214,12 +214,15 @@ void image_features(const mg_ocr_model* m, const Ws& w, const float* pix, const 
         GemmArgs o = ga(w.vctx, m->at<uint16_t>(l.wo), MV, vh, vh);
         if (tiled) { o.out_f32 = w.vht; gemm(o, EPI_RESID_NORM, st); }
         else { o.out_f32 = w.vh; o.ldo = vh; gemm(o, EPI_F32_RESID, st); }
-        layer_norm(false, m->rawp(p + "layer_norm2.weight"), m->rawp(p + "layer_norm2.bias"), m->rawp(p + "mlp.fc2.bias"), w.vx, nullptr, m->vka);
-        GemmArgs f1 = ga(w.vx, m->at<uint16_t>(l.fc1), MV, vi, m->vka);
+        // fc1: K = v_hidden, its bias in the epilogue (the QKV projection keeps its bias in the constant-one column of K: the per-head epilogue has no
+        // bias slot) - K = 768 is a multiple of the ping-pong kernel's 128 where 832 is not: 218 -> us per launch at 32 pages
+        layer_norm(false, m->rawp(p + "layer_norm2.weight"), m->rawp(p + "layer_norm2.bias"), m->rawp(p + "mlp.fc2.bias"), w.vx, nullptr, vh);
+        GemmArgs f1 = ga(w.vx, m->at<uint16_t>(l.fc1), MV, vi, vh);
+        f1.bias = m->rawp(p + "mlp.fc1.bias");
         if (gemm_has_gelu_epilogue(MV, vi)) {          // GELU in the GEMM epilogue: no fp32 round trip of [rows][v_inter]
             f1.out_pk = w.vy;
             gemm(f1, EPI_PK_GELU, st);
-        } else {                                       // small shapes (test fixtures): fp32 store + activation kernel
+        } else {                                       // small shapes (test fixtures): fp32 store (+ bias) + activation kernel
             f1.out_f32 = w.vtmp; f1.ldo = vi;
             gemm(f1, EPI_F32_STORE, st);
             ocr_gelu_pack(w.vtmp, w.vy, MV, vi, vi, st);
@@ -494,7 +497,7 @@ int mg_ocr_finalize(mg_ocr_model* m, void* stream) {
         pack(p + "self_attn.k_proj.weight", l.wqkv, vh, vh, vh, m->vka, p + "self_attn.k_proj.bias", 1.f, vh);
         pack(p + "self_attn.v_proj.weight", l.wqkv, 2 * vh, vh, vh, m->vka, p + "self_attn.v_proj.bias", 1.f, round_up(3 * vh, 32) - 2 * vh);
         pack(p + "self_attn.out_proj.weight", l.wo, 0, vh, vh, vh, "", 1.f, round_up(vh, 32));
-        pack(p + "mlp.fc1.weight", l.fc1, 0, vi, vh, m->vka, p + "mlp.fc1.bias", 1.f, round_up(vi, 32));
+        pack(p + "mlp.fc1.weight", l.fc1, 0, vi, vh, vh, "", 1.f, round_up(vi, 32));              // (bias: epilogue of the projection)
         pack(p + "mlp.fc2.weight", l.fc2, 0, vh, vi, vi, "", 1.f, round_up(vh, 32));
     }
     const int F = vh * c.scale_factor * c.scale_factor;

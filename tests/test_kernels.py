@@ -372,6 +372,32 @@ def test_attention_decoder_self_and_cross(be_name):
 
 
 @pytest.mark.parametrize("be_name", BACKENDS)
+@pytest.mark.parametrize("B,H,S", [(1, 2, 256), (8, 3, 512)])
+def test_attention_without_bias_over_full_rows(be_name, B, H, S):
+    """Bias-free attention over full rows of keys with no mask (the ChemicalOCR vision tower: every frame's patches attend all of them) takes the
+    encoder's second-form kernel without its bias path (attention_enc_kernel<.., PLAIN>): against numpy, and against the first-form kernel the
+    same call takes when a key mask is passed (all ones)."""
+    if be_name == "emu" and B > 1:
+        B, S = 2, 256
+    be = get_backend(be_name)
+    q, k, v = [pk.bf16_round(rnd((B, H, S, 64), 70 + i, 0.5)) for i in range(3)]
+    ref = np.zeros((B, H, S, 64), np.float32)
+    for b in range(B):
+        for h in range(H):
+            ref[b, h] = softmax_ref(q[b, h] @ k[b, h].T) @ v[b, h]
+    Q, K, V = be.buf(pack_heads_rows(q)), be.buf(pack_heads_rows(k)), be.buf(pack_heads_t(v))
+    out = []
+    for mask in (None, np.ones((B, S), np.uint8)):
+        ctx = be.zeros((B * S * H * 64,), np.uint16)
+        assert be.lib.mgk_attention(be.stream, 2, be.p(Q), be.p(K), be.p(V), be.p(ctx), B, H, S, S, S, S,
+                                    be.p(be.buf(mask)) if mask is not None else None, None, 0, None, None, None, None, None, None, None) == 0
+        out.append(pk.unpack_tiles(ctx.numpy(), B * S, H * 64).reshape(B, S, H, 64).transpose(0, 2, 1, 3).copy())
+    np.testing.assert_allclose(out[0], ref, rtol=0, atol=2e-2)
+    np.testing.assert_allclose(out[1], ref, rtol=0, atol=2e-2)
+    assert np.abs(out[0] - out[1]).max() < 1e-2
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
 @pytest.mark.parametrize("group", [1, 5])
 def test_attention_step(be_name, group):
     be = get_backend(be_name)
