@@ -98,7 +98,8 @@ def cpu_baseline(shape, sd, L=128, new_tokens=128, sample_steps=8, reps=3):
 def ocr_stage_run(B=32, new_tokens=256):
     """SURVEY.md §8 row f-1 (BASELINE configs[4] names the stage): ChemicalOCR = an Idefics3-class VLM, SmolDocling-256M geometry
     (INFERRED), one 512-px page per sequence, greedy.  EOS cannot occur (eos id -1), so the work is fixed: vision tower +
-    prompt prefill + `new_tokens` KV-cached steps.  Vision tower and prefill are in their first form (one kernel per operation); the decode step runs on the main path's
+    prompt prefill + `new_tokens` KV-cached steps.  Vision tower and prefill are in their second form (tiled fp32 residual streams, residual projections on the batched epilogue, tile-wise LayerNorm / RMSNorm,
+    the tower's attention on the encoder's second-form kernel without its bias path); the decode step runs on the main path's
     deferred-RMSNorm kernels, 4 launches per layer, replayed as a HIP graph."""
     import dataclasses
     import torch
@@ -156,7 +157,7 @@ def ocr_stage_run(B=32, new_tokens=256):
             "vision_plus_prefill_ms": round(t1 * 1e3, 2), "decode_step_ms": round(step_ms, 4),
             "dec_hbm_frac": round((wbytes + kvbytes) / (step_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
             "config": "ChemicalOCR stage alone: SmolDocling-256M geometry (INFERRED), recipe weights, one 512-px page per sequence, "
-                      "greedy, EOS impossible; vision tower / prefill: one kernel per operation with fp32 intermediates; decode step: 4 launches per layer at one row tile (rotary grouped-query attention + cache append, o_proj + norm, gate/up + SwiGLU, [down_proj + norm | next QKV]), replayed as a HIP graph"}
+                      "greedy, EOS impossible; vision tower / prefill: second form (tiled fp32 residual streams + batched residual epilogue, tile-wise LayerNorm / RMSNorm, bias-free attention on the encoder's second-form kernel); decode step: 4 launches per layer at one row tile (rotary grouped-query attention + cache append, o_proj + norm, gate/up + SwiGLU, [down_proj + norm | next QKV]), replayed as a HIP graph"}
 
 
 def configs4_run(eng, B, new_tokens, ocr_pages=128, n_scripts=32, ocr_slots=0, main_inflight=1, ocr_inflight=1, main_batch=None, overlap_slab=0):
