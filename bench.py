@@ -282,9 +282,10 @@ def pmc_traffic(args, nb=1):
             return None
         rows = sqlite3.connect(db).execute(
             "select kernel_name, value from counters_collection where counter_name = 'FETCH_SIZE'").fetchall()
-        xa = [v for n, v in rows if "attn_step_kernel<1, 8, true" in n]
+        xa = [v for n, v in rows if "attn_step_kernel<1, 8, true" in n or "xattn_stream_kernel" in n]
         xa = [v for v in xa if v > 0.5 * max(xa)] if xa else xa          # (the launches of the call itself)
-        dec = [v for n, v in rows if any(k in n for k in ("attn_step_kernel", "gemm_rows", "greedy_select", "embed_norm_rows"))]
+        dec = [v for n, v in rows if any(k in n for k in ("attn_step_kernel", "gemm_rows", "greedy_select", "embed_norm_rows", "xattn_stream_kernel",
+                                                         "xq_expand_kernel", "xctx_contract_kernel"))]
         if not xa or not dec:
             return None
         return {"cross_attention_bytes_per_launch": int(sum(xa) / len(xa) * 1024 * 2),
@@ -652,11 +653,15 @@ def main():
             _, msk = eng.encode(q["input_ids"], q["bbox"], q["attention_mask"], eng.preprocess(q["pages_u8"]))
             xl.append(msk.sum(dim=1).cpu().numpy().astype(np.float64))
         xlen = np.concatenate(xl)
+        absorbed = bool(eng.cross_absorb) and args.beams == 1
         traffic = None if (args.no_pmc or world > 1 or args.beams != 1) else pmc_traffic(args, int(round(nb_first)))
         def make_roof(n_l, ms, keys, empty_ms, with_traffic):
             if n_l.value <= 0:
                 return None
-            bytes_per_launch = keys.value / n_l.value * H * 64 * 2 * 2     # K and V rows of 64 bf16, all heads
+            survey_bytes = keys.value / n_l.value * H * 64 * 2 * 2         # K and V rows of 64 bf16, all heads
+            # weight-absorbed form (mg_set_cross_absorb, the default for greedy calls): the launch streams the attended encoder states
+            # themselves, d bf16 per position - the bytes the kernel MOVES; `frac` is on these
+            bytes_per_launch = keys.value / n_l.value * d * 2 if absorbed else survey_bytes
             raw_s = ms.value / n_l.value * 1e-3            # e0 -> e1 around the launch
             empty_s = empty_ms.value / n_l.value * 1e-3    # e1 -> e2 with nothing in between: cost of the bracket itself
             # The bracket over-reads the kernel by the dispatch latency behind the first record (rocprofv3 kernel trace of
@@ -666,17 +671,24 @@ def main():
             if with_traffic:
                 r.update({"traffic": traffic["cross_attention_bytes_per_launch"] if traffic else None, "traffic_unit": "bytes/launch",
                           "traffic_source": traffic["source"] if traffic else None,
-                          "kernel": "attn_step_kernel<1, 8, true> (decoder cross-attention, single query per image/head)"})
-            r.update({"bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(raw_s * 1e6, 2),
+                          "kernel": ("xattn_stream_kernel<16> (decoder cross-attention, weight-absorbed: one stream of the encoder states per layer, "
+                                     "scores and context on MFMA)") if absorbed else
+                                    "attn_step_kernel<1, 8, true> (decoder cross-attention, single query per image/head)"})
+            r.update({"bytes_per_launch": int(bytes_per_launch), "survey_bytes_per_launch": int(survey_bytes),
+                      "bytes_note": ("bytes_per_launch = bytes the launch moves (sum of attended positions x 2 d_model: the weight-absorbed form reads the encoder "
+                                     "states once per layer); survey_bytes_per_launch = SURVEY.md 8d's K + V formula (4 H d_kv per position), which the form no longer moves; "
+                                     "achieved / frac are on bytes_per_launch") if absorbed else "K and V rows of every attended position (SURVEY.md 8d)", "avg_launch_us": round(raw_s * 1e6, 2),
                       "empty_bracket_us": round(empty_s * 1e6, 2), "launches_timed": int(n_l.value)})
             return r
 
         # F_enc = N_enc*S*(8d^2 + 4*d*dff + 4*S*d) + 2*P*768*d;  F_xkv = N_dec*S_x*4d^2  (per image, S = attended positions)
         f_enc = float(np.sum(n_enc * xlen * (8 * d * d + 4 * d * dff + 4 * xlen * d) + 2 * P * (shape.num_channels * shape.patch_size ** 2) * d)) / n_pool
-        f_xkv = float(np.sum(n_dec * xlen * 4 * d * d)) / n_pool
+        # cross-K/V projections: executed only in the K / V form (the absorbed form needs none: the layers read the states themselves)
+        f_xkv = 0.0 if absorbed else float(np.sum(n_dec * xlen * 4 * d * d)) / n_pool
         tbar = (new_tokens - 1) / 2.0
         # Bytes_step = 2*(N_dec*16d^2 + d*V) + sum_b 2*N_dec*2*d*(S_x + t);  F_step = N_dec*(12d^2 + 4*d*dff) + N_dec*4*d*(S_x+t) + 2*d*V
-        bytes_step = 2.0 * (n_dec * 16 * d * d + d * V) + float(np.sum(2 * n_dec * 2 * d * (xlen + tbar))) / n_pool
+        # (absorbed form: one stream of d bf16 per attended position and layer instead of K and V)
+        bytes_step = 2.0 * (n_dec * 16 * d * d + d * V) + float(np.sum(n_dec * 2 * d * ((1 if absorbed else 2) * xlen + 2 * tbar))) / n_pool
         f_step = float(np.sum(n_dec * (12 * d * d + 4 * d * dff) + n_dec * 4 * d * (xlen + tbar) + 2 * d * V)) / n_pool
 
         # a call that holds nb batches streams the weights once per step and every batch's K/V

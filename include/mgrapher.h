@@ -191,6 +191,16 @@ int mg_set_padding_semantics(mg_model* m, int per_image);
  * hence off by default).  Same kernels, same results.  Takes effect from the context's next call (its captured decode step is dropped).
  * Returns the previous setting.  No counterpart in the reference (one batch at a time, utils_evaluation.py:269-285). */
 int mg_set_shared_gpu(mg_model* m, int shared);
+/* Cross-attention of the greedy decode step (num_beams = 1, batch and queue forms).  absorb = 1 (default wherever the geometry has the
+ * form: d_model a supported multiple of 64, at most 16 heads): weight-absorbed - with K_l = enc·Wk_l^T, V_l = enc·Wv_l^T (stock
+ * transformers models/udop/modeling_udop.py:524-550, reached from /root/reference/markushgrapher/utils/ocsr/utils_evaluation.py:278-281)
+ * softmax(q_h K_h^T) V_h = [softmax((q_h·Wk_h) enc^T) enc]·Wv_h^T, so every layer streams the attended encoder states (2·d_model bytes per
+ * position) instead of its own K and V (4·d_model): half the dominant HBM stream of decoding, no cross-K/V projections after the
+ * encoder, no per-layer K/V buffers (the workspace shrinks; sizes are computed for the current setting).  absorb = 0: the K / V form
+ * (what beam search always uses).  key_splits in 1..4: workgroups per decode row of the stream (0 keeps the setting).  The two forms
+ * round at different points (q' = q·Wk_h and the normalised context are rounded to bf16 instead of K and V): logits agree within the
+ * stated tolerance, not bitwise.  Takes effect from the context's next call.  Returns the previous `absorb`; absorb < 0 only queries. */
+int mg_set_cross_absorb(mg_model* m, int absorb, int key_splits);
 /* 1 if the last mg_generate replayed a captured graph, 0 if it launched eagerly (mode 0/2, capture unavailable). */
 int mg_decode_graph_active(const mg_model* m);
 
@@ -265,6 +275,14 @@ int mgk_attention_enc_skip(void* stream, const void* Q, const void* K, const voi
                            uint8_t* qbv_scratch);
 int mgk_attention_step(void* stream, const void* q, const void* Kc, const void* Vc, void* ctx_pk, int rows, int H,
                        int group, int cap, const int* len, int n_keys, const float* bias, const int* anc, int t);
+/* Weight-absorbed cross-attention of one decoder layer and step (mg_set_cross_absorb; kernels of markushgrapher_amd/csrc/k_xattn.hip):
+ * ctx[row][h] = softmax(q_h (enc Wk_h^T)^T) (enc Wv_h^T) (stock modeling_udop.py:524-575 without a position bias) evaluated as
+ * [softmax((q_h Wk_h) enc^T) enc] Wv_h^T on the states themselves.  q [rows][H][64] bf16; wkv fp32 [2*H*64][d], K rows first;
+ * enc [owners][cap][d] bf16; len [owners] keys per owner; kv_owner [rows] (null: row r reads owner r); scratch wk, wv (H*d*64 bf16
+ * each), qx (rows*H*d bf16), part (rows*nsplit*H*d fp32), ml (rows*nsplit*H*2 fp32); ctx_pk packed [rows padded to 32][H*64]. */
+int mgk_xattn(void* stream, const void* q, const float* wkv, const void* enc, const int* len, const int* kv_owner, int rows, int H, int d,
+              int cap, int nsplit, int nstg, void* wk, void* wv, void* qx, float* part, float* ml, void* ctx_pk);
+int mgk_enc_rows(void* stream, const void* src_pk, const int* row_map, void* dst, int B, int rows_per_image, int cap, int d);
 int mgk_embed_assemble(void* stream, void* meta_ws, const int64_t* input_ids, const float* bbox,
                        const uint8_t* attention_mask, const float* patch_emb, const void* tok_emb, const void* x_emb,
                        const void* y_emb, int B, int L, int P, int d, int n_side, int M2, int V, int S_cap,

@@ -142,6 +142,31 @@ int mgk_attention_step_trace(void* stream, const void* q, const void* Kc, const 
 }
 #endif
 
+// Weight-absorbed cross-attention of the greedy decode step (k_xattn.hip), the three launches of a layer + the weight re-ordering:
+// q [rows][H][64] bf16, wkv fp32 [2*H*64][d] (K rows first), enc [owners][cap][d] bf16 natural rows, len [owners], kv_owner [rows]
+// (nullable).  Scratch: wk, wv [H*d*64] bf16 each, qx [rows][H][d] bf16, part [rows][nsplit][H][d] fp32, ml [rows][nsplit][H][2] fp32.
+// Result: ctx_pk packed [rows padded to 32][H*64] bf16.
+int mgk_xattn(void* stream, const void* q, const float* wkv, const void* enc, const int* len, const int* kv_owner, int rows, int H, int d,
+              int cap, int nsplit, int nstg, void* wk, void* wv, void* qx, float* part, float* ml, void* ctx_pk) {
+    if (!xattn_supported(d, H) || nsplit < 1 || nsplit > 4 || nstg < 2 || nstg > 4) return MG_E_UNSUPPORTED;
+    mgStream_t st = (mgStream_t)stream;
+    xattn_pack_weights(wkv, (uint16_t*)wk, (uint16_t*)wv, H, d, st);
+    xattn_stream_prepare(d, nstg);
+    XAttnArgs a{};
+    a.q = (const uint16_t*)q; a.qx = (uint16_t*)qx; a.wk = (const uint16_t*)wk; a.wv = (const uint16_t*)wv; a.enc = (const uint16_t*)enc;
+    a.len = len; a.kv_owner = kv_owner; a.part = part; a.ml = ml; a.ctx = (uint16_t*)ctx_pk;
+    a.rows = rows; a.H = H; a.d = d; a.cap = cap; a.nsplit = nsplit; a.nstg = nstg;
+    xattn_expand(a, st);
+    xattn_stream(a, st);
+    xattn_contract(a, st);
+    return MG_OK;
+}
+// rows of a packed [B*rows_per_image][d] bf16 operand -> natural rows dst[b][row_map[r]][d] (k_xattn.hip enc_rows)
+int mgk_enc_rows(void* stream, const void* src_pk, const int* row_map, void* dst, int B, int rows_per_image, int cap, int d) {
+    enc_rows((const uint16_t*)src_pk, row_map, (uint16_t*)dst, B, rows_per_image, cap, d, (mgStream_t)stream);
+    return MG_OK;
+}
+
 size_t mgk_embed_meta_bytes(int B, int S_cap) { return embed_meta_bytes(B, S_cap); }
 
 int mgk_embed_assemble(void* stream, void* meta_ws, const int64_t* input_ids, const float* bbox,

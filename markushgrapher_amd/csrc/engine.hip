@@ -38,10 +38,12 @@ void e1_info(const mg_e1_model* m, int* tokens, int* d_model, int* src_image_siz
 namespace {
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 int round_up(int x, int a) { return (x + a - 1) / a * a; }
+bool use_absorb(const mg_model* m, int K);
 
 struct EncLayer { size_t wqkv, wo, ln0, wi, wo2, ln1; };
 // xq2 / wi2: product weights of the decode step (built by mg_finalize): [Wxq·G1 | Wxq·G1·Wo] and [Wi·G2 | Wi·G2·Wxo]
-struct DecLayer { size_t wqkv, wo, ln0, xq, xkv, xo, ln1, wi, wo2, ln2, xq2, wi2; };
+// xwk / xwv: absorbed cross-attention weights (k_xattn.hip): Wk_h feature-major, Wv_h in fragment order
+struct DecLayer { size_t wqkv, wo, ln0, xq, xkv, xo, ln1, wi, wo2, ln2, xq2, wi2, xwk, xwv; };
 
 }  // namespace
 
@@ -99,6 +101,9 @@ struct mg_model {
     std::vector<float> beam_div_host;
     int use_graph = 1;
     bool graph_active = false;
+    // Greedy decoding with the weight-absorbed cross-attention (k_xattn.hip): a layer streams the encoder states once instead of its K and V.
+    // absorb: 1 (default where the geometry is supported), 0: the K / V form for every call (A/B runs, MG_XATTN_ABSORB=0).  Beam search keeps the K / V form.
+    int absorb = 1, xa_split = 1, xa_stages = 4;
     int shared_gpu = 0;       // mg_set_shared_gpu: other contexts run beside this one (the cross-attention stream keeps one workgroup per CU resident)
     // optional phase timing of mg_generate (HIP events): [start, encoder + cross-K/V done, decode loop done]
     bool phase_on = false;
@@ -270,6 +275,9 @@ struct Ws {
     size_t e1_ws_bytes;
     // decode (generate)
     uint16_t *xk, *xv, *sk, *sv, *dq, *dx_pk, *dy_pk;
+    // weight-absorbed cross-attention (greedy): the states the decoder attends [B][Sx_cap][d], q' [rows][H][d], context partials
+    uint16_t *encx, *qx;
+    float *xpart, *xml;
     uint16_t *xa, *xb;        // packed [rows][d + inner] operand windows of the pair projections: [bf16(h) | attention context]
     float *dh, *logits, *slabs, *rs_part, *rs_part1, *rs_part2;
     float4* ptop;             // fused greedy tail: per-workgroup top-2 partials of the lm_head launch [rows][V/32]
@@ -347,8 +355,16 @@ void carve(const mg_model* m, char* base, int B, int L, int K, int max_len, int 
     if (max_len > 0) {
         const int R = B * K, Rp = round_up(R, 32);
         const size_t nl = m->dec.size();
-        w->xk = c.take<uint16_t>(nl * B * H * Sx_cap * 64);
-        w->xv = c.take<uint16_t>(nl * B * H * Sx_cap * 64);
+        w->xk = w->xv = w->encx = w->qx = nullptr; w->xpart = w->xml = nullptr;
+        if (use_absorb(m, K)) {
+            w->encx = c.take<uint16_t>((size_t)B * Sx_cap * d);
+            w->qx = c.take<uint16_t>((size_t)Rp * H * d);
+            w->xpart = c.take<float>((size_t)Rp * m->xa_split * H * d);
+            w->xml = c.take<float>((size_t)Rp * m->xa_split * H * 2);
+        } else {
+            w->xk = c.take<uint16_t>(nl * B * H * Sx_cap * 64);
+            w->xv = c.take<uint16_t>(nl * B * H * Sx_cap * 64);
+        }
         w->sk = c.take<uint16_t>(nl * R * H * (size_t)m->T_cap * 64);
         w->sv = c.take<uint16_t>(nl * R * H * (size_t)m->T_cap * 64);
         w->dq = c.take<uint16_t>((size_t)Rp * inner);
@@ -404,7 +420,9 @@ void carve(const mg_model* m, char* base, int B, int L, int K, int max_len, int 
 // (every image below it has finished: its pool entry may be overwritten), [8] N
 struct StreamWs {
     Ws enc;                   // encoder workspace of one chunk
-    uint16_t *xk, *xv;        // K/V pool [layer][pool entry][H][Sx_cap][64]
+    uint16_t *xk, *xv;        // K/V pool [layer][pool entry][H][Sx_cap][64]  (absorbed form: null; encx = pool of encoder states [pool entry][Sx_cap][d])
+    uint16_t *encx, *qx;
+    float *xpart, *xml;
     size_t pool_stride;       // elements between layers
     int* xlen_pool;           // [pool entries]
     uint16_t *sk, *sv, *dq, *dx_pk, *dy_pk, *xa, *xb;
@@ -428,8 +446,16 @@ void carve_stream(const mg_model* m, char* base, int chunk, int L, int slots_img
     const int Sx_cap = round_up(L + m->P, 64) + round_up(m->e1_M, 64), Rp = round_up(slots, 32);      // keys of an image: [e1 tokens | encoder positions]
     const size_t nl = m->dec.size(), entries = (size_t)pool_chunks * chunk;
     w->pool_stride = entries * H * Sx_cap * 64;
-    w->xk = c.take<uint16_t>(nl * w->pool_stride);
-    w->xv = c.take<uint16_t>(nl * w->pool_stride);
+    w->xk = w->xv = w->encx = w->qx = nullptr; w->xpart = w->xml = nullptr;
+    if (use_absorb(m, K)) {
+        w->encx = c.take<uint16_t>(entries * Sx_cap * d);
+        w->qx = c.take<uint16_t>((size_t)Rp * H * d);
+        w->xpart = c.take<float>((size_t)Rp * m->xa_split * H * d);
+        w->xml = c.take<float>((size_t)Rp * m->xa_split * H * 2);
+    } else {
+        w->xk = c.take<uint16_t>(nl * w->pool_stride);
+        w->xv = c.take<uint16_t>(nl * w->pool_stride);
+    }
     w->xlen_pool = c.take<int>(entries);
     w->sk = c.take<uint16_t>(nl * slots * H * (size_t)m->T_cap * 64);
     w->sv = c.take<uint16_t>(nl * slots * H * (size_t)m->T_cap * 64);
@@ -497,6 +523,9 @@ __global__ __launch_bounds__(64) void stream_ready_kernel(int n, int* ctr) {
     if (threadIdx.x == 0) ctr[5] += n;
 }
 
+// greedy calls stream the encoder states (k_xattn.hip); beam search keeps the per-layer K / V streams (its G rows of an image share one pass)
+bool use_absorb(const mg_model* m, int K) { return m->absorb != 0 && K == 1; }
+
 int check_launch(const char* what) {
     const int e = mg_peek_error();
     if (e != 0) {
@@ -554,6 +583,9 @@ void ffn_block(const mg_model* m, bool rows_mode, float* hidden, uint16_t* x_pk,
 // decoding: `slots.pos` non-null, every row at its own position on its own image, K/V streams in a pool).
 struct DecodeCtx {
     uint16_t *xk, *xv;        // cross K/V: [layer][owner][H][Sx_cap][64]
+    // absorbed form (encx non-null): the attended encoder states [owner][Sx_cap][d] + the scratch of the three launches
+    uint16_t *encx, *qx;
+    float *xpart, *xml;
     size_t xkv_stride;        // elements between layers
     int Sx_cap;
     const int* xlen;          // keys per K/V owner
@@ -659,13 +691,21 @@ static void decode_step(mg_model* m, const DecodeCtx& c, int t, const int* tdev,
         x.live = live; x.kv_owner = (K > 1 && stream) ? c.bpool : c.slots.pool;
         x.one_wg_per_cu = m->shared_gpu;       // (beams: one owner per image slot = group of K rows)
         const bool timed = time_cross && m->prof_used + 3 <= m->prof_ev.size();
+        XAttnArgs xa{};
+        if (c.encx) {      // weight-absorbed form: q' = q·Wk_h | stream of the states | ctx_h = c_h·Wv_h^T   (the bracket times the stream)
+            xa.q = c.dq; xa.qx = c.qx; xa.wk = m->at<uint16_t>(l.xwk); xa.wv = m->at<uint16_t>(l.xwv); xa.enc = c.encx; xa.len = c.xlen;
+            xa.kv_owner = c.slots.pool; xa.live = live; xa.qrs = rs1; xa.part = c.xpart; xa.ml = c.xml; xa.ctx = c.xb; xa.ctx_ld = K2; xa.ctx_col0 = d;
+            xa.rows = R; xa.H = H; xa.d = d; xa.cap = Sx_cap; xa.nsplit = m->xa_split; xa.nstg = m->xa_stages;
+            if (!(whatif & 8)) xattn_expand(xa, st);
+        }
         if (timed) mg_event_record(m->prof_ev[m->prof_used], st);
-        if (!(whatif & 8)) attention_step(x, st);
+        if (!(whatif & 8)) { if (c.encx) xattn_stream(xa, st); else attention_step(x, st); }
         if (timed) {   // third event right behind the second: the empty bracket calibrates what two records alone cost
             mg_event_record(m->prof_ev[m->prof_used + 1], st);
             mg_event_record(m->prof_ev[m->prof_used + 2], st);
             m->prof_used += 3;
         }
+        if (c.encx && !(whatif & 8)) xattn_contract(xa, st);
         {   // h += Wxo·ctx_x (partials -> rs2)   |   y = relu(wi·...) un-normalised -> dy_pk
             ResidArgs r{};
             r.X = c.xb; r.x_kts = kts2; r.x_k0 = kt_ctx; r.W = m->at<uint16_t>(l.xo); r.h = c.dh; r.part = c.rs_part2;
@@ -758,6 +798,10 @@ int mg_create(const mg_config* cfg, mg_model** out) {
     { const char* e = getenv("AMD_DIRECT_DISPATCH"); if (e && e[0] == '0') m->use_graph = 0; }
     { const char* e = getenv("MG_ENC_ROW_TILES"); if (e && e[0] == '0') m->row_tiles = false; }
     { const char* e = getenv("MG_DECODE_FUSED_TAIL"); if (e && e[0] == '0') m->fused_tail = false; }
+    { const char* e = getenv("MG_XATTN_ABSORB"); if (e && e[0] == '0') m->absorb = 0; }
+    { const char* e = getenv("MG_XATTN_SPLIT"); if (e && atoi(e) >= 1 && atoi(e) <= 4) m->xa_split = atoi(e); }
+    { const char* e = getenv("MG_XATTN_STAGES"); if (e && atoi(e) >= 2 && atoi(e) <= 4) m->xa_stages = atoi(e); }
+    if (!xattn_supported(c.d_model, c.num_heads)) m->absorb = 0;
     // arena layout
     size_t off = 0;
     auto take = [&](size_t bytes) { off = align_up(off, 256); size_t o = off; off += bytes; return o; };
@@ -787,10 +831,11 @@ int mg_create(const mg_config* cfg, mg_model** out) {
         l.ln1 = take((size_t)d * 4);
         l.wi = take(pk_elems(dff, d) * 2); l.wo2 = take(pk_elems(d, dff) * 2); l.ln2 = take((size_t)d * 4);
         l.xq2 = take(pk_elems(inner, d + inner) * 2); l.wi2 = take(pk_elems(dff, d + inner) * 2);
+        l.xwk = take((size_t)H * d * 64 * 2); l.xwv = take((size_t)H * d * 64 * 2);
         m->dec.push_back(l);
     }
     {   // fp32 scratch of mg_finalize (unpacked factors and one product)
-        const size_t nmax = (size_t)(dff > inner ? dff : inner);
+        const size_t nmax = (size_t)(dff > 2 * inner ? dff : 2 * inner);
         m->fin_a = take(nmax * d * 4); m->fin_b = take((size_t)d * inner * 4); m->fin_c = take(nmax * (d + inner) * 4);
     }
     m->arena_bytes = align_up(off, 256);
@@ -824,6 +869,7 @@ int mg_clone(const mg_model* src, mg_model** out) {
     m->fin_a = src->fin_a; m->fin_b = src->fin_b; m->fin_c = src->fin_c;
     m->use_graph = src->use_graph; m->enc_mode = src->enc_mode; m->enc_mask = src->enc_mask;
     m->row_tiles = src->row_tiles; m->trim_padding = src->trim_padding; m->fused_tail = src->fused_tail; m->tied = src->tied;
+    m->absorb = src->absorb; m->xa_split = src->xa_split; m->xa_stages = src->xa_stages;
     m->e1m = src->e1m; m->e1_M = src->e1_M;
     *out = m;
     return MG_OK;
@@ -1026,7 +1072,13 @@ int mg_finalize(mg_model* m, void* stream) {
             scale_cols_f32(A, m->at<float>(l.ln2), C, dff, d, K2, st);
             gemm_f32_scaled(A, m->at<float>(l.ln2), Bm, C + d, dff, d, inner, K2, st);
             pack_weight(C, 0, dff, K2, m->at<uint16_t>(l.wi2), round_up(dff, 32), st);
+            // absorbed cross-attention weights (exact re-orderings of the bf16 K / V weights)
+            if (xattn_supported(d, m->H)) {
+                unpack_weight(m->at<uint16_t>(l.xkv), A, 2 * inner, d, st);
+                xattn_pack_weights(A, m->at<uint16_t>(l.xwk), m->at<uint16_t>(l.xwv), m->H, d, st);
+            }
         }
+        if (xattn_supported(d, m->H)) xattn_stream_prepare(d, 4);
     }
     mg_stream_sync(st);    // the host tables above must outlive the copies
     const int rc = check_launch("mg_finalize");
@@ -1274,7 +1326,14 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
     // cross-attention K/V of every decoder layer, once per image (stock:524-538), compacted to attended positions; the
     // e1 tokens (if any) occupy rows [0, M_e1) of an image's stream, the attended encoder positions follow (xrow carries
     // the offset) - cross-attention has no positional term, so the order of the keys is immaterial
-    for (size_t li = 0; li < nl; ++li) {
+    const bool absorbed = use_absorb(m, K);
+    if (absorbed) {
+        // weight-absorbed form (k_xattn.hip): the decoder layers stream the attended states themselves - one compaction instead of
+        // 2 x N_dec projections
+        if (M64) enc_rows(w.e1_pk, w.e1_map, w.encx, B, M64, Sx_cap, d, st);
+        enc_rows(w.enc_pk, w.xrow, w.encx, B, S_cap, Sx_cap, d, st);
+    }
+    for (size_t li = 0; li < nl && !absorbed; ++li) {
         if (M64) {
             GemmArgs ke = gemm_args(w.e1_pk, m->at<uint16_t>(m->dec[li].xkv), B * M64, 2 * inner, d);
             set_heads(ke, H, M64, Sx_cap, w.xk + li * xkv_stride, HF_NATURAL, w.xv + li * xkv_stride, HF_NATURAL, nullptr, HF_NONE);
@@ -1317,6 +1376,7 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
     const int* live = (K == 1 && min_length < max_length && !m->dbg_logits && !m->dbg_forced) ? w.unfinished : nullptr;
     DecodeCtx dc{};
     dc.xk = w.xk; dc.xv = w.xv; dc.xkv_stride = xkv_stride; dc.Sx_cap = Sx_cap; dc.xlen = w.xlen;
+    dc.encx = w.encx; dc.qx = w.qx; dc.xpart = w.xpart; dc.xml = w.xml;
     dc.sk = w.sk; dc.sv = w.sv; dc.skv_stride = skv_stride;
     dc.dq = w.dq; dc.dx_pk = w.dx_pk; dc.dy_pk = w.dy_pk; dc.xa = w.xa; dc.xb = w.xb;
     dc.dh = w.dh; dc.logits = w.logits; dc.rs_part = w.rs_part; dc.rs_part1 = w.rs_part1; dc.rs_part2 = w.rs_part2;
@@ -1515,6 +1575,7 @@ static int generate_stream_impl(mg_model* m, void* stream, void* ws, size_t ws_b
     if (es != st) mg_stream_wait_event(es, m->start_ev);      // inputs / workspace are ordered behind the caller's earlier work
     DecodeCtx dc{};
     dc.xk = w.xk; dc.xv = w.xv; dc.xkv_stride = w.pool_stride; dc.Sx_cap = Sx_cap; dc.xlen = w.xlen_pool;
+    dc.encx = w.encx; dc.qx = w.qx; dc.xpart = w.xpart; dc.xml = w.xml;
     dc.sk = w.sk; dc.sv = w.sv; dc.skv_stride = (size_t)R * H * m->T_cap * 64;
     dc.dq = w.dq; dc.dx_pk = w.dx_pk; dc.dy_pk = w.dy_pk; dc.xa = w.xa; dc.xb = w.xb;
     dc.dh = w.dh; dc.logits = w.logits; dc.rs_part = w.rs_part; dc.rs_part1 = w.rs_part1; dc.rs_part2 = w.rs_part2;
@@ -1567,7 +1628,13 @@ static int generate_stream_impl(mg_model* m, void* stream, void* ws, size_t ws_b
         Ws we;
         carve(m, (char*)ws, n, L, 1, 0, 0, m->e1_M, &we);         // the chunk's own carving (a short last chunk uses less of the region)
         const size_t ent_off = (size_t)entry0 * H * Sx_cap * 64;
-        for (size_t li = 0; li < nl; ++li) {
+        const bool absorbed = w.encx != nullptr;
+        if (absorbed) {        // the chunk's attended states into its pool entries (as mg_generate)
+            uint16_t* ex = w.encx + (size_t)entry0 * Sx_cap * d;
+            if (M64) enc_rows(we.e1_pk, we.e1_map, ex, n, M64, Sx_cap, d, es);
+            enc_rows(we.enc_pk, we.xrow, ex, n, S_cap, Sx_cap, d, es);
+        }
+        for (size_t li = 0; li < nl && !absorbed; ++li) {
             if (M64) {          // the e1 tokens of the attached OCSR branch: rows [0, e1_M) of every image's key stream (as mg_generate)
                 GemmArgs ke = gemm_args(we.e1_pk, m->at<uint16_t>(m->dec[li].xkv), n * M64, 2 * inner, d);
                 set_heads(ke, H, M64, Sx_cap, w.xk + li * w.pool_stride + ent_off, HF_NATURAL, w.xv + li * w.pool_stride + ent_off, HF_NATURAL, nullptr, HF_NONE);
@@ -1747,6 +1814,18 @@ int mg_set_shared_gpu(mg_model* m, int shared) {
     m->shared_gpu = shared ? 1 : 0;
     if (m->shared_gpu) attention_step_allow_shared();
     if (prev != m->shared_gpu) { m->step_graph.reset(); m->stream_graph.reset(); }      // (the captured launches carry the LDS request)
+    return prev;
+}
+int mg_set_cross_absorb(mg_model* m, int absorb, int key_splits) {
+    if (!m) return fail(MG_E_ARG, "mg_set_cross_absorb: null model");
+    if (key_splits < 0 || key_splits > 4) return fail(MG_E_ARG, "mg_set_cross_absorb: key_splits must be in [0, 4] (0 = keep)");
+    std::lock_guard<std::recursive_mutex> lk(m->call_mu);
+    const int prev = m->absorb;
+    if (absorb < 0) return prev;                        // query
+    if (absorb && !xattn_supported(m->d, m->H)) return fail(MG_E_UNSUPPORTED, "mg_set_cross_absorb: d_model %d / %d heads have no absorbed form", m->d, m->H);
+    m->absorb = absorb ? 1 : 0;
+    if (key_splits) m->xa_split = key_splits;
+    m->step_graph.reset(); m->stream_graph.reset();      // (the captured steps hold the other form's launches and buffers)
     return prev;
 }
 // launches timed, their summed duration, and the summed number of (image, key) rows streamed per launch

@@ -200,6 +200,34 @@ MG_DEV f32x4 mfma16(const uint4& a, const uint4& b, const f32x4& c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mg_bf16x8, a), __builtin_bit_cast(mg_bf16x8, b), c, 0, 0, 0);
 #endif
 }
+// D = A·B + C for one 16x16x16 bf16 tile (v_mfma_f32_16x16x16_bf16).  a: lane holds A[row = l%16][k = 4*(l/16)+0..3];
+// b: lane holds B[k = 4*(l/16)+0..3][col = l%16];  result: lane holds D[row = 4*(l/16)+j][col = l%16], j = 0..3 - the k order of
+// the operands is the ROW order of a 16x16x32 result, so a transposed score tile feeds the second product without a lane exchange.
+MG_DEV f32x4 mfma16k16(const uint2& a, const uint2& b, const f32x4& c) {
+#ifdef MG_EMU
+    f32x4 d = c;
+    emu::mfma_16x16x16_bf16((const uint16_t*)&a, (const uint16_t*)&b, d.v);
+    return d;
+#else
+    typedef short mg_s16x4 __attribute__((ext_vector_type(4)));
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(mg_s16x4, a), __builtin_bit_cast(mg_s16x4, b), c, 0, 0, 0);
+#endif
+}
+// ds_read_b64_tr_b16 (gfx950): every 16 lanes read one [4 rows][16 columns] block of 16-bit elements - lane 4a + b of the group
+// supplies the 8-byte-aligned LDS address of row a, columns 4b .. 4b+3 - and receive it transposed: lane i of the group gets column i,
+// rows 0 .. 3.  A row-major [key][feature] image thus yields the operand "feature l%16, keys 4*(l/16) .. +3" of mfma16k16.
+MG_DEV uint2 lds_read_tr16(const void* lds_lane) {
+#ifdef MG_EMU
+    uint2 r;
+    emu::ds_read_tr16_b64(lds_lane, (uint16_t*)&r);
+    return r;
+#else
+    typedef __bf16 mg_bf16x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) mg_bf16x4* mg_lds_bf16x4_p;
+    const mg_bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((mg_lds_bf16x4_p)lds_lane);
+    return __builtin_bit_cast(uint2, v);
+#endif
+}
 MG_DEV f32x4 acc4_zero() {
     f32x4 c;
 #pragma unroll

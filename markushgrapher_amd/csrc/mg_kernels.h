@@ -312,6 +312,38 @@ void attention_step(const AttnStepArgs& a, mgStream_t stream);
 void attention_step_allow_shared();      // before the first launch with AttnStepArgs::one_wg_per_cu (sets the kernel's LDS limit; not inside a stream capture)
 void attention_step_trace(const AttnStepArgs& a, long long* trace, mgStream_t stream);   // phase stamps, cross form, group 1
 
+// ---- weight-absorbed cross-attention of the greedy decode step (k_xattn.hip; stock modeling_udop.py:524-575) ----
+// The layer's K / V streams are replaced by ONE stream of the encoder states themselves (layer-invariant, 2·d bytes per position):
+// q'_h = q_h·Wk_h (xattn_expand), scores and context against the states (xattn_stream), ctx_h = c_h·Wv_h^T (xattn_contract).
+struct XAttnArgs {
+    const uint16_t* q;        // [rows][H][64] bf16, un-normalised cross-attention queries (HF_STEP_Q)
+    uint16_t* qx;             // [rows][H][d] bf16: q' (written by xattn_expand, read by xattn_stream)
+    const uint16_t* wk;       // [H][d][64] bf16: Wk_h feature-major (xattn_pack_weights)
+    const uint16_t* wv;       // [H][d/32][4][64][8] bf16: Wv_h in fragment order (xattn_pack_weights)
+    const uint16_t* enc;      // [owners][cap][d] bf16: the states an image's rows attend, compacted to attended positions (enc_rows)
+    const int* len;           // keys per owner
+    const int* kv_owner;      // continuous decoding: pool entry read by a row (null: the row itself)
+    const int* live;          // nullable: rows with live[row] == 0 are skipped (see AttnStepArgs::live)
+    RowScale qrs;             // deferred RMSNorm scale of the query rows (applied to the scores)
+    float* part;              // [rows][nsplit][H][d] fp32: un-normalised context of a key split
+    float* ml;                // [rows][nsplit][H][2]: running max and sum of the split
+    uint16_t* ctx;            // packed window, as AttnStepArgs::ctx
+    int ctx_ld, ctx_col0;
+    int rows, H, d, cap;
+    int nsplit;               // key splits per row (1 .. 4): workgroups of the stream = rows * nsplit
+    int nstg;                 // stages of 16 keys in the stream's LDS ring
+};
+bool xattn_supported(int d, int H);
+int xattn_nf(int d);
+size_t xattn_stream_lds(int d, int nstg);
+void xattn_stream_prepare(int d, int nstg);    // once per width, outside any stream capture (LDS limit of the stream kernel)
+void xattn_expand(const XAttnArgs& a, mgStream_t stream);
+void xattn_stream(const XAttnArgs& a, mgStream_t stream);
+void xattn_contract(const XAttnArgs& a, mgStream_t stream);
+void xattn_pack_weights(const float* wkv_f32, uint16_t* wk, uint16_t* wv, int H, int d, mgStream_t stream);
+// rows of a packed [rows][d] bf16 operand -> natural rows dst[b][row_map[r]][d] (row_map < 0: dropped)
+void enc_rows(const uint16_t* src_pk, const int* row_map, uint16_t* dst, int B, int rows_per_image, int cap, int d, mgStream_t stream);
+
 // h[rows][d] = tok_emb[ids[row]]
 // embed_rows + rmsnorm_pack(h, gain, x_pk) in one launch (decode step); x2_pk (nullable) = the embedding rows, packed window
 void embed_norm_rows(const int64_t* ids, const uint16_t* tok_emb, float* h, const float* gain, uint16_t* x_pk, uint16_t* x2_pk, int x2_ld,

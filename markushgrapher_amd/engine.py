@@ -123,6 +123,7 @@ class Engine:
         L.mg_set_decode_graph.argtypes = [C.c_void_p, C.c_int]
         L.mg_attach_e1.argtypes = [C.c_void_p, C.c_void_p]
         L.mg_set_shared_gpu.argtypes = [C.c_void_p, C.c_int]
+        L.mg_set_cross_absorb.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.mg_decode_graph_active.argtypes = [C.c_void_p]
         L.mg_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
         L.mg_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -159,6 +160,18 @@ class Engine:
         workgroup per CU resident so that the other contexts' small launches find wave slots.  InFlight sets it on its contexts.  Returns the
         previous setting."""
         return bool(self.lib.mg_set_shared_gpu(self.model, 1 if shared else 0))
+
+    def set_cross_absorb(self, absorb: bool, key_splits: int = 0) -> bool:
+        """Greedy cross-attention form (include/mgrapher.h mg_set_cross_absorb): True = weight-absorbed (the layers stream the attended
+        encoder states), False = per-layer K / V streams.  The workspace is re-sized at the next call.  Returns the previous setting."""
+        prev = self._chk(self.lib.mg_set_cross_absorb(self.model, 1 if absorb else 0, int(key_splits)))
+        self._ws, self._ws_bytes = None, 0
+        return bool(prev)
+
+    @property
+    def cross_absorb(self) -> bool:
+        """True when greedy calls of this context run the weight-absorbed cross-attention (mg_set_cross_absorb)."""
+        return bool(self.lib.mg_set_cross_absorb(self.model, -1, 0))
 
     def clone(self):
         """A further execution context on this engine's weights (include/mgrapher.h mg_clone): same arena, own workspace, decode

@@ -163,6 +163,43 @@ void mfma_16x16x32_bf16(const uint16_t* a8, const uint16_t* b8, float* c4) {
     wave_sync();
 }
 
+// v_mfma_f32_16x16x16_bf16: A[i][k] in lane i+16*(k/4) elem k%4; B[k][j] in lane j+16*(k/4) elem k%4;
+// D[i][j] in lane j+16*(i/4), reg i%4   (checked on the hardware by tools/tr_probe.hip).
+void mfma_16x16x16_bf16(const uint16_t* a4, const uint16_t* b4, float* c4) {
+    Wave& w = B.waves[cur->lin_tid >> 6];
+    int lane = cur->lin_tid & 63;
+    if (w.nlanes != 64) { fprintf(stderr, "emu: mfma in a partial wave\n"); abort(); }
+    memcpy(w.slot[lane], a4, 8);
+    memcpy(w.slot[lane] + 16, b4, 8);
+    wave_sync();
+    int j = lane & 15, q = lane >> 4;
+    for (int r = 0; r < 4; ++r) {
+        int i = 4 * q + r;
+        float s = c4[r];
+        for (int k = 0; k < 16; ++k) {
+            const uint16_t* pa = (const uint16_t*)(w.slot[i + 16 * (k >> 2)]);
+            const uint16_t* pb = (const uint16_t*)(w.slot[j + 16 * (k >> 2)] + 16);
+            s += bf2f(pa[k & 3]) * bf2f(pb[k & 3]);
+        }
+        c4[r] = s;
+    }
+    wave_sync();
+}
+
+// ds_read_b64_tr_b16: per 16 lanes a [4][16] block of 16-bit elements, lane 4a + b supplying row a, columns 4b..4b+3; lane i
+// receives column i, rows 0..3   (checked on the hardware by tools/tr_probe.hip).
+void ds_read_tr16_b64(const void* lds_lane, uint16_t* out4) {
+    Wave& w = B.waves[cur->lin_tid >> 6];
+    int lane = cur->lin_tid & 63;
+    if (w.nlanes != 64) { fprintf(stderr, "emu: transposed LDS read in a partial wave\n"); abort(); }
+    if (((uintptr_t)lds_lane) & 7) { fprintf(stderr, "emu: ds_read_b64_tr_b16 address not 8-byte aligned\n"); abort(); }
+    memcpy(w.slot[lane], lds_lane, 8);
+    wave_sync();
+    const int base = lane & ~15, i = lane & 15;
+    for (int j = 0; j < 4; ++j) out4[j] = ((const uint16_t*)w.slot[base + 4 * j + (i >> 2)])[i & 3];
+    wave_sync();
+}
+
 // global_load_lds_dwordx4: LDS destination = wave-uniform base + lane*16 (cdna_hip_programming.md §5 caveat)
 void glds16(const void* gsrc_lane, void* lds_wave_base) {
     int lane = cur->lin_tid & 63;

@@ -30,6 +30,8 @@ char* smem();
 uint32_t shfl_u32(uint32_t v, int src_lane);
 void mfma_32x32x16_bf16(const uint16_t* a8, const uint16_t* b8, float* c16);
 void mfma_16x16x32_bf16(const uint16_t* a8, const uint16_t* b8, float* c4);
+void mfma_16x16x16_bf16(const uint16_t* a4, const uint16_t* b4, float* c4);
+void ds_read_tr16_b64(const void* lds_lane, uint16_t* out4);
 void glds16(const void* gsrc_lane, void* lds_wave_base);
 }  // namespace emu
 
