@@ -800,7 +800,6 @@ int mg_create(const mg_config* cfg, mg_model** out) {
     { const char* e = getenv("MG_DECODE_FUSED_TAIL"); if (e && e[0] == '0') m->fused_tail = false; }
     { const char* e = getenv("MG_XATTN_ABSORB"); if (e && e[0] == '0') m->absorb = 0; }
     { const char* e = getenv("MG_XATTN_SPLIT"); if (e && atoi(e) >= 1 && atoi(e) <= 4) m->xa_split = atoi(e); }
-    { const char* e = getenv("MG_XATTN_STAGES"); if (e && atoi(e) >= 2 && atoi(e) <= 4) m->xa_stages = atoi(e); }
     if (!xattn_supported(c.d_model, c.num_heads)) m->absorb = 0;
     // arena layout
     size_t off = 0;
@@ -1332,6 +1331,7 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
         // 2 x N_dec projections
         if (M64) enc_rows(w.e1_pk, w.e1_map, w.encx, B, M64, Sx_cap, d, st);
         enc_rows(w.enc_pk, w.xrow, w.encx, B, S_cap, Sx_cap, d, st);
+        enc_pad_rows(w.encx, w.xlen, B, Sx_cap, d, st);
     }
     for (size_t li = 0; li < nl && !absorbed; ++li) {
         if (M64) {
@@ -1633,6 +1633,7 @@ static int generate_stream_impl(mg_model* m, void* stream, void* ws, size_t ws_b
             uint16_t* ex = w.encx + (size_t)entry0 * Sx_cap * d;
             if (M64) enc_rows(we.e1_pk, we.e1_map, ex, n, M64, Sx_cap, d, es);
             enc_rows(we.enc_pk, we.xrow, ex, n, S_cap, Sx_cap, d, es);
+            enc_pad_rows(ex, we.xlen, n, Sx_cap, d, es);
         }
         for (size_t li = 0; li < nl && !absorbed; ++li) {
             if (M64) {          // the e1 tokens of the attached OCSR branch: rows [0, e1_M) of every image's key stream (as mg_generate)

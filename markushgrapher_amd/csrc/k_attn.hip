@@ -271,14 +271,6 @@ constexpr float AE_LOG2E = 1.4426950408889634f;
 constexpr int AE_MAXST = 64;                         // visited-stage list kept in LDS (S_cap <= 4096)
 constexpr int AE_SMEM = AE_RING * AT_STAGE_BYTES + AE_DEPTH * AE_IDX_BYTES + (AE_HV + 4) * 4 + (2 * AE_D1 + 4) * 4 + AE_MAXST * 4;
 
-MG_DEV float fast_exp2(float x) {
-#ifdef MG_EMU
-    return exp2f(x);
-#else
-    return __builtin_amdgcn_exp2f(x);
-#endif
-}
-
 // Pipeline: the registers of a workgroup (170+ per lane) allow one workgroup per CU, so all memory-level parallelism is the
 // prefetch depth: K / V^T stages and the wave's index words all travel by LDS-DMA (inline asm, invisible to hipcc's
 // s_waitcnt insertion) AE_DEPTH stages ahead; every wave waits with a COUNTED vmcnt for its own copies of the current stage

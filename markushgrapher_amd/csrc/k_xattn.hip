@@ -19,6 +19,7 @@ namespace mg {
 
 constexpr float XA_NEG = -1.0e30f;
 constexpr int XA_KEYS = 16;          // keys per stage of the stream
+constexpr float XA_DEFER = 8.0f;     // the running maximum may lag by this much (log2 units) before the accumulators are rescaled
 
 // LDS image of a stage: [16 keys][d/8 chunks of 16 B], chunk j of key k stored at chunk position j ^ xa_swz(k) (low bits only), so that
 // the 16 lanes of a ds_read_b128 group (16 different keys, two neighbouring chunks) and the 32 lanes of a transposed read (8 keys x 2
@@ -57,41 +58,64 @@ __global__ __launch_bounds__(256) void xq_expand_kernel(XAttnArgs a) {
 }
 
 // ---- the stream -------------------------------------------------------------------------------------------------------------
-// One workgroup = (sequence row, key split); NW = d / (16 NF) waves, wave w owns features [16 NF w, 16 NF (w + 1)).
-// Per stage of 16 keys (32·d bytes, copied global -> LDS by DMA, ring of `nstg` stages):
+// One workgroup = (sequence row, key split).  NG wave groups of NW = d / (16 NF) waves each: group gi takes the stages gi, gi + NG, ...
+// of the split (a stage = 16 keys), wave wq of a group owns features [16 NF wq, 16 NF (wq + 1)).  Two groups = two waves per SIMD whose
+// dependency chains (LDS round trips, MFMA results, the softmax's lane exchanges) overlap; each group keeps its own online-softmax state
+// and accumulators, the groups are merged once at the end through LDS in group order (a fixed function of the row's keys: a row's bits do
+// not depend on what else the call holds).
+// Per stage (32·d bytes, copied global -> LDS by DMA into a ring of `nstg` stages, by the waves of the group that consumes it):
 //   scores   S^T[key][head] partial over the wave's features: A = enc rows (ds_read_b128), B = q'^T (registers), mfma 16x16x32;
-//            partials of the NW waves summed through LDS in wave order (every wave ends with the complete tile);
+//            partials of the group's NW waves summed through LDS in wave order (every wave ends with the complete tile);
 //   softmax  online, per head (= lane % 16): a lane holds 4 keys of one head, the 4 lane groups the other 12;
 //   context  c^T[feature][head] += enc^T[feature][key] · P^T[key][head]: A = transposed LDS read of the same stage (4 keys x 16 features
 //            per 16 lanes), B = the rounded weights exactly as the score tile left them (k order of mfma 16x16x16 = row order of the
 //            16x16x32 result), accumulators [NF][4] per lane.
-template <int NF>
-__global__ __launch_bounds__(512) void xattn_stream_kernel(XAttnArgs a) {
+template <int KS>
+MG_DEV void xa_wait_copies(int later) {        // at most `later` stages' copies of this wave (KS each) may remain outstanding
+    if (later <= 0) MG_WAIT_VMCNT(0);
+    else if (later == 1) { if constexpr (KS == 1) MG_WAIT_VMCNT(1); else if constexpr (KS == 2) MG_WAIT_VMCNT(2); else if constexpr (KS == 4) MG_WAIT_VMCNT(4); else if constexpr (KS == 6) MG_WAIT_VMCNT(6); else MG_WAIT_VMCNT(8); }
+    else if (later == 2) { if constexpr (KS == 1) MG_WAIT_VMCNT(2); else if constexpr (KS == 2) MG_WAIT_VMCNT(4); else if constexpr (KS == 4) MG_WAIT_VMCNT(8); else if constexpr (KS == 6) MG_WAIT_VMCNT(12); else MG_WAIT_VMCNT(16); }
+    else { if constexpr (KS == 1) MG_WAIT_VMCNT(3); else if constexpr (KS == 2) MG_WAIT_VMCNT(6); else if constexpr (KS == 4) MG_WAIT_VMCNT(12); else if constexpr (KS == 6) MG_WAIT_VMCNT(18); else MG_WAIT_VMCNT(24); }
+}
+
+template <int NF, int NW, int NG>
+__global__ __launch_bounds__(NW * NG * 64) void xattn_stream_kernel(XAttnArgs a) {
     MG_DYN_SMEM(smem);
     constexpr int KS = NF / 2;                       // 32-feature k-steps of the score product per wave
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+#ifdef MG_EMU
+    const int w = tid >> 6;
+#else
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // (wave-uniform for the compiler: scalar copy addresses and branches)
+#endif
+    const int gi = w / NW, wq = w - gi * NW;         // wave group, feature slice inside it
     const int row = blockIdx.x / a.nsplit, split = blockIdx.x - row * a.nsplit;
     if (a.live && a.live[row] == 0) return;          // finished / idle row (whole workgroup)
     const int owner = a.kv_owner ? a.kv_owner[row] : row;
     const int nkeys = a.len[owner];
     const int d = a.d, H = a.H, nch = d >> 3;        // 16-byte chunks per key
     const int head = lane & 15, g = lane >> 4;
-    const int fb = w * 16 * NF;
+    const int fb = wq * 16 * NF;
     const int stage_bytes = XA_KEYS * d * 2;
+    const int R = a.nstg / NG;                       // ring depth in iterations (an iteration = one stage per group)
     char* ring = smem;
-    float* red = (float*)(smem + (size_t)a.nstg * stage_bytes);       // [nw][64][4]
-    // stages of this split
+    float* red = (float*)(smem + (size_t)R * NG * stage_bytes) + (size_t)gi * NW * 256;       // [group][NW][64][4]
+    // stages of this split, and of this group
     const int nst_all = (nkeys + XA_KEYS - 1) / XA_KEYS;
     const int per = (nst_all + a.nsplit - 1) / a.nsplit;
     const int st0 = split * per, st1 = (st0 + per < nst_all) ? st0 + per : nst_all;
     const int nst = st1 > st0 ? st1 - st0 : 0;
+    const int nit = (nst + NG - 1) / NG;             // iterations of the workgroup
+    const int nst_g = nst > gi ? (nst - gi + NG - 1) / NG : 0;      // stages of this group
 
     // q'^T fragments of the wave's features: lane (head, g) holds q'[head][fb + 32 ks + 8 g .. + 8]
-    uint4 qf[KS];
+    // (raw loads: the compiler must not know them, or it guards their first use inside the loop with an s_waitcnt vmcnt(0) that
+    //  drains the copies in flight every stage)
+    mg_raw16 qr[KS];
     {
         const uint16_t* qp = a.qx + ((size_t)row * H + (head < H ? head : 0)) * d + fb + 8 * g;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[ks] = head < H ? ld16(qp + ks * 32) : make_uint4(0, 0, 0, 0);
+        for (int ks = 0; ks < KS; ++ks) gld16_async(qr[ks], qp + ks * 32);
     }
     // deferred RMSNorm of the query row: the scale is applied to the scores (linear in q); fixed summation order
     float qs = 1.0f;
@@ -101,110 +125,155 @@ __global__ __launch_bounds__(512) void xattn_stream_kernel(XAttnArgs a) {
         t = sum_slots(sum8(t), lane);
         qs = rsqrtf(t * a.qrs.inv_d + a.qrs.eps);
     }
-    // copies of a stage: d/32 instructions of 64 x 16 B; wave w issues KS of them.  Slot s = (instruction, lane) holds chunk
-    // (s % nch) ^ swz(key) of key s / nch; keys past the image's last one re-read the last one (finite values; their weights are 0).
-    const uint16_t* ebase = a.enc + (size_t)owner * a.cap * d;
+    // Copies of a stage: d/32 instructions of 64 x 16 B; wave wq of the stage's group issues KS of them.  Slot s = (instruction, lane)
+    // holds chunk (s % nch) ^ swz(key) of key s / nch.  The lane's source offsets inside a stage are the same for every stage
+    // (registers); a stage is a scalar base + these.  Rows past the image's last key up to the next multiple of 16 are read too: the
+    // producer of `enc` keeps them finite (enc_pad_rows: zero), their weights are exactly 0.
+    const char* ebase = (const char*)(a.enc + (size_t)owner * a.cap * d);
     const int swz_mask = (nch < 16 ? nch : 16) - 1;
-    auto issue = [&](int i) {          // i-th stage of this split -> ring slot i % nstg
-        char* dst = ring + (size_t)(i % a.nstg) * stage_bytes;
-        const int k0 = (st0 + i) * XA_KEYS;
+    unsigned coff[KS];
 #pragma unroll
-        for (int c = 0; c < KS; ++c) {
-            const int inst = w * KS + c, s = inst * 64 + lane;
-            const int key = s / nch, jj = s - key * nch;
-            const int j = jj ^ (xa_swz(key) & swz_mask);
-            int kg = k0 + key;
-            kg = kg < nkeys ? kg : nkeys - 1;
-            glds16_async(ebase + (size_t)kg * d + j * 8, dst + inst * 1024);
-        }
+    for (int c = 0; c < KS; ++c) {
+        const int inst = wq * KS + c, s = inst * 64 + lane;
+        const int key = s / nch, jj = s - key * nch;
+        coff[c] = (unsigned)(key * d * 2 + ((jj ^ (xa_swz(key) & swz_mask)) << 4));
+    }
+    const mg_lds_t ring_lds = mg_lds_addr(ring);
+    auto issue = [&](int it, int slot_it) {          // this group's stage of iteration `it` -> ring slot (slot_it, gi)
+        const mg_lds_t dst = ring_lds + (unsigned)((slot_it * NG + gi) * stage_bytes + wq * KS * 1024);
+        const char* src = ebase + (size_t)(st0 + it * NG + gi) * (size_t)stage_bytes;
+#pragma unroll
+        for (int c = 0; c < KS; ++c) glds16_async_sv(src, coff[c], dst + c * 1024);
     };
-    // LDS byte offsets inside a stage (before the ring slot): score operand (key = lane % 16, chunks fb/8 + 4 ks + g) and transposed
-    // operand (key 4 g + a, features fb + 16 t + 4 b, a = (lane % 16) / 4, b = lane % 4).  The swizzle is an XOR on address bits 4..7;
-    // the k-step / tile index touches higher bits (ks * 64, t * 32 -> bits 5..9) - disjoint from the lane part only where noted, so the
-    // XOR is applied to the whole chunk index (cheap integer VALU, outside the MFMA dependency chains).
-    const int skey = head, sx = xa_swz(skey) & swz_mask;
-    const int ta = (lane & 15) >> 2, tb = lane & 3, tkey = 4 * g + ta, tx = xa_swz(tkey) & swz_mask;
+    // LDS byte offsets inside a stage: score operand (key = lane % 16, chunks fb/8 + 4 ks + g) and transposed operand (key 4 g + a,
+    // features fb + 16 t + 4 b, a = (lane % 16) / 4, b = lane % 4).  The swizzle is an XOR on the low 4 bits of the chunk index: the
+    // k-step / tile index changes those bits with period 4 / 8 and adds 256 B beyond - 4 + 8 offsets in registers, immediates for the rest.
+    constexpr int NSA = KS < 4 ? KS : 4, NTA = NF < 8 ? NF : 8;
+    unsigned sa[NSA], ta[NTA];
+    {
+        const int sx = xa_swz(head) & swz_mask;
+#pragma unroll
+        for (int k = 0; k < NSA; ++k) sa[k] = (unsigned)(head * d * 2 + ((((fb >> 3) + g + 4 * k) ^ sx) << 4));
+        const int ra = (lane & 15) >> 2, rb = lane & 3, tkey = 4 * g + ra, tx = xa_swz(tkey) & swz_mask;
+#pragma unroll
+        for (int k = 0; k < NTA; ++k) ta[k] = (unsigned)(tkey * d * 2 + ((((fb >> 3) + (rb >> 1) + 2 * k) ^ tx) << 4) + (rb & 1) * 8);
+    }
 
     f32x4 acc[NF];
 #pragma unroll
     for (int t = 0; t < NF; ++t) acc[t] = acc4_zero();
+    // running maximum in log2 units (scores are scaled by qs * log2(e), weights are exp2), stale by up to XA_DEFER: the accumulators are
+    // rescaled only when some head's maximum grew by more than that (weights stay below 2^XA_DEFER; fp32 sums, bf16 weights: no loss)
     float mrun = XA_NEG, lsum = 0.f;
+    const float qs2 = qs * 1.44269504088896341f;
 
-    if (nst > 0) {
-        MG_WAIT_VMCNT(0);              // retire the prologue's loads: from here on the vector-memory queue holds only the counted copies
-        // (the waits below count copies per wave: KS per stage)
-        const int lead = a.nstg - 1;   // stages in flight ahead of the one being consumed
-        for (int i = 0; i < lead && i < nst; ++i) issue(i);
-        for (int i = 0; i < nst; ++i) {
-            // own copies of stage i have landed when at most those of the later stages in flight remain outstanding
+    // retire the prologue's loads by hand: from here on the vector-memory queue holds only the counted copies
+    MG_WAIT_VMCNT(0);
+    uint4 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        MG_TIE(qr[ks]);
+        qf[ks] = head < H ? raw16_get(qr[ks]) : make_uint4(0, 0, 0, 0);
+    }
+    {
+        const int lead = R - 1;        // iterations in flight ahead of the one being consumed
+        for (int it = 0; it < lead && it < nst_g; ++it) issue(it, it);
+        int slot = 0, slot_lead = lead % R;
+        for (int it = 0; it < nit; ++it) {
+            // own copies of this iteration's stage have landed when at most those of the later ones in flight remain outstanding
+            // (a group that has run out of stages has nothing outstanding and only keeps the barriers company)
             {
-                int later = nst - 1 - i;
+                int later = nst_g - 1 - it;
                 later = later < lead - 1 ? later : lead - 1;
-                // stages i+1 .. i+later are in flight behind stage i (stage i + lead is issued after the barrier below)
-                const int outstanding = later * KS;
-                // counted wait with a run-time count: a small switch over the possible values (KS * {0, 1, 2, ...})
-                if (outstanding == 0) MG_WAIT_VMCNT(0);
-                else if (outstanding <= KS) { if constexpr (KS == 1) MG_WAIT_VMCNT(1); else if constexpr (KS == 2) MG_WAIT_VMCNT(2); else if constexpr (KS == 4) MG_WAIT_VMCNT(4); else if constexpr (KS == 6) MG_WAIT_VMCNT(6); else MG_WAIT_VMCNT(8); }
-                else if (outstanding <= 2 * KS) { if constexpr (KS == 1) MG_WAIT_VMCNT(2); else if constexpr (KS == 2) MG_WAIT_VMCNT(4); else if constexpr (KS == 4) MG_WAIT_VMCNT(8); else if constexpr (KS == 6) MG_WAIT_VMCNT(12); else MG_WAIT_VMCNT(16); }
-                else { if constexpr (KS == 1) MG_WAIT_VMCNT(3); else if constexpr (KS == 2) MG_WAIT_VMCNT(6); else if constexpr (KS == 4) MG_WAIT_VMCNT(12); else if constexpr (KS == 6) MG_WAIT_VMCNT(18); else MG_WAIT_VMCNT(24); }
+                xa_wait_copies<KS>(later);
             }
-            MG_BARRIER_RAW();          // everybody's copies of stage i have landed; everybody is done with stage i - 1 (its slot is free)
-            if (i + lead < nst) issue(i + lead);
-            const char* stg = ring + (size_t)(i % a.nstg) * stage_bytes;
+            MG_BARRIER_RAW();          // everybody's copies of the iteration have landed; everybody is done with the previous one (its slots are free)
+            const bool mine = it < nst_g;
+            if (it + lead < nst_g) issue(it + lead, slot_lead);
+            const char* stg = ring + (size_t)(slot * NG + gi) * stage_bytes;
+            slot = slot + 1 == R ? 0 : slot + 1;
+            slot_lead = slot_lead + 1 == R ? 0 : slot_lead + 1;
             // scores, partial over this wave's features (two accumulators: even / odd k-steps)
             f32x4 s0 = acc4_zero(), s1 = acc4_zero();
-            {
-                const char* kb = stg + (size_t)skey * d * 2;
-                const int c0 = (fb >> 3) + g;
+            if (mine) {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    const uint4 e = ld16(kb + (((c0 + 4 * ks) ^ sx) << 4));
+                    const uint4 e = ld16(stg + sa[ks & 3] + (ks >> 2) * 256);
                     if (ks & 1) s1 = mfma16(e, qf[ks], s1); else s0 = mfma16(e, qf[ks], s0);
                 }
-            }
-            {
-                float4* rp = (float4*)red + (size_t)w * 64 + lane;
+                float4* rp = (float4*)red + (size_t)wq * 64 + lane;
                 *rp = make_float4(s0[0] + s1[0], s0[1] + s1[1], s0[2] + s1[2], s0[3] + s1[3]);
             }
             MG_WAIT_LGKM0();           // (a __syncthreads() would also drain the copies in flight)
             MG_BARRIER_RAW();
+            if (!mine) continue;
             float sc[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int ww = 0; ww < nw; ++ww) {
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) {
                 const float4 v = ((const float4*)red)[(size_t)ww * 64 + lane];
                 sc[0] += v.x; sc[1] += v.y; sc[2] += v.z; sc[3] += v.w;
             }
             // online softmax over the stage's 16 keys; this lane: keys k0 + 4 g + {0..3} of head `head`
-            const int kbase = (st0 + i) * XA_KEYS + 4 * g;
-            float mx = XA_NEG;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                sc[e] = (kbase + e < nkeys) ? sc[e] * qs : XA_NEG;
-                mx = fmaxf(mx, sc[e]);
+            for (int e = 0; e < 4; ++e) sc[e] *= qs2;
+            const int sti = st0 + it * NG + gi;
+            if (sti + 1 == nst_all) {        // only an image's last stage holds keys past its end
+                const int kbase = sti * XA_KEYS + 4 * g;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sc[e] = (kbase + e < nkeys) ? sc[e] : XA_NEG;
             }
+            float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
             mx = fmaxf(mx, lane_xor<16>(mx, lane));
             mx = fmaxf(mx, lane_xor<32>(mx, lane));
-            const float mn = fmaxf(mrun, mx);
-            const float al = fast_exp(mrun - mn);
-            mrun = mn;
-            float p[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) p[e] = (kbase + e < nkeys) ? fast_exp(sc[e] - mn) : 0.f;
-            const uint2 pt = make_uint2(pack_bf16(p[0], p[1]), pack_bf16(p[2], p[3]));
-            lsum = lsum * al + ((bf16lo(pt.x) + bf16hi(pt.x)) + (bf16lo(pt.y) + bf16hi(pt.y)));      // the rounded weights, as the product sees them
-#pragma unroll
-            for (int t = 0; t < NF; ++t) {
-                acc[t][0] *= al; acc[t][1] *= al; acc[t][2] *= al; acc[t][3] *= al;
-            }
-            {
-                const char* tbp = stg + (size_t)tkey * d * 2 + (tb & 1) * 8;
-                const int c0 = (fb >> 3) + (tb >> 1);
+            if (wave_any(mx > mrun + XA_DEFER)) {          // (same values in every wave of the group: same decision)
+                const float mn = fmaxf(mrun, mx);
+                const float al = fast_exp2(mrun - mn);
+                mrun = mn;
+                lsum *= al;
 #pragma unroll
                 for (int t = 0; t < NF; ++t) {
-                    const uint2 e = lds_read_tr16(tbp + (((c0 + 2 * t) ^ tx) << 4));
-                    acc[t] = mfma16k16(e, pt, acc[t]);
+                    acc[t][0] *= al; acc[t][1] *= al; acc[t][2] *= al; acc[t][3] *= al;
+                }
+            }
+            const uint2 pt = make_uint2(pack_bf16(fast_exp2(sc[0] - mrun), fast_exp2(sc[1] - mrun)),
+                                        pack_bf16(fast_exp2(sc[2] - mrun), fast_exp2(sc[3] - mrun)));
+            lsum += (bf16lo(pt.x) + bf16hi(pt.x)) + (bf16lo(pt.y) + bf16hi(pt.y));      // the rounded weights, as the product sees them
+#pragma unroll
+            for (int t = 0; t < NF; ++t) {
+                const uint2 e = lds_read_tr16(stg + ta[t & 7] + (t >> 3) * 256);
+                acc[t] = mfma16k16(e, pt, acc[t]);
+            }
+        }
+    }
+    // merge the wave groups in group order (group 0 += group 1 ...) through the ring's memory: [wq][t][lane] float4 + (m, l) per lane
+    if constexpr (NG > 1) {
+        float4* mb = (float4*)smem;
+        float2* mm = (float2*)(smem + (size_t)NW * NF * 64 * 16);
+        for (int gsrc = 1; gsrc < NG; ++gsrc) {
+            MG_WAIT_LGKM0();
+            MG_BARRIER_RAW();          // the stages (or the previous group's block) have been read by everybody
+            if (gi == gsrc) {
+#pragma unroll
+                for (int t = 0; t < NF; ++t) mb[((size_t)wq * NF + t) * 64 + lane] = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+                mm[(size_t)wq * 64 + lane] = make_float2(mrun, lsum);
+            }
+            MG_WAIT_LGKM0();
+            MG_BARRIER_RAW();
+            if (gi == 0) {
+                const float2 o = mm[(size_t)wq * 64 + lane];
+                const float M = fmaxf(mrun, o.x);
+                const float f0 = fast_exp2(mrun - M), f1 = fast_exp2(o.x - M);
+                mrun = M;
+                lsum = lsum * f0 + o.y * f1;
+#pragma unroll
+                for (int t = 0; t < NF; ++t) {
+                    const float4 v = mb[((size_t)wq * NF + t) * 64 + lane];
+                    acc[t][0] = acc[t][0] * f0 + v.x * f1; acc[t][1] = acc[t][1] * f0 + v.y * f1;
+                    acc[t][2] = acc[t][2] * f0 + v.z * f1; acc[t][3] = acc[t][3] * f0 + v.w * f1;
                 }
             }
         }
+        if (gi != 0) return;
     }
     // a lane's l covers its own 4 keys per stage: complete it over the lane groups; write the un-normalised context and (m, l)
     lsum += lane_xor<16>(lsum, lane);
@@ -214,7 +283,7 @@ __global__ __launch_bounds__(512) void xattn_stream_kernel(XAttnArgs a) {
         float* pp = a.part + pi * d + fb + 4 * g;
 #pragma unroll
         for (int t = 0; t < NF; ++t) *(float4*)(pp + 16 * t) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
-        if (w == 0 && g == 0) { a.ml[pi * 2] = mrun; a.ml[pi * 2 + 1] = lsum; }
+        if (wq == 0 && g == 0) { a.ml[pi * 2] = mrun; a.ml[pi * 2 + 1] = lsum; }
     }
 }
 
@@ -241,7 +310,7 @@ __global__ __launch_bounds__(256) void xctx_contract_kernel(XAttnArgs a) {
             M = fmaxf(M, ms[s]);
         }
         float L = 0.f;
-        for (int s = 0; s < NS; ++s) { cs[s] = fast_exp(ms[s] - M); L += cs[s] * ls[s]; }
+        for (int s = 0; s < NS; ++s) { cs[s] = fast_exp2(ms[s] - M); L += cs[s] * ls[s]; }      // (the stream's maxima are in log2 units)
         const float inv = L > 0.f ? 1.0f / L : 0.f;
         for (int s = 0; s < NS; ++s) cs[s] *= inv;
     }
@@ -302,6 +371,19 @@ __global__ __launch_bounds__(256) void enc_rows_kernel(const uint16_t* src, cons
     }
 }
 
+// rows [len[b], next multiple of 16) of every image's stream cleared: the stream kernel reads whole stages of 16 keys (zero weight past the end)
+__global__ __launch_bounds__(256) void enc_pad_rows_kernel(uint16_t* dst, const int* len, int cap, int d) {
+    const int b = blockIdx.x, n = len[b];
+    int end = (n + XA_KEYS - 1) / XA_KEYS * XA_KEYS;
+    end = end < cap ? end : cap;
+    const int nch = d >> 3, total = (end - n) * nch;
+    for (int i = threadIdx.x; i < total; i += blockDim.x)
+        st16(dst + ((size_t)b * cap + n) * d + (size_t)i * 8, make_uint4(0, 0, 0, 0));
+}
+void enc_pad_rows(uint16_t* dst, const int* len, int B, int cap, int d, mgStream_t stream) {
+    MG_LAUNCH(enc_pad_rows_kernel, dim3(B), dim3(256), 0, stream, dst, len, cap, d);
+}
+
 // absorbed weights of one decoder layer from the fp32 row-major cross K/V weight [2 * inner][d] (K rows first)
 __global__ __launch_bounds__(256) void xattn_pack_weights_kernel(const float* wkv, uint16_t* wk, uint16_t* wv, int H, int d) {
     const int inner = H * 64, KT = d >> 5;
@@ -351,27 +433,24 @@ void xattn_expand(const XAttnArgs& a, mgStream_t stream) {
     MG_LAUNCH(xq_expand_kernel, dim3(a.H, a.d / (32 * nw)), dim3(nw * 64), 0, stream, a);
 }
 
+// wave groups of the stream kernel: 2 wherever the ring holds at least 2 stages per group
+constexpr int XA_NG = 2;
 void xattn_stream(const XAttnArgs& a, mgStream_t stream) {
     const int nf = xattn_nf(a.d), nw = a.d / (16 * nf);
-    const dim3 grid(a.rows * a.nsplit), block(nw * 64);
+    const dim3 grid(a.rows * a.nsplit), block(nw * XA_NG * 64);
     const size_t sh = xattn_stream_lds(a.d, a.nstg);
-    switch (nf) {
-#define MG_XS(N) case N: MG_LAUNCH((xattn_stream_kernel<N>), grid, block, sh, stream, a); break;
-        MG_XS(2) MG_XS(4) MG_XS(8) MG_XS(12) MG_XS(16)
+#define MG_XS(N, W) if (nf == N && nw == W) { MG_LAUNCH((xattn_stream_kernel<N, W, XA_NG>), grid, block, sh, stream, a); return; }
+    MG_XS(2, 2) MG_XS(2, 4) MG_XS(4, 4) MG_XS(8, 4) MG_XS(12, 4) MG_XS(16, 4)
 #undef MG_XS
-        default: break;
-    }
 }
 // the stream kernel's LDS request exceeds the default limit: set once, outside any stream capture
 void xattn_stream_prepare(int d, int nstg) {
+    const int nf = xattn_nf(d), nw = nf ? d / (16 * nf) : 0;
     const size_t sh = xattn_stream_lds(d, nstg);
-    (void)sh;
-    switch (xattn_nf(d)) {
-#define MG_XP(N) case N: MG_SET_MAX_SMEM((&xattn_stream_kernel<N>), sh); break;
-        MG_XP(2) MG_XP(4) MG_XP(8) MG_XP(12) MG_XP(16)
+    (void)sh; (void)nw;
+#define MG_XP(N, W) if (nf == N && nw == W) { MG_SET_MAX_SMEM((&xattn_stream_kernel<N, W, XA_NG>), sh); return; }
+    MG_XP(2, 2) MG_XP(2, 4) MG_XP(4, 4) MG_XP(8, 4) MG_XP(12, 4) MG_XP(16, 4)
 #undef MG_XP
-        default: break;
-    }
 }
 
 void xattn_contract(const XAttnArgs& a, mgStream_t stream) {

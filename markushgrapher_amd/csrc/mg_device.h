@@ -359,6 +359,24 @@ MG_DEV float fast_exp(float x) {
 #endif
 }
 
+MG_DEV float fast_exp2(float x) {
+#ifdef MG_EMU
+    return exp2f(x);
+#else
+    return __builtin_amdgcn_exp2f(x);       // v_exp_f32 (arguments below -126 flush to 0, which is what a masked score wants)
+#endif
+}
+// true in every lane if the predicate holds in any lane of the wave
+MG_DEV bool wave_any(bool p) {
+#ifdef MG_EMU
+    int v = p ? 1 : 0;
+    for (int m = 32; m >= 1; m >>= 1) v |= __shfl_xor(v, m);
+    return v != 0;
+#else
+    return __builtin_amdgcn_ballot_w64(p) != 0;
+#endif
+}
+
 // sum over each aligned group of 8 lanes, result in all 8 (DPP: quad_perm xor 1, quad_perm xor 2, row_half_mirror —
 // pure VALU, no LDS crossbar traffic unlike ds_bpermute-based shuffles)
 MG_DEV float sum8(float p) {

@@ -331,7 +331,7 @@ struct XAttnArgs {
     int ctx_ld, ctx_col0;
     int rows, H, d, cap;
     int nsplit;               // key splits per row (1 .. 4): workgroups of the stream = rows * nsplit
-    int nstg;                 // stages of 16 keys in the stream's LDS ring
+    int nstg;                 // stages of 16 keys in the stream's LDS ring (a multiple of the kernel's 2 wave groups: 4)
 };
 bool xattn_supported(int d, int H);
 int xattn_nf(int d);
@@ -343,6 +343,8 @@ void xattn_contract(const XAttnArgs& a, mgStream_t stream);
 void xattn_pack_weights(const float* wkv_f32, uint16_t* wk, uint16_t* wv, int H, int d, mgStream_t stream);
 // rows of a packed [rows][d] bf16 operand -> natural rows dst[b][row_map[r]][d] (row_map < 0: dropped)
 void enc_rows(const uint16_t* src_pk, const int* row_map, uint16_t* dst, int B, int rows_per_image, int cap, int d, mgStream_t stream);
+// rows [len[b], next multiple of 16) of dst[b] zeroed (the stream reads whole stages of 16 keys)
+void enc_pad_rows(uint16_t* dst, const int* len, int B, int cap, int d, mgStream_t stream);
 
 // h[rows][d] = tok_emb[ids[row]]
 // embed_rows + rmsnorm_pack(h, gain, x_pk) in one launch (decode step); x2_pk (nullable) = the embedding rows, packed window
