@@ -330,6 +330,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--repeats", type=int, default=3,
+                    help="the timed region of exactly --steps steps is run this many times, each bracketed by barrier + synchronize; "
+                         "`value` / `ms_per_step` are the MEDIAN region (value_min / value_max / ms_per_step_all beside them)")
     ap.add_argument("--shape", default="large")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--new-tokens", type=int, default=256)
@@ -528,23 +531,39 @@ def main():
         return n_l, ms, keys, empty_ms, n_ph, enc_ms, dec_ms
 
     profile_on()                       # on the first context: its launches are bracketed while the other contexts run beside it
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.time()
-    del calls_on_first[:]
-    ids = run_calls(timed_plan)
-    nb_first = float(np.mean(calls_on_first)) if calls_on_first else float(np.mean(timed_plan))
-    while handles:
-        all_ids, all_len = ex.wait(handles.pop(0))      # the last batch's exchange completes inside the timed region
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.time() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    import resource
+    import threading
+    repeats = max(1, args.repeats)
+    dts, cpu_s = [], []
+    for _rep in range(repeats):        # every repeat: EXACTLY --steps steps between barrier + synchronize on both sides, max over ranks
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ru0 = resource.getrusage(resource.RUSAGE_SELF)
+        t0 = time.time()
+        del calls_on_first[:]
+        ids = run_calls(timed_plan)
+        nb_first = float(np.mean(calls_on_first)) if calls_on_first else float(np.mean(timed_plan))
+        while handles:
+            all_ids, all_len = ex.wait(handles.pop(0))      # the last batch's exchange completes inside the timed region
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt = time.time() - t0
+        ru1 = resource.getrusage(resource.RUSAGE_SELF)
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        dts.append(dt)
+        cpu_s.append((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime))
+    dt = float(np.median(dts))         # `value` = the median region
+    host_threads = threading.active_count()
+    try:
+        with open("/proc/self/status") as f_:
+            host_threads_os = int([ln.split()[1] for ln in f_ if ln.startswith("Threads:")][0])
+    except Exception:
+        host_threads_os = None
     n_l, ms, keys, empty_ms, n_ph, enc_ms, dec_ms = profile_read()
     # the same step with ONE batch in flight (the reference's loop shape; rounds 1-2 measured this): untimed for `value`, it gives
     # the kernel's and the phases' uncontended figures beside the in-flight ones
@@ -928,6 +947,13 @@ def main():
         out = {
             "metric": METRIC, "value": round(world * B * args.steps / dt, 3), "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+            # `value` / `ms_per_step` = the median of `repeats` timed regions of exactly `steps` steps each (ms_per_step x steps x repeats of wall clock)
+            "repeats": repeats, "value_min": round(world * B * args.steps / max(dts), 3), "value_max": round(world * B * args.steps / min(dts), 3),
+            "ms_per_step_all": [round(x / args.steps * 1e3, 2) for x in dts],
+            # host side of one rank over a timed region: user + system CPU seconds of this process (all its threads) and its thread count;
+            # host_cpu_s / (ms_per_step x steps) = cores one rank keeps busy (what 8 ranks need of the node's cores)
+            "host_cpu_s": round(float(np.median(cpu_s)), 3), "host_cpu_cores_busy": round(float(np.median(cpu_s)) / dt, 2),
+            "host_threads": host_threads_os, "host_threads_python": host_threads,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "configs[1]: batch 32/GPU synthetic 1024x1024 u8 crops -> device LANCZOS 512px model input, greedy "
                                    f"decode, {new_tokens} forced new tokens (EOS suppressed), UDOP-large-shaped "

@@ -24,7 +24,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from .engine import Engine, TorchMem
+from .engine import Engine, MgError, TorchMem
 from .synth import ModelShape, state_dict_spec, tied_aliases
 
 
@@ -321,9 +321,25 @@ class MarkushgrapherForConditionalGeneration(nn.Module):
             eng.load_state_dict(sd)
             if self.computes_e1():              # the OCSR branch on the HIP engine, attached: calls without e1= evaluate it themselves
                 from .e1 import E1Engine
-                shape1, sd1 = self._e1_setup()
-                e1e = E1Engine(shape1, mem=TorchMem(dev)).load_state_dict({k: v.data for k, v in sd1.items()})
-                eng.attach_e1(e1e)
+                try:
+                    shape1, sd1 = self._e1_setup()
+                    e1e = E1Engine(shape1, mem=TorchMem(dev)).load_state_dict({k: v.data for k, v in sd1.items()})
+                    eng.attach_e1(e1e)
+                except (KeyError, ValueError, MgError) as exc:
+                    # an incomplete / unsupported branch: the engine stays unattached, so that a caller-supplied e1= still works
+                    # (a call WITHOUT e1= then fails in _check_e1 with the reason)
+                    self._e1_attach_error = str(exc)
+                    warnings.warn(f"OCSR branch (encoder.molscribe_*) not attached to the HIP engine: {exc}; pass e1= explicitly", stacklevel=2)
+                else:
+                    # What the fork does AROUND the Swin encoder is not in the reference tree (its transformers fork is absent): say once which
+                    # choices this build made, so that outputs differing from the reference's are not silent.
+                    warnings.warn(
+                        "OCSR vision branch attached from the checkpoint's encoder.molscribe_* tensors.  The Swin encoder is pinned on stock "
+                        "transformers SwinModel; the steps around it are INFERRED from the reference's README (fork source absent) and unpinned: "
+                        f"input = bilinear resize of pixel_values {shape1.src_image_size} -> {shape1.image_size} px with per-channel affine "
+                        f"scale {tuple(shape1.pix_scale)} / shift {tuple(shape1.pix_shift)} (MolScribe itself trains on ImageNet mean/std: set "
+                        "config.e1 = dict(markushgrapher_amd.e1_shapes.IMAGENET_RENORM) if your checkpoint expects that), projector activation "
+                        f"'{shape1.proj_act}', decoder keys = [e1 | VTL states].  Pass e1= to supply the tokens yourself.", stacklevel=2)
             self._engine, self._engine_device = eng, dev
         return self._engine
 

@@ -286,9 +286,13 @@ class Configs4Pipeline:
         stat = {"ocr_busy": 0.0, "steps": 0}
         errs = []
 
+        stop = threading.Event()
+
         def ocr_worker():
             try:
                 for p0 in range(0, B, slab):
+                    if stop.is_set():
+                        break
                     h0 = _time.perf_counter()
                     pix, new, steps = self.stage_ocr(pages_u8[p0:p0 + slab], page0=p0)
                     stat["ocr_busy"] += _time.perf_counter() - h0
@@ -299,22 +303,32 @@ class Configs4Pipeline:
             finally:
                 q.put(None)
         t0 = now()
-        th = threading.Thread(target=ocr_worker)
+        th = threading.Thread(target=ocr_worker, daemon=True)
         th.start()
         host_busy, parts, futures = 0.0, [], []
-        while True:
-            item = q.get()
-            if item is None:
-                break
-            p0, pix, new = item
-            h0 = _time.perf_counter()
-            part = self.stage_host(new)
-            host_busy += _time.perf_counter() - h0
-            parts.append((new,) + part)
-            ids_in, bbox, mask = part[2:]
-            for c0 in range(0, int(ids_in.shape[0]), per):
-                futures.append(fl.submit(lambda ctx, a: self.stage_main(*a, engine=ctx),
-                                         (pix[c0:c0 + per], ids_in[c0:c0 + per], bbox[c0:c0 + per], mask[c0:c0 + per])))
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                p0, pix, new = item
+                h0 = _time.perf_counter()
+                part = self.stage_host(new)
+                host_busy += _time.perf_counter() - h0
+                parts.append((new,) + part)
+                ids_in, bbox, mask = part[2:]
+                for c0 in range(0, int(ids_in.shape[0]), per):
+                    futures.append(fl.submit(lambda ctx, a: self.stage_main(*a, engine=ctx),
+                                             (pix[c0:c0 + per], ids_in[c0:c0 + per], bbox[c0:c0 + per], mask[c0:c0 + per])))
+        except BaseException:
+            # a failure of the host stage / a submit: stop the OCR worker (it may be blocked on the bounded queue) before re-raising
+            stop.set()
+            while th.is_alive():
+                try:
+                    q.get(timeout=0.1)
+                except queue.Empty:
+                    pass
+            raise
         th.join()
         if errs:
             raise errs[0]

@@ -121,7 +121,8 @@ def test_g4_greedy_free_running_ids_under_margin_rule():
     # non-degenerate: many different tokens, image-dependent sequences (the reference's ids: 0 repeats of one token)
     assert len({tuple(r) for r in ref.tolist()}) >= 16 and len(set(ref[:, 1:].ravel().tolist())) > 50
     same_rows = int((ids == ref).all(1).sum())
-    assert same_rows >= 16, same_rows         # measured 23 of 32 rows identical over all 16 steps; the others part at margins < 0.004
+    print(f"greedy, free-running: {same_rows} of 32 rows identical to stock over all 16 steps")
+    assert same_rows >= 20, same_rows         # measured 23 of 32 rows identical over all 16 steps (K / V form and weight-absorbed form alike); the others part at margins < 0.004; threshold = measured - 3
 
 
 def test_g4_decode_path_teacher_forced_top8():
@@ -199,13 +200,14 @@ def test_g4_beam5_all_32_images_against_stock():
     np.testing.assert_allclose(sc, gb["beam_scores"], atol=2 * LOGIT_TOL)
     hit = sum(bool(np.array_equal(ids[b], gb["beam_ids"][b]) or np.array_equal(ids[b], gb["beam_second_ids"][b])) for b in range(ids.shape[0]))
     print(f"beam-5, batch call: {hit} of {ids.shape[0]} hypotheses equal stock's best or second; max |score - stock| {np.abs(sc - gb['beam_scores']).max():.4f}")
-    assert hit >= 10, hit
+    assert hit >= 23, hit              # measured 26 (threshold = measured - 3)
     qi, ql, qs, _ = eng.generate_stream_beam(*args, num_beams=5, max_length=new + 1, min_length=new + 1, chunk=16, slots=16, pool_chunks=3)
     qi, ql, qs = eng.mem.numpy(qi), eng.mem.numpy(ql), eng.mem.numpy(qs)
     assert np.all(ql == new + 1)
     np.testing.assert_allclose(qs, gb["beam_scores"], atol=2 * LOGIT_TOL)
     hitq = sum(bool(np.array_equal(qi[b], gb["beam_ids"][b]) or np.array_equal(qi[b], gb["beam_second_ids"][b])) for b in range(qi.shape[0]))
-    assert hitq >= 10, hitq
+    print(f"beam-5, queue form: {hitq} of {qi.shape[0]} hypotheses equal stock's best or second")
+    assert hitq >= 23, hitq            # measured 26 (threshold = measured - 3)
 
 
 def test_g4_long_256_forced_steps_top8():
