@@ -123,6 +123,8 @@ struct mg_model {
     mgStream_t enc_stream = nullptr;
     std::vector<mgEvent_t> chunk_ev;     // per pool chunk: encoder + cross-K/V of the chunk done
     std::vector<mgEvent_t> rb_ev;        // read-back ring
+    std::vector<mgEvent_t> pace_ev;      // mg_generate: pacing of the launching host thread
+    int pace = 1;                        // MG_PACE=0: enqueue as fast as the runtime accepts (the launching thread then spins on a full queue)
     mgEvent_t start_ev = nullptr;
     long stream_steps = 0, stream_idle_steps = 0;      // statistics of the last mg_generate_stream call
     double stream_enc_ms = 0.0;
@@ -150,6 +152,7 @@ struct mg_model {
         if (enc_stream_ready && enc_stream) mg_stream_destroy(enc_stream);
         for (mgEvent_t e : chunk_ev) mg_event_destroy(e);
         for (mgEvent_t e : rb_ev) mg_event_destroy(e);
+        for (mgEvent_t e : pace_ev) mg_event_destroy(e);
         if (start_ev) mg_event_destroy(start_ev);
 #ifndef MG_EMU
         if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -799,6 +802,7 @@ int mg_create(const mg_config* cfg, mg_model** out) {
     { const char* e = getenv("MG_ENC_ROW_TILES"); if (e && e[0] == '0') m->row_tiles = false; }
     { const char* e = getenv("MG_DECODE_FUSED_TAIL"); if (e && e[0] == '0') m->fused_tail = false; }
     { const char* e = getenv("MG_XATTN_ABSORB"); if (e && e[0] == '0') m->absorb = 0; }
+    { const char* e = getenv("MG_PACE"); if (e && e[0] == '0') m->pace = 0; }
     { const char* e = getenv("MG_XATTN_SPLIT"); if (e && atoi(e) >= 1 && atoi(e) <= 4) m->xa_split = atoi(e); }
     if (!xattn_supported(c.d_model, c.num_heads)) m->absorb = 0;
     // arena layout
@@ -868,7 +872,7 @@ int mg_clone(const mg_model* src, mg_model** out) {
     m->fin_a = src->fin_a; m->fin_b = src->fin_b; m->fin_c = src->fin_c;
     m->use_graph = src->use_graph; m->enc_mode = src->enc_mode; m->enc_mask = src->enc_mask;
     m->row_tiles = src->row_tiles; m->trim_padding = src->trim_padding; m->fused_tail = src->fused_tail; m->tied = src->tied;
-    m->absorb = src->absorb; m->xa_split = src->xa_split; m->xa_stages = src->xa_stages;
+    m->absorb = src->absorb; m->xa_split = src->xa_split; m->xa_stages = src->xa_stages; m->pace = src->pace;
     m->e1m = src->e1m; m->e1_M = src->e1_M;
     *out = m;
     return MG_OK;
@@ -1424,7 +1428,18 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
     }
 #endif
     m->graph_active = graphed;
+    // The host enqueues steps far faster than the GPU runs them; a full runtime queue makes the launching thread SPIN inside the launch
+    // call (one busy core per execution context).  Pace it instead: every 8 steps an event is recorded, and before enqueueing further the
+    // thread sleeps (polling an event: mg_event_sync) until the steps of 16 .. 24 steps ago have run - the GPU always has >= 16 steps queued.
+    constexpr int PACE = 8, PACE_RING = 3;
+    while ((int)m->pace_ev.size() < PACE_RING) { mgEvent_t e; if (mg_event_create_notiming(&e) != 0) break; m->pace_ev.push_back(e); }
+    const bool paced = (int)m->pace_ev.size() == PACE_RING && m->pace;
     for (int t = 0; t + 1 < max_length; ++t) {
+        if (paced && (t % PACE) == 0) {
+            const int k = t / PACE;
+            if (k >= PACE_RING) mg_event_sync(m->pace_ev[k % PACE_RING]);      // recorded PACE_RING * PACE steps ago
+            mg_event_record(m->pace_ev[k % PACE_RING], st);
+        }
         const bool timed_step = m->prof_every > 0 && (t % m->prof_every) == 0;
 #ifndef MG_EMU
         if (graphed && !timed_step) {

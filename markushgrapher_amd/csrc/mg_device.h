@@ -23,6 +23,8 @@ struct f32x4 {
 };
 #else
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <unistd.h>
 #define MG_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
 #define MG_LAUNCH(kern, grid, block, shmem, stream, ...) \
     hipLaunchKernelGGL(kern, grid, block, shmem, stream, __VA_ARGS__)
@@ -63,7 +65,28 @@ static inline int mg_memset_async(void* p, int v, size_t n, mgStream_t st) { ret
 static inline int mg_memcpy_async(void* d, const void* s, size_t n, mgStream_t st) {
     return mg_track((int)hipMemcpyAsync(d, s, n, hipMemcpyDefault, st), "hipMemcpyAsync");
 }
-static inline int mg_stream_sync(mgStream_t st) { return mg_track((int)hipStreamSynchronize(st), "hipStreamSynchronize"); }
+// Waiting WITHOUT spinning: hipStreamSynchronize / hipEventSynchronize busy-wait on the host in this runtime (also for events created with
+// hipEventBlockingSync: measured, tools/spin_probe.py) - one core per waiting thread, five per rank with four execution contexts in flight.
+// Waits of this library poll the event and sleep in between (100 us: nothing here waits for less than a decode step).  MG_SPIN_SYNC=1
+// restores the runtime's own waits.
+static inline bool mg_spin_sync() { static const bool spin = [] { const char* e = getenv("MG_SPIN_SYNC"); return e && e[0] == '1'; }(); return spin; }
+static inline int mg_event_wait_sleeping(hipEvent_t ev) {
+    for (int i = 0;; ++i) {
+        const hipError_t r = hipEventQuery(ev);
+        if (r == hipSuccess) return 0;
+        if (r != hipErrorNotReady) return (int)r;
+        (void)hipGetLastError();                       // (hipErrorNotReady is sticky in the thread's last-error slot)
+        if (i >= 4) usleep(100);
+    }
+}
+static inline int mg_stream_sync(mgStream_t st) {
+    static thread_local hipEvent_t ev = nullptr;
+    if (!mg_spin_sync() && !ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
+    if (mg_spin_sync() || !ev) return mg_track((int)hipStreamSynchronize(st), "hipStreamSynchronize");
+    const int rc = mg_track((int)hipEventRecord(ev, st), "hipEventRecord");
+    if (rc != 0) return rc;
+    return mg_track(mg_event_wait_sleeping(ev), "hipEventQuery");
+}
 static inline int mg_peek_error() { return (int)hipGetLastError(); }
 static inline const char* mg_error_string(int e) { return hipGetErrorString((hipError_t)e); }
 typedef hipEvent_t mgEvent_t;
@@ -84,7 +107,7 @@ static inline void mg_stream_destroy(mgStream_t s) { (void)hipStreamDestroy(s); 
 static inline int mg_event_create_notiming(mgEvent_t* e) { return (int)hipEventCreateWithFlags(e, hipEventDisableTiming); }
 static inline int mg_stream_wait_event(mgStream_t s, mgEvent_t e) { return mg_track((int)hipStreamWaitEvent(s, e, 0), "hipStreamWaitEvent"); }
 static inline int mg_event_done(mgEvent_t e) { const hipError_t r = hipEventQuery(e); if (r == hipErrorNotReady) { (void)hipGetLastError(); return 0; } return 1; }
-static inline int mg_event_sync(mgEvent_t e) { return mg_track((int)hipEventSynchronize(e), "hipEventSynchronize"); }
+static inline int mg_event_sync(mgEvent_t e) { return mg_spin_sync() ? mg_track((int)hipEventSynchronize(e), "hipEventSynchronize") : mg_track(mg_event_wait_sleeping(e), "hipEventQuery"); }
 static inline void* mg_host_alloc(size_t n) { void* p = nullptr; return hipHostMalloc(&p, n, hipHostMallocDefault) == hipSuccess ? p : nullptr; }
 static inline void mg_host_free(void* p) { (void)hipHostFree(p); }
 #endif

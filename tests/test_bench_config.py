@@ -325,3 +325,52 @@ def test_g4_with_the_ocsr_branch_attached_at_production_dimensions():
         e1e.close()
     back, _, _ = eng.generate(*args, max_length=new + 1, min_length=new + 1)
     assert np.array_equal(eng.mem.numpy(back), ids_plain)       # detached: the plain VTL model again, bit for bit
+
+
+def test_g4_b1_second_pinned_batch_inside_a_160_row_call():
+    """A SECOND batch of the benchmark's timed region pinned on stock UDOP: batch j = 1 of bench.py's pool (seed + 1000, padded to the pool's
+    common text length; tests/golden/g4_bench_b1.npz, tools/make_golden.py g4b1), as the FIRST batch of a 160-row call whose five batches
+    are all different from the batch g4_bench.npz pins (pool batches 1 .. 5: what the second context's call of the timed region holds).
+    Encoder probes of the 32 images; free-running greedy ids under the margin rule with the per-step top-1 logit within LOGIT_TOL; and the
+    call's first batch bit-identical to a call on that batch alone (the bench's own ids_equal_one_batch_calls check)."""
+    g1 = load_golden("g4_bench_b1.npz")
+    _, shape, eng, _ = _setup()
+    B, new, L = int(g1["batch"]), int(g1["new_tokens"]), int(g1["text_len_padded"])
+    assert int(g1["synth_seed"]) == synth.BENCH_SEED + 1000 and int(g1["pool_batch"]) == 1
+    parts = []
+    for j in range(1, 6):
+        p = synth.synth_batch(shape, B, seed=synth.BENCH_SEED + 1000 * j, return_pages=True)
+        padn = L - p["input_ids"].shape[1]
+        assert padn >= 0
+        if padn:
+            p["input_ids"] = np.pad(p["input_ids"], ((0, 0), (0, padn)))
+            p["attention_mask"] = np.pad(p["attention_mask"], ((0, 0), (0, padn)))
+            p["bbox"] = np.pad(p["bbox"], ((0, 0), (0, padn), (0, 0)))
+        parts.append(p)
+    cat = {k: np.concatenate([p[k] for p in parts], 0) for k in parts[0]}
+    pix = eng.preprocess(cat["pages_u8"])
+    enc, mask = eng.encode(parts[0]["input_ids"], parts[0]["bbox"], parts[0]["attention_mask"], pix[:B])
+    enc, mask = eng.mem.numpy(enc), eng.mem.numpy(mask)
+    assert np.array_equal(mask, g1["enc_mask"].astype(np.uint8))
+    for b in range(B):
+        err = np.abs(enc[b][g1["enc_rows"][b]] - g1["enc_probe"][b])
+        assert err.max() < ENC_MAX and err.mean() < ENC_MEAN, (b, err.max(), err.mean())
+    ids, _, top2 = eng.generate(cat["input_ids"], cat["bbox"], cat["attention_mask"], pix, max_length=new + 1, min_length=new + 1, return_top2=True)
+    ids, top2 = eng.mem.numpy(ids).copy(), eng.mem.numpy(top2).copy()
+    assert ids.shape == (5 * B, new + 1)
+    ref, vals = g1["greedy_ids"], g1["step_top_vals"]
+    margin = vals[..., 0] - vals[..., 1]
+    compared = 0
+    for b in range(B):
+        for t in range(1, new + 1):
+            if margin[b, t - 1] < MARGIN_TOL:
+                break
+            assert ids[b, t] == ref[b, t], (b, t)
+            assert abs(top2[t, b, 0] - vals[b, t - 1, 0]) < LOGIT_TOL
+            compared += 1
+    expected = sum(int(np.argmax(np.append(margin[b] < MARGIN_TOL, True))) for b in range(B))
+    same_rows = int((ids[:B] == ref).all(1).sum())
+    print(f"G4-b1 inside a 160-row call: {compared} positions compared under the margin rule, {same_rows} of 32 rows identical to stock over all 16 steps")
+    assert compared == expected and compared >= 30, (compared, expected)
+    one, _, _ = eng.generate(parts[0]["input_ids"], parts[0]["bbox"], parts[0]["attention_mask"], pix[:B], max_length=new + 1, min_length=new + 1)
+    assert np.array_equal(eng.mem.numpy(one), ids[:B])
