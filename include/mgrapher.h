@@ -279,9 +279,9 @@ int mgk_attention_step(void* stream, const void* q, const void* Kc, const void* 
  * ctx[row][h] = softmax(q_h (enc Wk_h^T)^T) (enc Wv_h^T) (stock modeling_udop.py:524-575 without a position bias) evaluated as
  * [softmax((q_h Wk_h) enc^T) enc] Wv_h^T on the states themselves.  q [rows][H][64] bf16; wkv fp32 [2*H*64][d], K rows first;
  * enc [owners][cap][d] bf16; len [owners] keys per owner; kv_owner [rows] (null: row r reads owner r); scratch wk, wv (H*d*64 bf16
- * each), qx (rows*H*d bf16), part (rows*nsplit*H*d fp32), ml (rows*nsplit*H*2 fp32); ctx_pk packed [rows padded to 32][H*64]. */
+ * each), qx (rows*H*d bf16), part (rows*nsplit*H*d bf16), ml (rows*nsplit*H*2 fp32); ctx_pk packed [rows padded to 32][H*64]. */
 int mgk_xattn(void* stream, const void* q, const float* wkv, const void* enc, const int* len, const int* kv_owner, int rows, int H, int d,
-              int cap, int nsplit, int nstg, void* wk, void* wv, void* qx, float* part, float* ml, void* ctx_pk);
+              int cap, int nsplit, int nstg, void* wk, void* wv, void* qx, void* part, float* ml, void* ctx_pk);
 int mgk_enc_rows(void* stream, const void* src_pk, const int* row_map, void* dst, int B, int rows_per_image, int cap, int d);
 int mgk_embed_assemble(void* stream, void* meta_ws, const int64_t* input_ids, const float* bbox,
                        const uint8_t* attention_mask, const float* patch_emb, const void* tok_emb, const void* x_emb,

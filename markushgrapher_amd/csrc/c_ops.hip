@@ -145,17 +145,17 @@ int mgk_attention_step_trace(void* stream, const void* q, const void* Kc, const 
 
 // Weight-absorbed cross-attention of the greedy decode step (k_xattn.hip), the three launches of a layer + the weight re-ordering:
 // q [rows][H][64] bf16, wkv fp32 [2*H*64][d] (K rows first), enc [owners][cap][d] bf16 natural rows, len [owners], kv_owner [rows]
-// (nullable).  Scratch: wk, wv [H*d*64] bf16 each, qx [rows][H][d] bf16, part [rows][nsplit][H][d] fp32, ml [rows][nsplit][H][2] fp32.
+// (nullable).  Scratch: wk, wv [H*d*64] bf16 each, qx [rows][H][d] bf16, part [rows][nsplit][H][d] bf16, ml [rows][nsplit][H][2] fp32.
 // Result: ctx_pk packed [rows padded to 32][H*64] bf16.
 int mgk_xattn(void* stream, const void* q, const float* wkv, const void* enc, const int* len, const int* kv_owner, int rows, int H, int d,
-              int cap, int nsplit, int nstg, void* wk, void* wv, void* qx, float* part, float* ml, void* ctx_pk) {
+              int cap, int nsplit, int nstg, void* wk, void* wv, void* qx, void* part, float* ml, void* ctx_pk) {
     if (!xattn_supported(d, H) || nsplit < 1 || nsplit > 4 || nstg != 4) return MG_E_UNSUPPORTED;
     mgStream_t st = (mgStream_t)stream;
     xattn_pack_weights(wkv, (uint16_t*)wk, (uint16_t*)wv, H, d, st);
     xattn_stream_prepare(d, nstg);
     XAttnArgs a{};
     a.q = (const uint16_t*)q; a.qx = (uint16_t*)qx; a.wk = (const uint16_t*)wk; a.wv = (const uint16_t*)wv; a.enc = (const uint16_t*)enc;
-    a.len = len; a.kv_owner = kv_owner; a.part = part; a.ml = ml; a.ctx = (uint16_t*)ctx_pk;
+    a.len = len; a.kv_owner = kv_owner; a.part = (uint16_t*)part; a.ml = ml; a.ctx = (uint16_t*)ctx_pk;
     a.rows = rows; a.H = H; a.d = d; a.cap = cap; a.nsplit = nsplit; a.nstg = nstg;
     xattn_expand(a, st);
     xattn_stream(a, st);

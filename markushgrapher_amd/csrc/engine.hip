@@ -279,8 +279,8 @@ struct Ws {
     // decode (generate)
     uint16_t *xk, *xv, *sk, *sv, *dq, *dx_pk, *dy_pk;
     // weight-absorbed cross-attention (greedy): the states the decoder attends [B][Sx_cap][d], q' [rows][H][d], context partials
-    uint16_t *encx, *qx;
-    float *xpart, *xml;
+    uint16_t *encx, *qx, *xpart;
+    float *xml;
     uint16_t *xa, *xb;        // packed [rows][d + inner] operand windows of the pair projections: [bf16(h) | attention context]
     float *dh, *logits, *slabs, *rs_part, *rs_part1, *rs_part2;
     float4* ptop;             // fused greedy tail: per-workgroup top-2 partials of the lm_head launch [rows][V/32]
@@ -358,11 +358,11 @@ void carve(const mg_model* m, char* base, int B, int L, int K, int max_len, int 
     if (max_len > 0) {
         const int R = B * K, Rp = round_up(R, 32);
         const size_t nl = m->dec.size();
-        w->xk = w->xv = w->encx = w->qx = nullptr; w->xpart = w->xml = nullptr;
+        w->xk = w->xv = w->encx = w->qx = w->xpart = nullptr; w->xml = nullptr;
         if (use_absorb(m, K)) {
             w->encx = c.take<uint16_t>((size_t)B * Sx_cap * d);
             w->qx = c.take<uint16_t>((size_t)Rp * H * d);
-            w->xpart = c.take<float>((size_t)Rp * m->xa_split * H * d);
+            w->xpart = c.take<uint16_t>((size_t)Rp * m->xa_split * H * d);
             w->xml = c.take<float>((size_t)Rp * m->xa_split * H * 2);
         } else {
             w->xk = c.take<uint16_t>(nl * B * H * Sx_cap * 64);
@@ -424,8 +424,8 @@ void carve(const mg_model* m, char* base, int B, int L, int K, int max_len, int 
 struct StreamWs {
     Ws enc;                   // encoder workspace of one chunk
     uint16_t *xk, *xv;        // K/V pool [layer][pool entry][H][Sx_cap][64]  (absorbed form: null; encx = pool of encoder states [pool entry][Sx_cap][d])
-    uint16_t *encx, *qx;
-    float *xpart, *xml;
+    uint16_t *encx, *qx, *xpart;
+    float *xml;
     size_t pool_stride;       // elements between layers
     int* xlen_pool;           // [pool entries]
     uint16_t *sk, *sv, *dq, *dx_pk, *dy_pk, *xa, *xb;
@@ -449,11 +449,11 @@ void carve_stream(const mg_model* m, char* base, int chunk, int L, int slots_img
     const int Sx_cap = round_up(L + m->P, 64) + round_up(m->e1_M, 64), Rp = round_up(slots, 32);      // keys of an image: [e1 tokens | encoder positions]
     const size_t nl = m->dec.size(), entries = (size_t)pool_chunks * chunk;
     w->pool_stride = entries * H * Sx_cap * 64;
-    w->xk = w->xv = w->encx = w->qx = nullptr; w->xpart = w->xml = nullptr;
+    w->xk = w->xv = w->encx = w->qx = w->xpart = nullptr; w->xml = nullptr;
     if (use_absorb(m, K)) {
         w->encx = c.take<uint16_t>(entries * Sx_cap * d);
         w->qx = c.take<uint16_t>((size_t)Rp * H * d);
-        w->xpart = c.take<float>((size_t)Rp * m->xa_split * H * d);
+        w->xpart = c.take<uint16_t>((size_t)Rp * m->xa_split * H * d);
         w->xml = c.take<float>((size_t)Rp * m->xa_split * H * 2);
     } else {
         w->xk = c.take<uint16_t>(nl * w->pool_stride);
@@ -587,8 +587,8 @@ void ffn_block(const mg_model* m, bool rows_mode, float* hidden, uint16_t* x_pk,
 struct DecodeCtx {
     uint16_t *xk, *xv;        // cross K/V: [layer][owner][H][Sx_cap][64]
     // absorbed form (encx non-null): the attended encoder states [owner][Sx_cap][d] + the scratch of the three launches
-    uint16_t *encx, *qx;
-    float *xpart, *xml;
+    uint16_t *encx, *qx, *xpart;
+    float *xml;
     size_t xkv_stride;        // elements between layers
     int Sx_cap;
     const int* xlen;          // keys per K/V owner

@@ -9,10 +9,10 @@
 // cross-K/V projections of the encoder phase (12 % of its flops) and the per-layer K/V buffers disappear.
 //
 //   xq_expand_kernel      q [rows][H][64]  ->  q' [rows][H][d]          (per head a [rows x 64] x [64 x d] product, MFMA 16x16x32)
-//   xattn_stream_kernel   q', enc          ->  c [rows][split][H][d] fp32 un-normalised + (m, l) per head   (the HBM stream; MFMA)
+//   xattn_stream_kernel   q', enc          ->  c [rows][split][H][d] bf16, normalised per split, + (m, l) per head   (the HBM stream; MFMA)
 //   xctx_contract_kernel  c, (m, l)        ->  ctx [rows][H*64] bf16     (merge of the key splits, 1 / l, per head [rows x d] x [d x 64])
 //
-// Rounding points: q (bf16, as before), q' (bf16), P (bf16), c (fp32 -> bf16 after the normalisation), ctx (bf16, as before).
+// Rounding points: q (bf16, as before), q' (bf16), P (bf16), c (fp32 accumulation -> bf16 after the normalisation), ctx (bf16, as before).
 #include "mg_kernels.h"
 
 namespace mg {
@@ -146,7 +146,8 @@ __global__ __launch_bounds__(NW * NG * 64) void xattn_stream_kernel(XAttnArgs a)
         for (int c = 0; c < KS; ++c) glds16_async_sv(src, coff[c], dst + c * 1024);
     };
     // LDS byte offsets inside a stage: score operand (key = lane % 16, chunks fb/8 + 4 ks + g) and transposed operand (key 4 g + a,
-    // features fb + 16 t + 4 b, a = (lane % 16) / 4, b = lane % 4).  The swizzle is an XOR on the low 4 bits of the chunk index: the
+    // features fb + 32 (t / 2) + 8 b + 4 (t % 2) .. + 4, a = (lane % 16) / 4, b = lane % 4: result row 4 g' + i of tile t = feature
+    // fb + 32 (t / 2) + 8 g' + 4 (t % 2) + i).  The swizzle is an XOR on the low 4 bits of the chunk index: the
     // k-step / tile index changes those bits with period 4 / 8 and adds 256 B beyond - 4 + 8 offsets in registers, immediates for the rest.
     constexpr int NSA = KS < 4 ? KS : 4, NTA = NF < 8 ? NF : 8;
     unsigned sa[NSA], ta[NTA];
@@ -156,7 +157,8 @@ __global__ __launch_bounds__(NW * NG * 64) void xattn_stream_kernel(XAttnArgs a)
         for (int k = 0; k < NSA; ++k) sa[k] = (unsigned)(head * d * 2 + ((((fb >> 3) + g + 4 * k) ^ sx) << 4));
         const int ra = (lane & 15) >> 2, rb = lane & 3, tkey = 4 * g + ra, tx = xa_swz(tkey) & swz_mask;
 #pragma unroll
-        for (int k = 0; k < NTA; ++k) ta[k] = (unsigned)(tkey * d * 2 + ((((fb >> 3) + (rb >> 1) + 2 * k) ^ tx) << 4) + (rb & 1) * 8);
+        // (tiles 2p, 2p + 1 take the low / high 8 bytes of chunks fb/8 + 4p + b: a lane of the result then holds 8 consecutive features)
+        for (int k = 0; k < NTA; ++k) ta[k] = (unsigned)(tkey * d * 2 + ((((fb >> 3) + 4 * (k >> 1) + rb) ^ tx) << 4) + (k & 1) * 8);
     }
 
     f32x4 acc[NF];
@@ -275,14 +277,18 @@ __global__ __launch_bounds__(NW * NG * 64) void xattn_stream_kernel(XAttnArgs a)
         }
         if (gi != 0) return;
     }
-    // a lane's l covers its own 4 keys per stage: complete it over the lane groups; write the un-normalised context and (m, l)
+    // a lane's l covers its own 4 keys per stage: complete it over the lane groups; write the split's context NORMALISED by its own l as
+    // bf16 (with one split this is the value the contraction consumes: same bits as normalising there, half the bytes) and (m, l)
     lsum += lane_xor<16>(lsum, lane);
     lsum += lane_xor<32>(lsum, lane);
     if (head < H) {
         const size_t pi = ((size_t)row * a.nsplit + split) * H + head;
-        float* pp = a.part + pi * d + fb + 4 * g;
+        const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
+        uint16_t* pp = a.part + pi * d + fb + 8 * g;
 #pragma unroll
-        for (int t = 0; t < NF; ++t) *(float4*)(pp + 16 * t) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+        for (int p2 = 0; p2 < NF / 2; ++p2)
+            st16(pp + 32 * p2, make_uint4(pack_bf16(acc[2 * p2][0] * inv, acc[2 * p2][1] * inv), pack_bf16(acc[2 * p2][2] * inv, acc[2 * p2][3] * inv),
+                                          pack_bf16(acc[2 * p2 + 1][0] * inv, acc[2 * p2 + 1][1] * inv), pack_bf16(acc[2 * p2 + 1][2] * inv, acc[2 * p2 + 1][3] * inv)));
         if (wq == 0 && g == 0) { a.ml[pi * 2] = mrun; a.ml[pi * 2 + 1] = lsum; }
     }
 }
@@ -300,9 +306,9 @@ __global__ __launch_bounds__(256) void xctx_contract_kernel(XAttnArgs a) {
     int row = r0 + m;
     const bool in = row < a.rows;
     row = in ? row : a.rows - 1;
-    // merge weights of the key splits: c = sum_s exp(m_s - M) c_s / sum_s exp(m_s - M) l_s
+    // merge weights of the key splits (each stored normalised by its own l): c = sum_s exp2(m_s - M) l_s c_s / sum_s exp2(m_s - M) l_s
     float cs[4] = {0.f, 0.f, 0.f, 0.f};
-    {
+    if (NS > 1) {
         float ms[4], ls[4], M = XA_NEG;
         for (int s = 0; s < NS; ++s) {
             const size_t pi = ((size_t)row * NS + s) * H + h;
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(256) void xctx_contract_kernel(XAttnArgs a) {
             M = fmaxf(M, ms[s]);
         }
         float L = 0.f;
-        for (int s = 0; s < NS; ++s) { cs[s] = fast_exp2(ms[s] - M); L += cs[s] * ls[s]; }      // (the stream's maxima are in log2 units)
+        for (int s = 0; s < NS; ++s) { cs[s] = fast_exp2(ms[s] - M) * ls[s]; L += cs[s]; }      // (the stream's maxima are in log2 units)
         const float inv = L > 0.f ? 1.0f / L : 0.f;
         for (int s = 0; s < NS; ++s) cs[s] *= inv;
     }
@@ -318,14 +324,18 @@ __global__ __launch_bounds__(256) void xctx_contract_kernel(XAttnArgs a) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = acc4_zero();
     for (int ks = w; ks < KT; ks += 4) {
-        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < NS; ++s) {
-            const float* p = a.part + (((size_t)row * NS + s) * H + h) * d + 32 * ks + 8 * g;
-            const float4 x = *(const float4*)p, y = *(const float4*)(p + 4);
-            v[0] += cs[s] * x.x; v[1] += cs[s] * x.y; v[2] += cs[s] * x.z; v[3] += cs[s] * x.w;
-            v[4] += cs[s] * y.x; v[5] += cs[s] * y.y; v[6] += cs[s] * y.z; v[7] += cs[s] * y.w;
+        uint4 cb;
+        if (NS == 1) {
+            cb = ld16(a.part + ((size_t)row * H + h) * d + 32 * ks + 8 * g);          // one split: already the normalised bf16 context
+        } else {
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < NS; ++s) {
+                const uint4 x = ld16(a.part + (((size_t)row * NS + s) * H + h) * d + 32 * ks + 8 * g);
+                v[0] += cs[s] * bf16lo(x.x); v[1] += cs[s] * bf16hi(x.x); v[2] += cs[s] * bf16lo(x.y); v[3] += cs[s] * bf16hi(x.y);
+                v[4] += cs[s] * bf16lo(x.z); v[5] += cs[s] * bf16hi(x.z); v[6] += cs[s] * bf16lo(x.w); v[7] += cs[s] * bf16hi(x.w);
+            }
+            cb = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
         }
-        const uint4 cb = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
         const uint16_t* wp = a.wv + (((size_t)h * KT + ks) * 4) * 512 + lane * 8;
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = mfma16(ld16(wp + t * 512), cb, acc[t]);

@@ -325,7 +325,7 @@ struct XAttnArgs {
     const int* kv_owner;      // continuous decoding: pool entry read by a row (null: the row itself)
     const int* live;          // nullable: rows with live[row] == 0 are skipped (see AttnStepArgs::live)
     RowScale qrs;             // deferred RMSNorm scale of the query rows (applied to the scores)
-    float* part;              // [rows][nsplit][H][d] fp32: un-normalised context of a key split
+    uint16_t* part;           // [rows][nsplit][H][d] bf16: context of a key split, normalised by the split's own sum
     float* ml;                // [rows][nsplit][H][2]: running max and sum of the split
     uint16_t* ctx;            // packed window, as AttnStepArgs::ctx
     int ctx_ld, ctx_col0;

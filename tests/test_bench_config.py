@@ -122,7 +122,7 @@ def test_g4_greedy_free_running_ids_under_margin_rule():
     assert len({tuple(r) for r in ref.tolist()}) >= 16 and len(set(ref[:, 1:].ravel().tolist())) > 50
     same_rows = int((ids == ref).all(1).sum())
     print(f"greedy, free-running: {same_rows} of 32 rows identical to stock over all 16 steps")
-    assert same_rows >= 20, same_rows         # measured 23 of 32 rows identical over all 16 steps (K / V form and weight-absorbed form alike); the others part at margins < 0.004; threshold = measured - 3
+    assert same_rows >= 19, same_rows         # measured 23 (K / V form) and 22 (weight-absorbed form) of 32 rows identical over all 16 steps; the others part at margins < 0.004; threshold = measured - 3
 
 
 def test_g4_decode_path_teacher_forced_top8():
