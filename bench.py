@@ -443,6 +443,14 @@ def main():
     # per batch are identical to a call made alone (tests/test_inflight.py).
     from markushgrapher_amd.inflight import InFlight
     fl = InFlight(eng, max(1, args.inflight))
+    # Cross-attention form (mg_set_cross_absorb): the library's default picks it by the call's decode rows (weight-absorbed from 96 rows on).
+    # The timed region's calls hold bpc x 32 rows: their form is PINNED on every context, so that the per-batch identity check below (a batch
+    # of a packed call against a call on the batch alone) compares like with like; the one-batch and small-queue side runs go back to the default.
+    bpc_ = max(1, min(8, args.batches_per_call)) if args.beams == 1 else 1
+    pin_absorb = args.beams == 1 and bpc_ * B >= eng.ABSORB_AUTO_ROWS and eng.cross_absorb == "auto"
+    if pin_absorb:
+        for c_ in fl.contexts:
+            c_.set_cross_absorb(True)
 
     # up to `--batches-per-call` batches ride in one call (rows [0, B) = one batch, [B, 2B) the next ...): the same preprocess ->
     # encoder -> decode steps per batch, the decode step's weight stream shared by the batches of the call.
@@ -579,6 +587,8 @@ def main():
             one = job(eng, 1, first_call + j)
             eq.append(bool(torch.equal(ids_call[j * B:(j + 1) * B], one)))
         ids_equal_solo = bool(all(eq))
+        if pin_absorb:
+            eng.set_cross_absorb("auto")         # one batch of 32 rows per call: the library's default form for that call size (K / V streams)
         step()
         profile_on()
         torch.cuda.synchronize(); ts = time.time()
@@ -588,6 +598,8 @@ def main():
             ex.wait(handles.pop(0))
         torch.cuda.synchronize(); ts = time.time() - ts
         solo = (ts,) + profile_read()
+        if pin_absorb:
+            eng.set_cross_absorb(True)
         # ... and ONE call of the timed region's largest call shape alone on the first context: the dominant launch and the phases of
         # that shape without other contexts' kernels beside them
         nb_main = max(timed_plan) if timed_plan else 1
@@ -672,7 +684,8 @@ def main():
             _, msk = eng.encode(q["input_ids"], q["bbox"], q["attention_mask"], eng.preprocess(q["pages_u8"]))
             xl.append(msk.sum(dim=1).cpu().numpy().astype(np.float64))
         xlen = np.concatenate(xl)
-        absorbed = bool(eng.cross_absorb) and args.beams == 1
+        absorbed = args.beams == 1 and (eng.cross_absorb is True or (eng.cross_absorb == "auto" and int(round(nb_first)) * B >= eng.ABSORB_AUTO_ROWS))
+        absorbed_main = absorbed
         traffic = None if (args.no_pmc or world > 1 or args.beams != 1) else pmc_traffic(args, int(round(nb_first)))
         def make_roof(n_l, ms, keys, empty_ms, with_traffic):
             if n_l.value <= 0:
@@ -766,11 +779,20 @@ def main():
         single = None
         if solo is not None:
             ts = solo[0]
+            if pin_absorb:
+                absorbed = False          # the one-batch leg ran the default form of a 32-row call: K / V streams (accounting below follows)
+                f_xkv = float(np.sum(n_dec * xlen * 4 * d * d)) / n_pool
+                bytes_step = 2.0 * (n_dec * 16 * d * d + d * V) + float(np.sum(n_dec * 2 * d * (2 * xlen + 2 * tbar))) / n_pool
             single = {"images_per_s": round(B * SOLO_STEPS / ts, 2), "ms_per_batch": round(ts / SOLO_STEPS * 1e3, 2), "steps": SOLO_STEPS,
                       "roofline": make_roof(*solo[1:5], False), "phases": make_phases(*solo[5:8]),
                       "whole_job": whole_job(SOLO_STEPS, ts),
+                      "cross_attention_form": "weight-absorbed" if absorbed else "K / V streams (the library's default below 96 decode rows per call)",
                       "note": "the same step with one batch in flight (one context, one stream): the loop shape of the reference and of "
                               "rounds 1-2; kernel and phase figures without other batches' kernels beside them"}
+            if pin_absorb:
+                absorbed = absorbed_main
+                f_xkv = 0.0 if absorbed else f_xkv
+                bytes_step = 2.0 * (n_dec * 16 * d * d + d * V) + float(np.sum(n_dec * 2 * d * ((1 if absorbed else 2) * xlen + 2 * tbar))) / n_pool
         call_alone_rep = None
         if solo_call is not None:
             tc, nbm = solo_call[0], solo_call[1]
@@ -780,6 +802,9 @@ def main():
                                       "dominant launch streams the cross-attention K/V of all its batches in one grid; agrees with the rocprofv3 kernel "
                                       "trace of `bench.py --inflight 1` (profiles/)"}
         extra = None
+        if pin_absorb:               # the side runs below (EOS queues, beam search, configs[4]) take the library's default form for their call sizes
+            for c_ in fl.contexts:
+                c_.set_cross_absorb("auto")
         if not args.no_extra_runs and world == 1 and args.beams == 1:
             extra = {}
             # beam-5, BASELINE configs[2]: 160 live sequences, 128 new tokens
@@ -962,6 +987,8 @@ def main():
                        "num_beams": args.beams, "decode_graph": args.decode_graph, "batches_in_flight": int(sum(timed_plan[:len(fl)])),
                        "contexts": len(fl), "batches_per_call_max": bpc, "batches_per_call": timed_plan,
                        "ids_equal_one_batch_calls": ids_equal_solo, "distinct_batches": n_pool,
+                       "cross_attention_form": ("weight-absorbed (mg_set_cross_absorb pinned on the contexts: calls of %d decode rows)" % (bpc * B)) if absorbed_main
+                                               else "K / V streams",
                        "inputs": f"{n_pool} different batches of 32 images per rank (seed + 1000 j; j = 0 is the batch of tests/golden/g4_bench.npz), padded to the "
                                  f"pool's longest text ({int(L)} tokens): the calls of the timed region hold different images in every row",
                        "single_rank_rccl_group": bool(force_dist),

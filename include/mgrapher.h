@@ -191,15 +191,22 @@ int mg_set_padding_semantics(mg_model* m, int per_image);
  * hence off by default).  Same kernels, same results.  Takes effect from the context's next call (its captured decode step is dropped).
  * Returns the previous setting.  No counterpart in the reference (one batch at a time, utils_evaluation.py:269-285). */
 int mg_set_shared_gpu(mg_model* m, int shared);
-/* Cross-attention of the greedy decode step (num_beams = 1, batch and queue forms).  absorb = 1 (default wherever the geometry has the
- * form: d_model a supported multiple of 64, at most 16 heads): weight-absorbed - with K_l = enc·Wk_l^T, V_l = enc·Wv_l^T (stock
- * transformers models/udop/modeling_udop.py:524-550, reached from /root/reference/markushgrapher/utils/ocsr/utils_evaluation.py:278-281)
- * softmax(q_h K_h^T) V_h = [softmax((q_h·Wk_h) enc^T) enc]·Wv_h^T, so every layer streams the attended encoder states (2·d_model bytes per
- * position) instead of its own K and V (4·d_model): half the dominant HBM stream of decoding, no cross-K/V projections after the
- * encoder, no per-layer K/V buffers (the workspace shrinks; sizes are computed for the current setting).  absorb = 0: the K / V form
- * (what beam search always uses).  key_splits in 1..4: workgroups per decode row of the stream (0 keeps the setting).  The two forms
- * round at different points (q' = q·Wk_h and the normalised context are rounded to bf16 instead of K and V): logits agree within the
- * stated tolerance, not bitwise.  Takes effect from the context's next call.  Returns the previous `absorb`; absorb < 0 only queries. */
+/* Cross-attention of the greedy decode step (num_beams = 1, batch and queue forms).  Weight-absorbed form: with K_l = enc·Wk_l^T,
+ * V_l = enc·Wv_l^T (stock transformers models/udop/modeling_udop.py:524-550, reached from
+ * /root/reference/markushgrapher/utils/ocsr/utils_evaluation.py:278-281) softmax(q_h K_h^T) V_h = [softmax((q_h·Wk_h) enc^T) enc]·Wv_h^T, so
+ * every layer streams the attended encoder states (2·d_model bytes per position) instead of its own K and V (4·d_model): half the
+ * dominant HBM stream of decoding, no cross-K/V projections after the encoder, no per-layer K/V buffers (the workspace shrinks; sizes are
+ * computed for the current setting and call shape).  The stream runs one workgroup per decode row: it pays from ~100 rows per call on
+ * (160 rows, 4 contexts in flight: 148 -> 182 images/s) and loses below (32 rows alone: 82 -> 50 images/s, latency-bound).
+ *   absorb = 2 (default wherever the geometry has the form: d_model a supported multiple of 64, at most 16 heads): by the call's decode
+ *              rows - absorbed from 96 rows on, K / V form below;
+ *   absorb = 1: absorbed for every greedy call;   absorb = 0: the K / V form always (what beam search always uses);
+ *   absorb < 0: query only.
+ * key_splits in 1..4: workgroups per decode row of the stream (0 keeps the setting).  The two forms round at different points (q' = q·Wk_h
+ * and the normalised context are rounded to bf16 instead of K and V): logits agree within the stated tolerance, NOT bitwise - with
+ * absorb = 2 a row decoded in a 160-row call and the same row in a 32-row call go through different forms; pin 0 or 1 where ids must be
+ * reproducible across call sizes (markushgrapher_amd/inflight.py does, for the calls it packs).  Takes effect from the context's next
+ * call.  Returns the previous `absorb`. */
 int mg_set_cross_absorb(mg_model* m, int absorb, int key_splits);
 /* 1 if the last mg_generate replayed a captured graph, 0 if it launched eagerly (mode 0/2, capture unavailable). */
 int mg_decode_graph_active(const mg_model* m);

@@ -38,7 +38,8 @@ void e1_info(const mg_e1_model* m, int* tokens, int* d_model, int* src_image_siz
 namespace {
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 int round_up(int x, int a) { return (x + a - 1) / a * a; }
-bool use_absorb(const mg_model* m, int K);
+constexpr int MG_ABSORB_AUTO_ROWS = 96;
+bool use_absorb(const mg_model* m, int K, int rows);
 
 struct EncLayer { size_t wqkv, wo, ln0, wi, wo2, ln1; };
 // xq2 / wi2: product weights of the decode step (built by mg_finalize): [Wxq·G1 | Wxq·G1·Wo] and [Wi·G2 | Wi·G2·Wxo]
@@ -102,8 +103,9 @@ struct mg_model {
     int use_graph = 1;
     bool graph_active = false;
     // Greedy decoding with the weight-absorbed cross-attention (k_xattn.hip): a layer streams the encoder states once instead of its K and V.
-    // absorb: 1 (default where the geometry is supported), 0: the K / V form for every call (A/B runs, MG_XATTN_ABSORB=0).  Beam search keeps the K / V form.
-    int absorb = 1, xa_split = 1, xa_stages = 4;
+    // absorb: 2 (default where the geometry is supported) = by the call's decode rows (>= 96: absorbed), 1: every greedy call, 0: the K / V form for
+    // every call (mg_set_cross_absorb, MG_XATTN_ABSORB).  Beam search keeps the K / V form.
+    int absorb = 2, xa_split = 1, xa_stages = 4;
     int shared_gpu = 0;       // mg_set_shared_gpu: other contexts run beside this one (the cross-attention stream keeps one workgroup per CU resident)
     // optional phase timing of mg_generate (HIP events): [start, encoder + cross-K/V done, decode loop done]
     bool phase_on = false;
@@ -359,7 +361,7 @@ void carve(const mg_model* m, char* base, int B, int L, int K, int max_len, int 
         const int R = B * K, Rp = round_up(R, 32);
         const size_t nl = m->dec.size();
         w->xk = w->xv = w->encx = w->qx = w->xpart = nullptr; w->xml = nullptr;
-        if (use_absorb(m, K)) {
+        if (use_absorb(m, K, R)) {
             w->encx = c.take<uint16_t>((size_t)B * Sx_cap * d);
             w->qx = c.take<uint16_t>((size_t)Rp * H * d);
             w->xpart = c.take<uint16_t>((size_t)Rp * m->xa_split * H * d);
@@ -450,7 +452,7 @@ void carve_stream(const mg_model* m, char* base, int chunk, int L, int slots_img
     const size_t nl = m->dec.size(), entries = (size_t)pool_chunks * chunk;
     w->pool_stride = entries * H * Sx_cap * 64;
     w->xk = w->xv = w->encx = w->qx = w->xpart = nullptr; w->xml = nullptr;
-    if (use_absorb(m, K)) {
+    if (use_absorb(m, K, slots)) {
         w->encx = c.take<uint16_t>(entries * Sx_cap * d);
         w->qx = c.take<uint16_t>((size_t)Rp * H * d);
         w->xpart = c.take<uint16_t>((size_t)Rp * m->xa_split * H * d);
@@ -527,7 +529,8 @@ __global__ __launch_bounds__(64) void stream_ready_kernel(int n, int* ctr) {
 }
 
 // greedy calls stream the encoder states (k_xattn.hip); beam search keeps the per-layer K / V streams (its G rows of an image share one pass)
-bool use_absorb(const mg_model* m, int K) { return m->absorb != 0 && K == 1; }
+// (auto: from 96 decode rows on - below that the stream's one workgroup per row is latency-bound and the K / V form's 16 workgroups per row win)
+bool use_absorb(const mg_model* m, int K, int rows) { return K == 1 && (m->absorb == 1 || (m->absorb == 2 && rows >= MG_ABSORB_AUTO_ROWS)); }
 
 int check_launch(const char* what) {
     const int e = mg_peek_error();
@@ -801,7 +804,7 @@ int mg_create(const mg_config* cfg, mg_model** out) {
     { const char* e = getenv("AMD_DIRECT_DISPATCH"); if (e && e[0] == '0') m->use_graph = 0; }
     { const char* e = getenv("MG_ENC_ROW_TILES"); if (e && e[0] == '0') m->row_tiles = false; }
     { const char* e = getenv("MG_DECODE_FUSED_TAIL"); if (e && e[0] == '0') m->fused_tail = false; }
-    { const char* e = getenv("MG_XATTN_ABSORB"); if (e && e[0] == '0') m->absorb = 0; }
+    { const char* e = getenv("MG_XATTN_ABSORB"); if (e && e[0] >= '0' && e[0] <= '2') m->absorb = e[0] - '0'; }
     { const char* e = getenv("MG_PACE"); if (e && e[0] == '0') m->pace = 0; }
     { const char* e = getenv("MG_XATTN_SPLIT"); if (e && atoi(e) >= 1 && atoi(e) <= 4) m->xa_split = atoi(e); }
     if (!xattn_supported(c.d_model, c.num_heads)) m->absorb = 0;
@@ -1329,7 +1332,7 @@ int mg_generate(mg_model* m, void* stream, void* ws, size_t ws_bytes, const int6
     // cross-attention K/V of every decoder layer, once per image (stock:524-538), compacted to attended positions; the
     // e1 tokens (if any) occupy rows [0, M_e1) of an image's stream, the attended encoder positions follow (xrow carries
     // the offset) - cross-attention has no positional term, so the order of the keys is immaterial
-    const bool absorbed = use_absorb(m, K);
+    const bool absorbed = use_absorb(m, K, R);
     if (absorbed) {
         // weight-absorbed form (k_xattn.hip): the decoder layers stream the attended states themselves - one compaction instead of
         // 2 x N_dec projections
@@ -1838,8 +1841,9 @@ int mg_set_cross_absorb(mg_model* m, int absorb, int key_splits) {
     std::lock_guard<std::recursive_mutex> lk(m->call_mu);
     const int prev = m->absorb;
     if (absorb < 0) return prev;                        // query
+    if (absorb > 2) return fail(MG_E_ARG, "mg_set_cross_absorb: absorb must be 0 (K / V form), 1 (absorbed), 2 (by the call's rows) or < 0 (query)");
     if (absorb && !xattn_supported(m->d, m->H)) return fail(MG_E_UNSUPPORTED, "mg_set_cross_absorb: d_model %d / %d heads have no absorbed form", m->d, m->H);
-    m->absorb = absorb ? 1 : 0;
+    m->absorb = absorb;
     if (key_splits) m->xa_split = key_splits;
     m->step_graph.reset(); m->stream_graph.reset();      // (the captured steps hold the other form's launches and buffers)
     return prev;

@@ -161,17 +161,22 @@ class Engine:
         previous setting."""
         return bool(self.lib.mg_set_shared_gpu(self.model, 1 if shared else 0))
 
-    def set_cross_absorb(self, absorb: bool, key_splits: int = 0) -> bool:
-        """Greedy cross-attention form (include/mgrapher.h mg_set_cross_absorb): True = weight-absorbed (the layers stream the attended
-        encoder states), False = per-layer K / V streams.  The workspace is re-sized at the next call.  Returns the previous setting."""
-        prev = self._chk(self.lib.mg_set_cross_absorb(self.model, 1 if absorb else 0, int(key_splits)))
+    def set_cross_absorb(self, absorb, key_splits: int = 0):
+        """Greedy cross-attention form (include/mgrapher.h mg_set_cross_absorb): True / 1 = weight-absorbed (the layers stream the attended
+        encoder states), False / 0 = per-layer K / V streams, "auto" / 2 (default) = by the call's decode rows (absorbed from 96 on).  The
+        workspace is re-sized at the next call.  Returns the previous setting (False / True / "auto")."""
+        mode = 2 if absorb == "auto" else int(absorb)
+        prev = self._chk(self.lib.mg_set_cross_absorb(self.model, mode, int(key_splits)))
         self._ws, self._ws_bytes = None, 0
-        return bool(prev)
+        return "auto" if prev == 2 else bool(prev)
 
     @property
-    def cross_absorb(self) -> bool:
-        """True when greedy calls of this context run the weight-absorbed cross-attention (mg_set_cross_absorb)."""
-        return bool(self.lib.mg_set_cross_absorb(self.model, -1, 0))
+    def cross_absorb(self):
+        """False / True / "auto": the cross-attention form greedy calls of this context run (mg_set_cross_absorb)."""
+        prev = int(self.lib.mg_set_cross_absorb(self.model, -1, 0))
+        return "auto" if prev == 2 else bool(prev)
+
+    ABSORB_AUTO_ROWS = 96      # "auto": calls with at least this many decode rows take the absorbed form (engine.hip MG_ABSORB_AUTO_ROWS)
 
     def clone(self):
         """A further execution context on this engine's weights (include/mgrapher.h mg_clone): same arena, own workspace, decode

@@ -108,8 +108,8 @@ class InFlight:
     def generate_batches(self, batches, max_batches_per_call=4, **gen_kwargs):
         """Greedy `generate` over a list of batches (dicts with input_ids / bbox / attention_mask / pixel_values of EQUAL shapes: the same
         number of rows and the same padded text length) with up to `max_batches_per_call` of them per call (rows side by side: one pass
-        over the decoder's weights per step for the call's batches; up to 128 rows per call every image's ids are bit-identical to a call
-        on its batch alone) and the calls spread over the contexts (plan_calls).  Returns one host array of ids per batch, in order."""
+        over the decoder's weights per step for the call's batches; every image's ids are bit-identical to a call on its batch alone under
+        the same cross-attention form - the form is pinned for the invocation) and the calls spread over the contexts (plan_calls).  Returns one host array of ids per batch, in order."""
         import numpy as np
         torch = self._torch
         if gen_kwargs.get("num_beams", 1) != 1:
@@ -134,11 +134,25 @@ class InFlight:
             out = out.cpu().numpy() if hasattr(out, "cpu") else np.array(out, copy=True)
             return [out[j * rows:(j + 1) * rows] for j in range(len(group))]
 
-        futures, lo = [], 0
-        for nb in sizes:
-            futures.append(self.submit(job, batches[lo:lo + nb]))
-            lo += nb
-        return [ids for f in futures for ids in f.result()]
+        # the calls of one invocation may differ in size (3 + 2 batches ...): pin ONE cross-attention form for all of them, so that every batch
+        # goes through the same arithmetic whatever call it rides in (Engine.set_cross_absorb: "auto" picks the form by the call's rows)
+        pinned = None
+        if sizes and hasattr(self.contexts[0], "set_cross_absorb") and gen_kwargs.get("num_beams", 1) == 1:
+            form = bool(rows * max(sizes) >= getattr(self.contexts[0], "ABSORB_AUTO_ROWS", 96))
+            try:
+                pinned = [c.set_cross_absorb(form) for c in self.contexts]
+            except Exception:              # (a geometry without the absorbed form)
+                pinned = None
+        try:
+            futures, lo = [], 0
+            for nb in sizes:
+                futures.append(self.submit(job, batches[lo:lo + nb]))
+                lo += nb
+            return [ids for f in futures for ids in f.result()]
+        finally:
+            if pinned is not None:
+                for c, prev in zip(self.contexts, pinned):
+                    c.set_cross_absorb(prev)
 
     def close(self):
         self._pool.shutdown(wait=True)
