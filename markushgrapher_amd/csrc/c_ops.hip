@@ -149,7 +149,7 @@ int mgk_attention_step_trace(void* stream, const void* q, const void* Kc, const 
 // Result: ctx_pk packed [rows padded to 32][H*64] bf16.
 int mgk_xattn(void* stream, const void* q, const float* wkv, const void* enc, const int* len, const int* kv_owner, int rows, int H, int d,
               int cap, int nsplit, int nstg, void* wk, void* wv, void* qx, void* part, float* ml, void* ctx_pk) {
-    if (!xattn_supported(d, H) || nsplit < 1 || nsplit > 4 || nstg != 4) return MG_E_UNSUPPORTED;
+    if (!xattn_supported(d, H) || nsplit < 1 || nsplit > 4 || (nstg != 3 && nstg != 4)) return MG_E_UNSUPPORTED;
     mgStream_t st = (mgStream_t)stream;
     xattn_pack_weights(wkv, (uint16_t*)wk, (uint16_t*)wv, H, d, st);
     xattn_stream_prepare(d, nstg);

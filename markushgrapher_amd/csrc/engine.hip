@@ -105,7 +105,7 @@ struct mg_model {
     // Greedy decoding with the weight-absorbed cross-attention (k_xattn.hip): a layer streams the encoder states once instead of its K and V.
     // absorb: 2 (default where the geometry is supported) = by the call's decode rows (>= 96: absorbed), 1: every greedy call, 0: the K / V form for
     // every call (mg_set_cross_absorb, MG_XATTN_ABSORB).  Beam search keeps the K / V form.
-    int absorb = 2, xa_split = 1, xa_stages = 4;
+    int absorb = 2, xa_split = 1, xa_stages = 3;      // (xa_stages: 3 = one wave group, 100 KB of LDS - a decode projection's workgroup fits beside it on the CU; 4 = two groups, 136 KB)
     int shared_gpu = 0;       // mg_set_shared_gpu: other contexts run beside this one (the cross-attention stream keeps one workgroup per CU resident)
     // optional phase timing of mg_generate (HIP events): [start, encoder + cross-K/V done, decode loop done]
     bool phase_on = false;
@@ -807,6 +807,7 @@ int mg_create(const mg_config* cfg, mg_model** out) {
     { const char* e = getenv("MG_XATTN_ABSORB"); if (e && e[0] >= '0' && e[0] <= '2') m->absorb = e[0] - '0'; }
     { const char* e = getenv("MG_PACE"); if (e && e[0] == '0') m->pace = 0; }
     { const char* e = getenv("MG_XATTN_SPLIT"); if (e && atoi(e) >= 1 && atoi(e) <= 4) m->xa_split = atoi(e); }
+    { const char* e = getenv("MG_XATTN_STAGES"); if (e && (atoi(e) == 3 || atoi(e) == 4)) m->xa_stages = atoi(e); }
     if (!xattn_supported(c.d_model, c.num_heads)) m->absorb = 0;
     // arena layout
     size_t off = 0;
@@ -1084,7 +1085,7 @@ int mg_finalize(mg_model* m, void* stream) {
                 xattn_pack_weights(A, m->at<uint16_t>(l.xwk), m->at<uint16_t>(l.xwv), m->H, d, st);
             }
         }
-        if (xattn_supported(d, m->H)) xattn_stream_prepare(d, 4);
+        if (xattn_supported(d, m->H)) { xattn_stream_prepare(d, 4); xattn_stream_prepare(d, 3); }
     }
     mg_stream_sync(st);    // the host tables above must outlive the copies
     const int rc = check_launch("mg_finalize");

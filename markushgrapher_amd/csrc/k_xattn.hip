@@ -436,29 +436,35 @@ int xattn_nf(int d) {
 }
 bool xattn_supported(int d, int H) { return H >= 1 && H <= 16 && xattn_nf(d) > 0; }
 
-size_t xattn_stream_lds(int d, int nstg) { return (size_t)nstg * XA_KEYS * d * 2 + (size_t)8 * 64 * 16; }
+// Two forms of the stream kernel, chosen by the ring: nstg = 4 -> two wave groups (a ring of two iterations x two stages, 136 KB of LDS:
+// fastest per workgroup, but nothing else that needs LDS fits beside it on the CU); nstg = 3 -> one wave group, three stages (100 KB: a
+// workgroup of the decode projections - 33 KB - can share the CU).
+static int xa_groups(int nstg) { return (nstg % 2 == 0) ? 2 : 1; }
+size_t xattn_stream_lds(int d, int nstg) {
+    const int nf = xattn_nf(d), nw = nf ? d / (16 * nf) : 1;
+    return (size_t)nstg * XA_KEYS * d * 2 + (size_t)xa_groups(nstg) * nw * 64 * 16;       // ring + score partials
+}
 
 void xattn_expand(const XAttnArgs& a, mgStream_t stream) {
     const int nw = a.d >= 128 ? 4 : a.d / 32;
     MG_LAUNCH(xq_expand_kernel, dim3(a.H, a.d / (32 * nw)), dim3(nw * 64), 0, stream, a);
 }
 
-// wave groups of the stream kernel: 2 wherever the ring holds at least 2 stages per group
-constexpr int XA_NG = 2;
 void xattn_stream(const XAttnArgs& a, mgStream_t stream) {
-    const int nf = xattn_nf(a.d), nw = a.d / (16 * nf);
-    const dim3 grid(a.rows * a.nsplit), block(nw * XA_NG * 64);
+    const int nf = xattn_nf(a.d), nw = a.d / (16 * nf), ng = xa_groups(a.nstg);
+    const dim3 grid(a.rows * a.nsplit), block(nw * ng * 64);
     const size_t sh = xattn_stream_lds(a.d, a.nstg);
-#define MG_XS(N, W) if (nf == N && nw == W) { MG_LAUNCH((xattn_stream_kernel<N, W, XA_NG>), grid, block, sh, stream, a); return; }
+#define MG_XS(N, W) if (nf == N && nw == W) { if (ng == 2) MG_LAUNCH((xattn_stream_kernel<N, W, 2>), grid, block, sh, stream, a); \
+                                              else MG_LAUNCH((xattn_stream_kernel<N, W, 1>), grid, block, sh, stream, a); return; }
     MG_XS(2, 2) MG_XS(2, 4) MG_XS(4, 4) MG_XS(8, 4) MG_XS(12, 4) MG_XS(16, 4)
 #undef MG_XS
 }
-// the stream kernel's LDS request exceeds the default limit: set once, outside any stream capture
+// the stream kernel's LDS request exceeds the default limit: set once per form, outside any stream capture
 void xattn_stream_prepare(int d, int nstg) {
-    const int nf = xattn_nf(d), nw = nf ? d / (16 * nf) : 0;
+    const int nf = xattn_nf(d), nw = nf ? d / (16 * nf) : 0, ng = xa_groups(nstg);
     const size_t sh = xattn_stream_lds(d, nstg);
-    (void)sh; (void)nw;
-#define MG_XP(N, W) if (nf == N && nw == W) { MG_SET_MAX_SMEM((&xattn_stream_kernel<N, W, XA_NG>), sh); return; }
+    (void)sh; (void)nw; (void)ng;
+#define MG_XP(N, W) if (nf == N && nw == W) { if (ng == 2) MG_SET_MAX_SMEM((&xattn_stream_kernel<N, W, 2>), sh); else MG_SET_MAX_SMEM((&xattn_stream_kernel<N, W, 1>), sh); return; }
     MG_XP(2, 2) MG_XP(2, 4) MG_XP(4, 4) MG_XP(8, 4) MG_XP(12, 4) MG_XP(16, 4)
 #undef MG_XP
 }

@@ -331,7 +331,7 @@ struct XAttnArgs {
     int ctx_ld, ctx_col0;
     int rows, H, d, cap;
     int nsplit;               // key splits per row (1 .. 4): workgroups of the stream = rows * nsplit
-    int nstg;                 // stages of 16 keys in the stream's LDS ring (a multiple of the kernel's 2 wave groups: 4)
+    int nstg;                 // stages of 16 keys in the stream's LDS ring: 4 = two wave groups (136 KB), 3 = one wave group (100 KB)
 };
 bool xattn_supported(int d, int H);
 int xattn_nf(int d);
