@@ -1005,6 +1005,9 @@ def main():
             "kernel_alone_frac": (call_alone_rep or {}).get("roofline", {}).get("frac") if call_alone_rep and call_alone_rep.get("roofline") else
                                  ((single or {}).get("roofline") or {}).get("frac"),
             "images_per_s_with_e1_branch": e1_run["images_per_s"] if e1_run else None,
+            # the decode mode the reference ships (config/predict.yaml:13 beam search, 5 beams; utils_evaluation.py:278-281 max_length 512, EOS live),
+            # as a queue of images over the 4 contexts (mg_generate_stream_beam): extra_runs.beam5_eos_enabled_queue
+            "images_per_s_reference_default_mode": ((extra or {}).get("beam5_eos_enabled_queue") or {}).get("images_per_s"),
             "roofline": roof, "phases": phases, "one_call_alone": call_alone_rep, "one_batch_in_flight": single, "with_e1_branch": e1_run,
             "extra_runs": extra,
         }
