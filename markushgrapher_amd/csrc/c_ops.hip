@@ -157,6 +157,7 @@ int mgk_xattn(void* stream, const void* q, const float* wkv, const void* enc, co
     a.q = (const uint16_t*)q; a.qx = (uint16_t*)qx; a.wk = (const uint16_t*)wk; a.wv = (const uint16_t*)wv; a.enc = (const uint16_t*)enc;
     a.len = len; a.kv_owner = kv_owner; a.part = (uint16_t*)part; a.ml = ml; a.ctx = (uint16_t*)ctx_pk;
     a.rows = rows; a.H = H; a.d = d; a.cap = cap; a.nsplit = nsplit; a.nstg = nstg;
+    { const char* e = getenv("MG_XATTN_NT"); a.nt = e ? atoi(e) : 1; }
     xattn_expand(a, st);
     xattn_stream(a, st);
     xattn_contract(a, st);

@@ -105,7 +105,8 @@ struct mg_model {
     // Greedy decoding with the weight-absorbed cross-attention (k_xattn.hip): a layer streams the encoder states once instead of its K and V.
     // absorb: 2 (default where the geometry is supported) = by the call's decode rows (>= 96: absorbed), 1: every greedy call, 0: the K / V form for
     // every call (mg_set_cross_absorb, MG_XATTN_ABSORB).  Beam search keeps the K / V form.
-    int absorb = 2, xa_split = 1, xa_stages = 3;      // (xa_stages: 3 = one wave group, 100 KB of LDS - a decode projection's workgroup fits beside it on the CU; 4 = two groups, 136 KB)
+    int xa_nt = 1;           // the stream's copies carry the non-temporal hint (states read once per layer by one CU must not displace the weights in L2 / MALL: +5 % in flight; MG_XATTN_NT=0)
+    int absorb = 2, xa_split = 1, xa_stages = 4;      // (xa_stages: 4 = two wave groups, 136 KB of LDS: equal in flight, faster alone; 3 = one group, 100 KB - a decode projection's workgroup fits beside it on the CU)
     int shared_gpu = 0;       // mg_set_shared_gpu: other contexts run beside this one (the cross-attention stream keeps one workgroup per CU resident)
     // optional phase timing of mg_generate (HIP events): [start, encoder + cross-K/V done, decode loop done]
     bool phase_on = false;
@@ -701,7 +702,7 @@ static void decode_step(mg_model* m, const DecodeCtx& c, int t, const int* tdev,
         if (c.encx) {      // weight-absorbed form: q' = q·Wk_h | stream of the states | ctx_h = c_h·Wv_h^T   (the bracket times the stream)
             xa.q = c.dq; xa.qx = c.qx; xa.wk = m->at<uint16_t>(l.xwk); xa.wv = m->at<uint16_t>(l.xwv); xa.enc = c.encx; xa.len = c.xlen;
             xa.kv_owner = c.slots.pool; xa.live = live; xa.qrs = rs1; xa.part = c.xpart; xa.ml = c.xml; xa.ctx = c.xb; xa.ctx_ld = K2; xa.ctx_col0 = d;
-            xa.rows = R; xa.H = H; xa.d = d; xa.cap = Sx_cap; xa.nsplit = m->xa_split; xa.nstg = m->xa_stages;
+            xa.rows = R; xa.H = H; xa.d = d; xa.cap = Sx_cap; xa.nsplit = m->xa_split; xa.nstg = m->xa_stages; xa.nt = m->xa_nt;
             if (!(whatif & 8)) xattn_expand(xa, st);
         }
         if (timed) mg_event_record(m->prof_ev[m->prof_used], st);
@@ -806,6 +807,7 @@ int mg_create(const mg_config* cfg, mg_model** out) {
     { const char* e = getenv("MG_DECODE_FUSED_TAIL"); if (e && e[0] == '0') m->fused_tail = false; }
     { const char* e = getenv("MG_XATTN_ABSORB"); if (e && e[0] >= '0' && e[0] <= '2') m->absorb = e[0] - '0'; }
     { const char* e = getenv("MG_PACE"); if (e && e[0] == '0') m->pace = 0; }
+    { const char* e = getenv("MG_XATTN_NT"); if (e && e[0] == '0') m->xa_nt = 0; }
     { const char* e = getenv("MG_XATTN_SPLIT"); if (e && atoi(e) >= 1 && atoi(e) <= 4) m->xa_split = atoi(e); }
     { const char* e = getenv("MG_XATTN_STAGES"); if (e && (atoi(e) == 3 || atoi(e) == 4)) m->xa_stages = atoi(e); }
     if (!xattn_supported(c.d_model, c.num_heads)) m->absorb = 0;
@@ -876,7 +878,7 @@ int mg_clone(const mg_model* src, mg_model** out) {
     m->fin_a = src->fin_a; m->fin_b = src->fin_b; m->fin_c = src->fin_c;
     m->use_graph = src->use_graph; m->enc_mode = src->enc_mode; m->enc_mask = src->enc_mask;
     m->row_tiles = src->row_tiles; m->trim_padding = src->trim_padding; m->fused_tail = src->fused_tail; m->tied = src->tied;
-    m->absorb = src->absorb; m->xa_split = src->xa_split; m->xa_stages = src->xa_stages; m->pace = src->pace;
+    m->absorb = src->absorb; m->xa_split = src->xa_split; m->xa_stages = src->xa_stages; m->pace = src->pace; m->xa_nt = src->xa_nt;
     m->e1m = src->e1m; m->e1_M = src->e1_M;
     *out = m;
     return MG_OK;

@@ -142,8 +142,8 @@ __global__ __launch_bounds__(NW * NG * 64) void xattn_stream_kernel(XAttnArgs a)
     auto issue = [&](int it, int slot_it) {          // this group's stage of iteration `it` -> ring slot (slot_it, gi)
         const mg_lds_t dst = ring_lds + (unsigned)((slot_it * NG + gi) * stage_bytes + wq * KS * 1024);
         const char* src = ebase + (size_t)(st0 + it * NG + gi) * (size_t)stage_bytes;
-#pragma unroll
-        for (int c = 0; c < KS; ++c) glds16_async_sv(src, coff[c], dst + c * 1024);
+        if (a.nt) { for (int c = 0; c < KS; ++c) glds16_async_sv_nt(src, coff[c], dst + c * 1024); }
+        else { for (int c = 0; c < KS; ++c) glds16_async_sv(src, coff[c], dst + c * 1024); }
     };
     // LDS byte offsets inside a stage: score operand (key = lane % 16, chunks fb/8 + 4 ks + g) and transposed operand (key 4 g + a,
     // features fb + 32 (t / 2) + 8 b + 4 (t % 2) .. + 4, a = (lane % 16) / 4, b = lane % 4: result row 4 g' + i of tile t = feature

@@ -323,6 +323,18 @@ MG_DEV void glds16_async_sv(const char* src_uniform, unsigned lane_off, mg_lds_t
 #endif
 }
 
+// the same with the non-temporal hint: data that one CU reads once (a decode stream) should not displace what L2 / MALL could keep
+MG_DEV void glds16_async_sv_nt(const char* src_uniform, unsigned lane_off, mg_lds_t lds_wave_base) {
+#ifdef MG_EMU
+    emu::glds16(src_uniform + lane_off, (void*)lds_wave_base);
+#else
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_wave_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane_off), "s"(src_uniform), "s"(dst) : "memory");
+#endif
+}
+
 // 16-byte global load into registers that the compiler does not track (no s_waitcnt inserted on its behalf, it does not
 // count against the vmcnt the compiler computes for its own loads): for hand-pipelined prefetch several stages ahead.
 // The destination must not be read, copied or moved before MG_WAIT_VMCNT_TIE(N, regs...) has covered the load.

@@ -332,6 +332,7 @@ struct XAttnArgs {
     int rows, H, d, cap;
     int nsplit;               // key splits per row (1 .. 4): workgroups of the stream = rows * nsplit
     int nstg;                 // stages of 16 keys in the stream's LDS ring: 4 = two wave groups (136 KB), 3 = one wave group (100 KB)
+    int nt;                   // 1: the stream's copies carry the non-temporal hint
 };
 bool xattn_supported(int d, int H);
 int xattn_nf(int d);
