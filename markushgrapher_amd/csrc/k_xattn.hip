@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void xctx_contract_kernel(XAttnArgs a) {
     for (int ks = w; ks < KT; ks += 4) {
         uint4 cb;
         if (NS == 1) {
-            cb = ld16(a.part + ((size_t)row * H + h) * d + 32 * ks + 8 * g);          // one split: already the normalised bf16 context
+            cb = ld16_stream(a.part + ((size_t)row * H + h) * d + 32 * ks + 8 * g);          // one split: already the normalised bf16 context (read once)
         } else {
             float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             for (int s = 0; s < NS; ++s) {
