@@ -238,6 +238,10 @@ int mgk_im2col_pack(void* stream, const float* pix, void* x_pk, int B, int C, in
 int mgk_set_rows_split(int mode);
 /* residual projections of the decode step with several row tiles: 1 (default) 16 features per workgroup, 0: 8 */
 int mgk_set_resid_f16(int on);
+/* Half-tile decode projections with three or more 32-row tiles of live rows: 1 = a workgroup takes both 16-feature halves of a weight tile
+ * (half the activation re-reads through L2), 0 = one half per workgroup, -1 (default) = as the caller asks (the engine asks for it on
+ * contexts that share the GPU, mg_set_shared_gpu).  Same bits either way. */
+int mgk_set_rows_ft2(int mode);
 /* projections of the decode step with several row tiles: 1 the K-slab form (K chunks as workgroups, partial sums merged by the last
  * arrival in the one-workgroup forms' order) where the caller provides its scratch, 2 the same in two launches (partial sums, then a
  * chip-wide merge launch), 0 (default: measured faster) the one-workgroup forms */

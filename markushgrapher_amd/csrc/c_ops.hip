@@ -30,6 +30,7 @@ int mgk_im2col_pack(void* stream, const float* pix, void* x_pk, int B, int C, in
 // mode: 0 = tiled (large M), 1 = row-streaming (decode step)
 int mgk_set_rows_split(int mode) { gemm_rows_set_split(mode); return MG_OK; }
 int mgk_set_resid_f16(int on) { gemm_rows_set_resid_f16(on); return MG_OK; }
+int mgk_set_rows_ft2(int mode) { gemm_rows_set_ft2(mode); return MG_OK; }
 int mgk_gemm(void* stream, int mode, int epi, const void* X_pk, const void* W_pk, int M, int N, int K, float* out_f32,
              int ldo, const float* bias, void* out_pk) {
     if ((K & 63) || epi < 0 || (epi > EPI_PK && epi != EPI_PK_GELU)) return MG_E_SHAPE;

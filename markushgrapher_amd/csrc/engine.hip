@@ -675,6 +675,7 @@ static void decode_step(mg_model* m, const DecodeCtx& c, int t, const int* tdev,
                 set_heads(a, H, R, T_cap, c.dq, HF_STEP_Q, sk, HF_STEP_KV, sv, HF_STEP_KV);
                 a.heads.pos = t; a.heads.pos_dev = tdev; a.heads.pos_rows = c.slots.pos;
                 a.rs = li == 0 ? none : rs0;      // layer 0 reads the explicitly normalised embedding
+                a.both_halves = m->shared_gpu;    // (other contexts beside this one: fewer activation re-reads through L2 beat more workgroups)
                 if (!(whatif & 1)) gemm_rows(a, EPI_HEADS, st);      // q -> dq, k/v appended to the cache at position t
             }
             AttnStepArgs s{};
@@ -689,6 +690,7 @@ static void decode_step(mg_model* m, const DecodeCtx& c, int t, const int* tdev,
             r.part = c.rs_part1; r.M = R; r.N = d; r.K = inner;
             GemmArgs g = gemm_args(c.xa, m->at<uint16_t>(l.xq2), R, inner, K2);
             set_heads(g, H, R, T_cap, c.dq, HF_STEP_Q, nullptr, HF_NONE, nullptr, HF_NONE);
+            g.both_halves = m->shared_gpu;
             if (!(whatif & 4)) gemm_rows_pair(r, g, EPI_HEADS, st);
         }
         // cross-attention over the image's compacted K/V stream (all beams of an image share one pass)

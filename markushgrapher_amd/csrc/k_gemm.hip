@@ -671,30 +671,37 @@ MG_DEV void rows_block(const GemmArgs& a, int bid, char* smem) {
 // MFMA per two k-tiles and token group, every lane of a weight wave-load carries data.  Epilogues: packed bf16 rows
 // (optionally relu) or per-head stores; a lane holds 4 consecutive features of one token, two lanes (l, l^16) make one
 // 16-byte chunk.  Operand addressing as in resid_block16.
-template <int EPI, int MT, int NW, int U>
+// FT = 2 (several row tiles): the workgroup takes BOTH 16-feature halves of its weight tile - every activation fragment it pulls from L2
+// feeds two MFMAs instead of one (at 5 row tiles a workgroup reads 10 KB of activations per KB of weights; the activation re-reads of
+// all workgroups are what these launches cost beside other contexts).  Same K partition over the waves, same reduction order: the
+// results are bit-identical to the FT = 1 form (tests/test_kernels.py).
+template <int EPI, int MT, int NW, int U, int FT = 1>
 MG_DEV void rows_block16(const GemmArgs& a, int bid, char* smem) {
     static_assert(EPI == EPI_PK || EPI == EPI_PK_RELU || EPI == EPI_HEADS || EPI == EPI_PK_SWIGLU || EPI == EPI_F32_STORE,
                   "half-tile form: packed, per-head, SwiGLU and plain fp32 epilogues");
+    static_assert(FT == 1 || MT > 1, "both halves per workgroup: several row tiles only");
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r16 = lane & 15, kg = lane >> 4;
-    const int nt = bid >> 1, sub = bid & 1;
+    const int nt = FT == 2 ? bid : bid >> 1, sub0 = FT == 2 ? 0 : (bid & 1);
     const int kt16 = a.K >> 4, kp = kt16 >> 1;
     const int per = (kp + NW - 1) / NW;
     const int p0 = w * per, p1 = (p0 + per) < kp ? (p0 + per) : kp;
-    float* rsl = (float*)(smem + NW * 8 * 64 * sizeof(float));     // [32*MT] deferred RMSNorm scale per row
+    float* rsl = (float*)(smem + NW * 8 * FT * 64 * sizeof(float));     // [32*MT] deferred RMSNorm scale per row
     const size_t lane_off = (size_t)(kg >> 1) * TILE_BYTES + (size_t)(kg & 1) * 512;
-    const char* wp = (const char*)(a.W + pk_tile_off(nt, 0, a.K)) + lane_off + (size_t)(16 * sub + r16) * 16;
+    const char* wp = (const char*)(a.W + pk_tile_off(nt, 0, a.K)) + lane_off + (size_t)(16 * sub0 + r16) * 16;      // second half: + 256 B
     const int xkts = a.x_kts ? a.x_kts : kt16;
     const char* xp = (const char*)a.X + (size_t)a.x_k0 * TILE_BYTES + lane_off + (size_t)r16 * 16;
     RsRegs rsr;                                                  // load order = wait order, see resid_block16
     rs_issue(a.rs, a.M, 32 * MT, tid, NW * 64, rsr);
     int p = p0;
-    uint4 wf[U];
+    uint4 wf[U][FT];
     constexpr bool XPF = MT == 1;                                // see resid_block16
     uint4 xf[XPF ? U : 1][2];
     if (p + U <= p1) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) wf[u] = ld16_stream(wp + (size_t)(p + u) * (2 * TILE_BYTES));
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int f = 0; f < FT; ++f) wf[u][f] = ld16_stream(wp + (size_t)(p + u) * (2 * TILE_BYTES) + f * 256);
         if constexpr (XPF) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -704,13 +711,17 @@ MG_DEV void rows_block16(const GemmArgs& a, int bid, char* smem) {
         }
     }
     rs_finish(a.rs, a.M, 32 * MT, rsl, tid, NW * 64, rsr);
-    f32x4 acc[MT][2];
+    f32x4 acc[MT][2][FT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) { acc[i][0] = acc4_zero(); acc[i][1] = acc4_zero(); }
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int f = 0; f < FT; ++f) { acc[i][0][f] = acc4_zero(); acc[i][1][f] = acc4_zero(); }
     for (bool first = true; p + U <= p1; p += U, first = false) {
         if (!first) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) wf[u] = ld16_stream(wp + (size_t)(p + u) * (2 * TILE_BYTES));
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int f = 0; f < FT; ++f) wf[u][f] = ld16_stream(wp + (size_t)(p + u) * (2 * TILE_BYTES) + f * 256);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -718,42 +729,57 @@ MG_DEV void rows_block16(const GemmArgs& a, int bid, char* smem) {
             for (int i = 0; i < MT; ++i) {
                 const char* xt = xp + ((size_t)i * xkts + 2 * (p + u)) * TILE_BYTES;
                 if (XPF && first) {
-                    acc[i][0] = mfma16(wf[u], xf[XPF ? u : 0][0], acc[i][0]);
-                    acc[i][1] = mfma16(wf[u], xf[XPF ? u : 0][1], acc[i][1]);
+                    acc[i][0][0] = mfma16(wf[u][0], xf[XPF ? u : 0][0], acc[i][0][0]);
+                    acc[i][1][0] = mfma16(wf[u][0], xf[XPF ? u : 0][1], acc[i][1][0]);
                 } else {
-                    acc[i][0] = mfma16(wf[u], ld16(xt), acc[i][0]);
-                    acc[i][1] = mfma16(wf[u], ld16(xt + 256), acc[i][1]);
+                    const uint4 xa = ld16(xt), xb = ld16(xt + 256);
+#pragma unroll
+                    for (int f = 0; f < FT; ++f) {
+                        acc[i][0][f] = mfma16(wf[u][f], xa, acc[i][0][f]);
+                        acc[i][1][f] = mfma16(wf[u][f], xb, acc[i][1][f]);
+                    }
                 }
             }
         }
     }
     for (; p < p1; ++p) {
-        const uint4 w1 = ld16_stream(wp + (size_t)p * (2 * TILE_BYTES));
+        uint4 w1[FT];
+#pragma unroll
+        for (int f = 0; f < FT; ++f) w1[f] = ld16_stream(wp + (size_t)p * (2 * TILE_BYTES) + f * 256);
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const char* xt = xp + ((size_t)i * xkts + 2 * p) * TILE_BYTES;
-            acc[i][0] = mfma16(w1, ld16(xt), acc[i][0]);
-            acc[i][1] = mfma16(w1, ld16(xt + 256), acc[i][1]);
+            const uint4 xa = ld16(xt), xb = ld16(xt + 256);
+#pragma unroll
+            for (int f = 0; f < FT; ++f) {
+                acc[i][0][f] = mfma16(w1[f], xa, acc[i][0][f]);
+                acc[i][1][f] = mfma16(w1[f], xb, acc[i][1][f]);
+            }
         }
     }
-    float* slab = (float*)smem;                                  // [NW][8][64]
+    float* slab = (float*)smem;                                  // [NW][8 * FT][64]
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
+        for (int f = 0; f < FT; ++f)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) slab[(w * 8 + g * 4 + j) * 64 + lane] = acc[i][g][j];
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) slab[(w * 8 * FT + f * 8 + g * 4 + j) * 64 + lane] = acc[i][g][f][j];
         __syncthreads();
-        // unit f = 2*i + g (m-tile, token group) is finished by wave f % NW: two waves share a tile's epilogue
+        // unit (m-tile i, token group g, feature half f) is finished by wave ((2 i + g) FT + f) % NW: the waves share a tile's epilogue
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            if (((2 * i + g) % NW) == w) {
+#pragma unroll
+          for (int f = 0; f < FT; ++f) {
+            if ((((2 * i + g) * FT + f) % NW) == w) {
+                const int sub = sub0 + f;
                 const int m = 32 * i + 16 * g + r16;
                 float v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float t = 0.f;
-                    for (int ww = 0; ww < NW; ++ww) t += slab[(ww * 8 + g * 4 + j) * 64 + lane];
+                    for (int ww = 0; ww < NW; ++ww) t += slab[(ww * 8 * FT + f * 8 + g * 4 + j) * 64 + lane];
                     t *= rsl[32 * i + 16 * g + r16];
                     v[j] = (EPI == EPI_PK_RELU) ? fmaxf(t, 0.f) : t;
                 }
@@ -789,6 +815,7 @@ MG_DEV void rows_block16(const GemmArgs& a, int bid, char* smem) {
                     }
                 }
             }
+          }
         }
         __syncthreads();
     }
@@ -859,10 +886,10 @@ MG_DEV void rows_split_block(const GemmArgs& a, int ht, int g, char* smem) {
         }
     }
 }
-template <int EPI, int MT, bool HALF, int NW = 4>
+template <int EPI, int MT, bool HALF, int NW = 4, int FT = 1>
 __global__ __launch_bounds__(NW * 64) void gemm_rows_kernel(GemmArgs a) {
     MG_DYN_SMEM(smem);
-    if constexpr (HALF && (EPI == EPI_PK || EPI == EPI_PK_RELU || EPI == EPI_HEADS || EPI == EPI_PK_SWIGLU || EPI == EPI_F32_STORE)) rows_block16<EPI, MT, NW, 4>(a, blockIdx.x, smem);
+    if constexpr (HALF && (EPI == EPI_PK || EPI == EPI_PK_RELU || EPI == EPI_HEADS || EPI == EPI_PK_SWIGLU || EPI == EPI_F32_STORE)) rows_block16<EPI, MT, NW, 4, FT>(a, blockIdx.x, smem);
     else rows_block<EPI, MT, HALF, NW, 8>(a, blockIdx.x, smem);
 }
 
@@ -876,6 +903,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_rows_split_kernel(GemmArgs a) {
     else rows_block<EPI, 1, HALF, NW, 8>(a, blockIdx.x, smem);
 }
 
+// half-tile projections with >= 3 row tiles taking both halves per workgroup (same bits): -1 = as the call asks (GemmArgs::both_halves: the
+// engine sets it on contexts that share the GPU - +2 % in flight, -2.5 % for a call alone), 0 never, 1 always (gemm_rows_set_ft2 / MG_ROWS_FT2)
+static int g_rows_ft2 = [] { const char* e = getenv("MG_ROWS_FT2"); return (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : -1; }();
+void gemm_rows_set_ft2(int mode) { g_rows_ft2 = mode < 0 ? -1 : (mode ? 1 : 0); }
+static bool rows_ft2(const GemmArgs& a) { return g_rows_ft2 < 0 ? a.both_halves != 0 : g_rows_ft2 != 0; }
 template <int EPI>
 static void gemm_rows_mt(const GemmArgs& a, int mt, bool half, mgStream_t stream) {
     // half-tile projections (few workgroups, latency-bound): 8 waves split K so each wave's share is one load round
@@ -889,6 +921,16 @@ static void gemm_rows_mt(const GemmArgs& a, int mt, bool half, mgStream_t stream
         if (half) MG_LAUNCH((gemm_rows_split_kernel<EPI, true, 8>), grid, block, sh, stream, a);
         else MG_LAUNCH((gemm_rows_split_kernel<EPI, false, 4>), grid, block, sh, stream, a);
         return;
+    }
+    // from three row tiles on a half-tile workgroup takes both halves of its weight tile (rows_block16 FT = 2: half the activation
+    // re-reads from L2, half the workgroups; bit-identical)
+    if constexpr (EPI == EPI_PK || EPI == EPI_PK_RELU || EPI == EPI_HEADS || EPI == EPI_F32_STORE) {
+        if (half && mt >= 3 && rows_ft2(a) && (a.N % 32) == 0) {
+            const dim3 grid2((a.N + 31) / 32);
+#define MG_GR2(MTV) case MTV: MG_LAUNCH((gemm_rows_kernel<EPI, MTV, true, 8, 2>), grid2, block, sh, stream, a); return;
+            switch (mt) { MG_GR2(3) MG_GR2(4) MG_GR2(5) MG_GR2(6) MG_GR2(7) MG_GR2(8) default: break; }
+#undef MG_GR2
+        }
     }
 #define MG_GR(MTV)                                                                                   \
     case MTV:                                                                                        \
@@ -1683,11 +1725,11 @@ __global__ __launch_bounds__(512) void gemm_rows_pair_split_kernel(ResidArgs r, 
     const int u = (int)blockIdx.x - nres;
     rows_split_block<EPI, 8, 8>(g, (u >> 4) * 8 + (u & 7), (u >> 3) & 1, smem);
 }
-template <int EPI, int MT, bool HALF, bool F16 = false>
+template <int EPI, int MT, bool HALF, bool F16 = false, int FT = 1>
 __global__ __launch_bounds__(512) void gemm_rows_pair_kernel(ResidArgs r, GemmArgs g, int nres) {
     MG_DYN_SMEM(smem);
     if ((int)blockIdx.x < nres) resid_block16<MT, 8, 4, false, F16>(r, blockIdx.x, smem);
-    else if constexpr (HALF) rows_block16<EPI, MT, 8, 8>(g, (int)blockIdx.x - nres, smem);     // K = d + inner: 8 pairs per wave
+    else if constexpr (HALF) rows_block16<EPI, MT, 8, 8, FT>(g, (int)blockIdx.x - nres, smem);     // K = d + inner: 8 pairs per wave
     else rows_block<EPI, MT, false, 8, 16>(g, (int)blockIdx.x - nres, smem);
 }
 void gemm_rows_pair(const ResidArgs& r, const GemmArgs& g, int epi, mgStream_t stream) {
@@ -1706,9 +1748,15 @@ void gemm_rows_pair(const ResidArgs& r, const GemmArgs& g, int epi, mgStream_t s
         return;
     }
     const bool f16 = mt >= 2 && (r.N & 15) == 0 && g_resid_f16;      // residual part: 16 features per workgroup (resid_block16 F16)
-    const int nres = f16 ? r.N / 16 : r.N / 8, nrows = ((g.N + 31) / 32) * (full ? 1 : 2);
+    const bool ft2 = !full && mt >= 3 && rows_ft2(g) && (g.N % 32) == 0 && epi == EPI_HEADS && f16;      // (rows_block16 FT = 2, as gemm_rows: same bits)
+    const int nres = f16 ? r.N / 16 : r.N / 8, nrows = ((g.N + 31) / 32) * ((full || ft2) ? 1 : 2);
     const dim3 grid(nres + nrows), block(512);
     const size_t sh = (size_t)8 * 16 * 64 * sizeof(float) + (size_t)32 * mt * sizeof(float);
+    if (ft2) {
+#define MG_RPF(MTV) case MTV: MG_LAUNCH((gemm_rows_pair_kernel<EPI_HEADS, MTV, true, true, 2>), grid, block, sh, stream, r, g, nres); return;
+        switch (mt) { MG_RPF(3) MG_RPF(4) MG_RPF(5) MG_RPF(6) MG_RPF(7) MG_RPF(8) default: break; }
+#undef MG_RPF
+    }
 #define MG_RP2(MTV, FV)                                                                                              \
         if (epi == EPI_PK_RELU && full) MG_LAUNCH((gemm_rows_pair_kernel<EPI_PK_RELU, MTV, false, FV>), grid, block, sh, stream, r, g, nres); \
         else if (epi == EPI_PK_RELU) MG_LAUNCH((gemm_rows_pair_kernel<EPI_PK_RELU, MTV, true, FV>), grid, block, sh, stream, r, g, nres); \

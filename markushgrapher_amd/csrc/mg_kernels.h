@@ -82,6 +82,8 @@ struct GemmArgs {
     // benchmark's length distribution).  Kernels without list support ignore it and compute every row - the list is an optimisation.
     const int* row_tiles;
     const int* n_row_tiles;
+    int both_halves;       // decode-step half-tile projections with >= 3 row tiles: 1 = a workgroup takes both 16-feature halves of its weight tile (same bits;
+                           // half the activation re-reads through L2: better beside other contexts, slower for a call alone)
     int pp_colgroup;       // set by the ping-pong kernel's launcher: > 0: an XCD's tiles ordered column group by column group (that many column tiles wide)
     int pp_balance;        // set by the ping-pong kernel's launcher: cut the row tiles into blocks of balanced height (k_gemm_pp.hip)
     int pp_part, pp_parts; // set by the ping-pong kernel's launcher: this launch computes part pp_part of pp_parts of the row tiles (list entries or tiles
@@ -97,6 +99,7 @@ void gemm_set_variant(int v);   // 0: 128x128 kernel only; 1: + 256x128 three-st
 void gemm_rows(const GemmArgs& a, int epi, mgStream_t stream);
 void gemm_rows_set_resid_f16(int on);  // 1 (default): residual projections with several row tiles take 16 features per workgroup; 0: 8 (tests, A/B runs; same bits)
 void gemm_rows_set_mt(int on);   // 1: K-slab form (default 0: measured slower, k_gemm.hip) of the projections with several row tiles where the caller provides kpart / ticket; 0: one-workgroup forms (same bits)
+void gemm_rows_set_ft2(int mode);  // -1 (default): GemmArgs::both_halves decides; 0 / 1: never / always both 16-feature halves of a weight tile per workgroup (tests, A/B runs; same bits)
 void gemm_rows_set_split(int mode);   // row-tile split policy of the decode projections (-1 default by weight size, 0 never, 1 always one tile per workgroup)
 
 // split-K decode GEMM: P[ks][m*ldp + n] (ks < KS) = partial sums over the ks-th K range; consumers add the slabs

@@ -701,10 +701,12 @@ def test_tied_and_untied_lm_head(be_name):
 
 
 @pytest.mark.parametrize("be_name", BACKENDS)
-def test_e1_tokens_are_fused_into_the_cross_attention(be_name):
+@pytest.mark.parametrize("absorb", [False, True])
+def test_e1_tokens_are_fused_into_the_cross_attention(be_name, absorb):
     """optional precomputed OCSR-branch embeddings e1 [B, M, d].  The decoder cross-attends over
     [e1 | VTL states]; teacher-forced logits and greedy / beam ids against the oracle's statement of the same fusion
-    (Oracle.fuse_e1).  PARITY UNPINNED: the fork that defines the fusion is unavailable; the oracle is the build's own."""
+    (Oracle.fuse_e1).  PARITY UNPINNED: the fork that defines the fusion is unavailable; the oracle is the build's own.
+    absorb: the greedy cross-attention form pinned - the weight-absorbed form streams [e1 tokens | attended encoder states] rows."""
     from oracle.udop_oracle import Oracle
     g = load_golden("g3_trained_tiny.npz")
     shape, sd = _weights(g)
@@ -712,6 +714,7 @@ def test_e1_tokens_are_fused_into_the_cross_attention(be_name):
     B, M = inp["input_ids"].shape[0], 5
     e1 = synth.round_bf16(synth.uniform_pm1("e1.tokens", (B, M, shape.d_model), 2) * np.float32(1.5))
     eng = make_engine(be_name, shape, sd)
+    eng.set_cross_absorb(absorb)
     o = Oracle(shape, sd)
     args = (inp["input_ids"], inp["bbox"], inp["attention_mask"], inp["pixel_values"])
     labels = g["labels"]

@@ -1004,3 +1004,39 @@ def test_enc_rows_compaction(be_name):
     assert be.lib.mgk_enc_rows(be.stream, be.p(be.buf(pk.pack_tiles(x))), be.p(be.buf(rmap)), be.p(dst), B, S, cap, d) == 0
     got = pk.bf16_to_f32(dst.numpy()).reshape(B, cap, d)
     assert np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
+def test_half_tile_projections_both_halves_form_is_bit_identical(be_name):
+    """Half-tile decode projections with three or more row tiles of live rows: a workgroup takes BOTH 16-feature halves of its weight tile
+    (rows_block16 FT = 2: every activation fragment feeds two MFMAs, half the activation re-reads through L2, half the workgroups) - the
+    default - against one half per workgroup.  Same K partition over the waves, same reduction order: packed (plain / relu), fp32 and
+    per-head outputs (q + cache append) must be the SAME BITS; values against the fp32 reference."""
+    be = get_backend(be_name)
+    M, K, N, H, T = (160, 512, 128, 2, 8) if be_name == "hip" else (100, 128, 64, 1, 4)
+    inner = H * 64
+    x, w, wq = rnd((M, K), 320), rnd((N, K), 321, 0.1), rnd((3 * inner, K), 322, 0.1)
+    Mp = (M + 31) // 32 * 32
+    X, W, WQ = be.buf(pk.pack_tiles(x)), be.buf(pk.pack_tiles(w)), be.buf(pk.pack_tiles(wq))
+    res = {}
+    try:
+        assert be.lib.mgk_set_rows_split(0) == 0          # (small weights would otherwise take the one-row-tile-per-workgroup form)
+        for ft2 in (0, 1):
+            assert be.lib.mgk_set_rows_ft2(ft2) == 0
+            out_f, out_pk, out_relu = be.zeros((M, N), np.float32), be.zeros((Mp * N,), np.uint16), be.zeros((Mp * N,), np.uint16)
+            assert be.lib.mgk_gemm(be.stream, 1, 0, be.p(X), be.p(W), M, N, K, be.p(out_f), N, None, None) == 0
+            assert be.lib.mgk_gemm(be.stream, 1, 3, be.p(X), be.p(W), M, N, K, None, N, None, be.p(out_pk)) == 0
+            assert be.lib.mgk_gemm(be.stream, 1, 2, be.p(X), be.p(W), M, N, K, None, N, None, be.p(out_relu)) == 0
+            q, kc, vc = be.zeros((M, H, 64), np.uint16), be.zeros((M, H, T, 64), np.uint16), be.zeros((M, H, T, 64), np.uint16)
+            assert be.lib.mgk_gemm_heads(be.stream, 1, be.p(X), be.p(WQ), M, 3 * inner, K, be.p(q), be.p(kc), be.p(vc),
+                                         HF_STEP_Q, HF_STEP_KV, HF_STEP_KV, H, M, T, None, 3) == 0
+            res[ft2] = [np.array(a.numpy(), copy=True) for a in (out_f, out_pk, out_relu, q, kc, vc)]
+    finally:
+        be.lib.mgk_set_rows_ft2(-1)
+        be.lib.mgk_set_rows_split(-1)
+    ref = pk.bf16_round(x) @ pk.bf16_round(w).T
+    np.testing.assert_allclose(res[1][0], ref, rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(pk.unpack_tiles(res[1][2], M, N), np.maximum(ref, 0), rtol=1 / 128, atol=1e-3)
+    np.testing.assert_allclose(pk.bf16_to_f32(res[1][3]), (pk.bf16_round(x) @ pk.bf16_round(wq).T).reshape(M, 3, H, 64)[:, 0], rtol=1 / 128, atol=1e-3)
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b)

@@ -35,8 +35,11 @@ def _batch_rows(eng, inp, max_length, min_length=0):
 
 
 @pytest.mark.parametrize("be_name", BACKENDS)
-@pytest.mark.parametrize("chunk,slots,pool_chunks", [(4, 3, 2), (3, 5, 3), (6, 2, 2)])
-def test_stream_ids_equal_per_image_generate(be_name, chunk, slots, pool_chunks):
+@pytest.mark.parametrize("chunk,slots,pool_chunks,absorb", [(4, 3, 2, False), (3, 5, 3, False), (6, 2, 2, False), (3, 5, 3, True), (4, 3, 2, True)])
+def test_stream_ids_equal_per_image_generate(be_name, chunk, slots, pool_chunks, absorb):
+    """absorb: the cross-attention form pinned (mg_set_cross_absorb; the default picks it by the decode rows, i.e. by `slots`) - the
+    weight-absorbed form reads the image's attended encoder states from the pool through the slot table, skips idle slots and pads the
+    last 16-key stage of every pool entry."""
     g = load_golden("g3_trained_tiny.npz")
     shape, sd = _weights(g)
     inp = _inputs(g, shape)                                    # 6 images whose rows end at different steps
@@ -44,6 +47,7 @@ def test_stream_ids_equal_per_image_generate(be_name, chunk, slots, pool_chunks)
     q = _queue(inp, order)
     T = int(g["max_length"])
     eng = make_engine(be_name, shape, sd)
+    eng.set_cross_absorb(absorb)
     ids, lens, steps = eng.generate_stream(q["input_ids"], q["bbox"], q["attention_mask"], q["pixel_values"], max_length=T,
                                            chunk=chunk, slots=slots, pool_chunks=pool_chunks)
     ids, lens = _np(eng, ids), _np(eng, lens)
