@@ -197,7 +197,7 @@ int mg_set_shared_gpu(mg_model* m, int shared);
  * every layer streams the attended encoder states (2·d_model bytes per position) instead of its own K and V (4·d_model): half the
  * dominant HBM stream of decoding, no cross-K/V projections after the encoder, no per-layer K/V buffers (the workspace shrinks; sizes are
  * computed for the current setting and call shape).  The stream runs one workgroup per decode row: it pays from ~100 rows per call on
- * (160 rows, 4 contexts in flight: 148 -> 182 images/s) and loses below (32 rows alone: 82 -> 50 images/s, latency-bound).
+ * (160 rows, 4 contexts in flight: 148 -> 197 images/s) and loses below (32 rows alone: 82 -> 50 images/s, latency-bound).
  *   absorb = 2 (default wherever the geometry has the form: d_model a supported multiple of 64, at most 16 heads): by the call's decode
  *              rows - absorbed from 96 rows on, K / V form below;
  *   absorb = 1: absorbed for every greedy call;   absorb = 0: the K / V form always (what beam search always uses);
