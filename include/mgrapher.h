@@ -211,6 +211,19 @@ int mg_set_cross_absorb(mg_model* m, int absorb, int key_splits);
 /* 1 if the last mg_generate replayed a captured graph, 0 if it launched eagerly (mode 0/2, capture unavailable). */
 int mg_decode_graph_active(const mg_model* m);
 
+/* The multi-GPU path's one collective behind the C ABI (image shards are independent, the ranks exchange decoded ids):
+ * an RCCL all-gather of equal-sized byte blocks on a stream the caller names.  The library resolves librccl at run time (the copy the
+ * process already holds, else the system's) and adds no link dependency.  Rendezvous stays with the host: rank 0 calls
+ * mg_dist_unique_id and ships the 128 bytes to every rank by whatever it has (markushgrapher_amd/dist.py: torch.distributed's
+ * store / broadcast), then EVERY rank calls mg_dist_create (collective).  mg_dist_allgather enqueues ncclAllGather(send, recv) of
+ * bytes_per_rank bytes per rank (recv holds world x bytes_per_rank, rank order) and returns; the buffers must stay valid until the
+ * stream has passed it.  No counterpart in the reference (one device, /root/reference/markushgrapher/utils/ocsr/utils_evaluation.py:140). */
+typedef struct mg_dist mg_dist;
+int mg_dist_unique_id(void* out, int bytes);
+int mg_dist_create(const void* unique_id, int bytes, int rank, int world, mg_dist** out);
+int mg_dist_allgather(mg_dist* d, void* stream, const void* send, void* recv, size_t bytes_per_rank);
+void mg_dist_destroy(mg_dist* d);
+
 /* Page preprocessing on the device ("next" row f-3): replaces page_image.resize((512,512), Image.LANCZOS)
  * (/root/reference/markushgrapher/core/datasets/mdu_dataset.py:118) + MarkushgrapherImageProcessor's rescale 1/255 and
  * mean = std = 0.5 normalisation (/root/reference/markushgrapher/core/common/begin.py:105-109), bit-exactly (Pillow's

@@ -15,7 +15,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
 SOURCES = ["k_gemm.hip", "k_gemm_pp.hip", "k_pack.hip", "k_embed.hip", "k_attn.hip", "k_decode.hip", "k_xattn.hip", "k_beam.hip", "k_prep.hip", "c_ops.hip",
-           "engine.hip", "k_ocr.hip", "ocr.hip", "k_swin.hip", "swin.hip"]
+           "engine.hip", "dist.hip", "k_ocr.hip", "ocr.hip", "k_swin.hip", "swin.hip"]
 HIP_SO = os.path.join(ROOT, "markushgrapher_amd", "libmgrapher_hip.so")
 TOOLS_SO = os.path.join(ROOT, "tools", "_build", "libmgrapher_tools.so")
 EMU_DIR = os.path.join(ROOT, "tools", "simt_emu")

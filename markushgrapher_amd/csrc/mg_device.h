@@ -70,7 +70,16 @@ static inline int mg_memcpy_async(void* d, const void* s, size_t n, mgStream_t s
 // Waits of this library poll the event and sleep in between (100 us: nothing here waits for less than a decode step).  MG_SPIN_SYNC=1
 // restores the runtime's own waits.
 static inline bool mg_spin_sync() { static const bool spin = [] { const char* e = getenv("MG_SPIN_SYNC"); return e && e[0] == '1'; }(); return spin; }
+// An event poll returns hipErrorNotReady, which REPLACES whatever error an earlier launch of this thread left in the runtime's
+// last-error slot: a failed launch would go unnoticed by the entry point's final check.  Anything pending is therefore taken out of the
+// slot before polling and kept (mg_stashed_error) for mg_peek_error.
+inline int& mg_stashed_error() { static thread_local int e = 0; return e; }
+static inline void mg_stash_pending_error() {
+    const hipError_t pre = hipGetLastError();
+    if (pre != hipSuccess && pre != hipErrorNotReady && mg_stashed_error() == 0) mg_stashed_error() = (int)pre;
+}
 static inline int mg_event_wait_sleeping(hipEvent_t ev) {
+    mg_stash_pending_error();
     for (int i = 0;; ++i) {
         const hipError_t r = hipEventQuery(ev);
         if (r == hipSuccess) return 0;
@@ -87,7 +96,13 @@ static inline int mg_stream_sync(mgStream_t st) {
     if (rc != 0) return rc;
     return mg_track(mg_event_wait_sleeping(ev), "hipEventQuery");
 }
-static inline int mg_peek_error() { return (int)hipGetLastError(); }
+static inline int mg_peek_error() {
+    int e = (int)hipGetLastError();
+    if (e == (int)hipErrorNotReady) e = 0;
+    if (e == 0) e = mg_stashed_error();
+    mg_stashed_error() = 0;
+    return e;
+}
 static inline const char* mg_error_string(int e) { return hipGetErrorString((hipError_t)e); }
 typedef hipEvent_t mgEvent_t;
 static inline int mg_event_create(mgEvent_t* e) { return (int)hipEventCreate(e); }
@@ -106,7 +121,7 @@ static inline int mg_stream_create(mgStream_t* s, int low_priority, const uint32
 static inline void mg_stream_destroy(mgStream_t s) { (void)hipStreamDestroy(s); }
 static inline int mg_event_create_notiming(mgEvent_t* e) { return (int)hipEventCreateWithFlags(e, hipEventDisableTiming); }
 static inline int mg_stream_wait_event(mgStream_t s, mgEvent_t e) { return mg_track((int)hipStreamWaitEvent(s, e, 0), "hipStreamWaitEvent"); }
-static inline int mg_event_done(mgEvent_t e) { const hipError_t r = hipEventQuery(e); if (r == hipErrorNotReady) { (void)hipGetLastError(); return 0; } return 1; }
+static inline int mg_event_done(mgEvent_t e) { mg_stash_pending_error(); const hipError_t r = hipEventQuery(e); if (r == hipErrorNotReady) { (void)hipGetLastError(); return 0; } return 1; }
 static inline int mg_event_sync(mgEvent_t e) { return mg_spin_sync() ? mg_track((int)hipEventSynchronize(e), "hipEventSynchronize") : mg_track(mg_event_wait_sleeping(e), "hipEventQuery"); }
 static inline void* mg_host_alloc(size_t n) { void* p = nullptr; return hipHostMalloc(&p, n, hipHostMallocDefault) == hipSuccess ? p : nullptr; }
 static inline void mg_host_free(void* p) { (void)hipHostFree(p); }

@@ -38,11 +38,20 @@ class IdExchange:
     """
 
     def __init__(self, rows: int, device, pad_token_id: int = 0, group: Optional[dist.ProcessGroup] = None, cols: int = ID_COLS,
-                 always_collective: bool = False):
-        """always_collective: issue the all-gather even in a group of one rank (exercises the RCCL path on a single GPU)."""
+                 always_collective: bool = False, native: Optional[bool] = None):
+        """always_collective: issue the all-gather even in a group of one rank (exercises the RCCL path on a single GPU).
+        native: the gathers go through the library's own RCCL entry points (include/mgrapher.h mg_dist_*: ncclAllGather on a stream of
+        this object) instead of torch.distributed's; torch.distributed then only carries the 128-byte unique id at set-up.  Default: the
+        environment's MG_DIST_NATIVE=1, else torch.distributed (the path the multi-rank CPU tests cover)."""
         self.rows, self.cols, self.pad, self.group = rows, cols, pad_token_id, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.collective = self.world > 1 or (always_collective and dist.is_initialized())
+        if native is None:
+            import os
+            native = os.environ.get("MG_DIST_NATIVE", "0") == "1"
+        self._native = None
+        if native and self.collective and torch.device(device).type == "cuda":
+            self._native_setup(torch.device(device))
         mk = lambda *shape: torch.empty(shape, dtype=torch.int32, device=device)
         self.send = [mk(rows, cols), mk(rows, cols)]
         self.slen = [mk(rows), mk(rows)]
@@ -68,10 +77,54 @@ class IdExchange:
             self.recv[slot].copy_(s)
             self.rlen[slot].copy_(sl)
             self.pending[slot] = ()
+        elif self._native is not None:
+            import ctypes as C
+            lib, comm, st = self._native
+            ready = torch.cuda.Event()
+            ready.record()                               # the send blocks are complete on the caller's stream
+            st.wait_event(ready)
+            for src, dst in ((s, self.recv[slot]), (sl, self.rlen[slot])):
+                rc = lib.mg_dist_allgather(comm, C.c_void_p(st.cuda_stream), C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()),
+                                           C.c_size_t(src.numel() * src.element_size()))
+                if rc != 0:
+                    raise RuntimeError(f"mg_dist_allgather failed ({rc}): {lib.mg_last_error().decode()}")
+            done = torch.cuda.Event()
+            done.record(st)
+            self.pending[slot] = (_NativeWork(done),)
         else:
             self.pending[slot] = (dist.all_gather_into_tensor(self.recv[slot], s, group=self.group, async_op=True),
                                   dist.all_gather_into_tensor(self.rlen[slot], sl, group=self.group, async_op=True))
         return slot
+
+    def _native_setup(self, device):
+        """RCCL communicator of the library (mg_dist_create): rank 0's unique id travels through torch.distributed once."""
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        lib.mg_last_error.restype = C.c_char_p
+        lib.mg_dist_unique_id.argtypes = [C.c_void_p, C.c_int]
+        lib.mg_dist_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        lib.mg_dist_allgather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.mg_dist_destroy.argtypes = [C.c_void_p]
+        rank = dist.get_rank(self.group)
+        buf = (C.c_char * 128)()
+        if rank == 0 and lib.mg_dist_unique_id(buf, 128) != 0:
+            raise RuntimeError("mg_dist_unique_id: " + lib.mg_last_error().decode())
+        box = [bytes(buf)]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        comm = C.c_void_p()
+        with torch.cuda.device(device):
+            rc = lib.mg_dist_create(box[0], 128, rank, self.world, C.byref(comm))
+            if rc != 0:
+                raise RuntimeError("mg_dist_create: " + lib.mg_last_error().decode())
+            self._native = (lib, comm, torch.cuda.Stream(device=device))
+
+    def close(self):
+        if self._native is not None:
+            lib, comm, st = self._native
+            st.synchronize()
+            lib.mg_dist_destroy(comm)
+            self._native = None
 
     def wait(self, slot: int):
         works = self.pending[slot]
@@ -81,6 +134,19 @@ class IdExchange:
             w.wait()
         self.pending[slot] = None
         return self.recv[slot], self.rlen[slot]
+
+
+class _NativeWork:
+    """wait() of a gather issued through mg_dist_allgather: its event, polled (the runtime's own waits spin)."""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        import time
+        while not self.event.query():
+            time.sleep(0.0001)
+        torch.cuda.current_stream().wait_event(self.event)
 
 
 def sharded_generate(generate_fn: Callable[..., torch.Tensor], batch: Dict[str, torch.Tensor], max_length: int,

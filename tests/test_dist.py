@@ -164,17 +164,19 @@ import pytest
 
 
 @pytest.mark.gpu
-def test_id_exchange_over_rccl_single_rank_group():
+@pytest.mark.parametrize("native", [False, True])
+def test_id_exchange_over_rccl_single_rank_group(native):
     """The exchange's collective path on real hardware: a process group of one rank over RCCL (backend "nccl"), the ids of three batches
     posted asynchronously (double-buffered) as all-gathers while a second stream keeps the GPU busy - what every rank of `bench.py --gpus N`
-    runs, minus the peers."""
+    runs, minus the peers.  native: the gathers through the library's own entry points (mg_dist_create / mg_dist_allgather: ncclAllGather
+    called by libmgrapher_hip.so on the exchange's stream), torch.distributed carrying only the unique id."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(29500 + (os.getpid() + 311) % 1000)
+    os.environ["MASTER_PORT"] = str(29500 + (os.getpid() + 311 + (17 if native else 0)) % 1000)
     dev = torch.device("cuda", 0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
-        ex = IdExchange(32, dev, pad_token_id=0, always_collective=True)
-        assert ex.collective and ex.world == 1
+        ex = IdExchange(32, dev, pad_token_id=0, always_collective=True, native=native)
+        assert ex.collective and ex.world == 1 and (ex._native is not None) == native
         side = torch.cuda.Stream()
         busy = torch.randn(2048, 2048, device=dev)
         mk = lambda step: ((torch.arange(32 * (257 - step), dtype=torch.int64).reshape(32, 257 - step) % 33201) + step).to(dev)
@@ -190,6 +192,7 @@ def test_id_exchange_over_rccl_single_rank_group():
             assert a.shape == (32, ID_COLS) and a.dtype == np.int32 and np.all(l == t)
             assert np.array_equal(a[:, :t], mk(step).cpu().numpy()) and np.all(a[:, t:] == 0)
         torch.cuda.synchronize()
+        ex.close()
     finally:
         dist.destroy_process_group()
 
