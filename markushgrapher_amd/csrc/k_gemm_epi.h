@@ -88,7 +88,7 @@ MG_DEV void heads_store(const HeadsOut& ho, int ri, int h, int m, int dim0, cons
     } else if (fmt == HF_STEP_KV) {
         const int row = ho.row_map ? ho.row_map[m] : m;
         const int pos = ho.pos_rows ? ho.pos_rows[m] : (ho.pos_dev ? *ho.pos_dev : ho.pos);
-        st16(base + (((size_t)row * ho.H + h) * (size_t)ho.S_cap + (size_t)pos) * 64 + dim0, c);
+        st16_stream(base + (((size_t)row * ho.H + h) * (size_t)ho.S_cap + (size_t)pos) * 64 + dim0, c);
     }
 }
 

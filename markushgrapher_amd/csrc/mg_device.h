@@ -391,6 +391,16 @@ MG_DEV uint4 ld16_stream(const void* p) {
 #endif
 }
 MG_DEV void st16(void* p, const uint4& v) { *(uint4*)p = v; }
+// written now, read a decode step later at the earliest (cache appends): non-temporal store, does not displace reusable lines
+MG_DEV void st16_stream(void* p, const uint4& v) {
+#ifdef MG_EMU
+    *(uint4*)p = v;
+#else
+    typedef unsigned int mg_u32x4 __attribute__((ext_vector_type(4)));
+    const mg_u32x4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, (mg_u32x4*)p);
+#endif
+}
 
 // two packed bf16 pairs dotted into an fp32 accumulator
 MG_DEV float dot2_bf16(uint32_t a, uint32_t b, float acc) {
