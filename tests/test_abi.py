@@ -63,3 +63,37 @@ def test_create_validates_config_without_device_work():
     assert lib.mg_load_tensor(model, None, b"encoder.final_layer_norm.weight", C.c_void_p(16), 0, shp, 1) == -3
     lib.mg_destroy.argtypes = [C.c_void_p]
     lib.mg_destroy(model)
+
+
+def test_cross_absorb_setting_and_workspace_rule():
+    """mg_set_cross_absorb without device work: the default (2) picks the cross-attention form by the call's decode rows - from 96 rows on the
+    weight-absorbed form, whose workspace holds ONE buffer of encoder states instead of per-layer K / V - 1 / 0 pin a form, < 0 queries, beam
+    search always keeps K / V; bad arguments are refused."""
+    from markushgrapher_amd import _lib
+    from markushgrapher_amd.engine import MgConfig
+    lib = _lib.load()
+    lib.mg_last_error.restype = C.c_char_p
+    cfg = MgConfig(500, 64, 64, 128, 2, 2, 2, 32, 128, 128, 64, 16, 3, 0, 1, 0, 1e-6, 64)
+    model = C.c_void_p()
+    assert lib.mg_create(C.byref(cfg), C.byref(model)) == 0
+    lib.mg_set_cross_absorb.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.mg_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
+    need = C.c_size_t()
+
+    def ws(B, beams=1):
+        assert lib.mg_workspace_bytes(model, B, 8, beams, 16, 0, 0, C.byref(need)) == 0
+        return need.value
+    assert lib.mg_set_cross_absorb(model, -1, 0) == 2                   # default: by the call's rows
+    auto95, auto96, auto_beam = ws(95), ws(96), ws(32, 5)
+    assert lib.mg_set_cross_absorb(model, 0, 0) == 2                    # K / V form always; returns the previous setting
+    kv95, kv96, kv_beam = ws(95), ws(96), ws(32, 5)
+    assert lib.mg_set_cross_absorb(model, 1, 2) == 0                    # absorbed for every greedy call, two key splits
+    ab95, ab96, ab_beam = ws(95), ws(96), ws(32, 5)
+    assert auto95 == kv95 and auto96 < kv96 and ab95 < kv95             # the rule; the absorbed form needs less
+    assert auto_beam == kv_beam == ab_beam                              # beam search keeps the K / V form
+    assert lib.mg_set_cross_absorb(model, -1, 0) == 1
+    assert lib.mg_set_cross_absorb(model, 3, 0) < 0 and b"absorb" in lib.mg_last_error()
+    assert lib.mg_set_cross_absorb(model, 1, 5) < 0
+    assert lib.mg_set_cross_absorb(None, 1, 0) < 0
+    lib.mg_destroy.argtypes = [C.c_void_p]
+    lib.mg_destroy(model)

@@ -1007,6 +1007,31 @@ def test_enc_rows_compaction(be_name):
 
 
 @pytest.mark.parametrize("be_name", BACKENDS)
+def test_absorbed_cross_attention_ignores_what_lies_behind_the_last_key(be_name):
+    """The stream reads whole stages of 16 keys: rows between an image's last key and the next multiple of 16 carry weight exactly 0 (the
+    engine clears them, enc_pad_rows).  With finite junk there the result must be the SAME BITS as with zeros."""
+    be = get_backend(be_name)
+    d, H, cap, rows = 128, 2, 64, 3
+    lens = np.array([37, 1, 50], np.int32)
+    inner = H * 64
+    q = pk.bf16_round(rnd((rows, H, 64), 90, 0.5))
+    wkv = pk.bf16_round(rnd((2 * inner, d), 91, 1.0 / np.sqrt(d)))
+    enc = pk.bf16_round(rnd((rows, cap, d), 92, 1.0))
+    outs = []
+    for junk in (0.0, 7.5):
+        e = enc.copy()
+        for r in range(rows):
+            e[r, lens[r]:] = junk
+        ctx = be.zeros((32 * inner,), np.uint16)
+        wk, wv = be.zeros((H * d * 64,), np.uint16), be.zeros((H * d * 64,), np.uint16)
+        qx, part, ml = be.zeros((rows * H * d,), np.uint16), be.zeros((rows * H * d,), np.uint16), be.zeros((rows * H * 2,), np.float32)
+        assert be.lib.mgk_xattn(be.stream, be.p(be.buf(pk.bf16_bits(q))), be.p(be.buf(wkv)), be.p(be.buf(pk.bf16_bits(e))), be.p(be.buf(lens)), None,
+                                rows, H, d, cap, 1, 4, be.p(wk), be.p(wv), be.p(qx), be.p(part), be.p(ml), be.p(ctx)) == 0
+        outs.append(np.array(ctx.numpy(), copy=True))
+    assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("be_name", BACKENDS)
 def test_half_tile_projections_both_halves_form_is_bit_identical(be_name):
     """Half-tile decode projections with three or more row tiles of live rows: a workgroup takes BOTH 16-feature halves of its weight tile
     (rows_block16 FT = 2: every activation fragment feeds two MFMAs, half the activation re-reads through L2, half the workgroups) - the
