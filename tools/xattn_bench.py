@@ -1,6 +1,6 @@
 """Timing of the weight-absorbed cross-attention launches alone (k_xattn.hip through mgk_xattn): rows decode rows, each reading its own
 image's `keys` attended encoder states.  Per-kernel durations: run under `rocprofv3 --kernel-trace --stats`.
-  python tools/xattn_bench.py [rows] [keys] [nsplit] [nstg] [iters]"""
+  python tools/xattn_bench.py [rows] [keys] [nsplit] [nstg] [iters] [cap]"""
 import ctypes as C
 import sys
 import time
@@ -19,7 +19,7 @@ def main():
     nstg = int(sys.argv[4]) if len(sys.argv) > 4 else 4
     iters = int(sys.argv[5]) if len(sys.argv) > 5 else 50
     H, d = 16, 1024
-    cap = (keys + 63) // 64 * 64
+    cap = int(sys.argv[6]) if len(sys.argv) > 6 else (keys + 63) // 64 * 64
     lib = _lib.load()
     dev = "cuda"
     g = torch.Generator(device="cpu").manual_seed(1)
@@ -48,7 +48,7 @@ def main():
     torch.cuda.synchronize()
     dt = (time.time() - t0) / iters
     moved = float(lens.sum().item()) * d * 2
-    print(f"rows {rows} keys {keys} nsplit {nsplit} nstg {nstg}: {dt * 1e6:.1f} us per layer-step (4 launches incl. weight re-ordering), "
+    print(f"rows {rows} keys {keys} cap {cap} nsplit {nsplit} nstg {nstg}: {dt * 1e6:.1f} us per layer-step (4 launches incl. weight re-ordering), "
           f"stream bytes {moved / 1e6:.1f} MB -> {moved / dt / 1e12:.2f} TB/s if it were the stream alone")
 
 
