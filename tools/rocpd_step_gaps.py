@@ -1,6 +1,6 @@
 """Where a decode step's time goes, from a rocprofv3 kernel trace (rocpd SQLite): per queue, the kernels between two token selections
 (greedy_select*) are one step; per position in the step: kernel name, average duration, average gap to the previous kernel's end.
-Usage: rocpd_step_gaps.py results.db [out.md]"""
+Usage: rocpd_step_gaps.py results.db [out.md] [--mark kernel-name-prefix]   (default mark: greedy_select)"""
 import re
 import sqlite3
 import sys
@@ -13,6 +13,11 @@ def short(name):
 
 
 def main():
+    mark = "greedy_select"
+    if "--mark" in sys.argv:
+        i = sys.argv.index("--mark")
+        mark = sys.argv[i + 1]
+        del sys.argv[i:i + 2]
     db = sqlite3.connect(sys.argv[1])
     cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
     key = "queue_id" if "queue_id" in cols else "stream_id"
@@ -22,7 +27,7 @@ def main():
         per[q].append((s, e, short(n), gx // max(wx, 1)))
     out = []
     for q, ks in per.items():
-        sel = [i for i, k in enumerate(ks) if k[2].startswith("greedy_select")]
+        sel = [i for i, k in enumerate(ks) if k[2].startswith(mark)]
         if len(sel) < 6:
             continue
         steps = [ks[a:b + 1] for a, b in zip(sel[:-1], sel[1:])]          # [select_i, kernels of step i+1 ..., select_{i+1}]
