@@ -983,6 +983,8 @@ def main():
             "config": {"workload": "configs[1]: batch 32/GPU synthetic 1024x1024 u8 crops -> device LANCZOS 512px model input, greedy "
                                    f"decode, {new_tokens} forced new tokens (EOS suppressed), UDOP-large-shaped "
                                    "MarkushGrapher-2 VTL encoder + CXSMILES decoder, recipe weights = tests/golden/g4_bench.npz",
+                       "ocsr_branch": "not attached: `value` is the VTL-only model (BASELINE.json north_star's path); the reference's shipped "
+                                      "me-lf-stack-1 architecture also runs the OCSR vision branch e1 - same plan with it attached: images_per_s_with_e1_branch",
                        "shape": args.shape, "batch_per_gpu": B, "text_len_padded": int(L), "new_tokens": new_tokens,
                        "num_beams": args.beams, "decode_graph": args.decode_graph, "batches_in_flight": int(sum(timed_plan[:len(fl)])),
                        "contexts": len(fl), "batches_per_call_max": bpc, "batches_per_call": timed_plan,
